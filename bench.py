@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): Lagrangian model.yaml denoiser (dim 64, mults 1-2-4-8, 39.5 M parameters,
+random-init), 3 x 11 x 96 x 96 video, batch 4 per GPU, classifier-free guidance w = 5, dynamic thresholding.
+One "step" = one guided ancestral DDPM step p_sample(x_t, t) for the whole batch: the denoiser at batch 2B
+(conditional + unconditional branch), x0 prediction, exact 0.9-quantile, posterior update -- exactly what the
+reference executes 256 times per sample() call (vddp.py:956-975).  Inputs are resident in HBM.
+value = sampled frames/s = n_gpus * B * 11 frames / (256 steps * step time).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel family (implicit-GEMM conv/projection, fp32 MFMA
+bound) from HIP-event timing of every launch, and `cpu_baseline` = the oracle (CPU restatement) timed on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LAGRANGIAN = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=3, attn_heads=8, attn_dim_head=32, init_dim=None, init_kernel_size=7,
+                  use_sparse_linear_attn=True, resnet_groups=8, cond_bias=True, cond_attention="self-stacked", cond_attention_tokens=16,
+                  cond_att_GRU=False, use_temporal_attention_cond=True, cond_to_time="add", per_frame_cond=True, padding_mode="zeros")
+B_PER_GPU, T, HW, TIMESTEPS, W_GUIDE = 4, 11, 96, 256, 5.0
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(max_seconds: float = 40.0):
+    """Oracle (oracle/unet3d_oracle.py, parity-pinned CPU restatement of the reference) on the host cores."""
+    from oracle import unet3d_oracle as uo
+    torch.manual_seed(0)
+    import videometamaterials_amd as vm
+    model = vm.Unet3D(**LAGRANGIAN)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = uo.UnetCfg(**{k: v for k, v in LAGRANGIAN.items()})
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 3, T, HW, HW, generator=g)
+    t = torch.randint(0, TIMESTEPS, (1,), generator=g)
+    cond = torch.rand(1, 11, generator=g) * 2 - 1
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    times = []
+    with torch.no_grad():
+        t_begin = time.perf_counter()
+        for i in range(4):
+            t0 = time.perf_counter()
+            uo.unet3d_forward(sd, cfg, x, t, cond, torch.zeros(1, dtype=torch.bool))
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > max_seconds:
+                break
+    fwd = min(times[1:]) if len(times) > 1 else times[0]
+    step_s = fwd * 2 * B_PER_GPU  # guided step at batch 4 = 8 single-sample forwards
+    return {"value": B_PER_GPU * T / (TIMESTEPS * step_s), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"{len(times)} oracle Unet3D forwards (B=1, 11x96x96, Lagrangian widths, fp32, torch CPU {nthreads} threads); "
+                      f"best {fwd:.2f} s/forward, extrapolated x8 forwards per guided step (B=4) x 256 steps",
+            "forward_s_b1": fwd}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import videometamaterials_amd as vm
+    from videometamaterials_amd import hostmath
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    model = vm.Unet3D(**LAGRANGIAN).to(dev).eval()
+    diff = vm.GaussianDiffusion(model, image_size=HW, num_frames=T, channels=3, timesteps=TIMESTEPS, loss_type="l1", use_dynamic_thres=True,
+                                sampling_timesteps=TIMESTEPS).to(dev)
+    g = torch.Generator().manual_seed(2 + rank)
+    # rows of data/target_responses.csv are min-max normalised to [-1, 1] by the reference; synthetic stand-in of that range
+    cond = (torch.rand(B_PER_GPU, 11, generator=g) * 2 - 1).to(dev)
+    shape = (B_PER_GPU, 3, T, HW, HW)
+    img = torch.randn(shape, generator=g).to(dev)
+
+    model.static_weights = True
+    from videometamaterials_amd.diffusion import _GraphedStep
+    stepper = _GraphedStep(diff, shape, 11, W_GUIDE)
+    stepper.set_cond(cond)
+    if args.no_graph:
+        stepper.captured = True  # stay eager
+    ts = list(reversed(range(TIMESTEPS)))
+
+    def run_steps(n, offset=0):
+        nonlocal img
+        for j in range(n):
+            img = stepper(img, ts[(offset + j) % TIMESTEPS])
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = world * B_PER_GPU * T / (TIMESTEPS * ms_per_step * 1e-3)
+    finite = bool(torch.isfinite(img).all().item())
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel-family timing with HIP events on the launch stream (separate, un-timed pass)
+        pl = stepper.plan
+        fam_ms, fam_fl, fam_by, fam_n = {}, {}, {}, {}
+        reps = 3
+        for _ in range(reps):
+            for (name, fl, by), ms in zip(pl.meta, pl.launch_timed()):
+                fam_ms[name] = fam_ms.get(name, 0.0) + ms
+                fam_fl[name] = fam_fl.get(name, 0.0) + fl
+                fam_by[name] = fam_by.get(name, 0.0) + by
+                fam_n[name] = fam_n.get(name, 0) + 1
+        fwd_ms = sum(fam_ms.values()) / reps
+        dom = max(fam_ms, key=fam_ms.get)
+        ach_tflops = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
+        ach_gbs = fam_by[dom] / (fam_ms[dom] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": fam_n[dom] // reps, "avg_launch_ms": round(fam_ms[dom] / fam_n[dom], 4),
+                    "algorithmic_GFLOP_per_step": round(fam_fl[dom] / reps / 1e9, 1), "algorithmic_GB_per_step": round(fam_by[dom] / reps / 1e9, 2),
+                    "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
+                    "share_of_denoiser_time": round(fam_ms[dom] / sum(fam_ms.values()), 3)}
+        families = {k: round(v / reps, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        out = {
+            "metric": "sampled frames/sec (guided DDPM sampling, 11x96x96 video)", "value": round(frames_per_s, 4), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: Lagrangian model.yaml Unet3D (dim 64, 39.5M params, random init), 3x11x96x96, batch 4 per GPU, "
+                                   "guidance w=5, 256-step ancestral DDPM with dynamic thresholding; step = one guided p_sample over the batch "
+                                   "(denoiser at batch 8 + x0/quantile/posterior)",
+                       "batch_per_gpu": B_PER_GPU, "frames": T, "image": HW, "timesteps": TIMESTEPS, "guidance_scale": W_GUIDE,
+                       "hipgraph": stepper.graph is not None, "parallelism": f"independent sampling shards x{world} (no data-path collective)"},
+            "denoising_sample_steps_per_sec": round(world * B_PER_GPU / (ms_per_step * 1e-3), 3),
+            "full_sample_seconds": round(TIMESTEPS * ms_per_step * 1e-3, 2),
+            "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/* C ABI of libvmm_hip.so -- the MI355X (gfx950) hot path of VideoMetamaterials.
+ *
+ * Every entry point is a pure launcher: no allocation, no synchronisation, no global
+ * state; work is enqueued on the hipStream_t passed in (the host passes PyTorch's
+ * current stream so calls stay ordered with the surrounding torch ops).  Return value:
+ * 0 on success, otherwise the hipError_t of the failed launch / a negative value for a
+ * rejected argument.  All tensors are fp32 unless noted; "rows" are (b,t,h,w) positions
+ * of the frame-major channels-last working layout, `ld*` are row strides in floats.
+ *
+ * Reference interface each entry point replaces (vddp.py =
+ * /root/reference/denoising_diffusion_pytorch/video_denoising_diffusion_pytorch.py):
+ * the reference has no native code, so these stand in for the ATen ops its Python
+ * issues at the cited lines.
+ */
+#ifndef VMM_KERNELS_H
+#define VMM_KERNELS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vmm_stream_t; /* hipStream_t */
+
+/* ---- K1..K5, K8, K10: per-frame convolutions and projections as ONE implicit GEMM ----
+ * out[orow, co] = epi( sum_{tap, ci} A[(img, a*stride + dh(tap), b*stride + dw(tap)), ci] * W[tap*Cin + ci, co] )
+ * replaces nn.Conv3d (1,k,k) vddp.py:626,271,297,241,708; nn.ConvTranspose3d vddp.py:155 (as 4 phase
+ * sub-convolutions); nn.Conv2d 1x1 vddp.py:319,325; nn.Linear vddp.py:413,421.
+ * The input may be the channel-concatenation of two tensors (torch.cat skip, vddp.py:813,820).
+ * Epilogue (in this order): + bias, * q_scale on the first q_ncols columns, rotary rotation of the first
+ * rot_ncols columns (vddp.py:449,456,496; position = frame index of the row), + residual rows. */
+typedef struct vmm_conv_desc {
+  const float* a1;  const float* a2;      /* a2 may be NULL */
+  int32_t C1, C2, lda1, lda2;             /* channels (multiples of 4) and row strides of the sources */
+  const float* w;                          /* [ntaps*(C1+C2)][Cout], k-major */
+  const float* bias;                       /* [Cout] or NULL */
+  const float* res; int32_t ldres;         /* residual rows (indexed like out) or NULL */
+  float* out; int32_t ldo;
+  int32_t nimg, Hin, Win;                  /* B*T frames, input grid */
+  int32_t Hv, Wv, stride;                  /* grid the M dimension runs over (per frame) */
+  int32_t KH, KW, off_h, off_w, sgn_h, sgn_w; /* dh = off_h + sgn_h*kh, dw = off_w + sgn_w*kw */
+  int32_t Hout, Wout, oscale, ooh, oow;    /* out row = ((img*Hout + a*oscale+ooh)*Wout + b*oscale+oow) */
+  int32_t Cout;
+  const float* rot_tab;                    /* [rot_T][rot_dh/2][2] (cos,sin) or NULL */
+  int32_t rot_T, rot_HW, rot_ncols, rot_dh;
+  float q_scale; int32_t q_ncols;
+  /* A-operand transform fused into the tile load (0 = none, 1 = GroupNorm+FiLM+SiLU of the producer:
+   * silu(x*ga[b,c] + gb[b,c]), coefficients per (sample, channel) of source a1; vddp.py:279-285) */
+  int32_t a_mode; const float* a_coef; int32_t a_imgs_per_sample; /* frames per sample (T) */
+} vmm_conv_desc;
+int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
+
+/* ---- K6: GroupNorm(groups, C) statistics + fused affine/FiLM/SiLU (vddp.py:274-285) ---- */
+/* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */
+int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G,
+                        double* sums /* [B*G*2], zeroed by the call */, vmm_stream_t stream);
+/* mean/rstd from the sums, then coef[b,c] = (a, b'):  y = silu(x*a + b')  with a = rstd*gamma*(scale+1),
+ * b' = (beta - mean*rstd*gamma)*(scale+1)+shift;  film = [B][ldfilm] rows (scale | shift) or NULL (vddp.py:283,306).
+ * stats_out [B*G*2] = (mean, rstd) is kept for the backward pass (may be NULL). */
+int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
+                       const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef /* [B][C][2] */,
+                       float* stats_out, vmm_stream_t stream);
+/* y = silu(x*a + b') (+ res) ; in place allowed (vddp.py:285,311). */
+int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y, int32_t ldy,
+                    int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream);
+
+/* ---- K7: channel LayerNorm, gamma only, eps inside sqrt (vddp.py:245-254) ---- */
+int vmm_channel_layernorm(const float* x, int32_t ldx, const float* gamma, float* y, int32_t ldy, int64_t rows, int32_t C,
+                          float eps, vmm_stream_t stream);
+
+/* ---- K11/K13/K14: temporal softmax attention core (vddp.py:491-534), one (b, pixel, head) problem per 11 queries.
+ * qkv rows [(b,t,hw)][3*heads*dh] with q pre-scaled and q,k pre-rotated by the projection epilogue;
+ * ek/ev = conditioning keys/values [B][ntok][heads*dh] (ek pre-rotated when per-frame) or NULL;
+ * bias = relative position bias [heads][T][T]; bias_on_cond: also add it to the token half (vddp.py:505-510). */
+int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
+                           const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
+                           int32_t heads, int32_t dh, vmm_stream_t stream);
+
+/* ---- K12: mid-level spatial softmax attention per frame (vddp.py:687-689): n = HW queries, keys = [tokens | HW].
+ * tok_per_frame = 1: frame t sees only token t (vddp.py:459-462); 0: all ntok tokens. */
+int vmm_spatial_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
+                          int32_t tok_per_frame, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads,
+                          int32_t dh, vmm_stream_t stream);
+
+/* ---- K9: spatial linear attention core (vddp.py:367-376), per (b*T frame, head):
+ * ctx[d,e] = sum_n softmax_n(k)[d,n] * v[e,n]/HW over n = [tokens | HW pixels];  out[n, e] = sum_d ctx[d,e]*softmax_d(q[n,:])*scale */
+int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T,
+                        int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part /* [B*T*heads*nsplit][dh*dh+2*dh] */,
+                        float* ctx /* [B*T*heads][dh*dh] */, vmm_stream_t stream);
+int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
+                      int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+
+/* ---- K15: batched tiny dense layers (time_mlp, sign_emb, cond_token_to_hidden, ResnetBlock.mlp, to_k/to_v on tokens;
+ * vddp.py:290-293,322-323,416-417,637-661).  One launch runs `njobs` independent jobs:
+ * Y[r, o] = act_out( sum_k act_in(X[r,k]) * W[o,k] + b[o] ) (+ add[r,o]);  W is the torch (out,in) layout. */
+typedef struct vmm_dense_job {
+  const float* x; const float* w; const float* b; const float* add; float* y;
+  int32_t rows, K, N, ldx, ldy, ldadd;
+  int32_t act_in, act_out; /* 0 none, 1 SiLU, 2 GELU(erf) */
+} vmm_dense_job;
+/* max_units = max over jobs of N * ceil(rows/8) (one wave per output column and 8-row chunk) */
+int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_units, vmm_stream_t stream);
+
+/* sinusoidal timestep embedding (vddp.py:139-151): out[b] = [sin(t*f_i) | cos(t*f_i)], f_i = exp(-i*ln(1e4)/(half-1)) */
+int vmm_sinusoidal_embed(const int64_t* t, int32_t B, int32_t dim, float neg_step /* -ln(1e4)/(half-1) */, float* out,
+                         vmm_stream_t stream);
+/* per-frame conditioning (vddp.py:751-784): tokens[b,f,:] = cond[b,f]*w + bias; pooled = mean_f; then CFG replacement by the
+ * null token where mask[b] != 0. */
+int vmm_cond_tokens(const float* cond, const float* w, const float* bias, const float* null_token, const uint8_t* mask,
+                    int32_t B, int32_t F, int32_t D, float* tokens, float* pooled, vmm_stream_t stream);
+/* row-wise LayerNorm with affine (nn.LayerNorm, vddp.py:657) */
+int vmm_rows_layernorm_affine(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t D, float eps,
+                              vmm_stream_t stream);
+/* out[b,:] = mask[b] ? null[:] : x[b,:]   then (+ add[b,:])   (vddp.py:784-788) */
+int vmm_select_add(const float* x, const float* null_row, const uint8_t* mask, const float* add, float* out, int32_t B,
+                   int32_t D, vmm_stream_t stream);
+/* rotate token keys for temporal attention: ek[b, n, h*dh + d] with position n (vddp.py:470-471) */
+int vmm_rotary_rows(float* x, const float* rot_tab, int32_t B, int32_t N, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* relative position bias (vddp.py:70-108): embedding gather through the INTEGER T5 bucket table [n*n] that the host computes
+ * once per n (bit-exact integer arithmetic, videometamaterials_amd/hostmath.py) -> out [heads][n][n] */
+int vmm_relpos_bias(const float* emb /* [num_buckets][heads] */, const int32_t* buckets, int32_t n, int32_t heads, float* out,
+                    vmm_stream_t stream);
+
+/* SignalEmbedding 'CNN' stage (vddp.py:553-561): y = SiLU(Conv1d(k=4,s=2,p=1)(x)), x (B,Cin,Lin) -> y (B,Cout,Lin/2) */
+int vmm_conv1d_k4s2_silu(const float* x, const float* w /* [Cout][Cin][4] */, const float* bias, float* y, int32_t B, int32_t Cin,
+                         int32_t Cout, int32_t Lin, vmm_stream_t stream);
+/* tokens[b,n,:] = mask[b] ? null_token[n,:] : hidden[b,:] (vddp.py:767,774-777) */
+int vmm_tokens_from_hidden(const float* hidden, const float* null_token, const uint8_t* mask, int32_t B, int32_t N, int32_t D,
+                           float* tokens, vmm_stream_t stream);
+
+/* ---- layout edges: NCTHW (reference API) <-> channels-last rows ---- */
+int vmm_ncthw_to_rows(const float* x, int32_t B, int32_t C, int32_t T, int32_t HW, float* rows, int32_t ld /* >= C, pad = 0 */,
+                      vmm_stream_t stream);
+int vmm_rows_to_ncthw(const float* rows, int32_t ld, int32_t B, int32_t C, int32_t T, int32_t HW, float* x, vmm_stream_t stream);
+/* final 1x1x1 conv to a few output channels, written straight to NCTHW (vddp.py:708) */
+int vmm_pointwise_to_ncthw(const float* rows, int32_t ld, int32_t Cin, const float* w /* [Cout][Cin] */, const float* bias,
+                           int32_t B, int32_t Cout, int32_t T, int32_t HW, float* out, vmm_stream_t stream);
+
+/* ---- K17/K18/K20: diffusion-step arithmetic (vddp.py:920-963,1036-1060) ---- */
+/* x_t = a[t_b]*x0 + s[t_b]*noise  (q_sample, vddp.py:1036-1042); x0n = x*2-1 when normalize != 0 (vddp.py:1066,1109) */
+int vmm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1macp,
+                 int32_t normalize, float* out, int32_t B, int64_t per_sample, vmm_stream_t stream);
+/* eps = null + (cond-null)*w (vddp.py:728) [null may be NULL => eps = cond]; x0 = c_recip[t]*x - c_recipm1[t]*eps (920-924);
+ * writes x0 and |x0| (for the quantile). */
+int vmm_predict_x0(const float* x, const float* eps_cond, const float* eps_null, float w, const int64_t* t,
+                   const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, float* x0, float* absx0, int32_t B,
+                   int64_t per_sample, vmm_stream_t stream);
+/* per-sample linear-interpolated quantile of non-negative values (torch.quantile semantics, vddp.py:941-945):
+ * exact radix select of order statistics k_lo and k_lo+1, s = lerp(v_lo, v_hi, frac), then max(s, floor_min). */
+int vmm_quantile_rows(const float* absx, int32_t B, int64_t n, int64_t k_lo, float frac, float floor_min, float* s_out,
+                      uint32_t* scratch /* [B][4112] */, vmm_stream_t stream);
+/* clip_mode 0: x0c = x0; 1: clamp(x0,-1,1); 2: clamp(x0,-s[b],s[b])/s[b] (vddp.py:938-951);
+ * mean = c1[t]*x0c + c2[t]*x (926-930); out = mean + [t>0]*exp(0.5*logvar[t])*noise (960-963), or just mean when noise == NULL. */
+int vmm_posterior_step(const float* x0, const float* x, const float* noise, const float* s, const int64_t* t,
+                       const float* coef1, const float* coef2, const float* logvar, int32_t clip_mode, float* out, int32_t B,
+                       int64_t per_sample, vmm_stream_t stream);
+/* sum |a-b| or (a-b)^2 -> out[0] (fp64 accumulate, zeroed by the call); sign/diff for backward (vddp.py:1053-1056) */
+int vmm_loss_reduce(const float* a, const float* b, int64_t n, int32_t squared, double* acc, float* out_mean,
+                    vmm_stream_t stream);
+/* classifier-free guidance: out = null + (cond - null) * w (vddp.py:728) */
+int vmm_cfg_combine(const float* eps_cond, const float* eps_null, float w, float* out, int64_t n, vmm_stream_t stream);
+/* out = a*x + b*y + c*z + d (y, z optional): DDIM update (vddp.py:1014-1016), un/normalize_img (1109-1113) */
+int vmm_lincomb(const float* x, const float* y, const float* z, float a, float b, float c, float d, float* out, int64_t n,
+                vmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

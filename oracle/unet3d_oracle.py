@@ -305,16 +305,24 @@ def embed_condition(sd, cfg: UnetCfg, cond: Tensor, null_mask: Tensor):
 
 
 # --------------------------------------------------------------------------- the network
-def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor, cond: Tensor, null_mask: Tensor) -> Tensor:
+def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor, cond: Tensor, null_mask: Tensor,
+                   taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """Unet3D.forward (vddp.py:730-821) with the CFG drop mask passed explicitly
-    (null_cond_prob=0 -> all False, =1 -> all True; vddp.py:55-61)."""
+    (null_cond_prob=0 -> all False, =1 -> all True; vddp.py:55-61).
+    `taps`, if given, receives the output of every block (debug aid for the per-block GPU parity tests)."""
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v.detach().clone()
+        return v
+
     if cfg.padding_mode != "zeros":
         raise ValueError("oracle covers padding_mode='zeros' only (SURVEY a14)")
     g = cfg.resnet_groups
     T = x.shape[2]
     bias = rel_pos_bias(sd, T)
     x = frame_conv(x, sd["init_conv.weight"], sd["init_conv.bias"], pad=cfg.init_kernel_size // 2)
-    x = temporal_attention_block(sd, "init_temporal_attn", x, cfg, bias, None)
+    x = tap("init_temporal_attn", temporal_attention_block(sd, "init_temporal_attn", x, cfg, bias, None))
     r = x.clone()
     t = sinusoidal_embedding(time, cfg.dim)
     t = F.linear(t, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
@@ -326,27 +334,27 @@ def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor,
     skips = []
     n_lvl = len(cfg.level_io)
     for i in range(n_lvl):
-        x = resnet_block(sd, f"downs.{i}.0", x, t, g)
-        x = resnet_block(sd, f"downs.{i}.1", x, t, g)
-        x = linear_attention_block(sd, f"downs.{i}.2", x, cfg, tokens)
-        x = temporal_attention_block(sd, f"downs.{i}.3", x, cfg, bias, tokens_t)
+        x = tap(f"downs.{i}.0", resnet_block(sd, f"downs.{i}.0", x, t, g))
+        x = tap(f"downs.{i}.1", resnet_block(sd, f"downs.{i}.1", x, t, g))
+        x = tap(f"downs.{i}.2", linear_attention_block(sd, f"downs.{i}.2", x, cfg, tokens))
+        x = tap(f"downs.{i}.3", temporal_attention_block(sd, f"downs.{i}.3", x, cfg, bias, tokens_t))
         skips.append(x)
         if i < n_lvl - 1:
             x = frame_conv(x, sd[f"downs.{i}.4.weight"], sd[f"downs.{i}.4.bias"], stride=2, pad=1)
-    x = resnet_block(sd, "mid_block1", x, t, g)
-    x = mid_spatial_attention_block(sd, "mid_spatial_attn", x, cfg, tokens)
-    x = temporal_attention_block(sd, "mid_temporal_attn", x, cfg, bias, tokens_t)
-    x = resnet_block(sd, "mid_block2", x, t, g)
+    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g))
+    x = tap("mid_spatial_attn", mid_spatial_attention_block(sd, "mid_spatial_attn", x, cfg, tokens))
+    x = tap("mid_temporal_attn", temporal_attention_block(sd, "mid_temporal_attn", x, cfg, bias, tokens_t))
+    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g))
     for i in range(n_lvl):
         x = torch.cat((x, skips.pop()), dim=1)
-        x = resnet_block(sd, f"ups.{i}.0", x, t, g)
-        x = resnet_block(sd, f"ups.{i}.1", x, t, g)
-        x = linear_attention_block(sd, f"ups.{i}.2", x, cfg, tokens)
-        x = temporal_attention_block(sd, f"ups.{i}.3", x, cfg, bias, tokens_t)
+        x = tap(f"ups.{i}.0", resnet_block(sd, f"ups.{i}.0", x, t, g))
+        x = tap(f"ups.{i}.1", resnet_block(sd, f"ups.{i}.1", x, t, g))
+        x = tap(f"ups.{i}.2", linear_attention_block(sd, f"ups.{i}.2", x, cfg, tokens))
+        x = tap(f"ups.{i}.3", temporal_attention_block(sd, f"ups.{i}.3", x, cfg, bias, tokens_t))
         if i < n_lvl - 1:
             x = frame_conv_transpose(x, sd[f"ups.{i}.4.weight"], sd[f"ups.{i}.4.bias"])
     x = torch.cat((x, r), dim=1)
-    x = resnet_block(sd, "final_conv.0", x, None, g)
+    x = tap("final_conv.0", resnet_block(sd, "final_conv.0", x, None, g))
     return frame_conv(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
 
 

@@ -1,0 +1,355 @@
+"""Per-kernel parity on the MI355X: each C-ABI entry point against a plain PyTorch fp32 CPU reference
+of the same op, on seeded inputs.  Tolerances are fp32-roundoff class (the kernels compute in fp32)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from videometamaterials_amd import _native as N
+    return N, N.lib()
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rows_of(x):  # (B,C,T,H,W) -> (B*T*H*W, C)
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def unrows(r, B, T, H, W):  # (rows, C) -> (B,C,T,H,W)
+    return r.reshape(B, T, H, W, -1).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def run_conv(N, lib, dev, a1, w_packed, Cout, *, a2=None, bias=None, KH=1, KW=1, stride=1, off=(0, 0), sgn=(1, 1), nimg, Hin, Win, Hv, Wv,
+             Hout=None, Wout=None, oscale=1, oo=(0, 0), out=None, res=None, rot=None, rot_T=1, rot_ncols=0, q_scale=1.0, q_ncols=0, a_coef=None, T=1):
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = a1.data_ptr(), a1.shape[1], a1.shape[1]
+    if a2 is not None:
+        d.a2, d.C2, d.lda2 = a2.data_ptr(), a2.shape[1], a2.shape[1]
+    d.w = w_packed.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    Hout, Wout = Hout or Hv, Wout or Wv
+    if out is None:
+        out = torch.zeros(nimg * Hout * Wout, Cout, device=dev)
+    d.out, d.ldo = out.data_ptr(), Cout
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), res.shape[1]
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, Hin, Win, Hv, Wv, stride
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = KH, KW, off[0], off[1], sgn[0], sgn[1]
+    d.Hout, d.Wout, d.oscale, d.ooh, d.oow = Hout, Wout, oscale, oo[0], oo[1]
+    d.Cout = Cout
+    if rot is not None:
+        d.rot_tab = rot.data_ptr()
+    d.rot_T, d.rot_HW, d.rot_ncols, d.rot_dh = rot_T, Hin * Win, rot_ncols, 32
+    d.q_scale, d.q_ncols = q_scale, q_ncols
+    if a_coef is not None:
+        d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, a_coef.data_ptr(), T
+    N.check(lib.vmm_conv_igemm_f32(C.byref(d), _s()), "conv")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,k,stride", [
+    (2, 3, 12, 12, 16, 32, 3, 1), (1, 2, 24, 20, 64, 64, 3, 1), (1, 1, 12, 12, 256, 128, 3, 1), (2, 2, 16, 16, 32, 48, 1, 1),
+    (1, 2, 16, 16, 4, 16, 7, 1), (2, 2, 16, 16, 32, 32, 4, 2), (1, 11, 12, 12, 128, 512, 3, 1), (1, 2, 96, 96, 64, 64, 3, 1)])
+def test_conv_igemm(gpu, B, T, H, W, Cin, Cout, k, stride):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    pad = {3: 1, 1: 0, 7: 3, 4: 1}[k]
+    ref = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W), w, b, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[-2:]
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    wp = w.permute(2, 3, 1, 0).reshape(k * k * Cin, Cout).contiguous().to(gpu)
+    out = run_conv(N, lib, gpu, rows_of(x).to(gpu), wp, Cout, bias=b.to(gpu), KH=k, KW=k, stride=stride, off=(-pad, -pad), nimg=B * T, Hin=H, Win=W,
+                   Hv=Ho, Wv=Wo)
+    assert relerr(out.cpu(), ref_rows) < 2e-6
+
+
+def test_conv_concat_residual_and_fused_gn(gpu):
+    """two-source input (torch.cat skip), residual epilogue, and the fused GroupNorm+FiLM+SiLU operand transform."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(1)
+    B, T, H, W, C1, C2, Cout = 2, 2, 10, 14, 32, 16, 64
+    x1, x2 = torch.randn(B, C1, T, H, W, generator=g), torch.randn(B, C2, T, H, W, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)
+    res = torch.randn(B * T * H * W, Cout, generator=g)
+    ref = F.conv2d(torch.cat([x1, x2], 1).permute(0, 2, 1, 3, 4).reshape(B * T, C1 + C2, H, W), w, None, padding=1)
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, Cout) + res
+    wp = w.permute(2, 3, 1, 0).reshape(9 * (C1 + C2), Cout).contiguous().to(gpu)
+    out = run_conv(N, lib, gpu, rows_of(x1).to(gpu), wp, Cout, a2=rows_of(x2).to(gpu), KH=3, KW=3, off=(-1, -1), nimg=B * T, Hin=H, Win=W, Hv=H, Wv=W,
+                   res=res.to(gpu))
+    assert relerr(out.cpu(), ref_rows) < 2e-6
+    # fused transform: conv(silu(x*a+b)) with per-(sample, channel) coefficients, zero padding applied AFTER the activation
+    coef = torch.randn(B, C1, 2, generator=g)
+    xa = F.silu(x1 * coef[:, :, 0][:, :, None, None, None] + coef[:, :, 1][:, :, None, None, None])
+    w1 = torch.randn(Cout, C1, 3, 3, generator=g) / math.sqrt(C1 * 9)
+    ref = F.conv2d(xa.permute(0, 2, 1, 3, 4).reshape(B * T, C1, H, W), w1, None, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    wp = w1.permute(2, 3, 1, 0).reshape(9 * C1, Cout).contiguous().to(gpu)
+    out = run_conv(N, lib, gpu, rows_of(x1).to(gpu), wp, Cout, KH=3, KW=3, off=(-1, -1), nimg=B * T, Hin=H, Win=W, Hv=H, Wv=W, a_coef=coef.to(gpu), T=T)
+    assert relerr(out.cpu(), ref) < 5e-6
+
+
+def test_conv_transpose_as_four_phases(gpu):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(2)
+    B, T, H, W, Cc = 1, 2, 6, 8, 32
+    x = torch.randn(B, Cc, T, H, W, generator=g)
+    w = torch.randn(Cc, Cc, 4, 4, generator=g) / math.sqrt(Cc * 4)
+    b = torch.randn(Cc, generator=g)
+    ref = F.conv_transpose2d(x.permute(0, 2, 1, 3, 4).reshape(B * T, Cc, H, W), w, b, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    out = torch.zeros(B * T * 4 * H * W, Cc, device=gpu)
+    for ph in range(2):
+        for pw in range(2):
+            wp = w[:, :, [1 - ph, 3 - ph], :][:, :, :, [1 - pw, 3 - pw]].permute(2, 3, 0, 1).reshape(4 * Cc, Cc).contiguous().to(gpu)
+            run_conv(N, lib, gpu, rows_of(x).to(gpu), wp, Cc, bias=b.to(gpu), KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), nimg=B * T, Hin=H, Win=W, Hv=H, Wv=W,
+                     Hout=2 * H, Wout=2 * W, oscale=2, oo=(ph, pw), out=out)
+    assert relerr(out.cpu(), ref) < 2e-6
+
+
+def test_projection_rotary_epilogue(gpu):
+    """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
+    from videometamaterials_amd import hostmath
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(3)
+    B, T, H, W, Cc, heads = 2, 5, 4, 4, 32, 2
+    hid = heads * 32
+    x = torch.randn(B * T * H * W, Cc, generator=g)
+    w = torch.randn(3 * hid, Cc, generator=g) / math.sqrt(Cc)
+    rot = hostmath.rotary_table(T, 32)
+    out = run_conv(N, lib, gpu, x.to(gpu), w.t().contiguous().to(gpu), 3 * hid, nimg=B * T, Hin=H, Win=W, Hv=H, Wv=W, rot=rot.to(gpu), rot_T=T,
+                   rot_ncols=2 * hid, q_scale=32 ** -0.5, q_ncols=hid)
+    qkv = (x @ w.t()).reshape(B, T, H * W, 3, heads, 32)
+    q, k, v = qkv[:, :, :, 0] * 32 ** -0.5, qkv[:, :, :, 1], qkv[:, :, :, 2]
+    cos, sin = rot[:, :, 0].repeat_interleave(2, -1)[None, :, None, None], rot[:, :, 1].repeat_interleave(2, -1)[None, :, None, None]
+
+    def rotate(t):
+        pr = t.reshape(*t.shape[:-1], 16, 2)
+        rh = torch.stack((-pr[..., 1], pr[..., 0]), -1).reshape(t.shape)
+        return t * cos + rh * sin
+
+    ref = torch.stack((rotate(q), rotate(k), v), dim=3).reshape(B * T * H * W, 3 * hid)
+    assert relerr(out.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("C_,G", [(16, 8), (64, 8), (512, 8)])
+def test_groupnorm_film_silu(gpu, C_, G):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(4)
+    B, T, H, W = 2, 3, 12, 12
+    x = torch.randn(B, C_, T, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C_, generator=g), torch.randn(C_, generator=g)
+    film = torch.randn(B, 2 * C_, generator=g)
+    res = torch.randn(B * T * H * W, C_, generator=g)
+    y = F.group_norm(x, G, gamma, beta, eps=1e-5) * (film[:, :C_, None, None, None] + 1) + film[:, C_:, None, None, None]
+    ref = rows_of(F.silu(y)) + res
+    xr = rows_of(x).to(gpu)
+    rps = T * H * W
+    sums = torch.empty(B * G * 2, dtype=torch.float64, device=gpu)
+    coef = torch.empty(B, C_, 2, device=gpu)
+    stats = torch.empty(B * G * 2, device=gpu)
+    N.check(lib.vmm_groupnorm_stats(xr.data_ptr(), C_, B, rps, C_, G, sums.data_ptr(), _s()), "stats")
+    N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gamma.to(gpu).data_ptr(), beta.to(gpu).data_ptr(), film.to(gpu).data_ptr(),
+                                   2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), _s()), "coef")
+    out = torch.empty_like(xr)
+    N.check(lib.vmm_affine_silu(xr.data_ptr(), C_, coef.data_ptr(), res.to(gpu).data_ptr(), C_, out.data_ptr(), C_, xr.shape[0], rps, C_, _s()), "apply")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 5e-6
+    xs = x.reshape(B, G, -1)
+    assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 0], xs.mean(-1), atol=1e-5)
+    assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 1], 1 / torch.sqrt(xs.var(-1, unbiased=False) + 1e-5), rtol=1e-5)
+
+
+@pytest.mark.parametrize("C_", [16, 32, 64, 128, 512])
+def test_channel_layernorm(gpu, C_):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, C_, generator=g) * 3 + 1
+    gamma = torch.randn(C_, generator=g)
+    ref = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma
+    xg, out = x.to(gpu), torch.empty(1000, C_, device=gpu)
+    N.check(lib.vmm_channel_layernorm(xg.data_ptr(), C_, gamma.to(gpu).data_ptr(), out.data_ptr(), C_, 1000, C_, 1e-5, _s()), "ln")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 2e-6
+
+
+def _attn_ref(q, k, v, bias=None):
+    sim = torch.einsum("...id,...jd->...ij", q, k)
+    if bias is not None:
+        sim = sim + bias
+    return torch.einsum("...ij,...jd->...id", sim.softmax(-1), v)
+
+
+@pytest.mark.parametrize("ntok,bias_on_cond", [(0, 0), (7, 1), (16, 0)])
+def test_temporal_attention_core(gpu, ntok, bias_on_cond):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(6)
+    B, T, HW, heads = 2, 7, 10, 4
+    hid = heads * 32
+    qkv = torch.randn(B, T, HW, 3, heads, 32, generator=g)
+    bias = torch.randn(heads, T, T, generator=g)
+    q, k, v = (qkv[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))  # b hw h t d
+    bfull = bias[None, None]
+    ek = ev = None
+    if ntok:
+        ek, ev = torch.randn(B, ntok, heads, 32, generator=g), torch.randn(B, ntok, heads, 32, generator=g)
+        k = torch.cat([ek.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), k], dim=-2)
+        v = torch.cat([ev.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), v], dim=-2)
+        bfull = torch.cat([bias if bias_on_cond else torch.zeros(heads, T, ntok), bias], dim=-1)[None, None]
+    ref = _attn_ref(q, k, v, bfull).permute(0, 3, 1, 2, 4).reshape(B * T * HW, hid)
+    qg = qkv.reshape(B * T * HW, 3 * hid).to(gpu)
+    out = torch.empty(B * T * HW, hid, device=gpu)
+    ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    N.check(lib.vmm_temporal_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok,
+                                       bias.to(gpu).data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "temporal")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0)])
+def test_spatial_attention_core(gpu, HW, ntok, per_frame):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(7)
+    B, T, heads = 2, 5, 2
+    hid = heads * 32
+    qkv = torch.randn(B, T, HW, 3, heads, 32, generator=g)
+    q, k, v = (qkv[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))  # b t h n d
+    ek = ev = None
+    if ntok:
+        ek, ev = torch.randn(B, ntok, heads, 32, generator=g), torch.randn(B, ntok, heads, 32, generator=g)
+        if per_frame:
+            ekf, evf = ek.permute(0, 1, 2, 3)[:, :, :, None], ev[:, :, :, None]  # b t h 1 d  (token t for frame t)
+        else:
+            ekf = ek.permute(0, 2, 1, 3)[:, None].expand(B, T, heads, ntok, 32)
+            evf = ev.permute(0, 2, 1, 3)[:, None].expand(B, T, heads, ntok, 32)
+        k, v = torch.cat([ekf, k], -2), torch.cat([evf, v], -2)
+    ref = _attn_ref(q, k, v).permute(0, 1, 3, 2, 4).reshape(B * T * HW, hid)
+    out = torch.empty(B * T * HW, hid, device=gpu)
+    qg = qkv.reshape(B * T * HW, 3 * hid).to(gpu)
+    ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    N.check(lib.vmm_spatial_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, per_frame,
+                                      out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "spatial")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("HW,ntok,nsplit", [(144, 11, 1), (1000, 0, 4), (2304, 16, 7)])
+def test_linear_attention_core(gpu, HW, ntok, nsplit):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(8)
+    B, T, heads = 2, 3, 2
+    hid = heads * 32
+    qkv = torch.randn(B * T, HW, 3, heads, 32, generator=g) * 2
+    q, k, v = (qkv[:, :, i].permute(0, 2, 3, 1) for i in range(3))  # bt h d n
+    ek = ev = None
+    if ntok:
+        ek, ev = torch.randn(B, ntok, heads, 32, generator=g), torch.randn(B, ntok, heads, 32, generator=g)
+        ekf = ek.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        evf = ev.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        k, v = torch.cat([ekf, k], -1), torch.cat([evf, v], -1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(-1), v / HW)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q.softmax(-2) * 32 ** -0.5).permute(0, 3, 1, 2).reshape(B * T * HW, hid)
+    qg = qkv.reshape(B * T * HW, 3 * hid).to(gpu)
+    part = torch.empty(B * T * heads * nsplit * (1024 + 64), device=gpu)
+    ctxg = torch.empty(B * T * heads * 1024, device=gpu)
+    out = torch.empty(B * T * HW, hid, device=gpu)
+    ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    N.check(lib.vmm_linattn_context(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, B, T, HW, heads, 32,
+                                    nsplit, part.data_ptr(), ctxg.data_ptr(), _s()), "ctx")
+    N.check(lib.vmm_linattn_apply(qg.data_ptr(), 3 * hid, ctxg.data_ptr(), out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "apply")
+    torch.cuda.synchronize()
+    assert relerr(ctxg.cpu().reshape(B * T, heads, 32, 32), ctx) < 5e-6
+    assert relerr(out.cpu(), ref) < 5e-6
+
+
+def test_quantile_matches_torch(gpu):
+    from videometamaterials_amd import hostmath
+    from videometamaterials_amd.plan import Q_STRIDE
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    for n, B in ((304128, 4), (1000, 3), (33792, 2)):
+        x = torch.randn(B, n, generator=g).abs() * torch.tensor([0.2, 1.0, 3.0, 0.9][:B])[:, None]
+        x[0, : n // 3] = x[0, 0]  # heavy ties
+        want = torch.quantile(x, 0.9, dim=-1).clamp(min=1.0)
+        k_lo, frac = hostmath.quantile_rank(n, 0.9)
+        s = torch.empty(B, device=gpu)
+        scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=gpu)
+        N.check(lib.vmm_quantile_rows(x.to(gpu).data_ptr(), B, n, k_lo, frac, 1.0, s.data_ptr(), scratch.data_ptr(), _s()), "quantile")
+        torch.cuda.synchronize()
+        assert torch.equal(s.cpu(), want), (n, s.cpu(), want)
+
+
+def test_dense_batched_and_embeddings(gpu):
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(10)
+    jobs_spec = [(5, 64, 256, 0, 2, True), (44, 256, 256, 0, 0, False), (4, 256, 1024, 1, 0, True), (3, 1, 32, 0, 1, True)]
+    arr = (N.DenseJob * len(jobs_spec))()
+    keep, refs, outs = [], [], []
+    max_units = 0
+    for i, (rows, K, Nn, ai, ao, hasb) in enumerate(jobs_spec):
+        x, w, b = torch.randn(rows, K, generator=g), torch.randn(Nn, K, generator=g) / math.sqrt(K), torch.randn(Nn, generator=g)
+        act = {0: lambda t: t, 1: F.silu, 2: F.gelu}
+        refs.append(act[ao](F.linear(act[ai](x), w, b if hasb else None)))
+        xg, wg, bg, yg = x.to(gpu), w.to(gpu), b.to(gpu), torch.empty(rows, Nn, device=gpu)
+        keep += [xg, wg, bg]
+        outs.append(yg)
+        a = arr[i]
+        a.x, a.w, a.b, a.y = xg.data_ptr(), wg.data_ptr(), bg.data_ptr() if hasb else None, yg.data_ptr()
+        a.rows, a.K, a.N, a.ldx, a.ldy, a.ldadd, a.act_in, a.act_out = rows, K, Nn, K, Nn, Nn, ai, ao
+        max_units = max(max_units, Nn * ((rows + 7) // 8))
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_dense_batched(tab.data_ptr(), len(jobs_spec), max_units, _s()), "dense")
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert relerr(o.cpu(), r) < 2e-6
+    # sinusoidal embedding (vddp.py:139-151)
+    t = torch.tensor([0, 1, 17, 255])
+    dim = 64
+    half = dim // 2
+    emb = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = t[:, None] * emb[None, :]
+    ref = torch.cat((e.sin(), e.cos()), -1)
+    out = torch.empty(4, dim, device=gpu)
+    N.check(lib.vmm_sinusoidal_embed(t.to(gpu).data_ptr(), 4, dim, -(math.log(10000) / (half - 1)), out.data_ptr(), _s()), "sin")
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), ref, atol=2e-5)
+
+
+def test_diffusion_elementwise(gpu):
+    from videometamaterials_amd import GaussianDiffusion
+    from oracle import diffusion_oracle as do
+
+    class _Dummy(torch.nn.Module):
+        pass
+
+    g = torch.Generator().manual_seed(11)
+    d = GaussianDiffusion(_Dummy(), image_size=8, num_frames=3, channels=2, timesteps=256, sampling_timesteps=256).to(gpu)
+    sch = do.schedule_buffers(256)
+    for name in do.SCHEDULE_NAMES:
+        assert torch.equal(getattr(d, name).cpu(), sch[name])
+    x0, noise = torch.rand(3, 2, 3, 8, 8, generator=g) * 2 - 1, torch.randn(3, 2, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 100, 255])
+    got = d.q_sample(x0.to(gpu), t.to(gpu), noise.to(gpu)).cpu()
+    assert torch.allclose(got, do.q_sample(sch, x0, t, noise), rtol=1e-6, atol=1e-7)
+    eps = torch.randn(3, 2, 3, 8, 8, generator=g)
+    got = d.predict_start_from_noise(x0.to(gpu), t.to(gpu), eps.to(gpu)).cpu()
+    assert torch.allclose(got, do.predict_start_from_noise(sch, x0, t, eps), rtol=1e-5, atol=1e-6)
+    mean, var, logvar = d.q_posterior(eps.to(gpu), x0.to(gpu), t.to(gpu))
+    want_mean, want_logvar = do.q_posterior_mean_logvar(sch, eps, x0, t)
+    assert torch.allclose(mean.cpu(), want_mean, rtol=1e-5, atol=1e-6) and torch.equal(logvar.cpu(), want_logvar)

@@ -1,0 +1,112 @@
+"""ctypes binding of libvmm_hip.so (C ABI declared in include/vmm_kernels.h).
+
+The product path has NO fallback: if the HIP library is missing or a launch fails the
+call raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m videometamaterials_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmm_hip.so")
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_f32 = C.c_float
+c_ptr = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """vmm_conv_desc (include/vmm_kernels.h)."""
+
+    _fields_ = [
+        ("a1", c_ptr), ("a2", c_ptr),
+        ("C1", c_i32), ("C2", c_i32), ("lda1", c_i32), ("lda2", c_i32),
+        ("w", c_ptr), ("bias", c_ptr),
+        ("res", c_ptr), ("ldres", c_i32),
+        ("out", c_ptr), ("ldo", c_i32),
+        ("nimg", c_i32), ("Hin", c_i32), ("Win", c_i32),
+        ("Hv", c_i32), ("Wv", c_i32), ("stride", c_i32),
+        ("KH", c_i32), ("KW", c_i32), ("off_h", c_i32), ("off_w", c_i32), ("sgn_h", c_i32), ("sgn_w", c_i32),
+        ("Hout", c_i32), ("Wout", c_i32), ("oscale", c_i32), ("ooh", c_i32), ("oow", c_i32),
+        ("Cout", c_i32),
+        ("rot_tab", c_ptr),
+        ("rot_T", c_i32), ("rot_HW", c_i32), ("rot_ncols", c_i32), ("rot_dh", c_i32),
+        ("q_scale", c_f32), ("q_ncols", c_i32),
+        ("a_mode", c_i32), ("a_coef", c_ptr), ("a_imgs_per_sample", c_i32),
+    ]
+
+
+class DenseJob(C.Structure):
+    """vmm_dense_job (include/vmm_kernels.h)."""
+
+    _fields_ = [
+        ("x", c_ptr), ("w", c_ptr), ("b", c_ptr), ("add", c_ptr), ("y", c_ptr),
+        ("rows", c_i32), ("K", c_i32), ("N", c_i32), ("ldx", c_i32), ("ldy", c_i32), ("ldadd", c_i32),
+        ("act_in", c_i32), ("act_out", c_i32),
+    ]
+
+
+# name -> argtypes (restype is always int); must list EVERY symbol include/vmm_kernels.h declares
+SIGNATURES = {
+    "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_groupnorm_stats": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],
+    "vmm_temporal_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_linattn_context": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_linattn_apply": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_sinusoidal_embed": [c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr],
+    "vmm_cond_tokens": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_rows_layernorm_affine": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr],
+    "vmm_select_add": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_rotary_rows": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_relpos_bias": [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_conv1d_k4s2_silu": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_tokens_from_hidden": [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_ncthw_to_rows": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_rows_to_ncthw": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_pointwise_to_ncthw": [c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_q_sample": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr],
+    "vmm_predict_x0": [c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_ptr],
+    "vmm_quantile_rows": [c_ptr, c_i32, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
+    "vmm_posterior_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr],
+    "vmm_loss_reduce": [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_cfg_combine": [c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr],
+    "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: the HIP extension must be built (python -m videometamaterials_amd.build); "
+                "there is no CPU/PyTorch fallback for the hot path"
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise NativeError(f"{what} failed with code {code} (hipError_t if > 0, rejected argument if < 0)")

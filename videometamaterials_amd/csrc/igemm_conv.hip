@@ -1,0 +1,233 @@
+// Implicit-GEMM per-frame convolution / projection for gfx950, exact fp32 on the matrix cores
+// (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak).
+//
+// One kernel covers every dense contraction of the denoiser:
+//   3x3 / 7x7 / 4x4-stride-2 convolutions, the transposed 4x4-stride-2 convolution (as 4 output
+//   phases of 2x2 taps), 1x1 convolutions and nn.Linear projections.
+// Rows (M) are output positions in frame-major channels-last order, K runs over (tap, input channel),
+// N over output channels.  A tiles are gathered with zero padding straight from the channels-last
+// activation rows (16-byte loads along channels), optionally from two concatenated sources, optionally
+// through the producer's fused GroupNorm+FiLM+SiLU; B tiles are 16-byte loads of the k-major weights.
+// 256 threads = 4 waves; LDS double-buffered, global loads for chunk k+1 in flight during the MFMAs of k.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct RowInfo {
+  int img;      // frame index (b*T + t), -1 if the row is out of range
+  int ih0, iw0; // a*stride, b*stride
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const vmm_conv_desc p) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 32, NT = TN / 32;
+  constexpr int APAD = 4;
+  constexpr int A_PASSES = BM / 64;                        // 64 rows x 4 float4 per pass
+  constexpr int B_F4 = BK * BN / 4;                        // float4 per B tile
+  constexpr int B_PASSES = (B_F4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + APAD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long M = (long long)p.nimg * p.Hv * p.Wv;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = p.C1 + p.C2;
+  const int Ktot = p.KH * p.KW * Cin;
+  const int nk = (Ktot + BK - 1) / BK;
+
+  // ---- per-thread A row decode (fixed over the K loop)
+  RowInfo ri[A_PASSES];
+  const int a_k4 = tid & 3;
+#pragma unroll
+  for (int ps = 0; ps < A_PASSES; ++ps) {
+    long long m = m0 + ps * 64 + (tid >> 2);
+    if (m < M) {
+      int hw = p.Hv * p.Wv;
+      int img = (int)(m / hw);
+      int rem = (int)(m - (long long)img * hw);
+      int a = rem / p.Wv, b = rem - a * p.Wv;
+      ri[ps].img = img;
+      ri[ps].ih0 = a * p.stride;
+      ri[ps].iw0 = b * p.stride;
+    } else {
+      ri[ps].img = -1; ri[ps].ih0 = 0; ri[ps].iw0 = 0;
+    }
+  }
+  const int b_kk[2] = {tid / (BN / 4), (tid + 256) / (BN / 4)};
+  const int b_n4[2] = {tid % (BN / 4), (tid + 256) % (BN / 4)};
+
+  f32x4 areg[A_PASSES];
+  f32x4 breg[B_PASSES];
+
+  auto load_chunk = [&](int kc) {
+    // A: decode (tap, ci) of this thread's 4 consecutive k
+    const int k = kc * BK + a_k4 * 4;
+    int tap = k / Cin;
+    int ci = k - tap * Cin;
+    int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = p.off_h + p.sgn_h * kh, dw = p.off_w + p.sgn_w * kw;
+    const bool kvalid = k < Ktot;
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int ih = ri[ps].ih0 + dh, iw = ri[ps].iw0 + dw;
+      if (kvalid && ri[ps].img >= 0 && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
+        const long long pix = ((long long)ri[ps].img * p.Hin + ih) * p.Win + iw;
+        if (ci < p.C1) {
+          v = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci);
+          if (p.a_mode == 1) {
+            const int bsmp = ri[ps].img / p.a_imgs_per_sample;
+            const float* cf = p.a_coef + ((long long)bsmp * p.C1 + ci) * 2;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
+            v.x = silu_f(v.x * c0.x + c0.y);
+            v.y = silu_f(v.y * c0.z + c0.w);
+            v.z = silu_f(v.z * c1.x + c1.y);
+            v.w = silu_f(v.w * c1.z + c1.w);
+          }
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci - p.C1));
+        }
+      }
+      areg[ps] = v;
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int kk = kc * BK + b_kk[ps];
+      const int n = n0 + b_n4[ps] * 4;
+      if (b_kk[ps] < BK && kk < Ktot && n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (long long)kk * p.Cout + n);
+      breg[ps] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+      const int r = ps * 64 + (tid >> 2);
+      As[buf][a_k4 * 4 + 0][r] = areg[ps].x;
+      As[buf][a_k4 * 4 + 1][r] = areg[ps].y;
+      As[buf][a_k4 * 4 + 2][r] = areg[ps].z;
+      As[buf][a_k4 * 4 + 3][r] = areg[ps].w;
+    }
+#pragma unroll
+    for (int ps = 0; ps < B_PASSES; ++ps) {
+      if (b_kk[ps] < BK) *reinterpret_cast<f32x4*>(&Bs[buf][b_kk[ps]][b_n4[ps] * 4]) = breg[ps];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) load_chunk(kc + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = As[buf][kk + lk][wm * TM + i * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = Bs[buf][kk + lk][wn * TN + j * 32 + lrow];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool identity_rows = (p.oscale == 1 && p.Hout == p.Hv && p.Wout == p.Wv && p.ooh == 0 && p.oow == 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      long long orow = m;
+      int img = 0;
+      const bool mvalid = m < M;
+      if (mvalid && (!identity_rows || p.rot_ncols > 0)) {
+        const int hw = p.Hv * p.Wv;
+        img = (int)(m / hw);
+        if (!identity_rows) {
+          const int rem = (int)(m - (long long)img * hw);
+          const int a = rem / p.Wv, b = rem - a * p.Wv;
+          orow = ((long long)img * p.Hout + a * p.oscale + p.ooh) * p.Wout + b * p.oscale + p.oow;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + lrow;
+        const bool cvalid = col < p.Cout;
+        float v = acc[i][j][r];
+        if (p.bias && cvalid) v += p.bias[col];
+        if (col < p.q_ncols) v *= p.q_scale;
+        if (p.rot_ncols > 0) {  // uniform branch
+          const float partner = __shfl_xor(v, 1, 64);
+          if (mvalid && col < p.rot_ncols) {
+            const int t = (int)((m / p.rot_HW) % p.rot_T);
+            const int fi = (col % p.rot_dh) >> 1;
+            const float c = p.rot_tab[(t * (p.rot_dh >> 1) + fi) * 2 + 0];
+            const float s = p.rot_tab[(t * (p.rot_dh >> 1) + fi) * 2 + 1];
+            v = v * c + ((col & 1) ? partner : -partner) * s;
+          }
+        }
+        if (mvalid && cvalid) {
+          if (p.res) v += p.res[orow * p.ldres + col];
+          p.out[orow * p.ldo + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const vmm_conv_desc& d, hipStream_t s) {
+  const long long M = (long long)d.nimg * d.Hv * d.Wv;
+  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmm_conv_igemm_f32(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 64) return -1;
+  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & 1))) return -2;
+  if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
+  const long long M = (long long)d.nimg * d.Hv * d.Wv;
+  if (M <= 0 || d.Cout <= 0) return 0;
+  // tile choice: widest N tile that the layer fills; halve BM when the grid would not cover the 256 CUs twice
+  if (d.Cout >= 128) {
+    const long long blocks = (long long)cdiv(M, 128) * cdiv(d.Cout, 128);
+    if (blocks >= 512) return launch<128, 128, 2, 2>(d, s);
+    return launch<64, 128, 1, 4>(d, s);
+  }
+  if (d.Cout > 32) {
+    const long long blocks = (long long)cdiv(M, 128);
+    if (blocks >= 512) return launch<128, 64, 2, 2>(d, s);
+    return launch<64, 64, 2, 2>(d, s);
+  }
+  return launch<128, 32, 4, 1>(d, s);
+}

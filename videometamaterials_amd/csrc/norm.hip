@@ -1,0 +1,216 @@
+// GroupNorm(+FiLM+SiLU) and channel LayerNorm for channels-last rows on gfx950.
+// All of these are HBM-bound sweeps: 16-byte loads along channels, wave-shuffle reductions,
+// fp64 only for the cross-block GroupNorm sums (one atomic pair per block and group).
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------- GroupNorm statistics
+// grid = (blocks_per_sample, B); block = 256 threads; each thread owns one float4 column group and strides over rows.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, int rows_per_sample, int C, int G,
+                                                        int rows_per_block, double* __restrict__ sums) {
+  const int b = blockIdx.y;
+  const int c4n = C >> 2;                 // float4 columns per row
+  const int tid = threadIdx.x;
+  const int col4 = tid % c4n;
+  const int rlane = tid / c4n;            // row slot of this thread
+  const int rslots = 256 / c4n;           // rows covered per pass (c4n <= 256)
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(r_begin + rows_per_block, rows_per_sample);
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (rlane < rslots) {
+    const float* base = x + ((long long)b * rows_per_sample) * ldx + col4 * 4;
+    for (int r = r_begin + rlane; r < r_end; r += rslots) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ldx);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    }
+  }
+  // per-channel partials -> LDS -> per-group fp64
+  __shared__ float sh_s[256 * 4];
+  __shared__ float sh_q[256 * 4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh_s[tid * 4 + j] = s[j]; sh_q[tid * 4 + j] = q[j]; }
+  __syncthreads();
+  const int Cg = C / G;
+  if (tid < G) {
+    double ds = 0.0, dq = 0.0;
+    for (int c = tid * Cg; c < (tid + 1) * Cg; ++c) {
+      const int c4 = c >> 2, j = c & 3;
+      for (int rl = 0; rl < rslots; ++rl) {
+        ds += (double)sh_s[(rl * c4n + c4) * 4 + j];
+        dq += (double)sh_q[(rl * c4n + c4) * 4 + j];
+      }
+    }
+    atomicAdd(&sums[(b * G + tid) * 2 + 0], ds);
+    atomicAdd(&sums[(b * G + tid) * 2 + 1], dq);
+  }
+}
+
+// coef[b][c] = (a, b') ; one thread per (b, c)
+__global__ void gn_coef_kernel(const double* __restrict__ sums, double inv_count, float eps, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, int B, int C, int G,
+                               float* __restrict__ coef, float* __restrict__ stats_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  const int g = c / (C / G);
+  const double mean = sums[(b * G + g) * 2] * inv_count;
+  double var = sums[(b * G + g) * 2 + 1] * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  float a = rstd * gamma[c];
+  float bb = beta[c] - meanf * a;
+  if (film) {
+    const float sc = film[(long long)b * ldfilm + c] + 1.0f;
+    const float sh = film[(long long)b * ldfilm + C + c];
+    a *= sc;
+    bb = bb * sc + sh;
+  }
+  coef[i * 2 + 0] = a;
+  coef[i * 2 + 1] = bb;
+  if (stats_out && c == g * (C / G)) {
+    stats_out[(b * G + g) * 2 + 0] = meanf;
+    stats_out[(b * G + g) * 2 + 1] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coef,
+                                                          const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy,
+                                                          long long rows, int rows_per_sample, int C) {
+  const int c4n = C >> 2;
+  const long long total = rows * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const int b = (int)(r / rows_per_sample);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    const float* cf = coef + ((long long)b * C + c) * 2;
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
+    f32x4 o;
+    o.x = silu_f(v.x * c0.x + c0.y);
+    o.y = silu_f(v.y * c0.z + c0.w);
+    o.z = silu_f(v.z * c1.x + c1.y);
+    o.w = silu_f(v.w * c1.z + c1.w);
+    if (res) {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(res + r * ldres + c);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<f32x4*>(y + r * ldy + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------- channel LayerNorm
+// GS lanes cooperate on one row (GS = power of two <= 64); each lane strides float4s over C.
+template <int GS>
+__global__ __launch_bounds__(256) void chan_ln_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                      float* __restrict__ y, int ldy, long long rows, int C, float eps) {
+  const int tid = threadIdx.x;
+  const int sub = tid % GS;
+  const long long row = ((long long)blockIdx.x * 256 + tid) / GS;
+  const bool valid = row < rows;
+  const float* xr = x + (valid ? row : 0) * ldx;
+  constexpr int MAXV = 8;  // up to GS*4*MAXV channels held in registers (2048 at GS=64)
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c = (j * GS + sub) * 4;
+    v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (valid && c < C) v[j] = *reinterpret_cast<const f32x4*>(xr + c);
+    s += v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  s = group_sum(s, GS);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c = (j * GS + sub) * 4;
+    if (c < C) {
+      const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+      q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+  }
+  q = group_sum(q, GS);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  if (!valid) return;
+  float* yr = y + row * ldy;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c = (j * GS + sub) * 4;
+    if (c < C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+      f32x4 o;
+      o.x = (v[j].x - mean) * rstd * g.x;
+      o.y = (v[j].y - mean) * rstd * g.y;
+      o.z = (v[j].z - mean) * rstd * g.z;
+      o.w = (v[j].w - mean) * rstd * g.w;
+      *reinterpret_cast<f32x4*>(yr + c) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G,
+                                   double* sums, vmm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 3) || C > 1024 || C % G || G > 256 || (ldx & 3)) return -1;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * B * G * 2, s);
+  if (e != hipSuccess) return (int)e;
+  const int rslots = 256 / (C >> 2);
+  // enough blocks to fill the chip (>= ~2048 in total) while keeping >= 8 rows per thread slot
+  int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));
+  const int rows_per_block = cdiv(rows_per_sample, blocks);
+  blocks = cdiv(rows_per_sample, rows_per_block);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks, B), dim3(256), 0, s, x, ldx, rows_per_sample, C, G, rows_per_block, sums);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
+                                  const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef,
+                                  float* stats_out, vmm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C % G) return -1;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, sums, 1.0 / (double)count_per_group, eps, gamma,
+                     beta, film, ldfilm, B, C, G, coef, stats_out);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y,
+                               int32_t ldy, int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldres & 3))) return -1;
+  const long long total = rows * (C >> 2);
+  const int blocks = (int)min((long long)cdiv(total, 256), 8192LL);
+  hipLaunchKernelGGL(affine_silu_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, coef, res, ldres, y, ldy, (long long)rows,
+                     rows_per_sample, C);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_channel_layernorm(const float* x, int32_t ldx, const float* gamma, float* y, int32_t ldy, int64_t rows,
+                                     int32_t C, float eps, vmm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 3) || (ldx & 3) || (ldy & 3) || C > 2048) return -1;
+  const int c4 = C >> 2;
+  int gs = 1;
+  while (gs < 64 && gs < c4) gs <<= 1;  // smallest power of two >= C/4, capped at 64
+  const long long threads = rows * gs;
+  const int blocks = cdiv(threads, 256);
+#define LN_CASE(G)                                                                                                        \
+  case G:                                                                                                                 \
+    hipLaunchKernelGGL(chan_ln_kernel<G>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, y, ldy, (long long)rows, C, eps); \
+    break;
+  switch (gs) {
+    LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(16) LN_CASE(32) LN_CASE(64)
+  }
+#undef LN_CASE
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,290 @@
+// Small host-of-the-network pieces: batched tiny dense layers, embeddings,
+// conditioning tokens, layout edges.  Negligible FLOPs; the design goal is FEW launches (one grouped
+// launch per dependency level) and coalesced access.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == 1) return silu_f(v);
+  if (act == 2) return gelu_erf_f(v);
+  return v;
+}
+
+// one wave per (job, output column o, chunk of 8 rows): W[o,:] is streamed once and reused for the 8 rows
+constexpr int DR = 8;
+__global__ __launch_bounds__(256) void dense_batched_kernel(const vmm_dense_job* __restrict__ jobs) {
+  const vmm_dense_job jb = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rchunks = (jb.rows + DR - 1) / DR;
+  if (unit >= jb.N * rchunks) return;
+  const int o = unit % jb.N;
+  const int r0 = (unit / jb.N) * DR;
+  float acc[DR];
+#pragma unroll
+  for (int r = 0; r < DR; ++r) acc[r] = 0.f;
+  const float* wrow = jb.w + (long long)o * jb.K;
+  for (int k = lane; k < jb.K; k += 64) {
+    const float wv = wrow[k];
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      if (r0 + r < jb.rows) acc[r] = fmaf(act_apply(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), wv, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < DR; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+    const float bv = jb.b ? jb.b[o] : 0.f;
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      if (r0 + r < jb.rows) {
+        float v = act_apply(acc[r] + bv, jb.act_out);
+        if (jb.add) v += jb.add[(long long)(r0 + r) * jb.ldadd + o];
+        jb.y[(long long)(r0 + r) * jb.ldy + o] = v;
+      }
+    }
+  }
+}
+
+__global__ void sinusoidal_kernel(const int64_t* __restrict__ t, int B, int dim, float neg_step, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, j = i - b * half;
+  const float f = expf((float)j * neg_step);
+  const float a = (float)t[b] * f;
+  out[b * dim + j] = sinf(a);
+  out[b * dim + half + j] = cosf(a);
+}
+
+// block per sample b; thread per embedding column
+__global__ void cond_tokens_kernel(const float* __restrict__ cond, const float* __restrict__ w, const float* __restrict__ bias,
+                                   const float* __restrict__ null_token, const uint8_t* __restrict__ mask, int F, int D,
+                                   float* __restrict__ tokens, float* __restrict__ pooled) {
+  const int b = blockIdx.x;
+  const bool drop = mask && mask[b];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const float v = cond[b * F + f] * w[d] + bias[d];
+      s += v;
+      tokens[((long long)b * F + f) * D + d] = drop ? null_token[f * D + d] : v;
+    }
+    pooled[b * D + d] = s / (float)F;
+  }
+}
+
+// wave per row
+__global__ __launch_bounds__(64) void rows_ln_affine_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y, int D, float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* xr = x + (long long)row * D;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s += xr[k];
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  for (int k = lane; k < D; k += 64) y[(long long)row * D + k] = (xr[k] - mean) * rstd * w[k] + b[k];
+}
+
+__global__ void select_add_kernel(const float* __restrict__ x, const float* __restrict__ null_row, const uint8_t* __restrict__ mask,
+                                  const float* __restrict__ add, float* __restrict__ out, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  float v = (mask && mask[b]) ? null_row[d] : x[i];
+  if (add) v += add[i];
+  out[i] = v;
+}
+
+// in-place interleaved-pair rotation of x[b, n, h*dh + d] by position n; thread per pair
+__global__ void rotary_rows_kernel(float* __restrict__ x, const float* __restrict__ tab, int B, int N, int heads, int dh) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dh / 2;
+  const long long total = (long long)B * N * heads * half;
+  if (i >= total) return;
+  const int fi = (int)(i % half);
+  const int n = (int)((i / ((long long)half * heads)) % N);
+  float* p = x + i * 2;
+  const float c = tab[(n * half + fi) * 2], s = tab[(n * half + fi) * 2 + 1];
+  const float a = p[0], b = p[1];
+  p[0] = a * c - b * s;
+  p[1] = b * c + a * s;
+}
+
+__global__ void relpos_bias_kernel(const float* __restrict__ emb, const int32_t* __restrict__ buckets, int n, int heads,
+                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= heads * n * n) return;
+  const int h = i / (n * n), ij = i - h * n * n;
+  out[i] = emb[buckets[ij] * heads + h];
+}
+
+__global__ void ncthw_to_rows_kernel(const float* __restrict__ x, int C, int T, int HW, float* __restrict__ rows, int ld,
+                                     long long nrows) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int hw = (int)(r % HW);
+  const int t = (int)((r / HW) % T);
+  const long long b = r / ((long long)HW * T);
+  for (int c = 0; c < ld; ++c) rows[r * ld + c] = (c < C) ? x[((b * C + c) * T + t) * HW + hw] : 0.f;
+}
+
+__global__ void rows_to_ncthw_kernel(const float* __restrict__ rows, int ld, int C, int T, int HW, float* __restrict__ x,
+                                     long long nrows) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int hw = (int)(r % HW);
+  const int t = (int)((r / HW) % T);
+  const long long b = r / ((long long)HW * T);
+  for (int c = 0; c < C; ++c) x[((b * C + c) * T + t) * HW + hw] = rows[r * ld + c];
+}
+
+__global__ __launch_bounds__(256) void pointwise_to_ncthw_kernel(const float* __restrict__ rows, int ld, int Cin,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 int Cout, int T, int HW, float* __restrict__ out, long long nrows) {
+  extern __shared__ float ws[];  // [Cout][Cin]
+  for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int hw = (int)(r % HW);
+  const int t = (int)((r / HW) % T);
+  const long long b = r / ((long long)HW * T);
+  const float* xr = rows + r * ld;
+  for (int co = 0; co < Cout; ++co) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ci = 0; ci < Cin; ci += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xr + ci);
+      a0 = fmaf(v.x, ws[co * Cin + ci], a0); a1 = fmaf(v.y, ws[co * Cin + ci + 1], a1);
+      a2 = fmaf(v.z, ws[co * Cin + ci + 2], a2); a3 = fmaf(v.w, ws[co * Cin + ci + 3], a3);
+    }
+    out[((b * Cout + co) * T + t) * HW + hw] = (a0 + a1) + (a2 + a3) + (bias ? bias[co] : 0.f);
+  }
+}
+
+// Conv1d(k=4, s=2, p=1) + SiLU on (B, Cin, Lin) signals (SignalEmbedding 'CNN', vddp.py:553-561); thread per output
+__global__ void conv1d_k4s2_silu_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                        float* __restrict__ y, int B, int Cin, int Cout, int Lin, int Lout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Cout * Lout) return;
+  const int l = i % Lout, co = (i / Lout) % Cout, b = i / (Lout * Cout);
+  float acc = bias[co];
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xr = x + ((long long)b * Cin + ci) * Lin;
+    const float* wr = w + ((long long)co * Cin + ci) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = l * 2 - 1 + k;
+      if (p >= 0 && p < Lin) acc = fmaf(xr[p], wr[k], acc);
+    }
+  }
+  y[i] = silu_f(acc);
+}
+
+// tokens[b, n, :] = mask[b] ? null_token[n, :] : hidden[b, :]   (vddp.py:767,774-777)
+__global__ void tokens_from_hidden_kernel(const float* __restrict__ hidden, const float* __restrict__ null_token,
+                                          const uint8_t* __restrict__ mask, int B, int N, int D, float* __restrict__ tokens) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N * D) return;
+  const int d = i % D, n = (i / D) % N, b = i / (D * N);
+  tokens[i] = (mask && mask[b]) ? null_token[n * D + d] : hidden[b * D + d];
+}
+
+}  // namespace
+
+extern "C" int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_units, vmm_stream_t stream) {
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(dense_batched_kernel, dim3(cdiv(max_units, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_sinusoidal_embed(const int64_t* t, int32_t B, int32_t dim, float neg_step, float* out, vmm_stream_t stream) {
+  hipLaunchKernelGGL(sinusoidal_kernel, dim3(cdiv(B * (dim / 2), 128)), dim3(128), 0, (hipStream_t)stream, t, B, dim, neg_step, out);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_cond_tokens(const float* cond, const float* w, const float* bias, const float* null_token, const uint8_t* mask,
+                               int32_t B, int32_t F, int32_t D, float* tokens, float* pooled, vmm_stream_t stream) {
+  hipLaunchKernelGGL(cond_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cond, w, bias, null_token, mask, F, D, tokens,
+                     pooled);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_rows_layernorm_affine(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t D,
+                                         float eps, vmm_stream_t stream) {
+  hipLaunchKernelGGL(rows_ln_affine_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, x, w, b, y, D, eps);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_select_add(const float* x, const float* null_row, const uint8_t* mask, const float* add, float* out, int32_t B,
+                              int32_t D, vmm_stream_t stream) {
+  hipLaunchKernelGGL(select_add_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, null_row, mask, add, out, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_rotary_rows(float* x, const float* rot_tab, int32_t B, int32_t N, int32_t heads, int32_t dh,
+                               vmm_stream_t stream) {
+  const long long total = (long long)B * N * heads * (dh / 2);
+  hipLaunchKernelGGL(rotary_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, rot_tab, B, N, heads, dh);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_relpos_bias(const float* emb, const int32_t* buckets, int32_t n, int32_t heads, float* out, vmm_stream_t stream) {
+  hipLaunchKernelGGL(relpos_bias_kernel, dim3(cdiv(heads * n * n, 256)), dim3(256), 0, (hipStream_t)stream, emb, buckets, n, heads, out);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_ncthw_to_rows(const float* x, int32_t B, int32_t C, int32_t T, int32_t HW, float* rows, int32_t ld,
+                                 vmm_stream_t stream) {
+  const long long nrows = (long long)B * T * HW;
+  hipLaunchKernelGGL(ncthw_to_rows_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, x, C, T, HW, rows, ld, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_rows_to_ncthw(const float* rows, int32_t ld, int32_t B, int32_t C, int32_t T, int32_t HW, float* x,
+                                 vmm_stream_t stream) {
+  const long long nrows = (long long)B * T * HW;
+  hipLaunchKernelGGL(rows_to_ncthw_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, rows, ld, C, T, HW, x, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_pointwise_to_ncthw(const float* rows, int32_t ld, int32_t Cin, const float* w, const float* bias, int32_t B,
+                                      int32_t Cout, int32_t T, int32_t HW, float* out, vmm_stream_t stream) {
+  if ((Cin & 3) || (ld & 3) || Cout * Cin > 8192) return -1;
+  const long long nrows = (long long)B * T * HW;
+  hipLaunchKernelGGL(pointwise_to_ncthw_kernel, dim3(cdiv(nrows, 256)), dim3(256), sizeof(float) * Cout * Cin, (hipStream_t)stream,
+                     rows, ld, Cin, w, bias, Cout, T, HW, out, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_conv1d_k4s2_silu(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
+                                    int32_t Cout, int32_t Lin, vmm_stream_t stream) {
+  const int Lout = (Lin + 2 - 4) / 2 + 1;
+  if (Lout < 1) return -1;
+  hipLaunchKernelGGL(conv1d_k4s2_silu_kernel, dim3(cdiv(B * Cout * Lout, 128)), dim3(128), 0, (hipStream_t)stream, x, w, bias, y, B,
+                     Cin, Cout, Lin, Lout);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_tokens_from_hidden(const float* hidden, const float* null_token, const uint8_t* mask, int32_t B, int32_t N,
+                                      int32_t D, float* tokens, vmm_stream_t stream) {
+  hipLaunchKernelGGL(tokens_from_hidden_kernel, dim3(cdiv(B * N * D, 256)), dim3(256), 0, (hipStream_t)stream, hidden, null_token,
+                     mask, B, N, D, tokens);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

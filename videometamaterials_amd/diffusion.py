@@ -1,0 +1,321 @@
+"""GaussianDiffusion -- MI355X-native drop-in for the reference class of the same name
+(denoising_diffusion_pytorch/video_denoising_diffusion_pytorch.py:841-1067, "vddp.py").
+
+Same constructor signature, attributes, registered buffers and method names, so
+``main.py:82-91`` and ``Trainer`` (vddp.py:1449-1481, 1622, 1734, 1826) can use it unchanged.
+All per-element arithmetic runs in libvmm_hip.so; the 256-step ancestral sampler replays
+one captured hipGraph per step (denoiser at batch 2B for classifier-free guidance,
+x0 prediction, exact radix-select quantile, posterior update) with no host sync inside.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _native as N
+from . import hostmath
+from .plan import Q_STRIDE, _stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def normalize_img(t):
+    return lincomb(t, a=2.0, d=-1.0)  # vddp.py:1109
+
+
+def unnormalize_img(t):
+    return lincomb(t, a=0.5, d=0.5)  # (t + 1) * 0.5, vddp.py:1112
+
+
+def lincomb(x, y=None, z=None, a=1.0, b=0.0, c=0.0, d=0.0, out=None):
+    out = torch.empty_like(x) if out is None else out
+    N.check(N.lib().vmm_lincomb(_ptr(x), _ptr(y), _ptr(z), a, b, c, d, _ptr(out), x.numel(), _stream()), "vmm_lincomb")
+    return out
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(
+        self,
+        denoise_fn,
+        *,
+        image_size,
+        num_frames,
+        channels=4,
+        timesteps=1000,
+        loss_type="l1",
+        use_dynamic_thres=False,
+        dynamic_thres_percentile=0.9,
+        sampling_timesteps=1000,
+        ddim_sampling_eta=0.0,
+    ):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.num_frames = num_frames
+        self.denoise_fn = denoise_fn
+        for name, val in hostmath.schedule_buffers(timesteps).items():  # float64 -> fp32, vddp.py:862-900
+            self.register_buffer(name, val)
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.use_dynamic_thres = use_dynamic_thres
+        self.dynamic_thres_percentile = dynamic_thres_percentile
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
+        assert self.sampling_timesteps <= timesteps  # vddp.py:910
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        self._graph_cache = {}
+        self.use_graph = True
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_graph_cache"] = {}
+        return st
+
+    # ------------------------------------------------------------------ elementwise pieces (vddp.py:914-933, 1036-1042)
+    def q_mean_variance(self, x_start, t):
+        shp = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        mean = self.q_sample(x_start, t, noise=torch.zeros_like(x_start))
+        return mean, (1.0 - self.alphas_cumprod).gather(-1, t).reshape(shp), self.log_one_minus_alphas_cumprod.gather(-1, t).reshape(shp)
+
+    def q_sample(self, x_start, t, noise=None, _normalize=False):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_start, noise = x_start.contiguous(), noise.contiguous()
+        out = torch.empty_like(x_start)
+        B = x_start.shape[0]
+        N.check(N.lib().vmm_q_sample(_ptr(x_start), _ptr(noise), _ptr(t), _ptr(self.sqrt_alphas_cumprod), _ptr(self.sqrt_one_minus_alphas_cumprod),
+                                     1 if _normalize else 0, _ptr(out), B, x_start.numel() // B, _stream()), "vmm_q_sample")
+        return out
+
+    def _predict_x0(self, x_t, t, eps_c, eps_n, w, want_abs):
+        x_t = x_t.contiguous()
+        B = x_t.shape[0]
+        x0 = torch.empty_like(x_t)
+        ax0 = torch.empty_like(x_t) if want_abs else None
+        N.check(N.lib().vmm_predict_x0(_ptr(x_t), _ptr(eps_c), _ptr(eps_n), float(w), _ptr(t), _ptr(self.sqrt_recip_alphas_cumprod),
+                                       _ptr(self.sqrt_recipm1_alphas_cumprod), _ptr(x0), _ptr(ax0), B, x_t.numel() // B, _stream()), "vmm_predict_x0")
+        return x0, ax0
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return self._predict_x0(x_t, t, noise.contiguous(), None, 1.0, False)[0]
+
+    def _posterior(self, x0, x_t, t, noise, s, clip_mode):
+        B = x_t.shape[0]
+        out = torch.empty_like(x_t)
+        N.check(N.lib().vmm_posterior_step(_ptr(x0), _ptr(x_t), _ptr(noise), _ptr(s), _ptr(t), _ptr(self.posterior_mean_coef1),
+                                           _ptr(self.posterior_mean_coef2), _ptr(self.posterior_log_variance_clipped), clip_mode, _ptr(out), B,
+                                           x_t.numel() // B, _stream()), "vmm_posterior_step")
+        return out
+
+    def q_posterior(self, x_start, x_t, t):
+        shp = (x_t.shape[0],) + (1,) * (x_t.dim() - 1)
+        mean = self._posterior(x_start.contiguous(), x_t.contiguous(), t, None, None, 0)
+        return mean, self.posterior_variance.gather(-1, t).reshape(shp), self.posterior_log_variance_clipped.gather(-1, t).reshape(shp)
+
+    def _quantile(self, absx):
+        B = absx.shape[0]
+        n = absx.numel() // B
+        k_lo, frac = hostmath.quantile_rank(n, self.dynamic_thres_percentile)
+        s = torch.empty(B, dtype=torch.float32, device=absx.device)
+        scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=absx.device)
+        N.check(N.lib().vmm_quantile_rows(_ptr(absx), B, n, k_lo, frac, 1.0, _ptr(s), _ptr(scratch), _stream()), "vmm_quantile_rows")
+        return s
+
+    # ------------------------------------------------------------------ sampling (vddp.py:935-1018)
+    def _eps_pair(self, x, t, cond, guidance_scale):
+        if guidance_scale == 1:
+            return self.denoise_fn.forward(x, t, cond=cond, null_cond_prob=0.0), None
+        return self.denoise_fn.guided_pair(x, t, cond)
+
+    def p_mean_variance(self, x, t, clip_denoised: bool, cond=None, guidance_scale=1.0):
+        x = x.contiguous()
+        eps_c, eps_n = self._eps_pair(x, t, cond, guidance_scale)
+        dyn = clip_denoised and self.use_dynamic_thres
+        x0, ax0 = self._predict_x0(x, t, eps_c, eps_n, guidance_scale, dyn)
+        s = self._quantile(ax0) if dyn else None  # s = max(quantile(|x0|, p), 1)  (vddp.py:941-947)
+        mean = self._posterior(x0, x, t, None, s, 2 if dyn else (1 if clip_denoised else 0))
+        shp = (x.shape[0],) + (1,) * (x.dim() - 1)
+        return mean, self.posterior_variance.gather(-1, t).reshape(shp), self.posterior_log_variance_clipped.gather(-1, t).reshape(shp)
+
+    @torch.inference_mode()
+    def p_sample(self, x, t, cond=None, clip_denoised=True, guidance_scale=1.0, noise=None):
+        """One ancestral step (vddp.py:956-963).  `noise` may be injected for parity tests; default = device RNG."""
+        x = x.contiguous()
+        eps_c, eps_n = self._eps_pair(x, t, cond, guidance_scale)
+        dyn = clip_denoised and self.use_dynamic_thres
+        x0, ax0 = self._predict_x0(x, t, eps_c, eps_n, guidance_scale, dyn)
+        s = self._quantile(ax0) if dyn else None
+        noise = torch.randn_like(x) if noise is None else noise.contiguous()
+        return self._posterior(x0, x, t, noise, s, 2 if dyn else (1 if clip_denoised else 0))
+
+    @torch.inference_mode()
+    def p_sample_loop(self, shape, cond=None, guidance_scale=1.0, noises=None, x_T=None):
+        """vddp.py:965-975.  `x_T` / `noises` (one tensor per step, order t = T-1 .. 0) may be injected for parity tests."""
+        device = self.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).clone()
+        if cond is not None:
+            cond = cond.to(device).contiguous()
+        stepper = None
+        was_static = getattr(self.denoise_fn, "static_weights", False)
+        self.denoise_fn.static_weights = True  # weights cannot change inside the sampling loop
+        try:
+            if self.use_graph and noises is None and cond is not None and guidance_scale != 1:
+                stepper = self._graphed_step(tuple(shape), cond, float(guidance_scale))
+            for j, i in enumerate(reversed(range(0, self.num_timesteps))):
+                if stepper is not None:
+                    img = stepper(img, i)
+                else:
+                    t = torch.full((b,), i, device=device, dtype=torch.long)
+                    img = self.p_sample(img, t, cond=cond, guidance_scale=guidance_scale, noise=None if noises is None else noises[j].to(device))
+        finally:
+            self.denoise_fn.static_weights = was_static
+        return unnormalize_img(img)
+
+    @torch.inference_mode()
+    def sample(self, cond=None, batch_size=16, guidance_scale=1.0):
+        batch_size = cond.shape[0] if cond is not None else batch_size
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        return sample_fn((batch_size, self.channels, self.num_frames, self.image_size, self.image_size), cond=cond, guidance_scale=guidance_scale)
+
+    @torch.inference_mode()
+    def ddim_sample(self, shape, cond=None, guidance_scale=1.0, noises=None, x_T=None):
+        """vddp.py:986-1018 (no clipping / thresholding on this path; INTEGER time list bit-exact)."""
+        batch, device, eta = shape[0], self.betas.device, self.ddim_sampling_eta
+        pairs = hostmath.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).clone()
+        acp = self.alphas_cumprod.double().cpu()
+        from .plan import cfg_combine
+        for j, (time, time_next) in enumerate(pairs):
+            tt = torch.full((batch,), time, device=device, dtype=torch.long)
+            eps_c, eps_n = self._eps_pair(img, tt, cond, guidance_scale)
+            eps = eps_c if eps_n is None else cfg_combine(eps_c, eps_n, float(guidance_scale))
+            x0 = self.predict_start_from_noise(img, tt, eps)
+            if time_next < 0:
+                img = x0
+                continue
+            # scalar coefficients evaluated like the reference (fp32 0-d tensors, vddp.py:1006-1010)
+            a, an = self.alphas_cumprod[time].cpu(), self.alphas_cumprod[time_next].cpu()
+            sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+            c = (1 - an - sigma ** 2).sqrt()
+            noise = torch.randn_like(img) if noises is None else noises[j].to(device)
+            img = lincomb(x0, eps, noise, a=float(an.sqrt()), b=float(c), c=float(sigma))
+        return unnormalize_img(img)
+
+    @torch.inference_mode()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        raise NotImplementedError("interpolate() crashes in the reference for conditional models (SURVEY quirk 9) and is not built")
+
+    # ------------------------------------------------------------------ hipGraph-captured guided sampling step
+    def _graphed_step(self, shape, cond, w):
+        key = (shape, w, cond.shape[-1], str(cond.device))
+        st = self._graph_cache.get(key)
+        if st is None:
+            st = _GraphedStep(self, shape, cond.shape[-1], w)
+            self._graph_cache[key] = st
+        st.set_cond(cond)
+        return st
+
+    # ------------------------------------------------------------------ training (vddp.py:1044-1067)
+    def p_losses(self, x_start, t, cond=None, noise=None, **kwargs):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
+        x_recon = self.denoise_fn(x_noisy, t, cond=cond, **kwargs)
+        from .autograd import noise_loss
+        if self.loss_type not in ("l1", "l2"):
+            raise NotImplementedError()
+        return noise_loss(noise, x_recon, squared=self.loss_type == "l2")
+
+    def forward(self, x, *args, **kwargs):
+        b, device, img_size = x.shape[0], x.device, self.image_size
+        want = (self.channels, self.num_frames, img_size, img_size)
+        if tuple(x.shape[1:]) != want:  # check_shape, vddp.py:1064
+            raise ValueError(f"expected input of shape (b, {want[0]}, {want[1]}, {want[2]}, {want[3]}), got {tuple(x.shape)}")
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        x = normalize_img(x.contiguous())
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+class _GraphedStep:
+    """One guided ancestral step captured as a hipGraph: img <- p_sample(img, t) entirely on device."""
+
+    def __init__(self, diff: GaussianDiffusion, shape, cond_len: int, w: float):
+        self.diff, self.shape, self.w = diff, shape, w
+        dev = diff.betas.device
+        B = shape[0]
+        self.B = B
+        self.img = torch.zeros(shape, device=dev)
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)
+        self.t2 = torch.zeros(2 * B, dtype=torch.long, device=dev)
+        self.cond2 = torch.zeros(2 * B, cond_len, device=dev)
+        self.mask2 = torch.cat([torch.zeros(B, dtype=torch.uint8, device=dev), torch.ones(B, dtype=torch.uint8, device=dev)])
+        self.x0 = torch.empty(shape, device=dev)
+        self.ax0 = torch.empty(shape, device=dev)
+        self.noise = torch.empty(shape, device=dev)
+        self.s = torch.empty(B, device=dev)
+        self.scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=dev)
+        n = self.img.numel() // B
+        self.k_lo, self.frac = hostmath.quantile_rank(n, diff.dynamic_thres_percentile)
+        _, C_, T, H, W = shape
+        self.plan = diff.denoise_fn.get_plan(2 * B, T, H, W, cond_len, dev)
+        self.graph = None
+        self.captured = False
+
+    def set_cond(self, cond):
+        self.cond2[: self.B].copy_(cond)
+        self.cond2[self.B:].copy_(cond)
+        self.plan.cond_in.copy_(self.cond2)
+        self.plan.mask_in.copy_(self.mask2)
+
+    def _body(self):
+        d, lib, B = self.diff, N.lib(), self.B
+        pl = self.plan
+        pl.x_in[:B].copy_(self.img)
+        pl.x_in[B:].copy_(self.img)
+        pl.time_in[:B].copy_(self.t)
+        pl.time_in[B:].copy_(self.t)
+        pl.launch()
+        n = self.img.numel() // B
+        dyn = d.use_dynamic_thres
+        N.check(lib.vmm_predict_x0(_ptr(self.img), _ptr(pl.out[:B]), _ptr(pl.out[B:]), self.w, _ptr(self.t), _ptr(d.sqrt_recip_alphas_cumprod),
+                                   _ptr(d.sqrt_recipm1_alphas_cumprod), _ptr(self.x0), _ptr(self.ax0) if dyn else None, B, n, _stream()), "vmm_predict_x0")
+        if dyn:
+            N.check(lib.vmm_quantile_rows(_ptr(self.ax0), B, n, self.k_lo, self.frac, 1.0, _ptr(self.s), _ptr(self.scratch), _stream()), "vmm_quantile_rows")
+        self.noise.normal_()
+        N.check(lib.vmm_posterior_step(_ptr(self.x0), _ptr(self.img), _ptr(self.noise), _ptr(self.s), _ptr(self.t), _ptr(d.posterior_mean_coef1),
+                                       _ptr(d.posterior_mean_coef2), _ptr(d.posterior_log_variance_clipped), 2 if dyn else 1, _ptr(self.img), B, n,
+                                       _stream()), "vmm_posterior_step")
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._body()  # warm-up (also primes the RNG state registration)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self.graph = g
+
+    def __call__(self, img, i: int):
+        if self.img.data_ptr() != img.data_ptr():
+            self.img.copy_(img)
+        self.t.fill_(i)
+        if not self.captured:
+            saved = self.img.clone()
+            try:
+                self._capture()
+            except Exception:  # capture unsupported: stay on the eager HIP path (same kernels)
+                self.graph = None
+            self.captured = True
+            self.img.copy_(saved)
+            self.t.fill_(i)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        return self.img

@@ -1,0 +1,289 @@
+"""Unet3D -- MI355X-native drop-in for the reference denoiser.
+
+Same constructor / forward / forward_with_guidance_scale signatures and the same
+``state_dict`` key names as ``Unet3D`` in the reference
+(denoising_diffusion_pytorch/video_denoising_diffusion_pytorch.py:574-821, "vddp.py"),
+so ``main.py:62-80`` can construct it unchanged and a reference checkpoint loads.
+
+Nothing here executes arithmetic in PyTorch: ``forward`` replays a *plan* -- a
+static list of HIP kernel launches (libvmm_hip.so, include/vmm_kernels.h) over a
+static arena in HBM, built once per input shape by ``plan.build_plan``.  There is
+no fallback path; without the built library construction works (parameters are
+plain tensors) but ``forward`` raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import plan as _plan
+
+
+class _Node(nn.Module):
+    """Pure parameter container; gives parameters the reference's dotted names."""
+
+
+def _attach(root: nn.Module, dotted: str, value: torch.Tensor, *, buffer: bool = False) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Node())
+        mod = getattr(mod, p)
+    if buffer:
+        mod.register_buffer(parts[-1], value, persistent=True)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(value))
+
+
+def _uniform(shape, fan_in: int) -> torch.Tensor:
+    bound = 1.0 / math.sqrt(max(fan_in, 1))  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    return (torch.rand(shape) * 2 - 1) * bound
+
+
+class Unet3D(nn.Module):
+    def __init__(
+        self,
+        dim,
+        out_dim=None,
+        dim_mults=(1, 2, 4, 8),
+        channels=3,
+        attn_heads=8,
+        attn_dim_head=32,
+        init_dim=None,
+        init_kernel_size=7,
+        use_sparse_linear_attn=True,
+        resnet_groups=8,
+        cond_bias=False,
+        cond_attention="none",
+        cond_attention_tokens=6,
+        cond_att_GRU=False,
+        use_temporal_attention_cond=False,
+        cond_to_time="add",
+        per_frame_cond=False,
+        padding_mode="zeros",
+    ):
+        super().__init__()
+        assert init_kernel_size % 2 == 1  # vddp.py:621
+        if cond_att_GRU:
+            raise NotImplementedError("cond_att_GRU (ablation-only GRU embedding, vddp.py:546-549) is not built")
+        if padding_mode != "zeros":
+            raise NotImplementedError("circular padding variants (vddp.py:163-237) are not built; model.yaml uses 'zeros'")
+        if cond_to_time != "add":
+            raise NotImplementedError("cond_to_time='concat' is not built; model.yaml uses 'add'")
+        if attn_dim_head != 32:
+            raise NotImplementedError("attention kernels are specialised for dim_head = 32 (model.yaml:16)")
+        self.channels = channels
+        self.dim = dim
+        self.time_dim = dim * 4
+        self.cond_bias = cond_bias
+        self.cond_attention = cond_attention if not per_frame_cond else "self-stacked"  # vddp.py:602
+        self.cond_attention_tokens = cond_attention_tokens if not per_frame_cond else 11  # vddp.py:603
+        if self.cond_attention not in ("none", "self-stacked", "cross-attention"):
+            raise ValueError("cond_attention must be none, self-stacked or cross-attention")
+        if self.cond_attention == "cross-attention":
+            raise NotImplementedError("cond_attention='cross-attention' is unreachable with the shipped configs and not built")
+        self.cond_att_GRU = cond_att_GRU
+        self.cond_dim = self.time_dim
+        self.use_temporal_attention_cond = use_temporal_attention_cond
+        self.cond_to_time = cond_to_time
+        self.per_frame_cond = per_frame_cond
+        self.padding_mode = padding_mode
+        self.attn_heads = attn_heads
+        self.attn_dim_head = attn_dim_head
+        self.use_sparse_linear_attn = use_sparse_linear_attn
+        self.resnet_groups = resnet_groups
+        self.init_kernel_size = init_kernel_size
+        self.init_dim = init_dim if init_dim is not None else dim
+        self.out_dim = out_dim if out_dim is not None else channels
+        self.dim_mults = tuple(dim_mults)
+        dims = [self.init_dim] + [dim * m for m in dim_mults]
+        self.in_out: List[Tuple[int, int]] = list(zip(dims[:-1], dims[1:]))
+
+        self._build_parameters()
+        self._plans: Dict[tuple, "_plan.Plan"] = {}
+        self._weights_version = None
+        self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
+
+    # ------------------------------------------------------------------ parameters (names = reference module tree)
+    def _conv(self, name, cout, cin, k, bias=True):
+        _attach(self, name + ".weight", _uniform((cout, cin, 1, k, k), cin * k * k))
+        if bias:
+            _attach(self, name + ".bias", _uniform((cout,), cin * k * k))
+
+    def _linear(self, name, cout, cin, bias=True):
+        _attach(self, name + ".weight", _uniform((cout, cin), cin))
+        if bias:
+            _attach(self, name + ".bias", _uniform((cout,), cin))
+
+    def _resnet(self, name, cin, cout, temb: Optional[int]):
+        if temb is not None:
+            self._linear(name + ".mlp.1", cout * 2, temb)
+        for blk, ci in (("block1", cin), ("block2", cout)):
+            self._conv(f"{name}.{blk}.proj", cout, ci, 3)
+            _attach(self, f"{name}.{blk}.norm.weight", torch.ones(cout))
+            _attach(self, f"{name}.{blk}.norm.bias", torch.zeros(cout))
+        if cin != cout:
+            self._conv(name + ".res_conv", cout, cin, 1)
+
+    def _softmax_attn(self, name, dim, rotary: bool, dim_head: int):
+        hid = dim_head * self.attn_heads
+        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
+        p = name + ".fn.fn"
+        if rotary:
+            rot = min(32, dim_head)
+            freqs = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+            _attach(self, p + ".rotary_emb.freqs", freqs, buffer=True)
+        self._linear(p + ".to_qkv", hid * 3, dim, bias=False)
+        self._linear(p + ".to_q", hid, dim, bias=False)
+        self._linear(p + ".to_k", hid, self.cond_dim, bias=False)
+        self._linear(p + ".to_v", hid, self.cond_dim, bias=False)
+        self._linear(p + ".to_out", dim, hid, bias=False)
+
+    def _linear_attn(self, name, dim):
+        hid = 32 * self.attn_heads  # dim_head default (vddp.py:314, not forwarded at 679/700)
+        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
+        p = name + ".fn"
+        _attach(self, p + ".to_qkv.weight", _uniform((hid * 3, dim, 1, 1), dim))
+        _attach(self, p + ".to_q.weight", _uniform((hid, dim, 1, 1), dim))
+        self._linear(p + ".to_k", hid, self.cond_dim, bias=False)
+        self._linear(p + ".to_v", hid, self.cond_dim, bias=False)
+        _attach(self, p + ".to_out.weight", _uniform((dim, hid, 1, 1), hid))
+        _attach(self, p + ".to_out.bias", _uniform((dim,), hid))
+
+    def _build_parameters(self):
+        heads, td, cd = self.attn_heads, self.time_dim, self.cond_dim
+        _attach(self, "time_rel_pos_bias.relative_attention_bias.weight", torch.randn(32, heads))
+        k = self.init_kernel_size
+        self._conv("init_conv", self.init_dim, self.channels, k)
+        self._softmax_attn("init_temporal_attn.fn", self.init_dim, True, self.attn_dim_head)
+        self._linear("time_mlp.1", td, self.dim)
+        self._linear("time_mlp.3", td, td)
+        chain = [1, 16, 32, 64, 128, cd]
+        for i, (ci, co) in enumerate(zip(chain[:-1], chain[1:])):
+            _attach(self, f"sign_emb_CNN.emb_model.{2 * i}.weight", _uniform((co, ci, 4), ci * 4))
+            _attach(self, f"sign_emb_CNN.emb_model.{2 * i}.bias", _uniform((co,), ci * 4))
+        if self.per_frame_cond:
+            self._linear("sign_emb", cd, 1)
+            _attach(self, "cond_token_to_hidden.0.weight", torch.ones(cd))
+            _attach(self, "cond_token_to_hidden.0.bias", torch.zeros(cd))
+            self._linear("cond_token_to_hidden.1", cd, cd)
+            self._linear("cond_token_to_hidden.3", td, cd)
+        n_lvl = len(self.in_out)
+        for i, (ci, co) in enumerate(self.in_out):
+            self._resnet(f"downs.{i}.0", ci, co, cd)
+            self._resnet(f"downs.{i}.1", co, co, cd)
+            if self.use_sparse_linear_attn:
+                self._linear_attn(f"downs.{i}.2.fn", co)
+            self._softmax_attn(f"downs.{i}.3.fn", co, True, self.attn_dim_head)
+            if i < n_lvl - 1:
+                self._conv(f"downs.{i}.4", co, co, 4)
+        mid = self.in_out[-1][1]
+        self._resnet("mid_block1", mid, mid, cd)
+        self._softmax_attn("mid_spatial_attn.fn", mid, False, 32)
+        self._softmax_attn("mid_temporal_attn.fn", mid, True, self.attn_dim_head)
+        self._resnet("mid_block2", mid, mid, cd)
+        for i, (ci, co) in enumerate(reversed(self.in_out)):
+            self._resnet(f"ups.{i}.0", co * 2, ci, cd)
+            self._resnet(f"ups.{i}.1", ci, ci, cd)
+            if self.use_sparse_linear_attn:
+                self._linear_attn(f"ups.{i}.2.fn", ci)
+            self._softmax_attn(f"ups.{i}.3.fn", ci, True, self.attn_dim_head)
+            if i < n_lvl - 1:
+                self._conv(f"ups.{i}.4", ci, ci, 4)  # ConvTranspose3d weight is (in, out, 1, 4, 4); in == out here
+        self._resnet("final_conv.0", self.dim * 2, self.dim, None)
+        self._conv("final_conv.1", self.out_dim, self.dim, 1)
+        _attach(self, "null_text_token", torch.randn(1, self.cond_attention_tokens, cd))
+        _attach(self, "null_text_hidden", torch.randn(1, td))
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Accept checkpoints with or without the `...rotary_emb.freqs` entries (their presence depends on the
+        rotary_embedding_torch version) and with a DDP `module.` prefix."""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        own = super().state_dict()
+        for k in own:
+            if k.endswith("rotary_emb.freqs") and k not in sd:
+                sd[k] = own[k]
+        sd = {k: v for k, v in sd.items() if not (k.endswith("rotary_emb.freqs") and k not in own)}
+        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._weights_version = None
+        return out
+
+    # ------------------------------------------------------------------ execution
+    def _params_flat(self) -> Dict[str, torch.Tensor]:
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> "_plan.Plan":
+        key = (B, T, H, W, cond_len, str(device), training)
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training)
+            self._plans[key] = pl
+            pl.weights_version = None
+        if not (self.static_weights and pl.weights_version is not None):
+            ver = self._version_key()
+            if pl.weights_version != ver:
+                pl.refresh_weights(self._params_flat())
+                pl.weights_version = ver
+        return pl
+
+    def _mask(self, batch: int, prob: float, device) -> torch.Tensor:
+        """prob_mask_like (vddp.py:55-61) as uint8."""
+        if prob == 1:
+            return torch.ones(batch, dtype=torch.uint8, device=device)
+        if prob == 0:
+            return torch.zeros(batch, dtype=torch.uint8, device=device)
+        return (torch.zeros(batch, device=device).float().uniform_(0, 1) < prob).to(torch.uint8)
+
+    def _check_inputs(self, x, cond, focus_present_mask, prob_focus_present):
+        if x.dim() != 5 or x.shape[1] != self.channels:
+            raise ValueError(f"expected x of shape (b, {self.channels}, f, h, w), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("videometamaterials_amd.Unet3D runs on an MI355X only; move the model and inputs to 'cuda'")
+        if prob_focus_present != 0 or (focus_present_mask is not None and bool(focus_present_mask.any())):
+            raise NotImplementedError("focus_present_mask is inert on every shipped config (prob_focus_present = 0, main.py); "
+                                      "a non-trivial mask is not built")
+        if cond is None:
+            raise ValueError("cond is required (the reference dereferences it unconditionally, vddp.py:753,761)")
+        if self.per_frame_cond and x.shape[2] != 11:
+            raise ValueError("per_frame_cond is hard-wired to 11 frames (vddp.py:603)")
+
+    def forward(self, x, time, cond=None, null_cond_prob=0.0, focus_present_mask=None, prob_focus_present=0.0):
+        self._check_inputs(x, cond, focus_present_mask, prob_focus_present)
+        B, _, T, H, W = x.shape
+        mask = self._mask(B, null_cond_prob, x.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import unet_forward_with_grad
+            return unet_forward_with_grad(self, x, time, cond, mask)
+        pl = self.get_plan(B, T, H, W, cond.shape[-1], x.device)
+        return pl.run(x, time, cond, mask).clone()
+
+    def forward_with_guidance_scale(self, *args, **kwargs):
+        """vddp.py:715-728.  Both branches run as ONE batch of 2B (legal: every op is per-sample)."""
+        guidance_scale = kwargs.pop("guidance_scale", 5.0)
+        if guidance_scale == 1:
+            return self.forward(*args, null_cond_prob=0.0, **kwargs)
+        names = ("x", "time", "cond")
+        bound = dict(zip(names, args))
+        bound.update(kwargs)
+        x, time, cond = bound["x"], bound["time"], bound.get("cond")
+        self._check_inputs(x, cond, bound.get("focus_present_mask"), bound.get("prob_focus_present", 0.0))
+        eps_c, eps_n = self.guided_pair(x, time, cond)
+        return _plan.cfg_combine(eps_c, eps_n, float(guidance_scale))
+
+    @torch.no_grad()
+    def guided_pair(self, x, time, cond):
+        """(eps_cond, eps_null) views into the plan's static output (valid until the next call)."""
+        B, _, T, H, W = x.shape
+        pl = self.get_plan(2 * B, T, H, W, cond.shape[-1], x.device)
+        mask = torch.cat([torch.zeros(B, dtype=torch.uint8, device=x.device), torch.ones(B, dtype=torch.uint8, device=x.device)])
+        out = pl.run(torch.cat([x, x]), torch.cat([time, time]), torch.cat([cond, cond]), mask)
+        return out[:B], out[B:]
