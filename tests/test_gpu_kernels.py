@@ -161,11 +161,12 @@ def test_groupnorm_film_silu(gpu, C_, G):
     sums = torch.empty(B * G * 2, dtype=torch.float64, device=gpu)
     coef = torch.empty(B, C_, 2, device=gpu)
     stats = torch.empty(B * G * 2, device=gpu)
+    gg, bg, fg, rg = gamma.to(gpu), beta.to(gpu), film.to(gpu), res.to(gpu)  # keep the device copies alive across the launches
     N.check(lib.vmm_groupnorm_stats(xr.data_ptr(), C_, B, rps, C_, G, sums.data_ptr(), _s()), "stats")
-    N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gamma.to(gpu).data_ptr(), beta.to(gpu).data_ptr(), film.to(gpu).data_ptr(),
+    N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(),
                                    2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), _s()), "coef")
     out = torch.empty_like(xr)
-    N.check(lib.vmm_affine_silu(xr.data_ptr(), C_, coef.data_ptr(), res.to(gpu).data_ptr(), C_, out.data_ptr(), C_, xr.shape[0], rps, C_, _s()), "apply")
+    N.check(lib.vmm_affine_silu(xr.data_ptr(), C_, coef.data_ptr(), rg.data_ptr(), C_, out.data_ptr(), C_, xr.shape[0], rps, C_, _s()), "apply")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
     xs = x.reshape(B, G, -1)
@@ -180,8 +181,8 @@ def test_channel_layernorm(gpu, C_):
     x = torch.randn(1000, C_, generator=g) * 3 + 1
     gamma = torch.randn(C_, generator=g)
     ref = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma
-    xg, out = x.to(gpu), torch.empty(1000, C_, device=gpu)
-    N.check(lib.vmm_channel_layernorm(xg.data_ptr(), C_, gamma.to(gpu).data_ptr(), out.data_ptr(), C_, 1000, C_, 1e-5, _s()), "ln")
+    xg, gg, out = x.to(gpu), gamma.to(gpu), torch.empty(1000, C_, device=gpu)
+    N.check(lib.vmm_channel_layernorm(xg.data_ptr(), C_, gg.data_ptr(), out.data_ptr(), C_, 1000, C_, 1e-5, _s()), "ln")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 2e-6
 
@@ -214,8 +215,9 @@ def test_temporal_attention_core(gpu, ntok, bias_on_cond):
     out = torch.empty(B * T * HW, hid, device=gpu)
     ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    bg = bias.to(gpu)
     N.check(lib.vmm_temporal_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok,
-                                       bias.to(gpu).data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "temporal")
+                                       bg.data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "temporal")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
 
@@ -290,7 +292,8 @@ def test_quantile_matches_torch(gpu):
         k_lo, frac = hostmath.quantile_rank(n, 0.9)
         s = torch.empty(B, device=gpu)
         scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=gpu)
-        N.check(lib.vmm_quantile_rows(x.to(gpu).data_ptr(), B, n, k_lo, frac, 1.0, s.data_ptr(), scratch.data_ptr(), _s()), "quantile")
+        xg = x.to(gpu)
+        N.check(lib.vmm_quantile_rows(xg.data_ptr(), B, n, k_lo, frac, 1.0, s.data_ptr(), scratch.data_ptr(), _s()), "quantile")
         torch.cuda.synchronize()
         assert torch.equal(s.cpu(), want), (n, s.cpu(), want)
 
@@ -326,7 +329,8 @@ def test_dense_batched_and_embeddings(gpu):
     e = t[:, None] * emb[None, :]
     ref = torch.cat((e.sin(), e.cos()), -1)
     out = torch.empty(4, dim, device=gpu)
-    N.check(lib.vmm_sinusoidal_embed(t.to(gpu).data_ptr(), 4, dim, -(math.log(10000) / (half - 1)), out.data_ptr(), _s()), "sin")
+    tg = t.to(gpu)
+    N.check(lib.vmm_sinusoidal_embed(tg.data_ptr(), 4, dim, -(math.log(10000) / (half - 1)), out.data_ptr(), _s()), "sin")
     torch.cuda.synchronize()
     assert torch.allclose(out.cpu(), ref, atol=2e-5)
 

@@ -245,6 +245,10 @@ class _GraphedStep:
 
     def __init__(self, diff: GaussianDiffusion, shape, cond_len: int, w: float):
         self.diff, self.shape, self.w = diff, shape, w
+        with torch.inference_mode(False):
+            self._alloc(diff, shape, cond_len)
+
+    def _alloc(self, diff, shape, cond_len):
         dev = diff.betas.device
         B = shape[0]
         self.B = B

@@ -565,6 +565,12 @@ class _Builder:
 
 
 def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> Plan:
+    # plan buffers outlive the caller's autograd mode: never create them as inference tensors
+    with torch.inference_mode(False), torch.no_grad():
+        return _build_plan(model, B, T, H, W, cond_len, device, training)
+
+
+def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool) -> Plan:
     # pass 1: sizes only (addresses relative to 0); pass 2: identical allocation order over real buffers
     sizing = _Builder(model, B, T, H, W, cond_len, device, 0, 0, keep_all=training)
     sizing.build()
