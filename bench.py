@@ -34,7 +34,25 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 pea
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(max_seconds: float = 40.0):
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(max_seconds: float = 30.0):
     """Oracle (oracle/unet3d_oracle.py, parity-pinned CPU restatement of the reference) on the host cores."""
     from oracle import unet3d_oracle as uo
     torch.manual_seed(0)
@@ -46,7 +64,7 @@ def cpu_baseline(max_seconds: float = 40.0):
     x = torch.randn(1, 3, T, HW, HW, generator=g)
     t = torch.randint(0, TIMESTEPS, (1,), generator=g)
     cond = torch.rand(1, 11, generator=g) * 2 - 1
-    nthreads = os.cpu_count() or 1
+    nthreads = usable_cores()
     torch.set_num_threads(nthreads)
     times = []
     with torch.no_grad():

@@ -50,6 +50,24 @@ typedef struct vmm_conv_desc {
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 
+/* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
+ * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer
+ * (out/res/bias/rot fields ignored), the reduction is split over `nsplit` row slices combined with fp32 atomics, so
+ * dw_packed must be zeroed by the caller. */
+int vmm_conv_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit,
+                       vmm_stream_t stream);
+/* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
+int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
+/* batched weight packing: packed[(th*TW + tw)*Cp + c][n] <-> torch[n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw];
+ * direction 0: torch -> packed (channels c >= C are zero padding); 1: packed gradient -> torch (= or += per job). */
+typedef struct vmm_pack_job {
+  float* torch_w; float* packed;
+  int32_t TH, TW, C, Cp, N;
+  int32_t sn, sc, sh, sw, h0, hs, w0, ws;
+  int32_t accumulate;
+} vmm_pack_job;
+int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
+
 /* ---- K6: GroupNorm(groups, C) statistics + fused affine/FiLM/SiLU (vddp.py:274-285) ---- */
 /* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */
 int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G,
@@ -74,19 +92,21 @@ int vmm_channel_layernorm(const float* x, int32_t ldx, const float* gamma, float
  * bias = relative position bias [heads][T][T]; bias_on_cond: also add it to the token half (vddp.py:505-510). */
 int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                            const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
-                           int32_t heads, int32_t dh, vmm_stream_t stream);
+                           int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
+                           vmm_stream_t stream);
 
 /* ---- K12: mid-level spatial softmax attention per frame (vddp.py:687-689): n = HW queries, keys = [tokens | HW].
  * tok_per_frame = 1: frame t sees only token t (vddp.py:459-462); 0: all ntok tokens. */
 int vmm_spatial_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                           int32_t tok_per_frame, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads,
-                          int32_t dh, vmm_stream_t stream);
+                          int32_t dh, float* lse /* or NULL */, vmm_stream_t stream);
 
 /* ---- K9: spatial linear attention core (vddp.py:367-376), per (b*T frame, head):
  * ctx[d,e] = sum_n softmax_n(k)[d,n] * v[e,n]/HW over n = [tokens | HW pixels];  out[n, e] = sum_d ctx[d,e]*softmax_d(q[n,:])*scale */
 int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T,
                         int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part /* [B*T*heads*nsplit][dh*dh+2*dh] */,
-                        float* ctx /* [B*T*heads][dh*dh] */, vmm_stream_t stream);
+                        float* ctx /* [B*T*heads][dh*dh] */, float* kstat /* [B*T*heads][2*dh] (max | 1/sum) or NULL */,
+                        vmm_stream_t stream);
 int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                       int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
 
@@ -162,6 +182,56 @@ int vmm_cfg_combine(const float* eps_cond, const float* eps_null, float w, float
 /* out = a*x + b*y + c*z + d (y, z optional): DDIM update (vddp.py:1014-1016), un/normalize_img (1109-1113) */
 int vmm_lincomb(const float* x, const float* y, const float* z, float a, float b, float c, float d, float* out, int64_t n,
                 vmm_stream_t stream);
+
+/* ================================ training path (autograd of the calls above) ================================ */
+/* GroupNorm(+FiLM)+SiLU backward: dz = grad of z = silu(a*h + b'); writes dh (= or +=), accumulates dgamma/dbeta [C],
+ * writes dfilm [B][ldfilm] (scale | shift) when given.  stats = (mean, rstd) from vmm_groupnorm_coef. */
+int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, int32_t ldh, const float* coef, const float* stats,
+                      const float* gamma, const float* beta, const float* film, int32_t ldfilm, int32_t B, int32_t rows_per_sample,
+                      int32_t C, int32_t G, float* scratch /* [B*C*2 + B*G*2] */, float* dh, int32_t lddh, int32_t accumulate,
+                      float* dgamma, float* dbeta, float* dfilm, vmm_stream_t stream);
+int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, float* dx, int32_t lddx,
+                              int32_t accumulate, float* dgamma, int64_t rows, int32_t C, float eps, vmm_stream_t stream);
+/* softmax attention backward (mode 0 temporal, 1 mid spatial); qkv/out/lse as saved by the forward (q scaled+rotated, k rotated);
+ * writes dqkv (gradient of the raw to_qkv output: rotation and q-scale undone), accumulates dek/dev [B][ntok][heads*dh] and
+ * dbias [heads][T][T] with atomics (caller zeroes them); dbuf = scratch [rows*heads]. */
+int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
+                      int32_t tok_per_frame, const float* bias, int32_t bias_on_cond, const float* out, const float* dout, int32_t ldo,
+                      const float* lse, const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias,
+                      float* dbuf, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* linear attention backward; ctx and kstat (per (frame, head): max[32] | 1/sum[32] of the key softmax) saved by the forward */
+int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* ctx,
+                    const float* kstat, const float* dout, int32_t lddo, float* dctx /* [B*T*heads][32*32] scratch */, float* dqkv,
+                    float* dek, float* dev, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
+typedef struct vmm_dense_bwd_job {
+  const float* x; const float* w; const float* b; float* dy; float* dx; float* dw; float* db;
+  int32_t rows, K, N, ldx, lddy, lddx;
+  int32_t act_in, act_out, accumulate;
+} vmm_dense_bwd_job;
+int vmm_dense_bwd_batched(const vmm_dense_bwd_job* jobs_dev, int32_t njobs, int32_t max_N, int32_t max_xunits, vmm_stream_t stream);
+int vmm_cond_tokens_bwd(const float* cond, const uint8_t* mask, const float* dtokens, const float* dpooled, int32_t B, int32_t F, int32_t D,
+                        float* dw, float* dbias, float* dnull_token, vmm_stream_t stream);
+int vmm_rows_layernorm_affine_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t rows, int32_t D,
+                                  float eps, vmm_stream_t stream);
+int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dadd, int32_t B, int32_t D,
+                       vmm_stream_t stream);
+int vmm_relpos_bias_bwd(const float* dbias, const int32_t* buckets, int32_t n, int32_t heads, float* demb, vmm_stream_t stream);
+int vmm_tokens_from_hidden_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dhidden,
+                               float* dnull_token, vmm_stream_t stream);
+int vmm_conv1d_k4s2_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw, float* db, int32_t B,
+                             int32_t Cin, int32_t Cout, int32_t Lin, vmm_stream_t stream);
+int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t Cin, const float* w, const float* dout, int32_t B, int32_t Cout,
+                               int32_t T, int32_t HW, float* drows, int32_t lddr, float* dw, float* db, vmm_stream_t stream);
+/* d/dpred of mean|noise-pred| (or squared error) times the upstream scalar *gscale (NULL = 1) (vddp.py:1053-1056) */
+int vmm_loss_grad(const float* noise, const float* pred, int64_t n, int32_t squared, const float* gscale, float* dpred, vmm_stream_t stream);
+
+/* ---- K21: multi-tensor Adam (torch.optim.Adam defaults, vddp.py:1481,1633) and EMA (vddp.py:116-129) over a device job table */
+typedef struct vmm_optim_job { float* p; const float* g; float* m; float* v; int64_t n; } vmm_optim_job;
+int vmm_adam_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float lr, float beta1, float beta2, float eps, int32_t step,
+                  float grad_scale, vmm_stream_t stream);
+/* m (EMA weights) = copy_only ? p : beta*m + (1-beta)*p */
+int vmm_ema_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float beta, int32_t copy_only, vmm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,21 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+def _usable_cores() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
+    import torch
+
+    torch.set_num_threads(_usable_cores())  # the host may expose far more cores than the container's quota
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 

@@ -1,0 +1,62 @@
+"""N > 1 host logic on CPU with gloo (world_size 2): the bucketed tail-slice all-reduce and the sampling shard / gather rules."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videometamaterials_amd import hostmath
+        from videometamaterials_amd.dp import BucketedAllReduce
+        n = 10_000
+        flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        red = BucketedAllReduce(flat, n, bucket_floats=1500)
+        red.start()
+        for x in (9000, 8800, 7000, 6999, 3000, 100, 0):  # backward marks: the tail flat[x:] is final
+            red.mark(x)
+        red.finish()
+        want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok = torch.equal(flat, want)
+        covered = sorted(red.launched)
+        contiguous = covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        # sampling shards: contiguous floor(N/P) blocks, remainder on the last rank, pad -> all_gather -> strip
+        N_rows = 7
+        rows = hostmath.shard_rows(N_rows, rank, world, 2)
+        mine = torch.cat([torch.arange(a, b, dtype=torch.float32) for a, b in rows]) if rows else torch.zeros(0)
+        lengths = [sum(b - a for a, b in hostmath.shard_rows(N_rows, r, world, 2)) for r in range(world)]
+        max_len = max(lengths)
+        padded = torch.zeros(max_len)
+        padded[: mine.numel()] = mine
+        gathered = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(gathered, padded)
+        full = hostmath.strip_padding(torch.cat(gathered), lengths, max_len)
+        q.put((rank, ok, contiguous, len(red.launched), full.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_and_sharded_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, contiguous, nlaunch, full in res:
+        assert ok, f"rank {rank}: reduced buffer wrong"
+        assert contiguous, f"rank {rank}: buckets do not tile the buffer"
+        assert 2 <= nlaunch <= 7
+        assert full == [float(i) for i in range(7)]

@@ -113,7 +113,18 @@ def test_plan_construction_without_gpu():
     assert len(pl.steps) == len(pl.meta) > 200
     conv_flops = sum(f for k, f, _ in pl.meta if k == "vmm_conv_igemm_f32")
     assert conv_flops > 1e9
-    pl.refresh_weights(m._params_flat())
+    assert not pl.bwd_steps
     keep = plan.build_plan(m, B, T, H, W, cl, "cpu", training=True)
     assert keep.arena_floats > pl.arena_floats  # inference plans reuse dead buffers
     assert pl.out.shape == (B, 3, T, H, W) and pl.x_in.shape == (B, 3, T, H, W)
+    # training plan: a backward launch list and one flat gradient buffer covering exactly the parameters that receive gradients
+    with open(os.path.join(helpers.GOLDEN_DIR, "tables.json")) as f:
+        nograd = {k for k in json.load(f)["nograd_params_lagr16"] if not k.endswith("freqs")}
+    trainable = {k for k, _ in m.named_parameters()}
+    assert set(keep.param_slices) == trainable - nograd
+    assert len(keep.bwd_steps) > len(keep.steps)
+    # marks are monotone: later in the backward, a longer tail of the flat buffer is final
+    offs = [x for _, x in keep.bwd_marks]
+    assert offs == sorted(offs, reverse=True) and offs[-1] == 0
+    spans = sorted(keep.param_slices.values())
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))

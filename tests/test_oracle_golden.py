@@ -10,7 +10,6 @@ import helpers
 from oracle import diffusion_oracle as do
 from oracle import unet3d_oracle as uo
 
-torch.set_num_threads(max(1, os.cpu_count() or 1))
 RTOL = 2e-5  # oracle and reference are both CPU fp32; differences are summation-order only
 
 

@@ -50,16 +50,56 @@ class DenseJob(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """vmm_pack_job (include/vmm_kernels.h)."""
+
+    _fields_ = [("torch_w", c_ptr), ("packed", c_ptr)] + [(n, c_i32) for n in (
+        "TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate")]
+
+
+class DenseBwdJob(C.Structure):
+    """vmm_dense_bwd_job (include/vmm_kernels.h)."""
+
+    _fields_ = [("x", c_ptr), ("w", c_ptr), ("b", c_ptr), ("dy", c_ptr), ("dx", c_ptr), ("dw", c_ptr), ("db", c_ptr)] + [(n, c_i32) for n in (
+        "rows", "K", "N", "ldx", "lddy", "lddx", "act_in", "act_out", "accumulate")]
+
+
+class OptimJob(C.Structure):
+    """vmm_optim_job (include/vmm_kernels.h)."""
+
+    _fields_ = [("p", c_ptr), ("g", c_ptr), ("m", c_ptr), ("v", c_ptr), ("n", c_i64)]
+
+
 # name -> argtypes (restype is always int); must list EVERY symbol include/vmm_kernels.h declares
 SIGNATURES = {
     "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
+    "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_groupnorm_bwd": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32,
+                          c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_channel_layernorm_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i32, c_f32, c_ptr],
+    "vmm_attention_bwd": [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr,
+                          c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_dense_bwd_batched": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_cond_tokens_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_rows_layernorm_affine_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr],
+    "vmm_select_add_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_relpos_bias_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_tokens_from_hidden_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_conv1d_k4s2_silu_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_pointwise_to_ncthw_bwd": [c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_loss_grad": [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_adam_step": [c_ptr, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_ptr],
+    "vmm_ema_step": [c_ptr, c_i32, c_i64, c_f32, c_i32, c_ptr],
     "vmm_groupnorm_stats": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
     "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],
-    "vmm_temporal_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
-    "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
-    "vmm_linattn_context": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_temporal_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_linattn_context": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_linattn_apply": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
     "vmm_sinusoidal_embed": [c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr],

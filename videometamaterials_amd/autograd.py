@@ -1,6 +1,8 @@
-"""Training glue: the noise-prediction loss and the denoiser's backward pass as single autograd nodes.
+"""Autograd glue: the whole denoiser forward/backward is ONE autograd node (the backward is the hand-derived HIP launch
+list of the training plan, plan.py), so ``loss.backward()`` from the reference ``Trainer`` (vddp.py:1629) works unchanged.
 
-(Forward-only for now: the backward plan lands with the training milestone.)
+One forward -> one backward: the training plan keeps its intermediates in a static arena, so a second forward before
+the backward of the first would overwrite them (the reference training loop never does that, vddp.py:1620-1633).
 """
 from __future__ import annotations
 
@@ -10,17 +12,52 @@ from . import _native as N
 from .plan import _stream
 
 
-def noise_loss(noise: torch.Tensor, pred: torch.Tensor, squared: bool) -> torch.Tensor:
-    """F.l1_loss / F.mse_loss (vddp.py:1053-1056) through vmm_loss_reduce (fp64 accumulation)."""
-    if torch.is_grad_enabled() and pred.requires_grad:
-        raise NotImplementedError("backward pass of the HIP path is not built yet")
-    noise, pred = noise.contiguous(), pred.contiguous()
-    acc = torch.empty(1, dtype=torch.float64, device=pred.device)
-    out = torch.empty((), dtype=torch.float32, device=pred.device)
-    N.check(N.lib().vmm_loss_reduce(noise.data_ptr(), pred.data_ptr(), pred.numel(), 1 if squared else 0, acc.data_ptr(), out.data_ptr(), _stream()),
-            "vmm_loss_reduce")
-    return out
+class _UnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, plan, names, x, time, cond, mask, *params):
+        ctx.plan, ctx.names, ctx.model = plan, names, model
+        out = plan.run(x, time, cond, mask)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        pl = ctx.plan
+        pl.backward(dout.contiguous())
+        views = pl.grad_views(dict(ctx.model.named_parameters()))
+        grads = tuple(views[n].clone() if n in views else None for n in ctx.names)
+        return (None, None, None, None, None, None, None) + grads
 
 
 def unet_forward_with_grad(model, x, time, cond, mask):
-    raise NotImplementedError("backward pass of the HIP path is not built yet; call under torch.no_grad()")
+    B, _, T, H, W = x.shape
+    pl = model.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    names = tuple(n for n, _ in named)
+    return _UnetFn.apply(model, pl, names, x.contiguous(), time, cond.contiguous(), mask, *[p for _, p in named])
+
+
+class _NoiseLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, noise, pred, squared):
+        noise, pred = noise.contiguous(), pred.contiguous()
+        acc = torch.empty(1, dtype=torch.float64, device=pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        N.check(N.lib().vmm_loss_reduce(noise.data_ptr(), pred.data_ptr(), pred.numel(), 1 if squared else 0, acc.data_ptr(), out.data_ptr(), _stream()),
+                "vmm_loss_reduce")
+        ctx.save_for_backward(noise, pred)
+        ctx.squared = squared
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        noise, pred = ctx.saved_tensors
+        g = g.contiguous().float()
+        dpred = torch.empty_like(pred)
+        N.check(N.lib().vmm_loss_grad(noise.data_ptr(), pred.data_ptr(), pred.numel(), 1 if ctx.squared else 0, g.data_ptr(), dpred.data_ptr(), _stream()),
+                "vmm_loss_grad")
+        return None, dpred, None
+
+
+def noise_loss(noise: torch.Tensor, pred: torch.Tensor, squared: bool) -> torch.Tensor:
+    """F.l1_loss / F.mse_loss (vddp.py:1053-1056) through vmm_loss_reduce (fp64 accumulation) and vmm_loss_grad."""
+    return _NoiseLossFn.apply(noise, pred, squared)

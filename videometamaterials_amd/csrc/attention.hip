@@ -43,7 +43,7 @@ __device__ __forceinline__ void online_step(float s, const float* vrow, float& m
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
                                                             const float* __restrict__ ev, int ntok, const float* __restrict__ bias,
                                                             int bias_on_cond, float* __restrict__ out, int ldo, int B, int T, int HW,
-                                                            int heads) {
+                                                            int heads, float* __restrict__ lse) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * HW * heads * T;
   if (gid >= total) return;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     online_step(s, r + 2 * hid, m, l, acc);
   }
   const float inv = 1.0f / l;
+  if (lse) lse[(row0 + (long long)i * HW) * heads + head] = m + logf(l);
   float* o = out + (row0 + (long long)i * HW) * ldo + head * DH;
 #pragma unroll
   for (int d = 0; d < DH / 4; ++d) {
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
 constexpr int SA_TILE = 128;
 __global__ __launch_bounds__(128) void spatial_attn_kernel(const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
                                                            const float* __restrict__ ev, int ntok, int tok_per_frame,
-                                                           float* __restrict__ out, int ldo, int T, int HW, int heads) {
+                                                           float* __restrict__ out, int ldo, int T, int HW, int heads,
+                                                           float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) float Ks[SA_TILE][DH];
   __shared__ __attribute__((aligned(16))) float Vs[SA_TILE][DH];
   const int tid = threadIdx.x;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(128) void spatial_attn_kernel(const float* __restri
   }
   if (!qvalid) return;
   const float inv = 1.0f / l;
+  if (lse) lse[(row0 + qi) * heads + head] = m + logf(l);
   float* o = out + (row0 + qi) * ldo + head * DH;
 #pragma unroll
   for (int d = 0; d < DH / 4; ++d) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void linattn_partial_kernel(const float* __res
 // pass 2: merge the splits and the conditioning tokens; block per (frame, head), 256 threads as (d, e0)
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ ek,
                                                             const float* __restrict__ ev, int ntok, int T, int HW, int heads,
-                                                            float* __restrict__ ctx) {
+                                                            float* __restrict__ ctx, float* __restrict__ kstat) {
   const int tid = threadIdx.x;
   const int fh = blockIdx.x;
   const int head = fh % heads;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* __restr
       c[0] = fmaf(p, vv.x, c[0]); c[1] = fmaf(p, vv.y, c[1]); c[2] = fmaf(p, vv.z, c[2]); c[3] = fmaf(p, vv.w, c[3]);
     }
   }
+  if (kstat && (tid & 7) == 0) { kstat[(long long)fh * 2 * DH + d] = m; kstat[(long long)fh * 2 * DH + DH + d] = 1.0f / ssum; }
   const float sc = 1.0f / (ssum * (float)HW);  // softmax normaliser and v / (h*w) (vddp.py:371)
   *reinterpret_cast<f32x4*>(ctx + (long long)fh * DH * DH + d * DH + e0) = (f32x4){c[0] * sc, c[1] * sc, c[2] * sc, c[3] * sc};
 }
@@ -272,37 +276,37 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 
 extern "C" int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                                       const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T,
-                                      int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
+                                      int32_t HW, int32_t heads, int32_t dh, float* lse, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
   if (bias_on_cond && ek && ntok != T) return -2;  // the reference's in-place add needs tokens == frames
   const long long total = (long long)B * HW * heads * T;
   hipLaunchKernelGGL(temporal_attn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, ldqkv, ek, ev, ntok,
-                     bias, bias_on_cond, out, ldo, B, T, HW, heads);
+                     bias, bias_on_cond, out, ldo, B, T, HW, heads, lse);
   VMM_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmm_spatial_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                                      int32_t tok_per_frame, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
-                                     int32_t heads, int32_t dh, vmm_stream_t stream) {
+                                     int32_t heads, int32_t dh, float* lse, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
   if (tok_per_frame && ek && ntok != T) return -2;
   hipLaunchKernelGGL(spatial_attn_kernel, dim3(cdiv(HW, SA_TILE), B * T * heads), dim3(SA_TILE), 0, (hipStream_t)stream, qkv,
-                     ldqkv, ek, ev, ntok, tok_per_frame, out, ldo, T, HW, heads);
+                     ldqkv, ek, ev, ntok, tok_per_frame, out, ldo, T, HW, heads, lse);
   VMM_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B,
                                    int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part, float* ctx,
-                                   vmm_stream_t stream) {
+                                   float* kstat, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || nsplit < 1) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int rows_per_split = cdiv(cdiv(HW, nsplit), LA_TILE) * LA_TILE;
   hipLaunchKernelGGL(linattn_partial_kernel, dim3(nsplit, B * T * heads), dim3(256), 0, s, qkv, ldqkv, HW, heads, nsplit,
                      rows_per_split, part);
   VMM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * T * heads), dim3(256), 0, s, part, nsplit, ek, ev, ntok, T, HW, heads, ctx);
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * T * heads), dim3(256), 0, s, part, nsplit, ek, ev, ntok, T, HW, heads, ctx, kstat);
   VMM_LAUNCH_CHECK();
   return 0;
 }

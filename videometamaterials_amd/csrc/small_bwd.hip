@@ -1,0 +1,298 @@
+// Backward of the small host-of-the-network pieces (training path): tiny dense layers, conditioning tokens,
+// embeddings, the NCTHW output projection, the loss.  Sizes are a few thousand elements; everything is
+// atomics-into-zeroed-buffers for simplicity, one launch per dependency level.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float act_f(float v, int act) { return act == 1 ? silu_f(v) : (act == 2 ? gelu_erf_f(v) : v); }
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == 1) { const float s = 1.0f / (1.0f + expf(-v)); return s * (1.0f + v * (1.0f - s)); }
+  if (act == 2) return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+  return 1.0f;
+}
+
+// Stage 1, one wave per (job, output column o): recompute z = act_in(x) W^T + b, g = dy * act_out'(z) (written back over dy),
+// dW[o,:] (=|+=) sum_r g_r act_in(x_r,:), db[o] (=|+=) sum_r g_r.      K <= 1024, rows processed in chunks of 64.
+__global__ __launch_bounds__(256) void dense_bwd_w_kernel(const vmm_dense_bwd_job* __restrict__ jobs) {
+  __shared__ float gsh[4][64];
+  const vmm_dense_bwd_job jb = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int o = blockIdx.x * 4 + wv;
+  if (o >= jb.N) return;
+  const float* wrow = jb.w + (long long)o * jb.K;
+  const float bv = jb.b ? jb.b[o] : 0.f;
+  float db = 0.f;
+  float dwv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) dwv[t] = 0.f;
+  for (int r0 = 0; r0 < jb.rows; r0 += 64) {
+    const int nr = min(64, jb.rows - r0);
+    for (int r = 0; r < nr; ++r) {
+      float part = 0.f;
+      for (int k = lane; k < jb.K; k += 64) part = fmaf(act_f(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), wrow[k], part);
+      const float z = wave_sum(part) + bv;
+      const float g = jb.dy[(long long)(r0 + r) * jb.lddy + o] * act_grad(z, jb.act_out);
+      db += g;
+      if (lane == 0) { gsh[wv][r] = g; jb.dy[(long long)(r0 + r) * jb.lddy + o] = g; }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = lane + 64 * t;
+      if (k < jb.K)
+        for (int r = 0; r < nr; ++r) dwv[t] = fmaf(gsh[wv][r], act_f(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), dwv[t]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int k = lane + 64 * t;
+    if (k < jb.K && jb.dw) {
+      float* p = jb.dw + (long long)o * jb.K + k;
+      *p = jb.accumulate ? *p + dwv[t] : dwv[t];
+    }
+  }
+  if (lane == 0 && jb.db) jb.db[o] = jb.accumulate ? jb.db[o] + db : db;
+}
+
+// Stage 2, one wave per (job, row r, chunk of 64 input columns): dx[r,k] += act_in'(x[r,k]) * sum_o g[r,o] W[o,k]  (atomic: several
+// jobs of one launch may share x, e.g. the conditioning tokens feed every to_k / to_v)
+__global__ __launch_bounds__(256) void dense_bwd_x_kernel(const vmm_dense_bwd_job* __restrict__ jobs) {
+  const vmm_dense_bwd_job jb = jobs[blockIdx.y];
+  if (!jb.dx) return;
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int kchunks = (jb.K + 63) / 64;
+  if (unit >= jb.rows * kchunks) return;
+  const int r = unit / kchunks, k = (unit % kchunks) * 64 + lane;
+  if (k >= jb.K) return;
+  float acc = 0.f;
+  for (int o = 0; o < jb.N; ++o) acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
+  atomicAdd(&jb.dx[(long long)r * jb.lddx + k], acc * act_grad(jb.x[(long long)r * jb.ldx + k], jb.act_in));
+}
+
+// tokens[b,f,d] = cond[b,f]*w[d] + bias[d] (or null token), pooled = mean_f of the un-dropped tokens; thread per d
+__global__ void cond_tokens_bwd_kernel(const float* __restrict__ cond, const uint8_t* __restrict__ mask, const float* __restrict__ dtokens,
+                                       const float* __restrict__ dpooled, int B, int F, int D, float* __restrict__ dw, float* __restrict__ dbias,
+                                       float* __restrict__ dnull) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float gw = 0.f, gb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const bool drop = mask && mask[b];
+    const float gp = dpooled ? dpooled[b * D + d] / (float)F : 0.f;
+    for (int f = 0; f < F; ++f) {
+      const float gt = dtokens[((long long)b * F + f) * D + d];
+      const float g = (drop ? 0.f : gt) + gp;
+      gw = fmaf(g, cond[b * F + f], gw);
+      gb += g;
+      if (drop) dnull[f * D + d] += gt;  // exclusive owner of column d: no atomics needed
+    }
+  }
+  dw[d] += gw;
+  dbias[d] += gb;
+}
+
+// y = LN(x)*w + b over rows; wave per row
+__global__ __launch_bounds__(64) void rows_ln_affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw,
+                                                                float* __restrict__ db, int D, float eps) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* xr = x + (long long)row * D;
+  const float* gr = dy + (long long)row * D;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s += xr[k];
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float a1 = 0.f, a2 = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float xh = (xr[k] - mean) * rstd, g = gr[k] * w[k];
+    a1 += g;
+    a2 += g * xh;
+    atomicAdd(&dw[k], gr[k] * xh);
+    atomicAdd(&db[k], gr[k]);
+  }
+  a1 = wave_sum(a1) / (float)D;
+  a2 = wave_sum(a2) / (float)D;
+  for (int k = lane; k < D; k += 64) {
+    const float xh = (xr[k] - mean) * rstd;
+    atomicAdd(&dx[(long long)row * D + k], rstd * (gr[k] * w[k] - a1 - xh * a2));
+  }
+}
+
+// out[b,:] = (mask ? null : x[b,:]) + add[b,:]
+__global__ void select_add_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                      float* __restrict__ dnull, float* __restrict__ dadd, int B, int D) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float gn = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = dout[b * D + d];
+    if (mask && mask[b]) gn += g; else if (dx) dx[b * D + d] += g;
+    if (dadd) dadd[b * D + d] += g;
+  }
+  if (dnull) dnull[d] += gn;
+}
+
+__global__ void relpos_bias_bwd_kernel(const float* __restrict__ dbias, const int32_t* __restrict__ buckets, int n, int heads,
+                                       float* __restrict__ demb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= heads * n * n) return;
+  const int h = i / (n * n), ij = i - h * n * n;
+  atomicAdd(&demb[buckets[ij] * heads + h], dbias[i]);
+}
+
+// tokens[b,n,:] = mask ? null[n,:] : hidden[b,:]
+__global__ void tokens_from_hidden_bwd_kernel(const float* __restrict__ dtokens, const uint8_t* __restrict__ mask, int B, int N, int D,
+                                              float* __restrict__ dhidden, float* __restrict__ dnull) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  const int d = i % D, n = i / D;
+  for (int b = 0; b < B; ++b) {
+    const float g = dtokens[((long long)b * N + n) * D + d];
+    if (mask && mask[b]) dnull[i] += g; else atomicAdd(&dhidden[b * D + d], g);
+  }
+}
+
+// y = silu(conv1d_k4s2(x)); thread per output element, atomics into dx/dw/db
+__global__ void conv1d_k4s2_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                            const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                            int B, int Cin, int Cout, int Lin, int Lout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Cout * Lout) return;
+  const int l = i % Lout, co = (i / Lout) % Cout, b = i / (Lout * Cout);
+  float z = bias[co];
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int k = 0; k < 4; ++k) {
+      const int p = l * 2 - 1 + k;
+      if (p >= 0 && p < Lin) z = fmaf(x[((long long)b * Cin + ci) * Lin + p], w[((long long)co * Cin + ci) * 4 + k], z);
+    }
+  const float g = dy[i] * act_grad(z, 1);
+  atomicAdd(&db[co], g);
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int k = 0; k < 4; ++k) {
+      const int p = l * 2 - 1 + k;
+      if (p >= 0 && p < Lin) {
+        atomicAdd(&dw[((long long)co * Cin + ci) * 4 + k], g * x[((long long)b * Cin + ci) * Lin + p]);
+        if (dx) atomicAdd(&dx[((long long)b * Cin + ci) * Lin + p], g * w[((long long)co * Cin + ci) * 4 + k]);
+      }
+    }
+}
+
+// out[b,co,t,hw] = bias[co] + sum_ci rows[r,ci] w[co,ci]: drows (=), dw/db (atomics, block-reduced)
+__global__ __launch_bounds__(256) void pointwise_to_ncthw_bwd_kernel(const float* __restrict__ rows, int ld, int Cin, const float* __restrict__ w,
+                                                                     const float* __restrict__ dout, int Cout, int T, int HW,
+                                                                     float* __restrict__ drows, int lddr, float* __restrict__ dw,
+                                                                     float* __restrict__ db, long long nrows) {
+  extern __shared__ float sh[];  // w[Cout*Cin] | dwacc[Cout*Cin] | dbacc[Cout]
+  float* ws = sh;
+  float* dwa = sh + Cout * Cin;
+  float* dba = dwa + Cout * Cin;
+  for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) { ws[i] = w[i]; dwa[i] = 0.f; }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) dba[i] = 0.f;
+  __syncthreads();
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long long)gridDim.x * blockDim.x) {
+    const int hw = (int)(r % HW);
+    const int t = (int)((r / HW) % T);
+    const long long b = r / ((long long)HW * T);
+    for (int co = 0; co < Cout; ++co) atomicAdd(&dba[co], dout[((b * Cout + co) * T + t) * HW + hw]);
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float xv = rows[r * ld + ci];
+      float acc = 0.f;
+      for (int co = 0; co < Cout; ++co) {
+        const float g = dout[((b * Cout + co) * T + t) * HW + hw];
+        acc = fmaf(g, ws[co * Cin + ci], acc);
+        atomicAdd(&dwa[co * Cin + ci], g * xv);
+      }
+      drows[r * lddr + ci] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) atomicAdd(&dw[i], dwa[i]);
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) atomicAdd(&db[i], dba[i]);
+}
+
+// d loss / d pred for mean |noise - pred| or mean (noise - pred)^2, times the upstream scalar gradient
+__global__ void loss_grad_kernel(const float* __restrict__ noise, const float* __restrict__ pred, long long n, int squared,
+                                 const float* __restrict__ gscale, float* __restrict__ dpred) {
+  const float gs = (gscale ? gscale[0] : 1.0f) / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = pred[i] - noise[i];
+    dpred[i] = squared ? 2.0f * d * gs : (d > 0.f ? gs : (d < 0.f ? -gs : 0.f));
+  }
+}
+
+}  // namespace
+
+extern "C" int vmm_dense_bwd_batched(const vmm_dense_bwd_job* jobs_dev, int32_t njobs, int32_t max_N, int32_t max_xunits,
+                                     vmm_stream_t stream) {
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(max_N, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  VMM_LAUNCH_CHECK();
+  if (max_xunits > 0) {
+    hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(max_xunits, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    VMM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+extern "C" int vmm_cond_tokens_bwd(const float* cond, const uint8_t* mask, const float* dtokens, const float* dpooled, int32_t B, int32_t F,
+                                   int32_t D, float* dw, float* dbias, float* dnull_token, vmm_stream_t stream) {
+  hipLaunchKernelGGL(cond_tokens_bwd_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, cond, mask, dtokens, dpooled, B, F, D, dw, dbias,
+                     dnull_token);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_rows_layernorm_affine_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t rows,
+                                             int32_t D, float eps, vmm_stream_t stream) {
+  hipLaunchKernelGGL(rows_ln_affine_bwd_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, x, w, dy, dx, dw, db, D, eps);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dadd, int32_t B, int32_t D,
+                                  vmm_stream_t stream) {
+  hipLaunchKernelGGL(select_add_bwd_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dout, mask, dx, dnull_row, dadd, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_relpos_bias_bwd(const float* dbias, const int32_t* buckets, int32_t n, int32_t heads, float* demb, vmm_stream_t stream) {
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(cdiv(heads * n * n, 256)), dim3(256), 0, (hipStream_t)stream, dbias, buckets, n, heads, demb);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_tokens_from_hidden_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dhidden,
+                                          float* dnull_token, vmm_stream_t stream) {
+  hipLaunchKernelGGL(tokens_from_hidden_bwd_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, (hipStream_t)stream, dtokens, mask, B, N, D, dhidden,
+                     dnull_token);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_conv1d_k4s2_silu_bwd(const float* x, const float* w, const float* bias, const float* dy, float* dx, float* dw, float* db,
+                                        int32_t B, int32_t Cin, int32_t Cout, int32_t Lin, vmm_stream_t stream) {
+  const int Lout = (Lin + 2 - 4) / 2 + 1;
+  hipLaunchKernelGGL(conv1d_k4s2_silu_bwd_kernel, dim3(cdiv(B * Cout * Lout, 128)), dim3(128), 0, (hipStream_t)stream, x, w, bias, dy, dx, dw, db, B,
+                     Cin, Cout, Lin, Lout);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t Cin, const float* w, const float* dout, int32_t B, int32_t Cout,
+                                          int32_t T, int32_t HW, float* drows, int32_t lddr, float* dw, float* db, vmm_stream_t stream) {
+  if (Cout * Cin > 4096) return -1;
+  const long long nrows = (long long)B * T * HW;
+  const int blocks = (int)max(1LL, min((long long)cdiv(nrows, 256), 512LL));
+  const size_t shm = sizeof(float) * (2 * Cout * Cin + Cout);
+  hipLaunchKernelGGL(pointwise_to_ncthw_bwd_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, rows, ld, Cin, w, dout, Cout, T, HW, drows,
+                     lddr, dw, db, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_loss_grad(const float* noise, const float* pred, int64_t n, int32_t squared, const float* gscale, float* dpred,
+                             vmm_stream_t stream) {
+  const int blocks = (int)max(1LL, min((long long)cdiv(n, 256), 4096LL));
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, noise, pred, (long long)n, squared, gscale, dpred);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,191 @@
+// Weight-gradient GEMM and weight (un)packing for the training path (gfx950, exact fp32 on the matrix cores).
+//
+// wgrad:  dWp[(tap, ci)][co] += sum_m A[(img, a*stride + dh(tap), b*stride + dw(tap)), ci] * dY[orow(m), co]
+// i.e. the same gather as the forward implicit GEMM (igemm_conv.hip) with the reduction running over the
+// rows m.  Each workgroup owns a 64 x 64 tile of dWp for one slice of the rows and adds it with fp32 atomics
+// (the slices of one tile are spread over blockIdx.z).  LDS tiles are row-major by m, which is exactly the
+// operand order of v_mfma_f32_32x32x2_f32 for A^T * dY: no transposes anywhere.
+//
+// pack:   one batched launch converts every torch-layout weight into the k-major operand layouts the forward /
+// data-gradient GEMMs read, and (direction = 1) scatters packed weight gradients back into torch layout.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+constexpr int WK = 16;  // rows per K chunk
+constexpr int WI = 64, WJ = 64;
+
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, const float* __restrict__ dy, int lddy,
+                                                        float* __restrict__ dw, long long rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float As[2][WK][WI];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WK][WJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const int Cin = p.C1 + p.C2;
+  const int Ktot = p.KH * p.KW * Cin;
+  const int i0 = blockIdx.x * WI, j0 = blockIdx.y * WJ;
+  const long long M = (long long)p.nimg * p.Hv * p.Wv;
+  const long long m_begin = (long long)blockIdx.z * rows_per_split;
+  const long long m_end = min(m_begin + rows_per_split, M);
+  if (m_begin >= m_end) return;
+  const int nk = (int)((m_end - m_begin + WK - 1) / WK);
+
+  // loader roles: 16 rows x 16 float4 for both tiles
+  const int lr = tid >> 4, l4 = tid & 15;
+  // A column (tap, ci) of this thread is fixed
+  const int ia = i0 + l4 * 4;
+  const bool ivalid = ia < Ktot;
+  int tap = ivalid ? ia / Cin : 0;
+  const int ci = ia - tap * Cin;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int dh = p.off_h + p.sgn_h * kh, dwo = p.off_w + p.sgn_w * kw;
+  const int jb = j0 + l4 * 4;
+  const bool jvalid = jb < p.Cout;
+  const bool identity_rows = (p.oscale == 1 && p.Hout == p.Hv && p.Wout == p.Wv && p.ooh == 0 && p.oow == 0);
+  const int hw = p.Hv * p.Wv;
+
+  f32x4 areg, breg;
+  auto load_chunk = [&](int kc) {
+    const long long m = m_begin + (long long)kc * WK + lr;
+    areg = (f32x4){0.f, 0.f, 0.f, 0.f};
+    breg = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      const int img = (int)(m / hw);
+      const int rem = (int)(m - (long long)img * hw);
+      const int a = rem / p.Wv, b = rem - a * p.Wv;
+      if (ivalid) {
+        const int ih = a * p.stride + dh, iw = b * p.stride + dwo;
+        if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
+          const long long pix = ((long long)img * p.Hin + ih) * p.Win + iw;
+          if (ci < p.C1) {
+            areg = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci);
+            if (p.a_mode == 1) {
+              const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + ci) * 2;
+              const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
+              const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
+              areg.x = silu_f(areg.x * c0.x + c0.y);
+              areg.y = silu_f(areg.y * c0.z + c0.w);
+              areg.z = silu_f(areg.z * c1.x + c1.y);
+              areg.w = silu_f(areg.w * c1.z + c1.w);
+            }
+          } else {
+            areg = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci - p.C1));
+          }
+        }
+      }
+      if (jvalid) {
+        long long orow = m;
+        if (!identity_rows) orow = ((long long)img * p.Hout + a * p.oscale + p.ooh) * p.Wout + b * p.oscale + p.oow;
+        breg = *reinterpret_cast<const f32x4*>(dy + orow * lddy + jb);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    *reinterpret_cast<f32x4*>(&As[buf][lr][l4 * 4]) = areg;
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr][l4 * 4]) = breg;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  const int l31 = lane & 31, lk = lane >> 5;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) load_chunk(kc + 1);
+#pragma unroll
+    for (int kk = 0; kk < WK; kk += 2) {
+      const float av = As[buf][kk + lk][wi * 32 + l31];
+      const float bv = Bs[buf][kk + lk][wj * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (kc + 1 < nk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int j = j0 + wj * 32 + l31;
+    if (i < Ktot && j < p.Cout) atomicAdd(&dw[(long long)i * p.Cout + j], acc[r]);
+  }
+}
+
+// column sums: out[j] += sum_m x[m, j]   (bias gradients; also per-channel reductions elsewhere)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, long long rows, int C, float* __restrict__ out,
+                                                     long long rows_per_block) {
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int col4 = tid % c4n, rl = tid / c4n, rslots = 256 / c4n;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (rl < rslots)
+    for (long long r = r0 + rl; r < r1; r += rslots) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + col4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  __shared__ f32x4 sh[256];
+  sh[tid] = s;
+  __syncthreads();
+  if (tid < c4n) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < rslots; ++k) { const f32x4 v = sh[k * c4n + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    atomicAdd(&out[tid * 4 + 0], t.x); atomicAdd(&out[tid * 4 + 1], t.y);
+    atomicAdd(&out[tid * 4 + 2], t.z); atomicAdd(&out[tid * 4 + 3], t.w);
+  }
+}
+
+// batched (un)pack: packed[(th*TW + tw)*Cp + c][n]  <->  torch[ n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw ]
+__global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
+  const vmm_pack_job jb = jobs[blockIdx.y];
+  const long long total = (long long)jb.TH * jb.TW * jb.Cp * jb.N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % jb.N);
+    long long k = i / jb.N;
+    const int c = (int)(k % jb.Cp);
+    k /= jb.Cp;
+    const int tw = (int)(k % jb.TW), th = (int)(k / jb.TW);
+    const long long so = (long long)n * jb.sn + (long long)c * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh + (long long)(jb.w0 + tw * jb.ws) * jb.sw;
+    if (direction == 0) {
+      jb.packed[i] = (c < jb.C) ? jb.torch_w[so] : 0.f;
+    } else if (c < jb.C) {
+      if (jb.accumulate) jb.torch_w[so] += jb.packed[i]; else jb.torch_w[so] = jb.packed[i];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit,
+                                  vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || (lddy & 3) || nsplit < 1) return -1;
+  const long long M = (long long)d.nimg * d.Hv * d.Wv;
+  const int Ktot = d.KH * d.KW * (d.C1 + d.C2);
+  const long long rps = (cdiv(M, nsplit) + WK - 1) / WK * WK;
+  dim3 grid(cdiv(Ktot, WI), cdiv(d.Cout, WJ), cdiv(M, rps));
+  hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dy, lddy, dw_packed, rps);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream) {
+  if ((C & 3) || (ldx & 3) || C > 1024) return -1;
+  const int rslots = 256 / (C >> 2);
+  long long blocks = min((long long)cdiv(rows, rslots * 16), 1024LL);
+  if (blocks < 1) blocks = 1;
+  const long long rpb = cdiv(rows, blocks);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)rows, C, out, rpb);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream) {
+  if (njobs <= 0) return 0;
+  const int bx = (int)max(1LL, min((long long)cdiv(max_elems, 256 * 4), 64LL));
+  hipLaunchKernelGGL(pack_kernel, dim3(bx, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, direction);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

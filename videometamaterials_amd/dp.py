@@ -1,0 +1,196 @@
+"""Data-parallel training and sharded sampling over RCCL (replaces the reference's Accelerate + Gloo wrapper,
+main.py:31-34, vddp.py:1449, 1594-1672, 1506-1532, 1745-1749).
+
+One process per GPU; `torch.distributed` backend "nccl" IS RCCL on ROCm (gloo in the CPU tests).
+* Training: every rank runs the same training plan on its own minibatch (per-GPU batch = model.yaml `batch_size`), the
+  hand-written backward fills ONE flat fp32 gradient buffer laid out in first-use order, and `BucketedAllReduce` sums
+  contiguous tail slices of that buffer on a side stream as soon as the backward marks them final -- the all-reduce of
+  the deep layers overlaps the backward of the shallow ones.  The 31 parameters that never receive gradients in the
+  Lagrangian config are simply absent from the buffer (static set => no DDP unused-parameter bitmap exchange).
+  Then one multi-tensor Adam launch (gradient pre-scaled by 1/world) and, every 10 steps, one EMA launch.
+* Sampling: rows of the conditioning matrix are split exactly like Trainer.cond_to_gpu; results are padded to the longest
+  shard, all-gathered once and un-padded like Trainer.remove_padding.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from . import hostmath
+from .plan import _stream
+
+
+class BucketedAllReduce:
+    """Sum-all-reduce of a flat gradient buffer in contiguous buckets, driven by "tail is final" marks.
+
+    mark(X) promises that flat[X:] will not change any more.  Finished tail slices are merged until they reach
+    `bucket_floats`, then reduced asynchronously (on `comm_stream` for CUDA tensors).  finish() flushes the rest and
+    makes the caller's stream wait for every bucket."""
+
+    def __init__(self, flat: torch.Tensor, n_valid: int, bucket_floats: int = 6_400_000, group=None):
+        self.flat, self.n, self.bucket = flat, n_valid, bucket_floats
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cuda = flat.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.hi = n_valid
+        self.works = []
+        self.launched: List[Tuple[int, int]] = []
+
+    def start(self) -> None:
+        self.hi = self.n
+        self.works, self.launched = [], []
+
+    def _reduce(self, lo: int, hi: int) -> None:
+        if hi <= lo or self.world == 1:
+            return
+        sl = self.flat[lo:hi]
+        self.launched.append((lo, hi))
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()  # everything enqueued so far on the compute stream produced flat[lo:hi]
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def mark(self, x: int) -> None:
+        x = max(0, min(x, self.hi))
+        if self.hi - x >= self.bucket or x == 0:
+            self._reduce(x, self.hi)
+            self.hi = x
+
+    def finish(self) -> None:
+        self._reduce(0, self.hi)
+        self.hi = 0
+        for w in self.works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class DataParallelTrainer:
+    """Minimal counterpart of the reference Trainer's inner loop (vddp.py:1612-1640) for the HIP path."""
+
+    def __init__(self, diffusion, *, train_lr: float = 1e-4, ema_decay: float = 0.995, step_start_ema: int = 2000, update_ema_every: int = 10,
+                 null_cond_prob: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8, bucket_floats: int = 6_400_000, group=None):
+        self.model = diffusion
+        self.unet = diffusion.denoise_fn
+        self.ema_model = copy.deepcopy(diffusion)  # vddp.py:1453
+        self.lr, self.betas, self.eps = train_lr, betas, eps
+        self.ema_decay, self.step_start_ema, self.update_ema_every = ema_decay, step_start_ema, update_ema_every
+        self.null_cond_prob = null_cond_prob
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.step = 0
+        self.bucket_floats = bucket_floats
+        self._plan = None
+        self._reducer = None
+        self._adam_table = self._ema_table = None
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self) -> None:
+        """DDP's constructor broadcast (rank 0 -> all), SURVEY C1."""
+        for p in list(self.model.parameters()) + list(self.model.buffers()):
+            dist.broadcast(p.data, src=0, group=self.group)
+        self.ema_model.load_state_dict(self.model.state_dict())
+
+    # ------------------------------------------------------------------ setup for one input shape
+    def _prepare(self, x, cond):
+        B, _, T, H, W = x.shape
+        pl = self.unet.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True)
+        if pl is not self._plan:
+            self._plan = pl
+            dev = x.device
+            self.m_buf = torch.zeros_like(pl.pgrad)
+            self.v_buf = torch.zeros_like(pl.pgrad)
+            params = dict(self.unet.named_parameters())
+            ema_params = dict(self.ema_model.denoise_fn.named_parameters())
+            jobs = (N.OptimJob * len(pl.param_slices))()
+            ejobs = (N.OptimJob * len(params))()
+            self._max_n = 0
+            for i, (name, (off, n)) in enumerate(pl.param_slices.items()):
+                j = jobs[i]
+                j.p, j.g = params[name].data_ptr(), pl.pgrad.data_ptr() + 4 * off
+                j.m, j.v, j.n = self.m_buf.data_ptr() + 4 * off, self.v_buf.data_ptr() + 4 * off, n
+                self._max_n = max(self._max_n, n)
+            for i, (name, p) in enumerate(params.items()):  # EMA covers every parameter (vddp.py:121-124)
+                j = ejobs[i]
+                j.p, j.m, j.n = p.data_ptr(), ema_params[name].data_ptr(), p.numel()
+                self._max_n = max(self._max_n, p.numel())
+            self._adam_table = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), len(jobs))
+            self._ema_table = (torch.frombuffer(bytearray(bytes(ejobs)), dtype=torch.uint8).to(dev), len(ejobs))
+            self._ptr_sig = tuple(p.data_ptr() for p in params.values()) + tuple(p.data_ptr() for p in ema_params.values())
+            self._reducer = BucketedAllReduce(pl.pgrad, pl.pgrad_floats, self.bucket_floats, self.group)
+            self._acc = torch.empty(1, dtype=torch.float64, device=dev)
+            self._loss = torch.empty((), dtype=torch.float32, device=dev)
+        return pl
+
+    # ------------------------------------------------------------------ one optimisation step
+    def train_step(self, x: torch.Tensor, cond: torch.Tensor, *, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                   mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x in [0,1] (B,C,T,H,W), cond (B,F).  Returns the (device) loss of this rank.  t / noise / mask may be injected."""
+        d, lib = self.model, N.lib()
+        B = x.shape[0]
+        dev = x.device
+        pl = self._prepare(x, cond)
+        self.step += 1
+        t = torch.randint(0, d.num_timesteps, (B,), device=dev).long() if t is None else t  # vddp.py:1065
+        noise = torch.randn_like(x) if noise is None else noise  # vddp.py:1047
+        mask = self.unet._mask(B, self.null_cond_prob, dev) if mask is None else mask  # vddp.py:749
+        per = x.numel() // B
+        # x*2-1 and q_sample fused, straight into the plan's input slot (vddp.py:1066,1036-1042)
+        N.check(lib.vmm_q_sample(x.contiguous().data_ptr(), noise.contiguous().data_ptr(), t.data_ptr(), d.sqrt_alphas_cumprod.data_ptr(),
+                                 d.sqrt_one_minus_alphas_cumprod.data_ptr(), 1, pl.x_in.data_ptr(), B, per, _stream()), "vmm_q_sample")
+        pl.time_in.copy_(t)
+        pl.cond_in.copy_(cond)
+        pl.mask_in.copy_(mask)
+        # the plan re-packs its operand layouts from the live parameters (one launch) -- they changed in the last optimiser step
+        pl.refresh_weights(self.unet._params_flat())
+        pl.launch()
+        sq = 1 if d.loss_type == "l2" else 0
+        N.check(lib.vmm_loss_reduce(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, self._acc.data_ptr(), self._loss.data_ptr(), _stream()), "loss")
+        N.check(lib.vmm_loss_grad(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, None, pl.dout.data_ptr(), _stream()), "loss grad")
+        self._reducer.start()
+        pl.backward(None, on_mark=self._reducer.mark if self.world > 1 else None)
+        self._reducer.finish()
+        b1, b2 = self.betas
+        tab, n = self._adam_table
+        N.check(lib.vmm_adam_step(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, self.step, 1.0 / self.world, _stream()), "vmm_adam_step")
+        if self.step % self.update_ema_every == 0:  # vddp.py:1637-1639, 1500-1504
+            tab, n = self._ema_table
+            N.check(lib.vmm_ema_step(tab.data_ptr(), n, self._max_n, self.ema_decay, 1 if self.step < self.step_start_ema else 0, _stream()), "vmm_ema_step")
+        return self._loss
+
+    # ------------------------------------------------------------------ sharded sampling (vddp.py:1506-1532, 1816-1845)
+    @torch.no_grad()
+    def sample_sharded(self, cond_all: torch.Tensor, guidance_scale: float = 5.0, batch: int = 2, use_ema: bool = True) -> Optional[torch.Tensor]:
+        """Every rank samples its contiguous block of rows; rank 0 returns the (N, C, T, H, W) result, others None."""
+        model = self.ema_model if use_ema else self.model
+        dev = next(model.parameters()).device
+        if self.world > 1:  # the reference broadcasts the conditioning matrix as a pickled object; here: one raw tensor
+            cond_all = cond_all.to(dev).contiguous()
+            dist.broadcast(cond_all, src=0, group=self.group)
+        outs = [model.sample(cond=cond_all[a:b].to(dev), guidance_scale=guidance_scale) for a, b in
+                hostmath.shard_rows(cond_all.shape[0], self.rank, self.world, batch)]
+        shp = (model.channels, model.num_frames, model.image_size, model.image_size)
+        mine = torch.cat(outs, dim=0) if outs else torch.zeros((0,) + shp, device=dev)
+        if self.world == 1:
+            return mine
+        lengths = [len(range(*r)) for rk in range(self.world) for r in [(0, sum(b - a for a, b in hostmath.shard_rows(cond_all.shape[0], rk, self.world, batch)))]]
+        max_len = max(lengths)
+        padded = torch.zeros((max_len,) + shp, device=dev)
+        padded[: mine.shape[0]] = mine
+        gathered = [torch.empty_like(padded) for _ in range(self.world)]
+        dist.all_gather(gathered, padded, group=self.group)
+        if self.rank != 0:
+            return None
+        return hostmath.strip_padding(torch.cat(gathered, dim=0), lengths, max_len)

@@ -6,6 +6,13 @@ input shape.  It is built once (``build_plan``), its device addresses never chan
 makes the whole denoiser capturable into a hipGraph (diffusion.py does that for the
 256-step sampling loop).
 
+Inference plans reuse dead buffers (first-fit arena).  Training plans keep every
+intermediate, and carry a second launch list -- the hand-derived backward pass -- that
+writes parameter gradients (torch layout) into ONE flat buffer ordered by first use in
+the forward pass.  The backward list is annotated with marks "every gradient at offset
+>= X is final now", so the data-parallel engine (dp.py) can all-reduce contiguous tail
+slices of the buffer over RCCL while the rest of the backward is still running.
+
 Working layout: every feature map is "rows x channels" fp32 with rows = (b, t, h, w)
 (frame-major channels-last).  See DESIGN.md for the kernel inventory and data layout.
 """
@@ -24,6 +31,7 @@ from . import hostmath
 ALIGN = 64  # floats (256 B)
 LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
+PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate")
 
 
 def _stream() -> C.c_void_p:
@@ -68,8 +76,8 @@ class _Arena:
         self.peak = max(self.peak, self.top)
         return off
 
-    def free(self, off: int, n: int) -> None:
-        if self.keep_all:
+    def free(self, off: int, n: int, force: bool = False) -> None:
+        if self.keep_all and not force:
             return
         n = (n + ALIGN - 1) // ALIGN * ALIGN
         fl = self.free_list
@@ -87,25 +95,56 @@ class _Arena:
         self.free_list = merged
 
 
+def _pack_table(jobs: List[dict], base_of: Callable[[dict], int]):
+    arr = (N.PackJob * len(jobs))()
+    max_elems = 0
+    for i, j in enumerate(jobs):
+        a = arr[i]
+        a.torch_w = base_of(j)
+        a.packed = j["packed"]
+        for f in PACK_FIELDS:
+            setattr(a, f, j.get(f, 0))
+        max_elems = max(max_elems, j["TH"] * j["TW"] * j["Cp"] * j["N"])
+    return arr, max_elems
+
+
 class Plan:
     def __init__(self):
         self.steps: List[Tuple[Callable, tuple, str]] = []
         self.meta: List[Tuple[str, float, float]] = []  # per step: (kernel family, algorithmic flops, algorithmic bytes)
+        self.bwd_steps: List[Tuple[Callable, tuple, str]] = []
+        self.bwd_meta: List[Tuple[str, float, float]] = []
+        self.bwd_marks: List[Tuple[int, int]] = []  # (index into bwd_steps, X): gradients at float offsets >= X are final after that step
         self.arena: Optional[torch.Tensor] = None
         self.wbuf: Optional[torch.Tensor] = None
-        self.packers: List[Tuple[int, int, Callable]] = []  # (off, n, fn(params) -> tensor)
+        self.pgrad: Optional[torch.Tensor] = None  # flat parameter gradients, torch layouts, first-use order
+        self.gscratch: Optional[torch.Tensor] = None  # zeroed every backward: packed weight grads + atomically accumulated grads
+        self.pack_jobs: List[dict] = []  # forward / data-gradient operand layouts (torch -> packed)
+        self.pack_table = None  # (device tensor, njobs, max_elems, pointer signature)
+        self.param_slices: Dict[str, Tuple[int, int]] = {}  # name -> (offset, numel) in pgrad
         self.keepalive: list = []
-        self.x_in = self.time_in = self.cond_in = self.mask_in = self.out = None
+        self.x_in = self.time_in = self.cond_in = self.mask_in = self.out = self.dout = None
         self.weights_version = None
         self.named: Dict[str, Act] = {}  # debug taps (name -> feature map)
         self.shape = None
+        self.training = False
+        self.arena_floats = 0
 
+    # ------------------------------------------------------------------ weights
     def refresh_weights(self, params: Dict[str, torch.Tensor]) -> None:
-        with torch.no_grad():
-            for off, n, fn in self.packers:
-                src = fn(params).reshape(-1)
-                self.wbuf[off:off + src.numel()].copy_(src)
+        """Re-pack every operand layout from the current parameter values: ONE batched HIP launch."""
+        sig = tuple(params[j["name"]].data_ptr() for j in self.pack_jobs)
+        if self.pack_table is None or self.pack_table[3] != sig:
+            for j in self.pack_jobs:
+                if not params[j["name"]].is_contiguous():
+                    raise RuntimeError(f"parameter {j['name']} must be contiguous")
+            arr, mx = _pack_table(self.pack_jobs, lambda j: params[j["name"]].data_ptr() + 4 * j.get("src_off", 0))
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.wbuf.device)
+            self.pack_table = (dev, len(self.pack_jobs), mx, sig)
+        dev, n, mx, _ = self.pack_table
+        N.check(N.lib().vmm_pack_weights(dev.data_ptr(), n, mx, 0, _stream()), "vmm_pack_weights")
 
+    # ------------------------------------------------------------------ forward
     def launch(self) -> None:
         s = _stream()
         for fn, args, what in self.steps:
@@ -113,11 +152,11 @@ class Plan:
             if rc != 0:
                 N.check(rc, what)
 
-    def launch_timed(self) -> List[float]:
+    def launch_timed(self, steps=None) -> List[float]:
         """Replay with a HIP event pair around every launch (on the current stream); returns ms per step."""
         s = _stream()
         evs = []
-        for fn, args, what in self.steps:
+        for fn, args, what in (self.steps if steps is None else steps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args, s)
@@ -137,38 +176,67 @@ class Plan:
         self.launch()
         return self.out
 
+    # ------------------------------------------------------------------ backward (training plans)
+    def backward(self, dout: Optional[torch.Tensor] = None, on_mark: Optional[Callable[[int], None]] = None) -> torch.Tensor:
+        """Run the backward launch list for the forward just executed.  `dout` = d loss / d output (B,C,T,H,W)
+        (or already written to self.dout).  Returns the flat gradient buffer; `on_mark(X)` is called as soon as every
+        gradient at float offsets >= X is final (dp.py starts the all-reduce of that slice on its own stream)."""
+        assert self.training
+        if dout is not None:
+            self.dout.copy_(dout)
+        self.pgrad.zero_()
+        self.gscratch.zero_()
+        s = _stream()
+        marks = dict(self.bwd_marks)
+        for i, (fn, args, what) in enumerate(self.bwd_steps):
+            rc = fn(*args, s)
+            if rc != 0:
+                N.check(rc, what)
+            if on_mark is not None and i in marks:
+                on_mark(marks[i])
+        return self.pgrad
+
+    def grad_views(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        return {k: self.pgrad[o:o + n].view(params[k].shape) for k, (o, n) in self.param_slices.items() if k in params}
+
     def tap(self, name: str) -> torch.Tensor:
-        """Debug: a (rows, C) view of a named intermediate (only meaningful for keep_all plans)."""
+        """Debug: a (rows, C) view of a named intermediate (only meaningful for training plans)."""
         a = self.named[name]
         return self.arena[a.off:a.off + a.n].view(-1, a.C)
 
 
 def cfg_combine(eps_c: torch.Tensor, eps_n: torch.Tensor, w: float) -> torch.Tensor:
-    """null + (cond - null) * w  (vddp.py:728), on device through the diffusion kernel set."""
+    """null + (cond - null) * w  (vddp.py:728), same association as the reference."""
     out = torch.empty_like(eps_c)
-    lib = N.lib()
-    # predict_x0 with c_recip = 0, c_recipm1 = -1 would also do it; a dedicated axpby keeps the rounding of the reference:
-    # null + (cond - null) * w  ==  vmm_predict_x0's eps formula, exposed via vmm_axpby on (cond - null) is not bit-identical,
-    # so the guidance formula lives in vmm_cfg_combine.
-    rc = lib.vmm_cfg_combine(eps_c.data_ptr(), eps_n.data_ptr(), C.c_float(w), out.data_ptr(), eps_c.numel(), _stream())
+    rc = N.lib().vmm_cfg_combine(eps_c.data_ptr(), eps_n.data_ptr(), C.c_float(w), out.data_ptr(), eps_c.numel(), _stream())
     N.check(rc, "vmm_cfg_combine")
     return out
 
 
 # ====================================================================================== builder
 class _Builder:
-    def __init__(self, model, B, T, H, W, cond_len, device, base_ptr: int, wbase_ptr: int, keep_all: bool):
+    def __init__(self, model, B, T, H, W, cond_len, device, bases: Tuple[int, int, int, int], training: bool):
         self.m = model
         self.B, self.T, self.H, self.W, self.cond_len = B, T, H, W, cond_len
         self.device = device
-        self.base, self.wbase = base_ptr, wbase_ptr
-        self.arena = _Arena(keep_all)
-        self.wtop = 0
+        self.base, self.wbase, self.pgbase, self.gsbase = bases
+        self.training = training
+        self.arena = _Arena(keep_all=training)
+        self.wtop = self.pgtop = self.gstop = 0
         self.plan = Plan()
+        self.plan.training = training
         self.lib = N.lib()
         self.shapes = {k: tuple(v.shape) for k, v in model._params_flat().items()}
+        self.trainable = {k for k, p in model.named_parameters() if p.requires_grad}
         self.G = model.resnet_groups
         self.heads = model.attn_heads
+        self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
+        self.unpack_jobs: List[dict] = []
+        self.gacts: Dict[int, Act] = {}  # activation offset -> gradient buffer
+        self.gwritten: set = set()
+        self.in_bwd = False
+        self.job_uploads: List[Tuple[int, torch.Tensor]] = []
+        self.raw_slots: Dict[str, int] = {}
 
     # ---------------------------------------------------------------- memory
     def alloc(self, n: int) -> int:
@@ -188,29 +256,116 @@ class _Builder:
     def free_act(self, a: Act) -> None:
         self.free(a.off, a.n)
 
-    def wslot(self, n: int, packer: Callable) -> int:
-        """Reserve n floats in the packed-weight buffer; `packer(params) -> tensor` fills it on refresh."""
+    def tmp_free(self, a) -> None:
+        """Release a backward-phase temporary (allowed even in keep-all plans: it was allocated after every forward buffer)."""
+        if isinstance(a, Act):
+            self.arena.free(a.off, a.n, force=True)
+        else:
+            self.arena.free(a[0], a[1], force=True)
+
+    def scratch(self, n: int) -> int:
+        """Pointer to n floats that are zero at the start of every backward pass."""
+        off = self.gstop
+        self.gstop += (n + ALIGN - 1) // ALIGN * ALIGN
+        return self.gsbase + off * 4
+
+    def _touch(self, name: str) -> None:
+        """Fix the position of a parameter's gradient in the flat buffer: order of first use in the forward."""
+        if name not in self.plan.param_slices and name in self.trainable:
+            n = int(math.prod(self.shapes[name]))
+            self.plan.param_slices[name] = (self.pgtop, n)
+            self.pgtop += (n + 3) // 4 * 4
+
+    def pg(self, name: str) -> int:
+        """Device pointer of the (torch-layout) gradient of parameter `name`; 0 if it is frozen."""
+        self._touch(name)
+        if name not in self.plan.param_slices:
+            return 0
+        return self.pgbase + self.plan.param_slices[name][0] * 4
+
+    def wslot(self, n: int) -> int:
         off = self.wtop
         self.wtop += (n + ALIGN - 1) // ALIGN * ALIGN
-        self.plan.packers.append((off, n, packer))
         return self.wbase + off * 4
 
+    def pack(self, name: str, n_elems: int, want_grad: bool = True, **desc) -> Tuple[int, int]:
+        """Register an operand layout of parameter `name` (see vmm_pack_job); returns (packed ptr, packed-gradient ptr)."""
+        self._touch(name)
+        ptr = self.wslot(n_elems)
+        job = dict(name=name, packed=ptr, **desc)
+        self.plan.pack_jobs.append(job)
+        gptr = 0
+        if self.training and want_grad and name in self.trainable:
+            gptr = self.scratch(n_elems)
+            self.unpack_jobs.append(dict(job, packed=gptr, accumulate=1))
+        return ptr, gptr
+
     def wraw(self, name: str) -> int:
-        """Static copy of a parameter in its torch layout."""
-        n = int(math.prod(self.shapes[name]))
-        return self.wslot(n, lambda p, name=name: p[name])
+        """Static copy of a parameter in its torch layout (one per parameter)."""
+        if name not in self.raw_slots:
+            n = int(math.prod(self.shapes[name]))
+            self.raw_slots[name] = self.pack(name, n, want_grad=False, TH=1, TW=1, C=1, Cp=1, N=n, sn=1)[0]
+        return self.raw_slots[name]
+
+    def pack_conv(self, name: str, pad_cin_to: int = 0) -> Tuple[int, int]:
+        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, ci)][Cout]"""
+        co, ci, _, kh, kw = self.shapes[name]
+        cip = max(ci, pad_cin_to)
+        return self.pack(name, kh * kw * cip * co, TH=kh, TW=kw, C=ci, Cp=cip, N=co, sn=ci * kh * kw, sc=kh * kw, sh=kw, sw=1, hs=1, ws=1)
+
+    def pack_conv_dgrad(self, name: str, ci0: int, nci: int) -> int:
+        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, co)][ci0 : ci0+nci]  (data gradient of a stride-1 conv; the descriptor mirrors the taps)"""
+        co, ci, _, kh, kw = self.shapes[name]
+        return self.pack(name, kh * kw * co * nci, want_grad=False, TH=kh, TW=kw, C=co, Cp=co, N=nci, sn=kh * kw, sc=ci * kh * kw, sh=kw, sw=1, hs=1, ws=1,
+                         src_off=ci0 * kh * kw)[0]
+
+    def pack_linear(self, name: str) -> Tuple[int, int]:
+        """(out, in[,1,1[,1]]) -> [in][out]"""
+        shp = self.shapes[name]
+        co, ci = shp[0], shp[1]
+        return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1)
+
+    def pack_linear_slice(self, name: str, ci0: int, nci: int) -> int:
+        """torch (out, in) restricted to input columns [ci0, ci0+nci) as [out][nci]: the k-major operand of the data gradient."""
+        co, ci = self.shapes[name][0], self.shapes[name][1]
+        return self.pack(name, co * nci, want_grad=False, TH=1, TW=1, C=co, Cp=co, N=nci, sn=1, sc=ci, src_off=ci0)[0]
 
     def step(self, fn, args: tuple, what: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
-        self.plan.steps.append((fn, args, what))
-        self.plan.meta.append((fn.__name__, float(flops), float(nbytes)))
+        if self.in_bwd:
+            self.plan.bwd_steps.append((fn, args, what))
+            self.plan.bwd_meta.append((fn.__name__, float(flops), float(nbytes)))
+        else:
+            self.plan.steps.append((fn, args, what))
+            self.plan.meta.append((fn.__name__, float(flops), float(nbytes)))
+
+    def on_backward(self, emit: Callable[[], None], pg_start: int, uj_start: int) -> None:
+        if self.training:
+            self.tape.append((emit, pg_start, uj_start))
+
+    # ---------------------------------------------------------------- gradient bookkeeping
+    def grad_of(self, a: Act) -> Tuple[Act, int]:
+        """(gradient buffer of activation a, accumulate flag for the next writer)."""
+        g = self.gacts.get(a.off)
+        if g is None:
+            off = self.alloc(a.n)
+            g = Act(off, a.C, a.H, a.W, a.n, self.ptr(off))
+            self.gacts[a.off] = g
+        acc = 1 if a.off in self.gwritten else 0
+        self.gwritten.add(a.off)
+        return g, acc
+
+    def add_into(self, dst: Act, src_ptr: int) -> None:
+        """grad(dst) += src (or = src for the first writer)."""
+        g, acc = self.grad_of(dst)
+        self.step(self.lib.vmm_lincomb, (src_ptr, g.ptr if acc else None, None, 1.0, 1.0, 0.0, 0.0, g.ptr, g.n), "grad accumulate", nbytes=12.0 * g.n)
 
     # ---------------------------------------------------------------- emitters
-    def conv(self, *, a1: Act, a2: Optional[Act] = None, w: int, bias: int = 0, Cout: int, KH: int = 1, KW: int = 1, stride: int = 1,
-             off: Tuple[int, int] = (0, 0), sgn: Tuple[int, int] = (1, 1), out_ptr: int, ldo: int, Hv: int, Wv: int, Hout: int = 0,
-             Wout: int = 0, oscale: int = 1, oo: Tuple[int, int] = (0, 0), res_ptr: int = 0, ldres: int = 0, rot_tab: int = 0,
-             rot_ncols: int = 0, q_scale: float = 1.0, q_ncols: int = 0, a_coef: int = 0, what: str = "conv", a1_C: Optional[int] = None):
+    def conv_desc(self, *, a1: Act, a2: Optional[Act] = None, w: int, bias: int = 0, Cout: int, KH: int = 1, KW: int = 1, stride: int = 1,
+                  off: Tuple[int, int] = (0, 0), sgn: Tuple[int, int] = (1, 1), out_ptr: int, ldo: int, Hv: int, Wv: int, Hout: int = 0,
+                  Wout: int = 0, oscale: int = 1, oo: Tuple[int, int] = (0, 0), res_ptr: int = 0, ldres: int = 0, rot_tab: int = 0,
+                  rot_ncols: int = 0, q_scale: float = 1.0, q_ncols: int = 0, a_coef: int = 0) -> "N.ConvDesc":
         d = N.ConvDesc()
-        d.a1, d.C1, d.lda1 = a1.ptr, (a1_C if a1_C is not None else a1.C), a1.ld
+        d.a1, d.C1, d.lda1 = a1.ptr, a1.C, a1.ld
         if a2 is not None:
             d.a2, d.C2, d.lda2 = a2.ptr, a2.C, a2.ld
         d.w, d.bias = w, bias or None
@@ -226,147 +381,270 @@ class _Builder:
         d.q_scale, d.q_ncols = q_scale, q_ncols
         d.a_mode, d.a_coef, d.a_imgs_per_sample = (1 if a_coef else 0), a_coef or None, self.T
         self.plan.keepalive.append(d)
-        M = d.nimg * Hv * Wv
-        K = KH * KW * (d.C1 + d.C2)
+        return d
+
+    def conv(self, what: str = "conv", **kw) -> "N.ConvDesc":
+        d = self.conv_desc(**kw)
+        M = d.nimg * d.Hv * d.Wv
+        K = d.KH * d.KW * (d.C1 + d.C2)
         # algorithmic work: every input element, weight and output element touched once
-        nbytes = 4.0 * (d.nimg * a1.H * a1.W * (d.C1 + d.C2) + K * Cout + M * Cout + (M * Cout if res_ptr else 0))
-        self.step(self.lib.vmm_conv_igemm_f32, (C.byref(d),), what, flops=2.0 * M * K * Cout, nbytes=nbytes)
+        nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
+        self.step(self.lib.vmm_conv_igemm_f32, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+        return d
 
-    def pack_conv(self, name: str, pad_cin_to: int = 0) -> int:
-        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, ci)][Cout]"""
-        co, ci, _, kh, kw = self.shapes[name]
-        cip = max(ci, pad_cin_to)
+    def wgrad(self, d: "N.ConvDesc", dy_ptr: int, lddy: int, gw_ptr: int, what: str) -> None:
+        if not gw_ptr:
+            return
+        M = d.nimg * d.Hv * d.Wv
+        K = d.KH * d.KW * (d.C1 + d.C2)
+        tiles = -(-K // 64) * -(-d.Cout // 64)
+        nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
+        self.step(self.lib.vmm_conv_wgrad_f32, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit), what + " wgrad", flops=2.0 * M * K * d.Cout,
+                  nbytes=4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout))
 
-        def packer(p, name=name, ci=ci, cip=cip):
-            w = p[name][:, :, 0].permute(2, 3, 1, 0)  # kh kw ci co
-            if cip != ci:
-                w = torch.nn.functional.pad(w, (0, 0, 0, cip - ci))
-            return w.contiguous()
+    def colsum(self, x_ptr: int, ldx: int, rows: int, C_: int, out_ptr: int, what: str) -> None:
+        if out_ptr:
+            self.step(self.lib.vmm_colsum_accumulate, (x_ptr, ldx, rows, C_, out_ptr), what + " bias grad", nbytes=4.0 * rows * C_)
 
-        return self.wslot(kh * kw * cip * co, packer)
-
-    def pack_linear(self, name: str) -> int:
-        """(out, in[,1,1[,1]]) -> [in][out]"""
-        shp = self.shapes[name]
-        co, ci = shp[0], shp[1]
-        return self.wslot(co * ci, lambda p, name=name, co=co, ci=ci: p[name].reshape(co, ci).t().contiguous())
-
-    def pack_convT_phase(self, name: str, ph: int, pw: int) -> int:
-        """ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'."""
-        ci, co = self.shapes[name][0], self.shapes[name][1]
-
-        def packer(p, name=name, ph=ph, pw=pw):
-            w = p[name][:, :, 0]  # ci co kh kw
-            w = w[:, :, [1 - ph, 3 - ph], :][:, :, :, [1 - pw, 3 - pw]]
-            return w.permute(2, 3, 0, 1).contiguous()  # kh' kw' ci co
-
-        return self.wslot(4 * ci * co, packer)
-
-    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int) -> Tuple[int, int, int]:
-        """GroupNorm statistics of h and the fused (scale, shift) coefficients; returns (coef_off, n, ptr)."""
+    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int):
+        """GroupNorm statistics of h and the fused (scale, shift) coefficients; returns (coef_off, n, ptr, stats_ptr)."""
         B, G, C_ = self.B, self.G, h.C
         rows_ps = self.T * h.H * h.W
         sums_off = self.alloc(B * G * 4)
         coef_off = self.alloc(B * C_ * 2)
-        self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats")
+        stats_ptr = self.ptr(self.alloc(B * G * 2)) if self.training else 0
+        self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
         self.step(self.lib.vmm_groupnorm_coef,
                   (self.ptr(sums_off), rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
-                   film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), None), prefix + ".norm coef")
+                   film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None), prefix + ".norm coef")
         self.free(sums_off, B * G * 4)
-        return coef_off, B * C_ * 2, self.ptr(coef_off)
+        return coef_off, B * C_ * 2, self.ptr(coef_off), stats_ptr
 
-    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film_ptr: int) -> Act:
-        """ResnetBlock (vddp.py:287-311): conv-GN-FiLM-SiLU, conv-GN-SiLU, + res_conv(x)."""
+    def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
+        B, G, C_ = self.B, self.G, h.C
+        n_sc = B * C_ * 2 + B * G * 2
+        sc = self.alloc(n_sc)
+        gnw = self.pg(prefix + ".norm.weight") or self.scratch(C_)
+        gnb = self.pg(prefix + ".norm.bias") or self.scratch(C_)
+        self.step(self.lib.vmm_groupnorm_bwd,
+                  (dz_ptr, C_, h.ptr, h.ld, coef_ptr, stats_ptr, self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"), film_ptr or None, ldfilm,
+                   B, self.T * h.H * h.W, C_, G, self.ptr(sc), dh_ptr, C_, 0, gnw, gnb, dfilm_ptr or None), prefix + ".norm bwd", nbytes=20.0 * h.n)
+        self.tmp_free((sc, n_sc))
+
+    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film: Optional[Tuple[int, int]]) -> Act:
+        """ResnetBlock (vddp.py:287-311): conv-GN-FiLM-SiLU, conv-GN-SiLU, + res_conv(x).  film = (ptr, grad ptr)."""
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         Cout = self.shapes[name + ".block1.proj.weight"][0]
         H, W = x1.H, x1.W
         rows = self.B * self.T * H * W
+        film_ptr, dfilm_ptr = film if film else (0, 0)
+        w1, gw1 = self.pack_conv(name + ".block1.proj.weight")
         h1 = self.act(Cout, H, W)
-        self.conv(a1=x1, a2=x2, w=self.pack_conv(name + ".block1.proj.weight"), bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3,
-                  off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".block1.proj")
-        c1_off, c1_n, c1_ptr = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout)
+        d1 = self.conv(a1=x1, a2=x2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
+                       Wv=W, what=name + ".block1.proj")
+        c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout)
+        w2, gw2 = self.pack_conv(name + ".block2.proj.weight")
         h2 = self.act(Cout, H, W)
-        self.conv(a1=h1, w=self.pack_conv(name + ".block2.proj.weight"), bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3,
-                  off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W, a_coef=c1_ptr, what=name + ".block2.proj")
+        d2 = self.conv(a1=h1, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
+                       a_coef=c1_ptr, what=name + ".block2.proj")
         self.free_act(h1)
         self.free(c1_off, c1_n)
-        c2_off, c2_n, c2_ptr = self.gn_coef(h2, name + ".block2", 0, 0)
-        if (name + ".res_conv.weight") in self.shapes:
+        c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0)
+        has_res = (name + ".res_conv.weight") in self.shapes
+        out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
+        dr, gwr = None, 0
+        if has_res:
+            wr, gwr = self.pack_linear(name + ".res_conv.weight")
             r = self.act(Cout, H, W)
-            self.conv(a1=x1, a2=x2, w=self.pack_linear(name + ".res_conv.weight"), bias=self.wraw(name + ".res_conv.bias"), Cout=Cout,
-                      out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv")
+            dr = self.conv(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv")
             res_ptr, ldres = r.ptr, Cout
         else:
             assert x2 is None and x1.C == Cout
             r, res_ptr, ldres = None, x1.ptr, x1.ld
-        self.step(self.lib.vmm_affine_silu, (h2.ptr, Cout, c2_ptr, res_ptr, ldres, h2.ptr, Cout, rows, self.T * H * W, Cout), name + " out")
+        self.step(self.lib.vmm_affine_silu, (h2.ptr, Cout, c2_ptr, res_ptr, ldres, out.ptr, Cout, rows, self.T * H * W, Cout), name + " out", nbytes=12.0 * h2.n)
         if r is not None:
             self.free_act(r)
         self.free(c2_off, c2_n)
-        self.plan.named[name] = h2
-        return h2
+        self.plan.named[name] = out
+
+        def bwd():
+            gout, _ = self.grad_of(out)  # complete by now
+            srcs = [(x1, 0)] + ([(x2, x1.C)] if x2 is not None else [])
+            if has_res:  # residual branch through the 1x1 conv
+                self.wgrad(dr, gout.ptr, Cout, gwr, name + ".res_conv")
+                self.colsum(gout.ptr, Cout, rows, Cout, self.pg(name + ".res_conv.bias"), name + ".res_conv")
+                for xs, c0 in srcs:
+                    gx, acc = self.grad_of(xs)
+                    self.conv(a1=gout, w=self.pack_linear_slice(name + ".res_conv.weight", c0, xs.C), Cout=xs.C, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
+                              res_ptr=gx.ptr if acc else 0, ldres=xs.C, what=name + ".res_conv dgrad")
+            else:
+                self.add_into(x1, gout.ptr)
+            # main branch: GN2+SiLU, conv2, GN1+FiLM+SiLU, conv1
+            dh2 = self.act(Cout, H, W)
+            self.gn_bwd(name + ".block2", gout.ptr, h2, c2_ptr, st2, 0, 0, dh2.ptr, 0)
+            self.wgrad(d2, dh2.ptr, Cout, gw2, name + ".block2.proj")
+            self.colsum(dh2.ptr, Cout, rows, Cout, self.pg(name + ".block2.proj.bias"), name + ".block2.proj")
+            da1 = self.act(Cout, H, W)
+            self.conv(a1=dh2, w=self.pack_conv_dgrad(name + ".block2.proj.weight", 0, Cout), Cout=Cout, KH=3, KW=3, off=(1, 1), sgn=(-1, -1), out_ptr=da1.ptr,
+                      ldo=Cout, Hv=H, Wv=W, what=name + ".block2.proj dgrad")
+            self.tmp_free(dh2)
+            self.gn_bwd(name + ".block1", da1.ptr, h1, c1_ptr, st1, film_ptr, 2 * Cout, da1.ptr, dfilm_ptr)  # in place: dh1 overwrites da1
+            self.wgrad(d1, da1.ptr, Cout, gw1, name + ".block1.proj")
+            self.colsum(da1.ptr, Cout, rows, Cout, self.pg(name + ".block1.proj.bias"), name + ".block1.proj")
+            for xs, c0 in srcs:
+                gx, acc = self.grad_of(xs)
+                self.conv(a1=da1, w=self.pack_conv_dgrad(name + ".block1.proj.weight", c0, xs.C), Cout=xs.C, KH=3, KW=3, off=(1, 1), sgn=(-1, -1),
+                          out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W, res_ptr=gx.ptr if acc else 0, ldres=xs.C, what=name + ".block1.proj dgrad")
+            self.tmp_free(da1)
+        self.on_backward(bwd, pg_start, uj_start)
+        return out
 
     def layernorm(self, x: Act, gamma_name: str) -> Act:
         y = self.act(x.C, x.H, x.W)
         rows = self.B * self.T * x.H * x.W
-        self.step(self.lib.vmm_channel_layernorm, (x.ptr, x.ld, self.wraw(gamma_name), y.ptr, y.ld, rows, x.C, C.c_float(1e-5)), gamma_name)
+        self.step(self.lib.vmm_channel_layernorm, (x.ptr, x.ld, self.wraw(gamma_name), y.ptr, y.ld, rows, x.C, C.c_float(1e-5)), gamma_name, nbytes=8.0 * x.n)
         return y
 
-    def linear_attn_block(self, name: str, x: Act, ekv: Optional[Tuple[int, int, int]]) -> Act:
+    def layernorm_bwd(self, x: Act, gamma_name: str, dy_ptr: int) -> None:
+        gx, acc = self.grad_of(x)
+        rows = self.B * self.T * x.H * x.W
+        gg = self.pg(gamma_name) or self.scratch(x.C)
+        self.step(self.lib.vmm_channel_layernorm_bwd, (x.ptr, x.ld, self.wraw(gamma_name), dy_ptr, x.C, gx.ptr, x.C, acc, gg, rows, x.C, C.c_float(1e-5)),
+                  gamma_name + " bwd", nbytes=16.0 * x.n)
+
+    def token_kv_bwd(self, site: str) -> None:
+        """d(ek), d(ev) of one attention site -> dense backward jobs (collected, launched with the embedding backward)."""
+        pfx, eo, vo, geo, gvo, rotated = self.ekv_info[site]
+        if rotated:
+            self.step(self.lib.vmm_rotary_rows, (geo, self.rot_t_ptr, self.B, self.ntok, self.heads, 32), site + " un-rotate d(ek)")
+        D, hid, rows = self.m.cond_dim, 32 * self.heads, self.B * self.ntok
+        for wname, gy in ((pfx + ".to_k.weight", geo), (pfx + ".to_v.weight", gvo)):
+            self.bwd_lvl3.append(dict(x=self.tokens_ptr, w=self.wraw(wname), dy=gy, dx=self.dtokens_ptr, dw=self.pg(wname), rows=rows, K=D, N=hid))
+
+    def linear_attn_block(self, name: str, x: Act, site: Optional[str]) -> Act:
         """Residual(PreNorm(SpatialLinearAttention)) (vddp.py:313-378, 679)."""
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         B, T, heads = self.B, self.T, self.heads
         hid = 32 * heads
         HW = x.H * x.W
+        rows = B * T * HW
         y = self.layernorm(x, name + ".fn.norm.gamma")
+        wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight")
         qkv = self.act(3 * hid, x.H, x.W)
-        self.conv(a1=y, w=self.pack_linear(name + ".fn.fn.to_qkv.weight"), Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv")
+        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv")
         self.free_act(y)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
         part_n, ctx_n = B * T * heads * nsplit * LA_PART, B * T * heads * 1024
         part, ctx = self.alloc(part_n), self.alloc(ctx_n)
-        ek, ev, ntok = ekv if ekv else (0, 0, 0)
-        self.step(self.lib.vmm_linattn_context, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, B, T, HW, heads, 32, nsplit, self.ptr(part), self.ptr(ctx)),
-                  name + " context")
+        kstat_ptr = self.ptr(self.alloc(B * T * heads * 64)) if self.training else 0
+        ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
+        ntok = self.ntok if site else 0
+        self.step(self.lib.vmm_linattn_context, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, B, T, HW, heads, 32, nsplit, self.ptr(part), self.ptr(ctx),
+                                                 kstat_ptr or None), name + " context", nbytes=4.0 * rows * 2 * hid)
         o = self.act(hid, x.H, x.W)
-        self.step(self.lib.vmm_linattn_apply, (qkv.ptr, 3 * hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply")
+        self.step(self.lib.vmm_linattn_apply, (qkv.ptr, 3 * hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply", nbytes=4.0 * rows * 2 * hid)
         self.free_act(qkv)
         self.free(part, part_n)
         self.free(ctx, ctx_n)
+        wo, gwo = self.pack_linear(name + ".fn.fn.to_out.weight")
         out = self.act(x.C, x.H, x.W)
-        self.conv(a1=o, w=self.pack_linear(name + ".fn.fn.to_out.weight"), bias=self.wraw(name + ".fn.fn.to_out.bias"), Cout=x.C, out_ptr=out.ptr,
-                  ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out")
+        do = self.conv(a1=o, w=wo, bias=self.wraw(name + ".fn.fn.to_out.bias"), Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld,
+                       what=name + " to_out")
         self.free_act(o)
         self.plan.named[name] = out
+
+        def bwd():
+            gout, _ = self.grad_of(out)
+            self.add_into(x, gout.ptr)  # residual
+            self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
+            self.colsum(gout.ptr, x.C, rows, x.C, self.pg(name + ".fn.fn.to_out.bias"), name + " to_out")
+            go = self.act(hid, x.H, x.W)
+            self.conv(a1=gout, w=self.wraw(name + ".fn.fn.to_out.weight"), Cout=hid, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_out dgrad")
+            gqkv = self.act(3 * hid, x.H, x.W)
+            dctx = self.alloc(ctx_n)
+            geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
+            self.step(self.lib.vmm_linattn_bwd, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.ptr(ctx), kstat_ptr, go.ptr, hid, self.ptr(dctx), gqkv.ptr,
+                                                 geo or None, gvo or None, B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 7 * hid)
+            self.tmp_free(go)
+            self.tmp_free((dctx, ctx_n))
+            self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
+            gy = self.act(x.C, x.H, x.W)
+            self.conv(a1=gqkv, w=self.wraw(name + ".fn.fn.to_qkv.weight"), Cout=x.C, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W, what=name + " to_qkv dgrad")
+            self.tmp_free(gqkv)
+            self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+            self.tmp_free(gy)
+            if site:
+                self.token_kv_bwd(site)
+        self.on_backward(bwd, pg_start, uj_start)
         return out
 
-    def softmax_attn_block(self, name: str, x: Act, ekv: Optional[Tuple[int, int, int]], *, temporal: bool) -> Act:
+    def softmax_attn_block(self, name: str, x: Act, site: Optional[str], *, temporal: bool) -> Act:
         """Residual(PreNorm(EinopsToAndFrom(Attention))) (vddp.py:396-535; 615/630/680 temporal, 687-689 mid spatial)."""
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         B, T, heads = self.B, self.T, self.heads
         hid = 32 * heads
         HW = x.H * x.W
+        rows = B * T * HW
         p = name + ".fn.fn.fn"
         y = self.layernorm(x, name + ".fn.norm.gamma")
+        wq, gwq = self.pack_linear(p + ".to_qkv.weight")
         qkv = self.act(3 * hid, x.H, x.W)
-        self.conv(a1=y, w=self.pack_linear(p + ".to_qkv.weight"), Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W,
-                  rot_tab=self.rot_ptr if temporal else 0, rot_ncols=2 * hid if temporal else 0, q_scale=32 ** -0.5, q_ncols=hid, what=name + " to_qkv")
+        q_scale = 32 ** -0.5
+        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
+                       rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv")
         self.free_act(y)
         o = self.act(hid, x.H, x.W)
-        ek, ev, ntok = ekv if ekv else (0, 0, 0)
+        ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
+        ntok = self.ntok if site else 0
+        lse_ptr = self.ptr(self.alloc(rows * heads)) if self.training else 0
+        pfc = 1 if self.m.per_frame_cond else 0
         if temporal:
-            self.step(self.lib.vmm_temporal_attention,
-                      (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, 1 if self.m.per_frame_cond else 0, o.ptr, hid, B, T, HW, heads, 32),
-                      name + " core")
+            self.step(self.lib.vmm_temporal_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
+                                                        lse_ptr or None), name + " core", nbytes=4.0 * rows * 4 * hid)
         else:
-            self.step(self.lib.vmm_spatial_attention,
-                      (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, 1 if self.m.per_frame_cond else 0, o.ptr, hid, B, T, HW, heads, 32), name + " core")
+            self.step(self.lib.vmm_spatial_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, pfc, o.ptr, hid, B, T, HW, heads, 32, lse_ptr or None),
+                      name + " core", nbytes=4.0 * rows * 4 * hid)
         self.free_act(qkv)
+        wo, gwo = self.pack_linear(p + ".to_out.weight")
         out = self.act(x.C, x.H, x.W)
-        self.conv(a1=o, w=self.pack_linear(p + ".to_out.weight"), Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld,
-                  what=name + " to_out")
+        do = self.conv(a1=o, w=wo, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out")
         self.free_act(o)
         self.plan.named[name] = out
+
+        def bwd():
+            gout, _ = self.grad_of(out)
+            self.add_into(x, gout.ptr)
+            self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
+            go = self.act(hid, x.H, x.W)
+            self.conv(a1=gout, w=self.wraw(p + ".to_out.weight"), Cout=hid, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_out dgrad")
+            gqkv = self.act(3 * hid, x.H, x.W)
+            dbuf = self.alloc(rows * heads)
+            geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
+            self.step(self.lib.vmm_attention_bwd,
+                      (0 if temporal else 1, qkv.ptr, 3 * hid, ek or None, ev or None, ntok, 0 if temporal else pfc, self.bias_ptr if temporal else None,
+                       pfc if temporal else 0, o.ptr, go.ptr, hid, lse_ptr, self.rot_ptr if temporal else None, C.c_float(q_scale), gqkv.ptr, geo or None,
+                       gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
+            self.tmp_free(go)
+            self.tmp_free((dbuf, rows * heads))
+            self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
+            gy = self.act(x.C, x.H, x.W)
+            self.conv(a1=gqkv, w=self.wraw(p + ".to_qkv.weight"), Cout=x.C, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W, what=name + " to_qkv dgrad")
+            self.tmp_free(gqkv)
+            self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+            self.tmp_free(gy)
+            if site:
+                self.token_kv_bwd(site)
+        self.on_backward(bwd, pg_start, uj_start)
         return out
 
-    # ---------------------------------------------------------------- dense job tables
+    # ---------------------------------------------------------------- job tables
+    def _upload_table(self, arr) -> int:
+        nbytes = C.sizeof(arr)
+        off = self.alloc((nbytes + 3) // 4)  # never freed: the table must stay resident
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        self.job_uploads.append((off, host))
+        return self.ptr(off)
+
     def dense_level(self, jobs: List[dict], what: str) -> None:
         if not jobs:
             return
@@ -379,13 +657,32 @@ class _Builder:
             a.ldx, a.ldy, a.ldadd = j.get("ldx", j["K"]), j.get("ldy", j["N"]), j.get("ldadd", j["N"])
             a.act_in, a.act_out = j.get("act_in", 0), j.get("act_out", 0)
             max_units = max(max_units, j["N"] * ((j["rows"] + 7) // 8))
-        nbytes = C.sizeof(arr)
-        nfl = (nbytes + 3) // 4
-        off = self.alloc(nfl)  # never freed: the table must stay resident
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
-        self.plan.keepalive.append((off, host))
-        self.job_uploads.append((off, host))
-        self.step(self.lib.vmm_dense_batched, (self.ptr(off), len(jobs), max_units), what)
+        self.step(self.lib.vmm_dense_batched, (self._upload_table(arr), len(jobs), max_units), what)
+
+    def dense_bwd_level(self, jobs: List[dict], what: str) -> None:
+        jobs = [j for j in jobs if j.get("dw") or j.get("dx") or j.get("db")]
+        if not jobs:
+            return
+        arr = (N.DenseBwdJob * len(jobs))()
+        max_n = max_x = 0
+        for i, j in enumerate(jobs):
+            a = arr[i]
+            a.x, a.w, a.b, a.dy = j["x"], j["w"], j.get("b") or None, j["dy"]
+            a.dx, a.dw, a.db = j.get("dx") or None, j.get("dw") or None, j.get("db") or None
+            a.rows, a.K, a.N = j["rows"], j["K"], j["N"]
+            a.ldx, a.lddy, a.lddx = j["K"], j["N"], j["K"]
+            a.act_in, a.act_out, a.accumulate = j.get("act_in", 0), j.get("act_out", 0), 1
+            max_n = max(max_n, j["N"])
+            if j.get("dx"):
+                max_x = max(max_x, j["rows"] * ((j["K"] + 63) // 64))
+        self.step(self.lib.vmm_dense_bwd_batched, (self._upload_table(arr), len(jobs), max_n, max_x), what)
+
+    def emit_unpack(self, jobs: List[dict], what: str) -> None:
+        """Scatter packed weight gradients into the flat torch-layout gradient buffer (one batched launch)."""
+        if not jobs:
+            return
+        arr, mx = _pack_table(jobs, lambda j: self.pgbase + 4 * (self.plan.param_slices[j["name"]][0] + j.get("src_off", 0)))
+        self.step(self.lib.vmm_pack_weights, (self._upload_table(arr), len(jobs), mx, 1), what)
 
     # ---------------------------------------------------------------- the network
     def build(self) -> Plan:
@@ -393,7 +690,8 @@ class _Builder:
         lib, heads = self.lib, self.heads
         td, cd, D = m.time_dim, m.cond_dim, m.cond_dim
         Cx = m.channels
-        self.job_uploads: List[Tuple[int, torch.Tensor]] = []
+        hid = 32 * heads
+        tr = self.training
         rows0 = B * T * H * W
         # static inputs / outputs
         x_in_off = self.alloc(B * Cx * T * H * W)
@@ -401,31 +699,44 @@ class _Builder:
         cond_off = self.alloc(B * self.cond_len)
         mask_off = self.alloc((B + 3) // 4)
         out_off = self.alloc(B * m.out_dim * T * H * W)
-        self.io = (x_in_off, time_off, cond_off, mask_off, out_off)
+        dout_off = self.alloc(B * m.out_dim * T * H * W) if tr else 0
+        self.io = (x_in_off, time_off, cond_off, mask_off, out_off, dout_off)
         # constant tables
         rot = hostmath.rotary_table(T, 32)
-        rot_off = self.alloc(rot.numel())
+        rot_t = rot.clone()
+        rot_t[..., 1] = -rot_t[..., 1]  # transpose of the rotation (backward of rotated token keys)
+        rot_off, rot_t_off = self.alloc(rot.numel()), self.alloc(rot.numel())
         bk = hostmath.relpos_buckets(T, 32, 32)
         bk_off = self.alloc(bk.numel())
-        self.consts = [(rot_off, rot.reshape(-1)), (bk_off, bk.reshape(-1).view(torch.float32))]
-        self.rot_ptr = self.ptr(rot_off)
+        self.consts = [(rot_off, rot.reshape(-1)), (rot_t_off, rot_t.reshape(-1)), (bk_off, bk.reshape(-1).view(torch.float32))]
+        self.rot_ptr, self.rot_t_ptr = self.ptr(rot_off), self.ptr(rot_t_off)
         bias_off = self.alloc(heads * T * T)
         self.bias_ptr = self.ptr(bias_off)
-        self.step(lib.vmm_relpos_bias, (self.wraw("time_rel_pos_bias.relative_attention_bias.weight"), self.ptr(bk_off), T, heads, self.bias_ptr),
-                  "time_rel_pos_bias")
+        self.dbias_ptr = self.scratch(heads * T * T) if tr else 0
+        emb_name = "time_rel_pos_bias.relative_attention_bias.weight"
+        self.step(lib.vmm_relpos_bias, (self.wraw(emb_name), self.ptr(bk_off), T, heads, self.bias_ptr), "time_rel_pos_bias")
 
         # ---- conditioning / time embedding (vddp.py:745-795)
         se = self.alloc(B * m.dim)
         self.step(lib.vmm_sinusoidal_embed, (self.ptr(time_off), B, m.dim, C.c_float(-(math.log(10000) / (m.dim // 2 - 1))), self.ptr(se)), "time sinusoid")
         h1, t2, hidden, temb = self.alloc(B * td), self.alloc(B * td), self.alloc(B * td), self.alloc(B * td)
-        ntok = m.cond_attention_tokens
+        gh1, gt2, ghidden, gtemb = [self.scratch(B * td) for _ in range(4)] if tr else (0, 0, 0, 0)
+        ntok = self.ntok = m.cond_attention_tokens
         tokens = self.alloc(B * ntok * D) if m.cond_attention != "none" else None
+        self.tokens_ptr = self.ptr(tokens) if tokens is not None else 0
+        self.dtokens_ptr = self.scratch(B * ntok * D) if (tr and tokens is not None) else 0
         lvl1 = [dict(x=self.ptr(se), w=self.wraw("time_mlp.1.weight"), b=self.wraw("time_mlp.1.bias"), y=self.ptr(h1), rows=B, K=m.dim, N=td, act_out=2)]
         lvl2 = [dict(x=self.ptr(h1), w=self.wraw("time_mlp.3.weight"), b=self.wraw("time_mlp.3.bias"), y=self.ptr(t2), rows=B, K=td, N=td)]
+        bwd_lvl1 = [dict(x=self.ptr(se), w=self.wraw("time_mlp.1.weight"), b=self.wraw("time_mlp.1.bias"), dy=gh1, dw=self.pg("time_mlp.1.weight"),
+                         db=self.pg("time_mlp.1.bias"), rows=B, K=m.dim, N=td, act_out=2)] if tr else []
+        bwd_lvl2 = [dict(x=self.ptr(h1), w=self.wraw("time_mlp.3.weight"), dy=gt2, dx=gh1, dw=self.pg("time_mlp.3.weight"), db=self.pg("time_mlp.3.bias"),
+                         rows=B, K=td, N=td)] if tr else []
+        cond_bwd: List[Callable[[], None]] = []
         if m.per_frame_cond:
             if self.cond_len != ntok:
                 raise ValueError(f"per_frame_cond expects cond of shape (b, {ntok})")
             pooled, pl, c1 = self.alloc(B * D), self.alloc(B * D), self.alloc(B * D)
+            gpooled, gpl, gc1 = [self.scratch(B * D) for _ in range(3)] if tr else (0, 0, 0)
             self.step(lib.vmm_cond_tokens, (self.ptr(cond_off), self.wraw("sign_emb.weight"), self.wraw("sign_emb.bias"), self.wraw("null_text_token"),
                                             self.ptr(mask_off), B, ntok, D, self.ptr(tokens), self.ptr(pooled)), "sign_emb tokens")
             self.step(lib.vmm_rows_layernorm_affine, (self.ptr(pooled), self.wraw("cond_token_to_hidden.0.weight"), self.wraw("cond_token_to_hidden.0.bias"),
@@ -434,49 +745,88 @@ class _Builder:
                              K=D, N=D, act_out=1))
             lvl2.append(dict(x=self.ptr(c1), w=self.wraw("cond_token_to_hidden.3.weight"), b=self.wraw("cond_token_to_hidden.3.bias"), y=self.ptr(hidden),
                              rows=B, K=D, N=td))
+            if tr:
+                bwd_lvl2.append(dict(x=self.ptr(c1), w=self.wraw("cond_token_to_hidden.3.weight"), dy=ghidden, dx=gc1, dw=self.pg("cond_token_to_hidden.3.weight"),
+                                     db=self.pg("cond_token_to_hidden.3.bias"), rows=B, K=D, N=td))
+                bwd_lvl1.append(dict(x=self.ptr(pl), w=self.wraw("cond_token_to_hidden.1.weight"), b=self.wraw("cond_token_to_hidden.1.bias"), dy=gc1, dx=gpl,
+                                     dw=self.pg("cond_token_to_hidden.1.weight"), db=self.pg("cond_token_to_hidden.1.bias"), rows=B, K=D, N=D, act_out=1))
+                for nm_ in ("cond_token_to_hidden.0.weight", "cond_token_to_hidden.0.bias", "sign_emb.weight", "sign_emb.bias", "null_text_token"):
+                    self._touch(nm_)
+
+                def cond_b():
+                    self.step(lib.vmm_rows_layernorm_affine_bwd, (self.ptr(pooled), self.wraw("cond_token_to_hidden.0.weight"), gpl, gpooled,
+                                                                  self.pg("cond_token_to_hidden.0.weight"), self.pg("cond_token_to_hidden.0.bias"), B, D,
+                                                                  C.c_float(1e-5)), "cond_token_to_hidden.0 bwd")
+                    self.step(lib.vmm_cond_tokens_bwd, (self.ptr(cond_off), self.ptr(mask_off), self.dtokens_ptr, gpooled, B, ntok, D, self.pg("sign_emb.weight"),
+                                                        self.pg("sign_emb.bias"), self.pg("null_text_token")), "sign_emb bwd")
+                cond_bwd.append(cond_b)
         else:
             chain = [1, 16, 32, 64, 128, cd]
             L = self.cond_len
             cur, cur_C = self.ptr(cond_off), 1
+            stages = []
             for i, co in enumerate(chain[1:]):
                 Lout = (L + 2 - 4) // 2 + 1
                 nxt = self.ptr(hidden) if i == 4 else self.ptr(self.alloc(B * co * Lout))
-                self.step(lib.vmm_conv1d_k4s2_silu, (cur, self.wraw(f"sign_emb_CNN.emb_model.{2 * i}.weight"), self.wraw(f"sign_emb_CNN.emb_model.{2 * i}.bias"), nxt,
-                                                     B, cur_C, co, L), f"sign_emb_CNN.{2 * i}")
+                gnx = (ghidden if i == 4 else self.scratch(B * co * Lout)) if tr else 0
+                wn, bn = f"sign_emb_CNN.emb_model.{2 * i}.weight", f"sign_emb_CNN.emb_model.{2 * i}.bias"
+                self.step(lib.vmm_conv1d_k4s2_silu, (cur, self.wraw(wn), self.wraw(bn), nxt, B, cur_C, co, L), f"sign_emb_CNN.{2 * i}")
+                self._touch(wn)
+                self._touch(bn)
+                stages.append((i, cur, cur_C, co, L, gnx))
                 cur, cur_C, L = nxt, co, Lout
             if L != 1:
                 raise ValueError("sign_emb_CNN must reduce the conditioning signal to length 1 (cond length 32..63)")
             if tokens is not None:
                 self.step(lib.vmm_tokens_from_hidden, (self.ptr(hidden), self.wraw("null_text_token"), self.ptr(mask_off), B, ntok, D, self.ptr(tokens)), "tokens")
+            if tr:
+                def cond_b():
+                    if tokens is not None:
+                        self.step(lib.vmm_tokens_from_hidden_bwd, (self.dtokens_ptr, self.ptr(mask_off), B, ntok, D, ghidden, self.pg("null_text_token")),
+                                  "tokens bwd")
+                    rev = list(reversed(stages))
+                    for (i, xin, cin, co, Lin, gy), prev in zip(rev, rev[1:] + [None]):
+                        gx = prev[5] if prev is not None else None
+                        wn, bn = f"sign_emb_CNN.emb_model.{2 * i}.weight", f"sign_emb_CNN.emb_model.{2 * i}.bias"
+                        self.step(lib.vmm_conv1d_k4s2_silu_bwd, (xin, self.wraw(wn), self.wraw(bn), gy, gx, self.pg(wn) or self.scratch(co * cin * 4),
+                                                                 self.pg(bn) or self.scratch(co), B, cin, co, Lin), f"sign_emb_CNN.{2 * i} bwd")
+                cond_bwd.append(cond_b)
         self.dense_level(lvl1, "embed level 1")
         self.dense_level(lvl2, "embed level 2")
         self.step(lib.vmm_select_add, (self.ptr(hidden), self.wraw("null_text_hidden"), self.ptr(mask_off), self.ptr(t2), self.ptr(temb), B, td), "t + hidden")
+        self._touch("null_text_hidden")
 
         # level 3: every ResnetBlock.mlp and every to_k/to_v on the tokens, one launch
         lvl3: List[dict] = []
-        film: Dict[str, int] = {}
+        self.bwd_lvl3: List[dict] = []
+        film: Dict[str, Tuple[int, int]] = {}
         res_names = [f"downs.{i}.{j}" for i in range(len(m.in_out)) for j in (0, 1)] + ["mid_block1", "mid_block2"] + \
                     [f"ups.{i}.{j}" for i in range(len(m.in_out)) for j in (0, 1)]
         for rn in res_names:
             n_out = self.shapes[rn + ".mlp.1.weight"][0]
             fo = self.alloc(B * n_out)
-            film[rn] = self.ptr(fo)
+            gfo = self.scratch(B * n_out) if tr else 0
+            film[rn] = (self.ptr(fo), gfo)
             lvl3.append(dict(x=self.ptr(temb), w=self.wraw(rn + ".mlp.1.weight"), b=self.wraw(rn + ".mlp.1.bias"), y=self.ptr(fo), rows=B, K=td, N=n_out, act_in=1))
-        ekv: Dict[str, Tuple[int, int, int]] = {}
-        hid = 32 * heads
+            if tr:
+                self.bwd_lvl3.append(dict(x=self.ptr(temb), w=self.wraw(rn + ".mlp.1.weight"), dy=gfo, dx=gtemb, dw=self.pg(rn + ".mlp.1.weight"),
+                                          db=self.pg(rn + ".mlp.1.bias"), rows=B, K=td, N=n_out, act_in=1))
+        self.ekv_info: Dict[str, tuple] = {}
         rot_sites: List[int] = []
 
         def add_ekv(site: str, pfx: str, rotate: bool):
             eo, vo = self.alloc(B * ntok * hid), self.alloc(B * ntok * hid)
             lvl3.append(dict(x=self.ptr(tokens), w=self.wraw(pfx + ".to_k.weight"), y=self.ptr(eo), rows=B * ntok, K=D, N=hid))
             lvl3.append(dict(x=self.ptr(tokens), w=self.wraw(pfx + ".to_v.weight"), y=self.ptr(vo), rows=B * ntok, K=D, N=hid))
-            ekv[site] = (self.ptr(eo), self.ptr(vo), ntok)
+            geo, gvo = (self.scratch(B * ntok * hid), self.scratch(B * ntok * hid)) if tr else (0, 0)
+            self._touch(pfx + ".to_k.weight")
+            self._touch(pfx + ".to_v.weight")
+            self.ekv_info[site] = (pfx, self.ptr(eo), self.ptr(vo), geo, gvo, rotate)
             if rotate:
                 rot_sites.append(self.ptr(eo))
 
         if tokens is not None:
-            lvls = range(len(m.in_out))
-            for i in lvls:
+            for i in range(len(m.in_out)):
                 for side in ("downs", "ups"):
                     if m.use_sparse_linear_attn:
                         add_ekv(f"{side}.{i}.2", f"{side}.{i}.2.fn.fn", False)
@@ -492,17 +842,36 @@ class _Builder:
             for p_ in rot_sites:
                 self.step(lib.vmm_rotary_rows, (p_, self.rot_ptr, B, ntok, heads, 32), "rotate token keys")
 
+        def embed_bwd():
+            self.dense_bwd_level(self.bwd_lvl3, "embed level 3 bwd")
+            self.step(lib.vmm_select_add_bwd, (gtemb, self.ptr(mask_off), ghidden, self.pg("null_text_hidden") or None, gt2, B, td), "t + hidden bwd")
+            self.dense_bwd_level(bwd_lvl2, "embed level 2 bwd")
+            self.dense_bwd_level(bwd_lvl1, "embed level 1 bwd")
+            for f_ in cond_bwd:
+                f_()
+            self.step(lib.vmm_relpos_bias_bwd, (self.dbias_ptr, self.ptr(bk_off), T, heads, self.pg(emb_name) or self.scratch(32 * heads)), "time_rel_pos_bias bwd")
+        self.on_backward(embed_bwd, 0, 0)
+
         # ---- stem
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         xin = Act(self.alloc(rows0 * 4), 4, H, W, rows0 * 4)
         xin.ptr = self.ptr(xin.off)
         self.step(lib.vmm_ncthw_to_rows, (self.ptr(x_in_off), B, Cx, T, H * W, xin.ptr, 4), "ncthw -> rows")
         k = m.init_kernel_size
-        x = self.act(m.init_dim, H, W)
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
-        self.conv(a1=xin, w=self.pack_conv("init_conv.weight", pad_cin_to=4), bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)),
-                  out_ptr=x.ptr, ldo=m.init_dim, Hv=H, Wv=W, what="init_conv")
+        wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
+        x = self.act(m.init_dim, H, W)
+        dinit = self.conv(a1=xin, w=wi, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr, ldo=m.init_dim,
+                          Hv=H, Wv=W, what="init_conv")
         self.free_act(xin)
+        x0 = x
+
+        def init_bwd():
+            g0, _ = self.grad_of(x0)
+            self.wgrad(dinit, g0.ptr, m.init_dim, gwi, "init_conv")
+            self.colsum(g0.ptr, m.init_dim, rows0, m.init_dim, self.pg("init_conv.bias"), "init_conv")
+        self.on_backward(init_bwd, pg_start, uj_start)
         x_new = self.softmax_attn_block("init_temporal_attn", x, None, temporal=True)
         self.free_act(x)
         x = x_new
@@ -517,11 +886,13 @@ class _Builder:
             y2 = self.resnet_block(f"{side}.{i}.1", y1, None, film[f"{side}.{i}.1"])
             self.free_act(y1)
             if m.use_sparse_linear_attn:
-                y3 = self.linear_attn_block(f"{side}.{i}.2", y2, ekv.get(f"{side}.{i}.2"))
+                s2 = f"{side}.{i}.2"
+                y3 = self.linear_attn_block(s2, y2, s2 if s2 in self.ekv_info else None)
                 self.free_act(y2)
             else:
                 y3 = y2
-            y4 = self.softmax_attn_block(f"{side}.{i}.3", y3, ekv.get(f"{side}.{i}.3"), temporal=True)
+            s3 = f"{side}.{i}.3"
+            y4 = self.softmax_attn_block(s3, y3, s3 if s3 in self.ekv_info else None, temporal=True)
             self.free_act(y3)
             return y4
 
@@ -531,36 +902,100 @@ class _Builder:
             x = stage("downs", i, x, None)
             skips.append(x)
             if i < n_lvl - 1:
+                pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
+                xs = x
+                nm = f"downs.{i}.4"
+                wd, gwd = self.pack_conv(nm + ".weight")
                 d = self.act(x.C, x.H // 2, x.W // 2)
-                self.conv(a1=x, w=self.pack_conv(f"downs.{i}.4.weight"), bias=self.wraw(f"downs.{i}.4.bias"), Cout=x.C, KH=4, KW=4, stride=2, off=(-1, -1),
-                          out_ptr=d.ptr, ldo=x.C, Hv=x.H // 2, Wv=x.W // 2, what=f"downs.{i}.4")
+                dd = self.conv(a1=xs, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C, Hv=xs.H // 2,
+                               Wv=xs.W // 2, what=nm)
+
+                def down_bwd(nm=nm, xs=xs, d=d, dd=dd, gwd=gwd):
+                    gd, _ = self.grad_of(d)
+                    self.wgrad(dd, gd.ptr, xs.C, gwd, nm)
+                    self.colsum(gd.ptr, xs.C, B * T * d.H * d.W, xs.C, self.pg(nm + ".bias"), nm)
+                    gx, acc = self.grad_of(xs)
+                    co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
+                    for ph in range(2):
+                        for pw in range(2):
+                            # dIn[2c+ph] = sum_kh' dOut[c + ph - kh'] W[(1-ph)+2kh']^T : [(kh', kw', co)][ci]
+                            wp = self.pack(nm + ".weight", 4 * co_ * ci_, want_grad=False, TH=2, TW=2, C=co_, Cp=co_, N=ci_, sn=16, sc=ci_ * 16, sh=4, sw=1,
+                                           h0=1 - ph, hs=2, w0=1 - pw, ws=2)[0]
+                            self.conv(a1=gd, w=wp, Cout=ci_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=gx.ptr, ldo=ci_, Hv=d.H, Wv=d.W, Hout=xs.H,
+                                      Wout=xs.W, oscale=2, oo=(ph, pw), res_ptr=gx.ptr if acc else 0, ldres=ci_, what=nm + f" dgrad phase {ph}{pw}")
+                self.on_backward(down_bwd, pg_start, uj_start)
                 x = d
         # the deepest skip is also the mid input: keep it alive, do not free through `stage`
         mid_in = x
         y = self.resnet_block("mid_block1", mid_in, None, film["mid_block1"])
-        y2 = self.softmax_attn_block("mid_spatial_attn", y, ekv.get("mid_spatial_attn"), temporal=False)
+        y2 = self.softmax_attn_block("mid_spatial_attn", y, "mid_spatial_attn" if "mid_spatial_attn" in self.ekv_info else None, temporal=False)
         self.free_act(y)
-        y3 = self.softmax_attn_block("mid_temporal_attn", y2, ekv.get("mid_temporal_attn"), temporal=True)
+        y3 = self.softmax_attn_block("mid_temporal_attn", y2, "mid_temporal_attn" if "mid_temporal_attn" in self.ekv_info else None, temporal=True)
         self.free_act(y2)
         x = self.resnet_block("mid_block2", y3, None, film["mid_block2"])
         self.free_act(y3)
         for i in range(n_lvl):
             x = stage("ups", i, x, skips.pop())
             if i < n_lvl - 1:
-                u = self.act(x.C, x.H * 2, x.W * 2)
+                pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
+                xs = x
+                nm = f"ups.{i}.4"
+                ci_, co_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
+                u = self.act(co_, xs.H * 2, xs.W * 2)
+                phases = []
                 for ph in range(2):
                     for pw in range(2):
-                        self.conv(a1=x, w=self.pack_convT_phase(f"ups.{i}.4.weight", ph, pw), bias=self.wraw(f"ups.{i}.4.bias"), Cout=x.C, KH=2, KW=2,
-                                  off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=x.C, Hv=x.H, Wv=x.W, Hout=x.H * 2, Wout=x.W * 2, oscale=2, oo=(ph, pw),
-                                  what=f"ups.{i}.4 phase {ph}{pw}")
-                self.free_act(x)
+                        # ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'
+                        wp, gwp = self.pack(nm + ".weight", 4 * ci_ * co_, TH=2, TW=2, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, h0=1 - ph, hs=2,
+                                            w0=1 - pw, ws=2)
+                        du = self.conv(a1=xs, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
+                                       Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw), what=nm + f" phase {ph}{pw}")
+                        phases.append((du, gwp))
+
+                def up_bwd(nm=nm, xs=xs, u=u, phases=phases, ci_=ci_, co_=co_):
+                    gu, _ = self.grad_of(u)
+                    for du, gwp in phases:
+                        self.wgrad(du, gu.ptr, co_, gwp, nm)
+                    self.colsum(gu.ptr, co_, B * T * u.H * u.W, co_, self.pg(nm + ".bias"), nm)
+                    gx, acc = self.grad_of(xs)
+                    # dX[a][ci] = sum_{kh,kw,co} dU[2a-1+kh][co] W[ci][co][kh][kw]: a stride-2 conv over dU with [(kh,kw,co)][ci]
+                    wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1, hs=1, ws=1)[0]
+                    self.conv(a1=gu, w=wp, Cout=ci_, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=gx.ptr, ldo=ci_, Hv=xs.H, Wv=xs.W, res_ptr=gx.ptr if acc else 0,
+                              ldres=ci_, what=nm + " dgrad")
+                self.on_backward(up_bwd, pg_start, uj_start)
+                self.free_act(xs)
                 x = u
-        f = self.resnet_block("final_conv.0", x, r, 0)
+        f = self.resnet_block("final_conv.0", x, r, None)
         self.free_act(x)
         self.free_act(r)
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         self.step(lib.vmm_pointwise_to_ncthw, (f.ptr, f.ld, f.C, self.wraw("final_conv.1.weight"), self.wraw("final_conv.1.bias"), B, m.out_dim, T, H * W,
                                                self.ptr(out_off)), "final_conv.1")
+        self._touch("final_conv.1.weight")
+        self._touch("final_conv.1.bias")
+
+        def final_bwd():
+            gf, _ = self.grad_of(f)
+            self.step(lib.vmm_pointwise_to_ncthw_bwd, (f.ptr, f.ld, f.C, self.wraw("final_conv.1.weight"), self.ptr(dout_off), B, m.out_dim, T, H * W, gf.ptr, f.C,
+                                                       self.pg("final_conv.1.weight") or self.scratch(m.out_dim * f.C),
+                                                       self.pg("final_conv.1.bias") or self.scratch(m.out_dim)), "final_conv.1 bwd")
+        self.on_backward(final_bwd, pg_start, uj_start)
         self.free_act(f)
+
+        if tr:
+            # Emit the backward list in reverse block order.  After block k's emitter (plus the scatter of the packed weight
+            # gradients registered by blocks >= k) every gradient at offsets >= pg_start(k) is final: parameters are laid out in
+            # first-use order, and the only parameters touched again later in the backward (conditioning / time embedding,
+            # token k/v, FiLM layers) were first used in the embedding stage, i.e. they sit in front of every block.
+            self.in_bwd = True
+            uj_hi = len(self.unpack_jobs)
+            for emit, pg_start, uj_start in reversed(self.tape):
+                emit()
+                self.emit_unpack(self.unpack_jobs[uj_start:uj_hi], "scatter weight gradients")
+                uj_hi = min(uj_hi, uj_start)
+                if self.plan.bwd_steps:
+                    self.plan.bwd_marks.append((len(self.plan.bwd_steps) - 1, pg_start))
+            self.in_bwd = False
         return self.plan
 
 
@@ -572,20 +1007,24 @@ def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, 
 
 def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool) -> Plan:
     # pass 1: sizes only (addresses relative to 0); pass 2: identical allocation order over real buffers
-    sizing = _Builder(model, B, T, H, W, cond_len, device, 0, 0, keep_all=training)
+    # (fake but non-zero bases, so "pointer or None" decisions are identical in both passes)
+    sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training)
     sizing.build()
     arena = torch.empty(sizing.arena.peak + ALIGN, dtype=torch.float32, device=device)
     wbuf = torch.zeros(sizing.wtop + ALIGN, dtype=torch.float32, device=device)
-    b = _Builder(model, B, T, H, W, cond_len, device, arena.data_ptr(), wbuf.data_ptr(), keep_all=training)
+    pgrad = torch.zeros(sizing.pgtop + ALIGN, dtype=torch.float32, device=device) if training else None
+    gscr = torch.zeros(sizing.gstop + ALIGN, dtype=torch.float32, device=device) if training else None
+    bases = (arena.data_ptr(), wbuf.data_ptr(), pgrad.data_ptr() if training else 0, gscr.data_ptr() if training else 0)
+    b = _Builder(model, B, T, H, W, cond_len, device, bases, training)
     plan = b.build()
-    assert b.arena.peak == sizing.arena.peak and b.wtop == sizing.wtop
-    plan.arena, plan.wbuf = arena, wbuf
+    assert b.arena.peak == sizing.arena.peak and b.wtop == sizing.wtop and b.pgtop == sizing.pgtop and b.gstop == sizing.gstop
+    plan.arena, plan.wbuf, plan.pgrad, plan.gscratch = arena, wbuf, pgrad, gscr
     plan.shape = (B, T, H, W, cond_len)
     for off, host in b.job_uploads:
         arena[off:off + (host.numel() + 3) // 4].view(torch.uint8)[: host.numel()].copy_(host)
     for off, t in b.consts:
         arena[off:off + t.numel()].copy_(t.to(device))
-    x_off, t_off, c_off, m_off, o_off = b.io
+    x_off, t_off, c_off, m_off, o_off, do_off = b.io
     Cx = model.channels
     plan.x_in = arena[x_off:x_off + B * Cx * T * H * W].view(B, Cx, T, H, W)
     plan.time_in = arena[t_off:t_off + B * 2].view(torch.int64)
@@ -593,4 +1032,7 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     plan.mask_in = arena[m_off:m_off + (B + 3) // 4].view(torch.uint8)[:B]
     plan.out = arena[o_off:o_off + B * model.out_dim * T * H * W].view(B, model.out_dim, T, H, W)
     plan.arena_floats = sizing.arena.peak
+    if training:
+        plan.dout = arena[do_off:do_off + B * model.out_dim * T * H * W].view(B, model.out_dim, T, H, W)
+        plan.pgrad_floats = sizing.pgtop
     return plan
