@@ -49,6 +49,9 @@ typedef struct vmm_conv_desc {
   int32_t a_mode; const float* a_coef; int32_t a_imgs_per_sample; /* frames per sample (T) */
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
+/* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
+ * ~1e-5 relative error): d->w must point to the fmt-1 output of vmm_pack_weights (pre-split, pre-transposed bf16 weights). */
+int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
 
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
  * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer
@@ -65,6 +68,7 @@ typedef struct vmm_pack_job {
   int32_t TH, TW, C, Cp, N;
   int32_t sn, sc, sh, sw, h0, hs, w0, ws;
   int32_t accumulate;
+  int32_t fmt; /* 0: fp32 [K][N];  1: split bf16 for vmm_conv_igemm_bf16x3: [N][Kpad] hi plane, then lo plane (Kpad = K rounded up to 32) */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 

@@ -79,6 +79,43 @@ def test_conv_igemm(gpu, B, T, H, W, Cin, Cout, k, stride):
     assert relerr(out.cpu(), ref_rows) < 2e-6
 
 
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,k,stride", [
+    (2, 3, 12, 12, 16, 32, 3, 1), (1, 2, 24, 20, 64, 64, 3, 1), (1, 1, 12, 12, 256, 128, 3, 1), (1, 2, 16, 16, 4, 16, 7, 1), (2, 2, 16, 16, 32, 32, 4, 2),
+    (1, 11, 12, 12, 128, 512, 3, 1), (1, 2, 96, 96, 64, 64, 3, 1), (1, 2, 20, 20, 36, 768, 1, 1)])
+def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
+    """Split-bf16 matrix-core path: weights through vmm_pack_weights fmt 1, result within 5e-5 of the fp32 convolution."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    pad = {3: 1, 1: 0, 7: 3, 4: 1}[k]
+    ref = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W), w, b, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[-2:]
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    K = k * k * Cin
+    Kpad = (K + 31) // 32 * 32
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros(Cout * Kpad, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = k, k, Cin, Cin, Cout
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * k * k, k * k, k, 1, 0, 1, 0, 1, 0, 1
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
+    d = N.ConvDesc()
+    xr, bg = rows_of(x).to(gpu), b.to(gpu)
+    out = torch.zeros(B * T * Ho * Wo, Cout, device=gpu)
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = xr.data_ptr(), Cin, Cin, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, H, W, Ho, Wo, stride
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = k, k, -pad, -pad, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = Ho, Wo, 1, Cout, 32, 1.0
+    N.check(lib.vmm_conv_igemm_bf16x3(C.byref(d), _s()), "conv x3")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref_rows) < 5e-5
+
+
 def test_conv_concat_residual_and_fused_gn(gpu):
     """two-source input (torch.cat skip), residual epilogue, and the fused GroupNorm+FiLM+SiLU operand transform."""
     N, lib = _lib()
@@ -217,7 +254,7 @@ def test_temporal_attention_core(gpu, ntok, bias_on_cond):
     evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
     bg = bias.to(gpu)
     N.check(lib.vmm_temporal_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok,
-                                       bg.data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "temporal")
+                                       bg.data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, None, _s()), "temporal")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
 
@@ -245,7 +282,7 @@ def test_spatial_attention_core(gpu, HW, ntok, per_frame):
     ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
     N.check(lib.vmm_spatial_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, per_frame,
-                                      out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "spatial")
+                                      out.data_ptr(), hid, B, T, HW, heads, 32, None, _s()), "spatial")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
 
@@ -273,7 +310,7 @@ def test_linear_attention_core(gpu, HW, ntok, nsplit):
     ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
     N.check(lib.vmm_linattn_context(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, B, T, HW, heads, 32,
-                                    nsplit, part.data_ptr(), ctxg.data_ptr(), _s()), "ctx")
+                                    nsplit, part.data_ptr(), ctxg.data_ptr(), None, _s()), "ctx")
     N.check(lib.vmm_linattn_apply(qg.data_ptr(), 3 * hid, ctxg.data_ptr(), out.data_ptr(), hid, B, T, HW, heads, 32, _s()), "apply")
     torch.cuda.synchronize()
     assert relerr(ctxg.cpu().reshape(B * T, heads, 32, 32), ctx) < 5e-6

@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3  # BASELINE.json north_star: "within 1e-3 relative fp32"; measured errors are ~1e-6 (exact-fp32 MFMA)
 
 
-def make_model(cfg_name, dev):
+def make_model(cfg_name, dev, precision="bf16x3"):
     import videometamaterials_amd as vm
     kw, _, _ = helpers.CONFIGS[cfg_name]
     m = vm.Unet3D(**kw)
+    m.precision = precision
     m.load_state_dict(helpers.synth_state_dict(helpers.load_shapes(cfg_name)), strict=True)
     return m.to(dev).eval()
 
@@ -43,9 +44,11 @@ def diagnose(cfg_name, model, x, t, cond, mask_val, dev):
     return "\n".join(lines)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("cfg_name", list(helpers.CONFIGS))
-def test_forward_matches_reference_golden(gpu, cfg_name):
-    model = make_model(cfg_name, gpu)
+def test_forward_matches_reference_golden(gpu, cfg_name, precision):
+    """fp32 = exact-fp32 MFMA (expect ~1e-6); bf16x3 = split-bf16 matrix-core path (default, expect ~1e-5): both inside 1e-3."""
+    model = make_model(cfg_name, gpu, precision)
     gold = np.load(os.path.join(helpers.GOLDEN_DIR, f"unet_{cfg_name}.npz"))
     x, t, cond = helpers.synth_inputs(cfg_name)
     with torch.no_grad():
@@ -55,7 +58,8 @@ def test_forward_matches_reference_golden(gpu, cfg_name):
     errs = {k: helpers.rel_err(v, torch.from_numpy(gold[g])) for k, v, g in (("cond", e_c, "eps_cond"), ("null", e_n, "eps_null"), ("w5", e_5, "eps_w5"))}
     if max(errs.values()) >= TOL:
         pytest.fail(f"{cfg_name}: {errs}\n" + diagnose(cfg_name, model, x, t, cond, 0, gpu))
-    assert errs["cond"] < 1e-4 and errs["null"] < 1e-4, errs  # fp32 kernels: expect ~1e-6, far inside the 1e-3 bar
+    print(f"{cfg_name} {precision}: {errs}")
+    assert errs["cond"] < 2e-4 and errs["null"] < 2e-4, errs  # far inside the 1e-3 bar for both arithmetic modes
 
 
 def test_guidance_scales_and_state_dict_roundtrip(gpu):

@@ -54,7 +54,7 @@ class PackJob(C.Structure):
     """vmm_pack_job (include/vmm_kernels.h)."""
 
     _fields_ = [("torch_w", c_ptr), ("packed", c_ptr)] + [(n, c_i32) for n in (
-        "TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate")]
+        "TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate", "fmt")]
 
 
 class DenseBwdJob(C.Structure):
@@ -73,6 +73,7 @@ class OptimJob(C.Structure):
 # name -> argtypes (restype is always int); must list EVERY symbol include/vmm_kernels.h declares
 SIGNATURES = {
     "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],

@@ -1,5 +1,6 @@
 // Implicit-GEMM per-frame convolution / projection for gfx950, exact fp32 on the matrix cores
-// (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak).
+// (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain, 157 TFLOP/s peak).  Used by the training plans (forward, data
+// gradients) and by inference when Unet3D.precision == "fp32"; the default inference path is igemm_bf16x3.hip.
 //
 // One kernel covers every dense contraction of the denoiser:
 //   3x3 / 7x7 / 4x4-stride-2 convolutions, the transposed 4x4-stride-2 convolution (as 4 output
@@ -9,20 +10,15 @@
 // activation rows (16-byte loads along channels), optionally from two concatenated sources, optionally
 // through the producer's fused GroupNorm+FiLM+SiLU; B tiles are 16-byte loads of the k-major weights.
 // 256 threads = 4 waves; LDS double-buffered, global loads for chunk k+1 in flight during the MFMAs of k.
-#include "vmm_common.h"
-#include "../../include/vmm_kernels.h"
+// Grid: one dimension, N tiles fastest, so the blocks that share an A row panel run together (L2 reuse).
+#include "igemm_common.h"
 
 namespace {
 
 constexpr int BK = 16;
 
-struct RowInfo {
-  int img;      // frame index (b*T + t), -1 if the row is out of range
-  int ih0, iw0; // a*stride, b*stride
-};
-
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const vmm_conv_desc p) {
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const vmm_conv_desc p, int n_tiles) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int APAD = 4;
@@ -36,69 +32,29 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const vmm_conv_desc p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const long long M = (long long)p.nimg * p.Hv * p.Wv;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const unsigned M = (unsigned)(p.nimg * p.Hv * p.Wv);
+  const unsigned m0 = (blockIdx.x / n_tiles) * BM;
+  const int n0 = (blockIdx.x % n_tiles) * BN;
   const int Cin = p.C1 + p.C2;
   const int Ktot = p.KH * p.KW * Cin;
   const int nk = (Ktot + BK - 1) / BK;
 
-  // ---- per-thread A row decode (fixed over the K loop)
-  RowInfo ri[A_PASSES];
-  const int a_k4 = tid & 3;
+  igemm::RowInfo ri[A_PASSES];
 #pragma unroll
-  for (int ps = 0; ps < A_PASSES; ++ps) {
-    long long m = m0 + ps * 64 + (tid >> 2);
-    if (m < M) {
-      int hw = p.Hv * p.Wv;
-      int img = (int)(m / hw);
-      int rem = (int)(m - (long long)img * hw);
-      int a = rem / p.Wv, b = rem - a * p.Wv;
-      ri[ps].img = img;
-      ri[ps].ih0 = a * p.stride;
-      ri[ps].iw0 = b * p.stride;
-    } else {
-      ri[ps].img = -1; ri[ps].ih0 = 0; ri[ps].iw0 = 0;
-    }
-  }
+  for (int ps = 0; ps < A_PASSES; ++ps) ri[ps] = igemm::decode_row(p, m0 + ps * 64 + (tid >> 2), M);
+  const int a_k4 = tid & 3;
+  igemm::KPos kp;
+  kp.init(p, a_k4 * 4, Cin);
   const int b_kk[2] = {tid / (BN / 4), (tid + 256) / (BN / 4)};
   const int b_n4[2] = {tid % (BN / 4), (tid + 256) % (BN / 4)};
 
   f32x4 areg[A_PASSES];
   f32x4 breg[B_PASSES];
 
-  auto load_chunk = [&](int kc) {
-    // A: decode (tap, ci) of this thread's 4 consecutive k
-    const int k = kc * BK + a_k4 * 4;
-    int tap = k / Cin;
-    int ci = k - tap * Cin;
-    int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int dh = p.off_h + p.sgn_h * kh, dw = p.off_w + p.sgn_w * kw;
-    const bool kvalid = k < Ktot;
+  auto load_chunk = [&](int kc) {  // must be called with kc = 0, 1, 2, ... (kp advances incrementally)
 #pragma unroll
-    for (int ps = 0; ps < A_PASSES; ++ps) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int ih = ri[ps].ih0 + dh, iw = ri[ps].iw0 + dw;
-      if (kvalid && ri[ps].img >= 0 && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
-        const long long pix = ((long long)ri[ps].img * p.Hin + ih) * p.Win + iw;
-        if (ci < p.C1) {
-          v = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci);
-          if (p.a_mode == 1) {
-            const int bsmp = ri[ps].img / p.a_imgs_per_sample;
-            const float* cf = p.a_coef + ((long long)bsmp * p.C1 + ci) * 2;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
-            v.x = silu_f(v.x * c0.x + c0.y);
-            v.y = silu_f(v.y * c0.z + c0.w);
-            v.z = silu_f(v.z * c1.x + c1.y);
-            v.w = silu_f(v.w * c1.z + c1.w);
-          }
-        } else {
-          v = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci - p.C1));
-        }
-      }
-      areg[ps] = v;
-    }
+    for (int ps = 0; ps < A_PASSES; ++ps) areg[ps] = igemm::load_a4(p, ri[ps], kp, Ktot);
+    kp.advance(p, BK, Cin);
 #pragma unroll
     for (int ps = 0; ps < B_PASSES; ++ps) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -153,57 +109,14 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const vmm_conv_desc p) {
     if (kc + 1 < nk) store_chunk(buf ^ 1);
     __syncthreads();
   }
-
-  // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool identity_rows = (p.oscale == 1 && p.Hout == p.Hv && p.Wout == p.Wv && p.ooh == 0 && p.oow == 0);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long long m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      long long orow = m;
-      int img = 0;
-      const bool mvalid = m < M;
-      if (mvalid && (!identity_rows || p.rot_ncols > 0)) {
-        const int hw = p.Hv * p.Wv;
-        img = (int)(m / hw);
-        if (!identity_rows) {
-          const int rem = (int)(m - (long long)img * hw);
-          const int a = rem / p.Wv, b = rem - a * p.Wv;
-          orow = ((long long)img * p.Hout + a * p.oscale + p.ooh) * p.Wout + b * p.oscale + p.oow;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * TN + j * 32 + lrow;
-        const bool cvalid = col < p.Cout;
-        float v = acc[i][j][r];
-        if (p.bias && cvalid) v += p.bias[col];
-        if (col < p.q_ncols) v *= p.q_scale;
-        if (p.rot_ncols > 0) {  // uniform branch
-          const float partner = __shfl_xor(v, 1, 64);
-          if (mvalid && col < p.rot_ncols) {
-            const int t = (int)((m / p.rot_HW) % p.rot_T);
-            const int fi = (col % p.rot_dh) >> 1;
-            const float c = p.rot_tab[(t * (p.rot_dh >> 1) + fi) * 2 + 0];
-            const float s = p.rot_tab[(t * (p.rot_dh >> 1) + fi) * 2 + 1];
-            v = v * c + ((col & 1) ? partner : -partner) * s;
-          }
-        }
-        if (mvalid && cvalid) {
-          if (p.res) v += p.res[orow * p.ldres + col];
-          p.out[orow * p.ldo + col] = v;
-        }
-      }
-    }
-  }
+  igemm::epilogue<MT, NT>(p, acc, m0 + wm * TM, n0 + wn * TN, M, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch(const vmm_conv_desc& d, hipStream_t s) {
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
-  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+  const int nt = cdiv(d.Cout, BN);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), dim3((unsigned)(cdiv(M, BM) * (long long)nt)), dim3(256), 0, s, d, nt);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -214,9 +127,10 @@ extern "C" int vmm_conv_igemm_f32(const vmm_conv_desc* dp, vmm_stream_t stream) 
   const vmm_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 64) return -1;
-  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & 1))) return -2;
+  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)))) return -2;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
+  if (M >= (1LL << 31) || (long long)d.nimg * d.Hin * d.Win >= (1LL << 31)) return -4;
   if (M <= 0 || d.Cout <= 0) return 0;
   // tile choice: widest N tile that the layer fills; halve BM when the grid would not cover the 256 CUs twice
   if (d.Cout >= 128) {

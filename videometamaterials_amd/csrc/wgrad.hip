@@ -140,6 +140,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // batched (un)pack: packed[(th*TW + tw)*Cp + c][n]  <->  torch[ n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw ]
 __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
   const vmm_pack_job jb = jobs[blockIdx.y];
+  if (jb.fmt == 1) {
+    // split-bf16 operand for igemm_bf16x3.hip: [N][Kpad] hi plane then lo plane, K = (th, tw, c) padded to a multiple of 32
+    if (direction != 0) return;
+    const int K = jb.TH * jb.TW * jb.Cp;
+    const int Kpad = (K + 31) / 32 * 32;
+    unsigned short* hi = reinterpret_cast<unsigned short*>(jb.packed);
+    unsigned short* lo = hi + (long long)jb.N * Kpad;
+    const long long tot = (long long)jb.N * Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+      float v = 0.f;
+      if (k < K) {
+        const int c = k % jb.Cp, t = k / jb.Cp;
+        const int tw = t % jb.TW, th = t / jb.TW;
+        if (c < jb.C) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh + (long long)(jb.w0 + tw * jb.ws) * jb.sw];
+      }
+      const __bf16 h = (__bf16)v;
+      const __bf16 l = (__bf16)(v - (float)h);
+      hi[i] = __builtin_bit_cast(unsigned short, h);
+      lo[i] = __builtin_bit_cast(unsigned short, l);
+    }
+    return;
+  }
   const long long total = (long long)jb.TH * jb.TW * jb.Cp * jb.N;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i % jb.N);

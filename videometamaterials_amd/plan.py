@@ -20,6 +20,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+import sys
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -31,7 +33,7 @@ from . import hostmath
 ALIGN = 64  # floats (256 B)
 LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
-PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate")
+PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate", "fmt")
 
 
 def _stream() -> C.c_void_p:
@@ -188,10 +190,15 @@ class Plan:
         self.gscratch.zero_()
         s = _stream()
         marks = dict(self.bwd_marks)
+        debug = bool(os.environ.get("VMM_DEBUG_SYNC"))
         for i, (fn, args, what) in enumerate(self.bwd_steps):
+            if debug:
+                print(f"[vmm bwd {i}/{len(self.bwd_steps)}] {fn.__name__}: {what}", file=sys.stderr, flush=True)
             rc = fn(*args, s)
             if rc != 0:
                 N.check(rc, what)
+            if debug:
+                torch.cuda.synchronize()
             if on_mark is not None and i in marks:
                 on_mark(marks[i])
         return self.pgrad
@@ -230,6 +237,8 @@ class _Builder:
         self.trainable = {k for k, p in model.named_parameters() if p.requires_grad}
         self.G = model.resnet_groups
         self.heads = model.attn_heads
+        # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
+        self.x3 = (getattr(model, "precision", "fp32") == "bf16x3") and not training
         self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
         self.unpack_jobs: List[dict] = []
         self.gacts: Dict[int, Act] = {}  # activation offset -> gradient buffer
@@ -291,6 +300,10 @@ class _Builder:
     def pack(self, name: str, n_elems: int, want_grad: bool = True, **desc) -> Tuple[int, int]:
         """Register an operand layout of parameter `name` (see vmm_pack_job); returns (packed ptr, packed-gradient ptr)."""
         self._touch(name)
+        if want_grad and self.x3 and not self.in_bwd:  # forward GEMM operand -> pre-split, pre-transposed bf16 (igemm_bf16x3.hip)
+            k = desc["TH"] * desc["TW"] * desc["Cp"]
+            n_elems = desc["N"] * ((k + 31) // 32 * 32)
+            desc = dict(desc, fmt=1)
         ptr = self.wslot(n_elems)
         job = dict(name=name, packed=ptr, **desc)
         self.plan.pack_jobs.append(job)
@@ -389,7 +402,8 @@ class _Builder:
         K = d.KH * d.KW * (d.C1 + d.C2)
         # algorithmic work: every input element, weight and output element touched once
         nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
-        self.step(self.lib.vmm_conv_igemm_f32, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+        fn = self.lib.vmm_conv_igemm_bf16x3 if (self.x3 and not self.in_bwd) else self.lib.vmm_conv_igemm_f32
+        self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
     def wgrad(self, d: "N.ConvDesc", dy_ptr: int, lddy: int, gw_ptr: int, what: str) -> None:

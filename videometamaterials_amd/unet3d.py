@@ -107,6 +107,9 @@ class Unet3D(nn.Module):
         self._plans: Dict[tuple, "_plan.Plan"] = {}
         self._weights_version = None
         self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
+        # matrix-core arithmetic of the inference contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative,
+        # 5x the MFMA rate); "fp32" = exact fp32 MFMA (1e-6).  Training plans always use fp32.
+        self.precision = "bf16x3"
 
     # ------------------------------------------------------------------ parameters (names = reference module tree)
     def _conv(self, name, cout, cin, k, bias=True):
@@ -213,6 +216,12 @@ class Unet3D(nn.Module):
         return out
 
     # ------------------------------------------------------------------ execution
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_plans"] = {}  # plans hold ctypes descriptors and device arenas: rebuilt on demand
+        st["_weights_version"] = None
+        return st
+
     def _params_flat(self) -> Dict[str, torch.Tensor]:
         d = dict(self.named_parameters())
         d.update(dict(self.named_buffers()))
@@ -222,7 +231,7 @@ class Unet3D(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> "_plan.Plan":
-        key = (B, T, H, W, cond_len, str(device), training)
+        key = (B, T, H, W, cond_len, str(device), training, self.precision)
         pl = self._plans.get(key)
         if pl is None:
             pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training)
