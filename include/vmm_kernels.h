@@ -52,6 +52,10 @@ int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
  * ~1e-5 relative error): d->w must point to the fmt-1 output of vmm_pack_weights (pre-split, pre-transposed bf16 weights). */
 int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* 3x3 / stride 1 / pad 1 specialisation of the above with an LDS-resident halo patch (each input element is staged once per
+ * channel chunk instead of once per tap).  Needs C1, C2 multiples of 32, Cout >= 64, W <= 127; returns 1 (nothing launched) when the
+ * descriptor is outside that envelope. */
+int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
 
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
  * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer

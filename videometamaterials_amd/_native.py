@@ -74,6 +74,7 @@ class OptimJob(C.Structure):
 SIGNATURES = {
     "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],

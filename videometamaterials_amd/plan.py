@@ -402,7 +402,14 @@ class _Builder:
         K = d.KH * d.KW * (d.C1 + d.C2)
         # algorithmic work: every input element, weight and output element touched once
         nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
-        fn = self.lib.vmm_conv_igemm_bf16x3 if (self.x3 and not self.in_bwd) else self.lib.vmm_conv_igemm_f32
+        fn = self.lib.vmm_conv_igemm_f32
+        if self.x3 and not self.in_bwd:
+            fn = self.lib.vmm_conv_igemm_bf16x3
+            halo_ok = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.off_h == -1 and d.off_w == -1 and d.sgn_h == 1 and d.sgn_w == 1 and d.Hv == d.Hin
+                       and d.Wv == d.Win and d.oscale == 1 and d.rot_ncols == 0 and d.q_ncols == 0 and d.C1 % 32 == 0 and d.C2 % 32 == 0 and d.Cout >= 64
+                       and d.Win <= 127)
+            if halo_ok and getattr(self.m, "use_halo_conv", True):
+                fn = self.lib.vmm_conv3x3_bf16x3  # LDS-resident halo patch: every input element staged once per channel chunk
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
@@ -653,11 +660,13 @@ class _Builder:
 
     # ---------------------------------------------------------------- job tables
     def _upload_table(self, arr) -> int:
+        # Job tables are written once at build time, so they must never share memory with buffers that kernels write at run
+        # time (the arena recycles backward temporaries): they live in the weight buffer, next to the packed operands.
         nbytes = C.sizeof(arr)
-        off = self.alloc((nbytes + 3) // 4)  # never freed: the table must stay resident
+        ptr = self.wslot((nbytes + 3) // 4)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
-        self.job_uploads.append((off, host))
-        return self.ptr(off)
+        self.job_uploads.append(((ptr - self.wbase) // 4, host))
+        return ptr
 
     def dense_level(self, jobs: List[dict], what: str) -> None:
         if not jobs:
@@ -1035,7 +1044,7 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     plan.arena, plan.wbuf, plan.pgrad, plan.gscratch = arena, wbuf, pgrad, gscr
     plan.shape = (B, T, H, W, cond_len)
     for off, host in b.job_uploads:
-        arena[off:off + (host.numel() + 3) // 4].view(torch.uint8)[: host.numel()].copy_(host)
+        wbuf[off:off + (host.numel() + 3) // 4].view(torch.uint8)[: host.numel()].copy_(host)
     for off, t in b.consts:
         arena[off:off + t.numel()].copy_(t.to(device))
     x_off, t_off, c_off, m_off, o_off, do_off = b.io
