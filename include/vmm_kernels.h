@@ -103,6 +103,15 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
                            int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
                            vmm_stream_t stream);
 
+/* Fused temporal-attention BLOCK for the full-resolution level (vddp.py:615,630,680: x + to_out(attn(rotary(to_qkv(LayerNorm(x)))))):
+ * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections on the split-bf16 matrix cores
+ * (wqkv_packed / wout_packed = vmm_pack_weights fmt 1 of to_qkv (768,64) and to_out (64,256)), softmax in fp32 VALU.
+ * Envelope: C == 64, heads == 8, dim_head == 32, T <= 12, HW % 16 == 0; returns 1 (nothing launched) otherwise. */
+int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
+                              const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                              const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
+                              float q_scale, float eps, vmm_stream_t stream);
+
 /* ---- K12: mid-level spatial softmax attention per frame (vddp.py:687-689): n = HW queries, keys = [tokens | HW].
  * tok_per_frame = 1: frame t sees only token t (vddp.py:459-462); 0: all ntok tokens. */
 int vmm_spatial_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,

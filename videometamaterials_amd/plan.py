@@ -607,6 +607,19 @@ class _Builder:
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
+        if (temporal and self.x3 and x.C == 64 and heads == 8 and T <= 12 and HW % 16 == 0 and getattr(self.m, "use_fused_temporal", True)):
+            # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
+            wq, _ = self.pack_linear(p + ".to_qkv.weight")
+            wo, _ = self.pack_linear(p + ".to_out.weight")
+            ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
+            out = self.act(x.C, x.H, x.W)
+            flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + (self.ntok if site else 0))
+            self.step(self.lib.vmm_temporal_block_bf16x3,
+                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, self.ntok if site else 0, self.bias_ptr,
+                       1 if self.m.per_frame_cond else 0, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
+                      name + " fused block", flops=flops, nbytes=8.0 * x.n)
+            self.plan.named[name] = out
+            return out
         y = self.layernorm(x, name + ".fn.norm.gamma")
         wq, gwq = self.pack_linear(p + ".to_qkv.weight")
         qkv = self.act(3 * hid, x.H, x.W)
