@@ -47,7 +47,7 @@ struct TBArgs {
   const float* bias; int bias_on_cond;
   const float* rot;            // [T][16][2]
   float* out; int ldo;
-  int T, HW; float q_scale; float eps;
+  int T, HW; float q_scale; float eps; int dbg;  // dbg: ablation bits (1: skip phase 1, 2: skip phase 2, 4: skip phase 3), VMM_TB_DBG
 };
 
 __global__ __launch_bounds__(256) void temporal_block_kernel(const TBArgs a) {
@@ -311,6 +311,7 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
   a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0;
   a.bias = bias; a.bias_on_cond = bias_on_cond; a.rot = rot_tab;
   a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.q_scale = q_scale; a.eps = eps;
+  { const char* e = getenv("VMM_TB_DBG"); a.dbg = e ? atoi(e) : 0; }
   const size_t shm = sizeof(unsigned short) * 2 * TRP * XPITCH + sizeof(float) * (TRP * QPITCH + 12 * 32 + HEADS * 12 * 12);
   static bool attr_set = false;
   if (!attr_set) {
