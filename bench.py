@@ -211,7 +211,7 @@ def main():
         if args.detail:
             ms = pl.launch_timed()
             rows_ = sorted(zip(ms, pl.steps, pl.meta), key=lambda r: -r[0])
-            for t_ms, (_, _, what), (fam, fl, by) in rows_[:45]:
+            for t_ms, (_, _, what), (fam, fl, by) in rows_:
                 print(f"  {t_ms:8.3f} ms  {fl / max(t_ms, 1e-9) / 1e9:8.1f} TFLOP/s  {by / max(t_ms, 1e-9) / 1e6:8.1f} GB/s  {what}", file=sys.stderr)
         fwd_ms = sum(fam_ms.values()) / reps
         dom = max(fam_ms, key=fam_ms.get)

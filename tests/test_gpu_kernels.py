@@ -117,9 +117,11 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
 
 
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 12, 12, 64, 0, 64, False), (2, 1, 24, 24, 32, 32, 128, False), (1, 2, 96, 96, 64, 0, 64, True),
-                                                      (1, 1, 12, 12, 512, 512, 256, False), (1, 3, 10, 20, 64, 64, 96, True)])
+                                                      (1, 1, 12, 12, 512, 512, 256, False), (2, 3, 10, 20, 64, 64, 128, True), (2, 1, 32, 32, 64, 0, 64, True),
+                                                      (2, 1, 48, 48, 32, 32, 128, True), (1, 11, 12, 12, 256, 0, 512, False)])
 def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
-    """LDS halo-patch 3x3 kernel: borders, partial tiles (HW not a multiple of 128), two sources, fused GN+SiLU operand, residual."""
+    """LDS halo-patch 3x3 kernel (weights in fragment order, fmt 2): image borders, flat row tiles running across frames and samples with a
+    partial last tile, 2-D pixel tiles, two sources, fused per-sample GN+SiLU operand, residual, split channel chunks (atomics)."""
     N, lib = _lib()
     g = torch.Generator().manual_seed(12)
     Cin = C1 + C2
@@ -138,12 +140,12 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
     K = 9 * Cin
     Kpad = (K + 31) // 32 * 32
     wg = w.contiguous().to(gpu)
-    packed = torch.zeros(Cout * Kpad, device=gpu)
+    packed = torch.zeros((Cout + 31) // 32 * 32 * Kpad, device=gpu)
     job = (N.PackJob * 1)()
     j = job[0]
     j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
     j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
-    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 1
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 2
     tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
     N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
     d = N.ConvDesc()

@@ -1,14 +1,24 @@
-// 3x3 (stride 1, zero padding 1) per-frame convolution with an LDS-resident halo patch, split-bf16 MFMA ("bf16x3"), gfx950.
+// 3x3 stride-1 "same" convolution with an LDS-resident halo patch and register-fed weights, split-bf16 MFMA, gfx950.
 //
-// The generic implicit GEMM (igemm_bf16x3.hip) gathers the A operand once per tap: 9 loads, 9 fp32->bf16 splits and 9
-// GroupNorm+SiLU evaluations per activation element, which leaves the matrix cores waiting on L2 latency.  Here a workgroup
-// owns 128 consecutive rows (pixels in frame-major order; a tile may straddle frames); for each chunk of 32 input channels it
-// stages the rows [m0-(W+1), m0+128+(W+1)) ONCE (transform + hi/lo split fused into the staging), and the nine taps are nine
-// row-shifted views of that patch: A fragments are ds_read_b128 at patch row (r + (W+1) + dh*W + dw).  Image borders -- and
-// therefore also every read that would cross into a neighbouring frame -- are applied as per-lane tap masks.
-// Weights (fmt-1 pre-split bf16, [Cout][Kpad]) stream through a double-buffered LDS tile, one (tap, channel chunk) at a time,
-// prefetched two taps ahead in registers.  The next patch chunk is prefetched into registers while the 9 x 12..24 MFMAs of the
-// current one run.  Layers with few rows (12x12 level) split the channel chunks over blockIdx.y and combine with fp32 atomics.
+// The ResnetBlock projections (vddp.py:268-285, Conv3d (1,3,3) pad (0,1,1)) are 60 % of the denoiser's flops.  The generic
+// implicit-GEMM kernel gathers every input element nine times (once per tap), stages the weights through LDS and synchronises
+// the workgroup once per K chunk.  Here, per 32-channel chunk:
+//   A  the tile's pixels plus a one-pixel halo are staged ONCE in LDS as bf16 hi | lo; the nine taps are nine row offsets into
+//      that patch.  Big frames use 2-D pixel tiles (TH x 16 pixels, patch (TH+2) x 18, 27-41 % halo, out-of-image patch rows are
+//      zeros); small frames use flat row tiles over the whole [frame][h][w] row space (patch = tile +- (W+1) rows, no partial
+//      tiles at frame ends) with per-pixel tap masks for the image borders.
+//   B  weights come pre-split and pre-arranged in MFMA fragment order (vmm_pack_weights fmt 2): one 32-column x 16-k fragment
+//      plane is 1 KB contiguous, so each wave loads its B operands with fully coalesced 16-byte-per-lane global loads straight
+//      into registers, one k16 step ahead of use.  No LDS traffic, no LDS footprint and NO workgroup barrier for the weights:
+//      the only barriers are the two around the patch refresh at a channel-chunk boundary (every 18 k16 steps).
+// LDS traffic per MFMA drops to the A fragments only (1/3 of the LDS read bandwidth at full MFMA rate), the weights ride the
+// vector-memory/L1 path in parallel, and at <= 52 KB LDS / <= 256 VGPRs two workgroups share a CU so that one computes while the
+// other refreshes its patch or drains its epilogue.
+//
+// Wave tile 64 rows x 64 columns (2 x 2 MFMA 32x32x16 tiles, 3 passes: lo*hi + hi*lo + hi*hi, see igemm_bf16x3.hip); workgroup =
+// 4 waves as 4 x 1 (256 pixels x 64 columns, Cout == 64) or 2 x 2 (128 pixels x 128 columns).  Few-row layers (12 x 12 level) split
+// the channel chunks over blockIdx.y and meet in fp32 atomics.  Fused input transform (GroupNorm * FiLM -> SiLU, a_mode 1), bias,
+// two-source channel concat and the residual add are the same as in the generic kernel.
 #include "igemm_common.h"
 
 namespace {
@@ -18,8 +28,20 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CK = 32;    // channels per chunk
-constexpr int CROW = 40;  // LDS row pitch in bf16 (80 bytes)
-constexpr int CM = 128;   // rows per workgroup
+constexpr int CROW = 72;  // LDS patch row pitch in bf16: 32 hi | 32 lo | 8 pad = 144 bytes (9 x 16 B: ds_read_b128 over consecutive rows is conflict-free)
+
+struct C3Args {
+  vmm_conv_desc p;
+  int n_tiles;                   // column tiles
+  int mode;                      // 0: flat row tiles across frames, 1: 2-D TH x 16 pixel tiles
+  int tiles_x, tiles_per_frame;  // 2-D mode
+  int PR;                        // patch rows
+  int pitch;                     // patch rows per image row step (2-D: 18, flat: W)
+  int halo;                      // flat mode: W + 1
+  int KS;                        // k16 steps per 32-column tile in the packed weights
+  int chunks_per_split;
+  int total_rows;                // nimg * H * W
+};
 
 __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) {
   const f32x2 v = {x0, x1};
@@ -28,269 +50,326 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int BN, int MAXP>
-__global__ __launch_bounds__(256) void conv3x3_x3_kernel(const vmm_conv_desc p, int Kpad, int n_tiles, int PR, int ksplit) {
-  constexpr int TN = BN / 2, NT = TN / 32, MT = 2;  // 2 x 2 waves, wave tile 64 x TN
-  constexpr int B_ITEMS = BN * 8, B_PASSES = (B_ITEMS + 255) / 256;
+template <int WM, int WN, int MAXP, int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
+  constexpr int BM = WM * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ph = smem;
-  unsigned short* Pl = Ph + PR * CROW;
-  unsigned short* Bh = Pl + PR * CROW;      // [2][BN][CROW]
-  unsigned short* Bl = Bh + 2 * BN * CROW;  // [2][BN][CROW]
+  const vmm_conv_desc& p = a.p;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane & 31, lk = lane >> 5;
   const int W = p.Win, H = p.Hin, HW = H * W;
-  const int M = p.nimg * HW;
-  const int m0 = (blockIdx.x / n_tiles) * CM;
-  const int n0 = (blockIdx.x % n_tiles) * BN;
+  const int mtile = blockIdx.x / a.n_tiles;
+  const int n0 = (blockIdx.x % a.n_tiles) * (WN * 64);
   const int Cin = p.C1 + p.C2;
-  const int nch_all = Cin / CK;
-  const int c_begin = (int)((long long)blockIdx.y * nch_all / ksplit), c_end = (int)((long long)(blockIdx.y + 1) * nch_all / ksplit);
-  const int halo = W + 1;
+  const int nchunks = Cin / CK;
+  const int c_begin = blockIdx.y * a.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + a.chunks_per_split);
+  if (c_begin >= c_end) return;
 
-  // tap masks of this lane's output pixels (bit t = kh*3+kw set when the tap reads inside the image of the pixel's own frame)
-  unsigned tapmask[MT];
-  int prow[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int local = wm * 64 + i * 32 + lrow;
-    const int m = m0 + local;
-    prow[i] = local + halo;
-    unsigned msk = 0;
-    if (m < M) {
-      const int pix = m % HW;
-      const int h = pix / W, w = pix - h * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) msk |= 1u << t;
-      }
-    }
-    tapmask[i] = msk;
+  int img = 0, ty0 = 0, tx0 = 0, g0 = 0;
+  if (MODE) {
+    img = mtile / a.tiles_per_frame;
+    const int t = mtile - img * a.tiles_per_frame;
+    const int tyi = t / a.tiles_x;
+    ty0 = tyi * (BM / 16);
+    tx0 = (t - tyi * a.tiles_x) * 16;
+  } else {
+    g0 = mtile * BM;
   }
 
-  // patch staging roles: item e = tid + ps*256 -> patch row e>>3 (global row m0 - halo + row), float4 e&7 of the channel chunk
-  const int n_items = PR * 8;
+  // this lane's two output pixels: patch row of the centre tap and the mask of taps that read inside the image
+  int prow[2];
+  unsigned tapmask[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wm * 64 + i * 32 + lrow;
+    if (MODE) {
+      prow[i] = ((m >> 4) + 1) * a.pitch + (m & 15) + 1;
+      tapmask[i] = 0x1FFu;  // out-of-image patch rows hold zeros
+    } else {
+      prow[i] = m + a.halo;
+      unsigned msk = 0;
+      const int g = g0 + m;
+      if (g < a.total_rows) {
+        const int pix = g % HW;
+        const int h = pix / W, w = pix - h * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+          if (hh >= 0 && hh < H && ww >= 0 && ww < W) msk |= 1u << t;
+        }
+      }
+      tapmask[i] = msk;
+    }
+  }
+
+  // patch staging: item (row r, 4 channels k4); source row of every item is chunk-invariant
   const int k4 = tid & 7;
+  auto src_row = [&](int ps) -> int {  // recomputed per chunk rather than kept in MAXP registers
+    const int r = (tid >> 3) + ps * 32;
+    int s = -1;
+    if (r < a.PR) {
+      if (MODE) {
+        const int py = r / 18, px = r - py * 18;
+        const int h = ty0 - 1 + py, w = tx0 - 1 + px;
+        if (h >= 0 && h < H && w >= 0 && w < W) s = img * HW + h * W + w;
+      } else {
+        const int g = g0 - a.halo + r;
+        if (g >= 0 && g < a.total_rows) s = g;
+      }
+    }
+    return s;
+  };
   f32x4 preg[MAXP];
-  auto load_patch = [&](int cc) {
+  auto load_patch = [&](int cc) {  // raw loads only, so that they stay in flight under the MFMAs; the operand transform runs at store time
     const int c0 = cc * CK;
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
     const int ld = src1 ? p.lda1 : p.lda2;
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
-    const bool xform = src1 && p.a_mode == 1;
-    const int rows_per_sample = HW * p.a_imgs_per_sample;
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
-      const int e = tid + ps * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int g = m0 - halo + (e >> 3);
-      if (e < n_items && g >= 0 && g < M) {
-        v = *reinterpret_cast<const f32x4*>(src + (long long)g * ld + cb);
-        if (xform) {
-          const float* cf = p.a_coef + ((long long)(g / rows_per_sample) * p.C1 + cb) * 2;
-          const f32x4 a = *reinterpret_cast<const f32x4*>(cf);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(cf + 4);
-          v.x = igemm::silu_fast(v.x * a.x + a.y);
-          v.y = igemm::silu_fast(v.y * a.z + a.w);
-          v.z = igemm::silu_fast(v.z * b.x + b.y);
-          v.w = igemm::silu_fast(v.w * b.z + b.w);
-        }
-      }
+      const int sr = src_row(ps);
+      if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
       preg[ps] = v;
     }
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&](int cc) {
+    const int c0 = cc * CK;
+    const bool xform = c0 < p.C1 && p.a_mode == 1;
+    const int rows_per_sample = HW * p.a_imgs_per_sample;
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
-      const int e = tid + ps * 256;
-      if (e < n_items) {
+      const int r = (tid >> 3) + ps * 32;
+      if (r < a.PR) {
+        f32x4 v = preg[ps];
+        const int sr = xform ? src_row(ps) : -1;
+        if (sr >= 0) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
+          const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
+          const f32x4 ca = *reinterpret_cast<const f32x4*>(cf);
+          const f32x4 cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
+          v.x = igemm::silu_fast(v.x * ca.x + ca.y);
+          v.y = igemm::silu_fast(v.y * ca.z + ca.w);
+          v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
+          v.w = igemm::silu_fast(v.w * cb4.z + cb4.w);
+        }
         unsigned h0, l0, h1, l1;
-        split2c(preg[ps].x, preg[ps].y, h0, l0);
-        split2c(preg[ps].z, preg[ps].w, h1, l1);
-        *reinterpret_cast<uint2*>(&Ph[(e >> 3) * CROW + k4 * 4]) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(&Pl[(e >> 3) * CROW + k4 * 4]) = make_uint2(l0, l1);
-      }
-    }
-  };
-  // weight tile roles; tiles are numbered q = (cc - c_begin)*9 + tap
-  const unsigned short* wbase = reinterpret_cast<const unsigned short*>(p.w);
-  const long long plane = (long long)p.Cout * Kpad;
-  const int n_tiles_b = (c_end - c_begin) * 9;
-  auto load_b = [&](int q, uint4 (&reg)[B_PASSES]) {
-    const int cc = c_begin + q / 9, tap = q % 9;
-    const int koff = tap * Cin + cc * CK;
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-      const int e = tid + ps * 256;
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (e < B_ITEMS && q < n_tiles_b) {
-        const int seg = e & 3, n = (e >> 2) % BN, pl = e / (4 * BN);
-        if (n0 + n < p.Cout) v = *reinterpret_cast<const uint4*>(wbase + pl * plane + (long long)(n0 + n) * Kpad + koff + seg * 8);
-      }
-      reg[ps] = v;
-    }
-  };
-  auto store_b = [&](int buf, const uint4 (&reg)[B_PASSES]) {
-#pragma unroll
-    for (int ps = 0; ps < B_PASSES; ++ps) {
-      const int e = tid + ps * 256;
-      if (e < B_ITEMS) {
-        const int seg = e & 3, n = (e >> 2) % BN, pl = e / (4 * BN);
-        unsigned short* dst = (pl ? Bl : Bh) + (buf * BN + n) * CROW + seg * 8;
-        *reinterpret_cast<uint4*>(dst) = reg[ps];
+        split2c(v.x, v.y, h0, l0);
+        split2c(v.z, v.w, h1, l1);
+        *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
       }
     }
   };
 
-  f32x16 acc[MT][NT];
+  // weight fragments: plane (column tile nt, k16 step ks, hi|lo) = 64 lanes x 16 bytes contiguous
+  const uint4* wf = reinterpret_cast<const uint4*>(p.w);
+  const uint4* bbase[2];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < 2; ++j) bbase[j] = wf + (long long)((n0 + wn * 64) / 32 + j) * a.KS * 128 + lane;
+  const int cin16 = Cin / 16;
+  auto load_b = [&](uint4 (&d)[4], int ks) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const uint4* q = bbase[j] + (long long)ks * 128;
+      d[2 * j] = q[0];
+      d[2 * j + 1] = q[64];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // one tap: MFMAs of B tile `q` (LDS buffer q&1) against the patch, while B tile q+2 is fetched and q+1 moves regs -> LDS
-  auto tap_step = [&](int q, int tap, uint4 (&reg_next)[B_PASSES], uint4 (&reg_far)[B_PASSES], bool patch_swap) {
-    load_b(q + 2, reg_far);
-    const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
-    const int bbuf = q & 1;
-    const unsigned short* bh_t = Bh + bbuf * BN * CROW;
-    const unsigned short* bl_t = Bl + bbuf * BN * CROW;
+  // A fragments of one k16 step: [i*2 + plane], double-buffered like the weights so that the LDS reads of step q+1 are in
+  // flight while the twelve MFMAs of step q issue
+  // patch addressing: one base per (pixel, kernel row); the kernel column, k16 half and hi|lo plane are immediate offsets
+  const int pitch = MODE ? 18 : a.pitch;
+  int abase[2][3];  // element offsets into Ph
 #pragma unroll
-    for (int s = 0; s < CK / 16; ++s) {
-      const int ko = s * 16 + lk * 8;
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        uint4 vh = *reinterpret_cast<const uint4*>(&Ph[(prow[i] + toff) * CROW + ko]);
-        uint4 vl = *reinterpret_cast<const uint4*>(&Pl[(prow[i] + toff) * CROW + ko]);
-        if (!((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
-        ah[i] = __builtin_bit_cast(bf16x8, vh);
-        al[i] = __builtin_bit_cast(bf16x8, vl);
-      }
+    for (int kh = 0; kh < 3; ++kh) abase[i][kh] = (prow[i] + (kh - 1) * pitch - 1) * CROW + lk * 8;
+  auto load_a = [&](uint4 (&d)[4], int tap, int s) {
+    const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&bh_t[(wn * TN + j * 32 + lrow) * CROW + ko]));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&bl_t[(wn * TN + j * 32 + lrow) * CROW + ko]));
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* q = Ph + abase[i][kh] + (kw * CROW + s * 16);
+      uint4 vh = *reinterpret_cast<const uint4*>(q);
+      uint4 vl = *reinterpret_cast<const uint4*>(q + CK);
+      if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+      d[2 * i] = vh;
+      d[2 * i + 1] = vl;
     }
-    store_b(bbuf ^ 1, reg_next);  // tile q+1 (fetched one tap ago); the buffer was last read before the previous barrier
-    if (patch_swap) {
-      __syncthreads();  // every wave is done reading the patch of this channel chunk
-      store_patch();
-    }
-    __syncthreads();
+  };
+  auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
+    const bf16x8 ah0 = __builtin_bit_cast(bf16x8, av[0]), al0 = __builtin_bit_cast(bf16x8, av[1]);
+    const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
+    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
+    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
+    // pass-major: consecutive MFMAs never share an accumulator
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
   };
 
-  if (c_begin < c_end) {
-    uint4 regA[B_PASSES], regB[B_PASSES];
-    load_patch(c_begin);
-    load_b(0, regA);
-    load_b(1, regB);
-    store_patch();
-    store_b(0, regA);
-    __syncthreads();
-    // tile q is consumed from LDS[q&1]; tile q+1 sits in regB (even q) / regA (odd q); tile q+2 is fetched into the other set
-    int q = 0;
-    for (int cc = c_begin; cc < c_end; ++cc) {
-      const bool more = cc + 1 < c_end;
-      if (more) load_patch(cc + 1);  // in flight during the nine taps
+  // software pipeline over k16 steps q = (chunk, tap, half): operands of step q+1 are requested before the MFMAs of step q.
+  // sched_barrier pins that order (the scheduler otherwise sinks the loads next to their uses to save registers).
+  uint4 b0[4], b1[4], a0[4], a1[4];
+  load_patch(c_begin);
+  load_b(b0, c_begin * 2);
+  store_patch(c_begin);
+  __syncthreads();
+  load_a(a0, 0, 0);
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    const bool more = cc + 1 < c_end;
+    // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
+    // instead of being hoisted out of the loop into 36 address registers
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const bool swap = (tap == 8) && more;
-        if ((q & 1) == 0) tap_step(q, tap, regB, regA, swap);
-        else tap_step(q, tap, regA, regB, swap);
-        ++q;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
+    if (more) load_patch(cc + 1);  // in flight during the nine taps
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ks = tap * cin16 + cc * 2;
+      load_b(b1, ks + 1);
+      load_a(a1, tap, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) {
+        load_b(b0, ks + cin16);
+        load_a(a0, tap + 1, 0);
+      } else if (more) {
+        load_b(b0, cc * 2 + 2);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+      __syncthreads();  // every wave is done reading the patch of chunk cc
+      store_patch(cc + 1);
+      __syncthreads();
+      load_a(a0, 0, 0);
     }
   }
 
   // epilogue
   const bool first = blockIdx.y == 0;
+  const bool atomic = gridDim.y > 1;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (m >= M) continue;
+      const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      long long orow;
+      if (MODE) {
+        orow = (long long)img * HW + (ty0 + (m >> 4)) * W + tx0 + (m & 15);
+      } else {
+        if (g0 + m >= a.total_rows) continue;
+        orow = g0 + m;
+      }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * TN + j * 32 + lrow;
-        if (col < p.Cout) {
-          float v = acc[i][j][r];
-          if (first) {
-            if (p.bias) v += p.bias[col];
-            if (p.res) v += p.res[(long long)m * p.ldres + col];
-          }
-          float* o = p.out + (long long)m * p.ldo + col;
-          if (ksplit > 1) atomicAdd(o, v); else *o = v;
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lrow;
+        float v = acc[i][j][r];
+        if (first) {
+          if (p.bias) v += p.bias[col];
+          if (p.res) v += p.res[orow * p.ldres + col];
         }
+        float* o = p.out + orow * p.ldo + col;
+        if (atomic) atomicAdd(o, v); else *o = v;
       }
     }
   }
 }
 
-template <int BN, int MAXP>
-int launch_c3(const vmm_conv_desc& d, int Kpad, int PR, int ksplit, hipStream_t s) {
-  const long long M = (long long)d.nimg * d.Hin * d.Win;
-  const int nt = cdiv(d.Cout, BN);
-  const size_t shm = sizeof(unsigned short) * ((size_t)2 * PR * CROW + (size_t)4 * BN * CROW);
+template <int WM, int WN, int MAXP, int MODE>
+int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
+  const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<BN, MAXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_x3_kernel<BN, MAXP>), dim3((unsigned)(cdiv(M, CM) * nt), ksplit), dim3(256), shm, s, d, Kpad, nt, PR, ksplit);
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE>), dim3((unsigned)(mtiles * a.n_tiles), ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
-// Returns 1 when the descriptor is outside this kernel's envelope (caller falls back to vmm_conv_igemm_bf16x3).
+// Weights: vmm_pack_weights fmt 2 (MFMA fragment order).  Returns 1 (nothing launched) when the descriptor is outside this
+// kernel's envelope: 3x3 / stride 1 / pad 1, C1 % 32 == C2 % 32 == 0, Cout == 64 or Cout % 128 == 0, W <= 31 or (W % 16 == 0 and
+// H % 16 == 0) -- the caller then uses vmm_conv_igemm_bf16x3 with fmt-1 weights.
 extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 &&
                         d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 &&
                         d.rot_ncols == 0 && d.q_ncols == 0;
-  const bool chan_ok = (d.C1 % CK == 0) && (d.C2 % CK == 0) && (d.Cout % 4 == 0) && d.Cout >= 64 && (d.lda1 & 3) == 0 && (!d.C2 || (d.lda2 & 3) == 0);
-  const int PR = CM + 2 * (d.Win + 1);
-  if (!shape_ok || !chan_ok || PR > 384) return 1;
+  const bool chan_ok = (d.C1 % CK == 0) && (d.C2 % CK == 0) && d.C1 > 0 && (d.Cout == 64 || d.Cout % 128 == 0) && (d.lda1 & 3) == 0 &&
+                       (!d.C2 || (d.lda2 & 3) == 0);
+  if (!shape_ok || !chan_ok) return 1;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   const long long M = (long long)d.nimg * d.Hin * d.Win;
-  if (M >= (1LL << 31)) return -4;
-  const int Ktot = 9 * (d.C1 + d.C2);
-  const int Kpad = (Ktot + 31) / 32 * 32;
-  hipStream_t s = (hipStream_t)stream;
-  const int bn = d.Cout >= 128 ? 128 : 64;
-  // few-row layers (12x12 level): split the channel chunks so that >= ~1000 workgroups are in flight; partial sums meet in fp32 atomics
-  const long long blocks = (long long)cdiv(M, CM) * cdiv(d.Cout, bn);
+  if (M >= (1LL << 31) || M <= 0) return M <= 0 ? 0 : -4;
+  const bool wide = d.Cout >= 128;  // 2 x 2 waves, 128 pixels x 128 columns; else 4 x 1 waves, 256 pixels x 64 columns
+  const int BM = wide ? 128 : 256, TH = BM / 16;
+  C3Args a;
+  a.p = d;
+  a.n_tiles = wide ? d.Cout / 128 : 1;
+  a.total_rows = (int)M;
+  a.KS = 9 * (d.C1 + d.C2) / 16;
+  int mtiles;
+  if (d.Win >= 32 && d.Win % 16 == 0 && d.Hin % TH == 0) {
+    a.mode = 1;
+    a.tiles_x = d.Win / 16;
+    a.tiles_per_frame = a.tiles_x * (d.Hin / TH);
+    a.pitch = 18;
+    a.halo = 0;
+    a.PR = (TH + 2) * 18;
+    mtiles = d.nimg * a.tiles_per_frame;
+  } else {
+    a.mode = 0;
+    a.tiles_x = a.tiles_per_frame = 1;
+    a.pitch = d.Win;
+    a.halo = d.Win + 1;
+    a.PR = BM + 2 * a.halo;
+    mtiles = (int)cdiv(M, BM);
+  }
+  if (a.PR > (wide ? 6 : 11) * 32) return 1;
+  // few-row layers (12 x 12 level): split the channel chunks so that both workgroup slots of every CU are filled a few times over;
+  // the partial sums meet in fp32 atomics on a zeroed output
   const int nch = (d.C1 + d.C2) / CK;
+  const long long blocks = (long long)mtiles * a.n_tiles;
   int ksplit = 1;
-  if (blocks < 768) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
+  if (blocks < 1024 && d.ldo == d.Cout && d.res != d.out) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
+  a.chunks_per_split = (int)cdiv(nch, ksplit);
+  ksplit = (int)cdiv(nch, a.chunks_per_split);
+  hipStream_t s = (hipStream_t)stream;
   if (ksplit > 1) {
-    if (d.ldo != d.Cout) return 1;
     hipError_t e = hipMemsetAsync(d.out, 0, sizeof(float) * (size_t)M * d.Cout, s);
     if (e != hipSuccess) return (int)e;
   }
-  const bool small = PR <= 8 * 32;  // W <= 63: 8 patch items per thread instead of 12 (fewer VGPRs)
-  if (bn == 128) return small ? launch_c3<128, 8>(d, Kpad, PR, ksplit, s) : launch_c3<128, 12>(d, Kpad, PR, ksplit, s);
-  return small ? launch_c3<64, 8>(d, Kpad, PR, ksplit, s) : launch_c3<64, 12>(d, Kpad, PR, ksplit, s);
+  if (wide) return a.mode ? launch_c3<2, 2, 6, 1>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0>(a, mtiles, ksplit, s);
+  return a.mode ? launch_c3<4, 1, 11, 1>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0>(a, mtiles, ksplit, s);
 }

@@ -163,6 +163,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
+  if (jb.fmt == 2) {
+    // split-bf16 operand in MFMA fragment order for conv3x3_bf16x3.hip / proj_bf16x3.hip: plane (column tile nt of 32, k16 step ks, hi|lo)
+    // = 64 lanes x 8 bf16; lane l holds column nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +7.  K = (th, tw, c) padded to 32, N to 32.
+    if (direction != 0) return;
+    const int K = jb.TH * jb.TW * jb.Cp;
+    const int KS = (K + 31) / 32 * 2;
+    const int NT = (jb.N + 31) / 32;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(jb.packed);
+    const long long tot = (long long)NT * KS * 512;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int e = (int)(i & 7), l = (int)(i >> 3) & 63;
+      const long long pl = i >> 9;  // nt*KS + ks
+      const int ks = (int)(pl % KS), nt = (int)(pl / KS);
+      const int n = nt * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 + e;
+      float v = 0.f;
+      if (k < K && n < jb.N) {
+        const int c = k % jb.Cp, t = k / jb.Cp;
+        const int tw = t % jb.TW, th = t / jb.TW;
+        if (c < jb.C) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh + (long long)(jb.w0 + tw * jb.ws) * jb.sw];
+      }
+      const __bf16 h = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)h);
+      const long long o = pl * 1024 + l * 8 + e;
+      dst[o] = __builtin_bit_cast(unsigned short, h);
+      dst[o + 512] = __builtin_bit_cast(unsigned short, lo);
+    }
+    return;
+  }
   const long long total = (long long)jb.TH * jb.TW * jb.Cp * jb.N;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i % jb.N);

@@ -300,10 +300,15 @@ class _Builder:
     def pack(self, name: str, n_elems: int, want_grad: bool = True, **desc) -> Tuple[int, int]:
         """Register an operand layout of parameter `name` (see vmm_pack_job); returns (packed ptr, packed-gradient ptr)."""
         self._touch(name)
-        if want_grad and self.x3 and not self.in_bwd:  # forward GEMM operand -> pre-split, pre-transposed bf16 (igemm_bf16x3.hip)
-            k = desc["TH"] * desc["TW"] * desc["Cp"]
-            n_elems = desc["N"] * ((k + 31) // 32 * 32)
-            desc = dict(desc, fmt=1)
+        frag = desc.pop("frag", False)
+        if want_grad and self.x3 and not self.in_bwd:  # forward GEMM operand -> pre-split bf16 hi|lo
+            kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
+            if frag:  # MFMA fragment order, read straight into registers (conv3x3_bf16x3.hip)
+                n_elems = (desc["N"] + 31) // 32 * 32 * kpad
+                desc = dict(desc, fmt=2)
+            else:     # [N][Kpad] planes, staged through LDS (igemm_bf16x3.hip)
+                n_elems = desc["N"] * kpad
+                desc = dict(desc, fmt=1)
         ptr = self.wslot(n_elems)
         job = dict(name=name, packed=ptr, **desc)
         self.plan.pack_jobs.append(job)
@@ -320,11 +325,22 @@ class _Builder:
             self.raw_slots[name] = self.pack(name, n, want_grad=False, TH=1, TW=1, C=1, Cp=1, N=n, sn=1)[0]
         return self.raw_slots[name]
 
-    def pack_conv(self, name: str, pad_cin_to: int = 0) -> Tuple[int, int]:
+    def pack_conv(self, name: str, pad_cin_to: int = 0, frag: bool = False) -> Tuple[int, int]:
         """(Cout, Cin, 1, KH, KW) -> [(kh, kw, ci)][Cout]"""
         co, ci, _, kh, kw = self.shapes[name]
         cip = max(ci, pad_cin_to)
-        return self.pack(name, kh * kw * cip * co, TH=kh, TW=kw, C=ci, Cp=cip, N=co, sn=ci * kh * kw, sc=kh * kw, sh=kw, sw=1, hs=1, ws=1)
+        return self.pack(name, kh * kw * cip * co, TH=kh, TW=kw, C=ci, Cp=cip, N=co, sn=ci * kh * kw, sc=kh * kw, sh=kw, sw=1, hs=1, ws=1, frag=frag)
+
+    def halo_ok(self, c1: int, c2: int, cout: int, H: int, W: int) -> bool:
+        """Envelope of vmm_conv3x3_bf16x3 (LDS halo patch + register-fed fragment-order weights)."""
+        if not (self.x3 and not self.in_bwd and getattr(self.m, "use_halo_conv", True)):
+            return False
+        if c1 % 32 or c2 % 32 or not (cout == 64 or cout % 128 == 0):
+            return False
+        bm = 128 if cout >= 128 else 256
+        if W >= 32 and W % 16 == 0 and H % (bm // 16) == 0:
+            return True
+        return bm + 2 * (W + 1) <= (6 if cout >= 128 else 11) * 32
 
     def pack_conv_dgrad(self, name: str, ci0: int, nci: int) -> int:
         """(Cout, Cin, 1, KH, KW) -> [(kh, kw, co)][ci0 : ci0+nci]  (data gradient of a stride-1 conv; the descriptor mirrors the taps)"""
@@ -396,7 +412,7 @@ class _Builder:
         self.plan.keepalive.append(d)
         return d
 
-    def conv(self, what: str = "conv", **kw) -> "N.ConvDesc":
+    def conv(self, what: str = "conv", halo: bool = False, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
@@ -405,11 +421,8 @@ class _Builder:
         fn = self.lib.vmm_conv_igemm_f32
         if self.x3 and not self.in_bwd:
             fn = self.lib.vmm_conv_igemm_bf16x3
-            halo_ok = (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.off_h == -1 and d.off_w == -1 and d.sgn_h == 1 and d.sgn_w == 1 and d.Hv == d.Hin
-                       and d.Wv == d.Win and d.oscale == 1 and d.rot_ncols == 0 and d.q_ncols == 0 and d.C1 % 32 == 0 and d.C2 % 32 == 0 and d.Cout >= 64
-                       and d.Win <= 127)
-            if halo_ok and getattr(self.m, "use_halo_conv", True):
-                fn = self.lib.vmm_conv3x3_bf16x3  # LDS-resident halo patch: every input element staged once per channel chunk
+            if halo:  # weights were packed in fragment order for it (halo_ok)
+                fn = self.lib.vmm_conv3x3_bf16x3
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
@@ -459,15 +472,17 @@ class _Builder:
         H, W = x1.H, x1.W
         rows = self.B * self.T * H * W
         film_ptr, dfilm_ptr = film if film else (0, 0)
-        w1, gw1 = self.pack_conv(name + ".block1.proj.weight")
+        halo1 = self.halo_ok(x1.C, x2.C if x2 is not None else 0, Cout, H, W)
+        w1, gw1 = self.pack_conv(name + ".block1.proj.weight", frag=halo1)
         h1 = self.act(Cout, H, W)
         d1 = self.conv(a1=x1, a2=x2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
-                       Wv=W, what=name + ".block1.proj")
+                       Wv=W, what=name + ".block1.proj", halo=halo1)
         c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout)
-        w2, gw2 = self.pack_conv(name + ".block2.proj.weight")
+        halo2 = self.halo_ok(Cout, 0, Cout, H, W)
+        w2, gw2 = self.pack_conv(name + ".block2.proj.weight", frag=halo2)
         h2 = self.act(Cout, H, W)
         d2 = self.conv(a1=h1, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
-                       a_coef=c1_ptr, what=name + ".block2.proj")
+                       a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2)
         self.free_act(h1)
         self.free(c1_off, c1_n)
         c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0)
