@@ -72,7 +72,10 @@ typedef struct vmm_pack_job {
   int32_t TH, TW, C, Cp, N;
   int32_t sn, sc, sh, sw, h0, hs, w0, ws;
   int32_t accumulate;
-  int32_t fmt; /* 0: fp32 [K][N];  1: split bf16 for vmm_conv_igemm_bf16x3: [N][Kpad] hi plane, then lo plane (Kpad = K rounded up to 32) */
+  int32_t fmt; /* 0: fp32 [K][N];  1: split bf16 for vmm_conv_igemm_bf16x3: [N][Kpad] hi plane, then lo plane (Kpad = K rounded up to 32);
+                * 2: split bf16 in MFMA fragment order for vmm_conv3x3_bf16x3 / vmm_linattn_block_bf16x3: [N/32][Kpad/16][hi|lo][64 lanes][8],
+                *    lane l = column (l & 31), k = step*16 + (l >> 5)*8 .. +7 (N and K padded to 32 with zeros);
+                * 3: as 2 with k permuted inside every 32-block to the accumulator-register order (linattn_block.hip).  1-3: direction 0 only. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 
@@ -102,6 +105,16 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
                            const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
                            int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
                            vmm_stream_t stream);
+
+/* Fused spatial linear-attention BLOCK for the full-resolution level (vddp.py:313-378 inside Residual(PreNorm(.)), vddp.py:613/628):
+ * out = x + to_out(linear_attention(to_qkv(LayerNorm(x)))) + bias with the conditioning tokens ek/ev [B][ntok][256] stacked onto k, v.
+ * q, k, v never touch HBM (x read twice, out written once).  wqkv_frag = vmm_pack_weights fmt 2 of to_qkv (768,64), wout_frag = fmt 3
+ * of to_out (64,256); workspace = vmm_linattn_block_workspace(B,T,HW) floats.
+ * Envelope: C == 64, heads == 8, dim_head == 32, HW % 32 == 0; returns 1 (nothing launched) otherwise. */
+int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW);
+int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                             const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                             int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
 
 /* Fused temporal-attention BLOCK for the full-resolution level (vddp.py:615,630,680: x + to_out(attn(rotary(to_qkv(LayerNorm(x)))))):
  * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections on the split-bf16 matrix cores

@@ -338,6 +338,56 @@ def test_spatial_attention_core(gpu, HW, ntok, per_frame):
     assert relerr(out.cpu(), ref) < 5e-6
 
 
+def _pack_frag(N, lib, gpu, w2d, fmt):
+    """(out, in) weight -> vmm_pack_weights fragment-order operand (fmt 2 / 3)."""
+    co, ci = w2d.shape
+    wg = w2d.contiguous().to(gpu)
+    packed = torch.zeros((co + 31) // 32 * 32 * ((ci + 31) // 32 * 32), device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 1, 1, ci, ci, co
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = ci, 1, 0, 0, 0, 0, 0, 0, 0, fmt
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, packed.numel(), 0, _s()), "pack")
+    torch.cuda.synchronize()
+    return packed
+
+
+@pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 16, 16, 11), (1, 2, 96, 96, 0), (3, 1, 8, 12, 6)])
+def test_fused_linear_attention_block(gpu, B, T, H, W, ntok):
+    """vmm_linattn_block_bf16x3 (LayerNorm -> to_qkv -> linear attention with stacked tokens -> to_out -> +x in three launches, q/k/v on chip)
+    against the oracle's block; several pixel splits per frame, more than one sample (token keys differ per sample)."""
+    from oracle import unet3d_oracle as uo
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(21)
+    Cc, heads, hid = 64, 8, 256
+    x = torch.randn(B, Cc, T, H, W, generator=g)
+    sd = {"a.fn.norm.gamma": 1 + 0.2 * torch.randn(1, Cc, 1, 1, 1, generator=g),
+          "a.fn.fn.to_qkv.weight": torch.randn(3 * hid, Cc, 1, 1, generator=g) * 0.3,
+          "a.fn.fn.to_out.weight": torch.randn(Cc, hid, 1, 1, generator=g) / 16,
+          "a.fn.fn.to_out.bias": torch.randn(Cc, generator=g),
+          "a.fn.fn.to_k.weight": torch.randn(hid, 32, generator=g) / 4,
+          "a.fn.fn.to_v.weight": torch.randn(hid, 32, generator=g) / 4}
+    tokens = torch.randn(B, ntok, 32, generator=g) if ntok else None
+    cfg = uo.UnetCfg(cond_attention="self-stacked" if ntok else "none")
+    ref = rows_of(uo.linear_attention_block(sd, "a", x, cfg, tokens))
+    wq = _pack_frag(N, lib, gpu, sd["a.fn.fn.to_qkv.weight"].reshape(3 * hid, Cc), 2)
+    wo = _pack_frag(N, lib, gpu, sd["a.fn.fn.to_out.weight"].reshape(Cc, hid), 3)
+    xg, gam, bo = rows_of(x).to(gpu), sd["a.fn.norm.gamma"].reshape(-1).to(gpu), sd["a.fn.fn.to_out.bias"].to(gpu)
+    ek = ev = None
+    if ntok:
+        ek = torch.nn.functional.linear(tokens, sd["a.fn.fn.to_k.weight"]).to(gpu)
+        ev = torch.nn.functional.linear(tokens, sd["a.fn.fn.to_v.weight"]).to(gpu)
+    ws = torch.empty(int(lib.vmm_linattn_block_workspace(B, T, H * W)), device=gpu)
+    out = torch.empty_like(xg)
+    N.check(lib.vmm_linattn_block_bf16x3(xg.data_ptr(), Cc, gam.data_ptr(), wq.data_ptr(), wo.data_ptr(), bo.data_ptr(), ek.data_ptr() if ntok else None,
+                                         ev.data_ptr() if ntok else None, ntok, ws.data_ptr(), out.data_ptr(), Cc, B, T, H * W, Cc, heads, 1e-5, _s()),
+            "fused linear attention")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu() - rows_of(x), ref - rows_of(x)) < 5e-5  # on the attention branch alone (the residual would mask errors)
+
+
 @pytest.mark.parametrize("HW,ntok,nsplit", [(144, 11, 1), (1000, 0, 4), (2304, 16, 7)])
 def test_linear_attention_core(gpu, HW, ntok, nsplit):
     N, lib = _lib()

@@ -22,7 +22,7 @@ def _gold_tables():
 def test_c_abi_exports_every_declared_symbol():
     from videometamaterials_amd import _native as N
     hdr = open(os.path.join(ROOT, "include", "vmm_kernels.h")).read()
-    declared = set(re.findall(r"^int (vmm_\w+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t) (vmm_\w+)\(", hdr, flags=re.M))
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     lib = N.lib()  # raises if the library is missing or a symbol is not exported (no compute calls here)
     for name in declared:

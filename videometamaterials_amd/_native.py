@@ -103,6 +103,9 @@ SIGNATURES = {
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_linattn_block_workspace": [c_i32, c_i32, c_i32],
+    "vmm_linattn_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_f32, c_ptr],
     "vmm_linattn_context": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_linattn_apply": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
@@ -126,6 +129,8 @@ SIGNATURES = {
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
+RESTYPES = {"vmm_linattn_block_workspace": c_i64}  # everything else returns int (0 = ok)
+
 _lib = None
 
 
@@ -146,7 +151,7 @@ def lib() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = RESTYPES.get(name, C.c_int)
         _lib = handle
     return _lib
 

@@ -1,0 +1,352 @@
+// Fused spatial linear-attention BLOCK for the full-resolution level (C = 64, 8 heads x 32), split-bf16 MFMA, gfx950.
+//
+//   out = x + to_out( ctx^T . softmax_d(q) * scale ) + bias,   ctx = softmax_n([k_tok | k]) . ([v_tok | v] / HW)^T,   q,k,v = to_qkv(LayerNorm(x))
+//   (vddp.py:313-378 SpatialLinearAttention inside Residual(PreNorm(.)), vddp.py:613/628)
+//
+// The unfused path writes the 768-wide qkv rows (2.5 GB per site at batch 8) and reads them back twice.  Here q, k, v, the
+// softmax numerators and the per-head outputs never leave the registers of the wave that produced them:
+//   pass A  (linattn_ctx_kernel)      x -> LayerNorm -> k, v tiles (MFMA) -> online softmax over pixels -> ctx^T += v^T . p (MFMA);
+//                                     one partial (max, sum, 32x32 ctx^T) per (frame, split, head)
+//   combine (linattn_combine_kernel)  merges the partials with the conditioning-token keys/values and writes ctx^T * scale /
+//                                     (sum * HW) as ready-made MFMA operand fragments
+//   pass B  (linattn_apply_kernel)    x -> LayerNorm -> q^T tile (MFMA) -> softmax over d -> o^T = ctx^T . q (MFMA) ->
+//                                     partial to_out (MFMA) -> 8-head sum through LDS + bias + residual -> out
+// HBM traffic per site: x read twice (+ once more from L2 for the residual), out written once.
+//
+// One wave = one head (512-thread workgroups): its weight fragments stay in registers for the whole kernel (no LDS, no barrier in
+// pass A; one barrier per 32-pixel tile in pass B for the head sum).  The trick that removes every transposition: an MFMA 32x32
+// accumulator holds, per lane, ONE column (lane & 31) and 16 rows; that is exactly an A or B operand of the next MFMA whose
+// contraction runs over those rows, provided both operands enumerate the contraction index in the same (register) order:
+//   k16 step s, lane half lk, element j  <->  row (j & 3) + 8 * (2 s + (j >> 2)) + 4 lk.
+// Operands produced in-kernel (p, v, q, o) have that order by construction; the static ones that meet them (ctx^T fragments,
+// to_out weights) are written in that order by the combine kernel / vmm_pack_weights fmt 3.
+#include "igemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int LC = 64;            // channels
+constexpr int LH = 8;             // heads (= waves per workgroup)
+constexpr int LD = 32;            // dim_head
+constexpr int PART = 64 + LD * LD;  // floats per partial: max[32] | sum[32] | ctx^T[e][d]
+
+struct LAArgs {
+  const float* x; int ldx;
+  const float* gamma; float eps;
+  const uint4* wqkv;   // fmt 2 fragments, N = 768 (q | k | v), K = 64 (4 k16 steps)
+  const uint4* wout;   // fmt 3 fragments, N = 64, K = 256 (16 k16 steps)
+  const float* bias_out;
+  const float* ek; const float* ev; int ntok;
+  float* part;         // [frame][split][head][PART]
+  uint4* ctxfrag;      // [frame][head][2 steps][hi|lo][64 lanes]
+  float* out; int ldo;
+  int T, HW, nsplit, sps;  // sps: 32-pixel tiles per split
+  float q_scale;
+};
+
+__device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) {
+  const f32x2 v = {a, b};
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  return hi;
+}
+
+// 8 consecutive accumulator registers -> one k16 operand fragment (hi, lo)
+__device__ __forceinline__ void split8(const f32x16& c, int r0, uint4& hi, uint4& lo) {
+  hi.x = pack_split(c[r0 + 0], c[r0 + 1], lo.x);
+  hi.y = pack_split(c[r0 + 2], c[r0 + 3], lo.y);
+  hi.z = pack_split(c[r0 + 4], c[r0 + 5], lo.z);
+  hi.w = pack_split(c[r0 + 6], c[r0 + 7], lo.w);
+}
+
+__device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  return c;
+}
+
+// LayerNorm of 32 pixel rows as operand fragments: lane (pixel = lane & 31, lk) owns channels s*16 + lk*8 .. +7 of its row for
+// the four k16 steps s.  The same registers serve as an A operand (rows = pixels) or a B operand (columns = pixels).
+__device__ __forceinline__ void load_norm_rows(const LAArgs& a, long long row, int lk, uint4 (&yh)[4], uint4 (&yl)[4]) {
+  const float* xr = a.x + row * a.ldx + lk * 8;
+  f32x4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
+    v[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + i * 16 + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s * (1.0f / LC);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  q += __shfl_xor(q, 32, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / LC) + a.eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8 + 4);
+    const f32x4 u = v[2 * i], w = v[2 * i + 1];
+    yh[i].x = pack_split(u.x * rstd * g0.x, u.y * rstd * g0.y, yl[i].x);
+    yh[i].y = pack_split(u.z * rstd * g0.z, u.w * rstd * g0.w, yl[i].y);
+    yh[i].z = pack_split(w.x * rstd * g1.x, w.y * rstd * g1.y, yl[i].z);
+    yh[i].w = pack_split(w.z * rstd * g1.z, w.w * rstd * g1.w, yl[i].w);
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pass A
+__global__ __launch_bounds__(512, 2) void linattn_ctx_kernel(const LAArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
+  const int tiles = a.HW / 32;
+  const int t_begin = split * a.sps, t_end = min(tiles, t_begin + a.sps);
+
+  uint4 wkh[4], wkl[4], wvh[4], wvl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4* qk = a.wqkv + (((long long)(LH + h) * 4 + s) * 2) * 64 + lane;
+    const uint4* qv = a.wqkv + (((long long)(2 * LH + h) * 4 + s) * 2) * 64 + lane;
+    wkh[s] = qk[0]; wkl[s] = qk[64];
+    wvh[s] = qv[0]; wvl[s] = qv[64];
+  }
+  float m = -INFINITY, ssum = 0.f;
+  f32x16 ctx = zero16();  // rows e, column d = lrow
+  for (int t = t_begin; t < t_end; ++t) {
+    uint4 yh[4], yl[4];
+    load_norm_rows(a, (long long)frame * a.HW + t * 32 + lrow, lk, yh, yl);
+    f32x16 kt = zero16(), vt = zero16();  // rows pixels, column d (resp. e) = lrow
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kt = mfma3(yh[s], yl[s], wkh[s], wkl[s], kt);
+      vt = mfma3(yh[s], yl[s], wvh[s], wvl[s], vt);
+    }
+    float tm = kt[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float mn = fmaxf(m, tm);
+    const float f = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      kt[r] = __expf(kt[r] - mn);
+      ps += kt[r];
+      ctx[r] *= f;
+    }
+    ssum = ssum * f + ps;
+    m = mn;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 ph, pl, vh, vl;
+      split8(kt, s * 8, ph, pl);
+      split8(vt, s * 8, vh, vl);
+      ctx = mfma3(vh, vl, ph, pl, ctx);  // ctx^T[e][d] += sum_pixels v[pixel][e] p[pixel][d]
+    }
+  }
+  ssum += __shfl_xor(ssum, 32, 64);
+  float* pp = a.part + (((long long)frame * a.nsplit + split) * LH + h) * PART;
+  if (lk == 0) { pp[lrow] = m; pp[32 + lrow] = ssum; }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    pp[64 + e * LD + lrow] = ctx[r];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------- combine
+// one workgroup per (frame, head): thread (eg = tid >> 5, d = tid & 31) owns ctx^T[e][d] for e = eg*4 .. eg*4+3
+__global__ __launch_bounds__(256) void linattn_combine_kernel(const LAArgs a) {
+  const int frame = blockIdx.x / LH, h = blockIdx.x - frame * LH;
+  const int d = threadIdx.x & 31, eg = threadIdx.x >> 5;
+  const int b = frame / a.T;
+  const float* pbase = a.part + ((long long)frame * a.nsplit * LH + h) * PART;
+  const long long pstride = (long long)LH * PART;
+  const float* ekb = a.ek ? a.ek + ((long long)b * a.ntok) * (LH * LD) + h * LD : nullptr;
+  const float* evb = a.ev ? a.ev + ((long long)b * a.ntok) * (LH * LD) + h * LD : nullptr;
+  const int ntok = a.ek ? a.ntok : 0;
+  float M = -INFINITY;
+  for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, pbase[s * pstride + d]);
+  for (int j = 0; j < ntok; ++j) M = fmaxf(M, ekb[(long long)j * (LH * LD) + d]);
+  float Z = 0.f, c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.nsplit; ++s) {
+    const float* pp = pbase + s * pstride;
+    const float f = __expf(pp[d] - M);
+    Z += pp[32 + d] * f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] += pp[64 + (eg * 4 + i) * LD + d] * f;
+  }
+  for (int j = 0; j < ntok; ++j) {
+    const float p = __expf(ekb[(long long)j * (LH * LD) + d] - M);
+    Z += p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] += p * evb[(long long)j * (LH * LD) + eg * 4 + i];
+  }
+  const float sc = a.q_scale / (Z * (float)a.HW);
+  // operand order: contraction index d <-> (step s, half lk, element j) with d = (j & 3) + 8 (2 s + (j >> 2)) + 4 lk
+  const int s = d >> 4, lk = (d >> 2) & 1, j = (d & 3) + 4 * ((d >> 3) & 1);
+  unsigned short* fb = reinterpret_cast<unsigned short*>(a.ctxfrag + ((long long)frame * LH + h) * 256);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = c[i] * sc;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int lane = lk * 32 + eg * 4 + i;
+    fb[((s * 2 + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, hi);
+    fb[((s * 2 + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pass B
+__global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2 buffers][8 heads][32 pixels][64 channels]
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
+  const int tiles = a.HW / 32;
+  const int t_begin = split * a.sps, t_end = min(tiles, t_begin + a.sps);
+
+  uint4 wqh[4], wql[4], woh[2][2], wol[2][2], ch[2], cl[2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4* q = a.wqkv + (((long long)h * 4 + s) * 2) * 64 + lane;
+    wqh[s] = q[0]; wql[s] = q[64];
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint4* q = a.wout + (((long long)ct * 16 + 2 * h + s) * 2) * 64 + lane;
+      woh[ct][s] = q[0]; wol[ct][s] = q[64];
+    }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const uint4* q = a.ctxfrag + ((long long)frame * LH + h) * 256 + (s * 2) * 64 + lane;
+    ch[s] = q[0]; cl[s] = q[64];
+  }
+  // reduction role: pixel rp, channels rc .. rc+3
+  const int rp = tid >> 4, rc = (tid & 15) * 4;
+  const f32x4 bias = a.bias_out ? *reinterpret_cast<const f32x4*>(a.bias_out + rc) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+    const long long row0 = (long long)frame * a.HW + t * 32;
+    uint4 yh[4], yl[4];
+    load_norm_rows(a, row0 + lrow, lk, yh, yl);
+    f32x16 qt = zero16();  // rows d, column pixel = lrow
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qt = mfma3(wqh[s], wql[s], yh[s], yl[s], qt);
+    float mx = qt[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { qt[r] = __expf(qt[r] - mx); sum += qt[r]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qt[r] *= inv;
+    f32x16 ot = zero16();  // rows e, column pixel
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 qh, ql;
+      split8(qt, s * 8, qh, ql);
+      ot = mfma3(ch[s], cl[s], qh, ql, ot);
+    }
+    f32x16 pc[2] = {zero16(), zero16()};  // rows pixels, column channel ct*32 + lrow
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 oh, ol;
+      split8(ot, s * 8, oh, ol);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+    }
+    float* rb = red + ((buf * LH + h) * 32) * LC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      rb[px * LC + lrow] = pc[0][r];
+      rb[px * LC + 32 + lrow] = pc[1][r];
+    }
+    __syncthreads();  // (the other buffer is free again: its readers passed the previous barrier)
+    f32x4 acc = bias;
+#pragma unroll
+    for (int w = 0; w < LH; ++w) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((buf * LH + w) * 32 + rp) * LC + rc);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const f32x4 xr = *reinterpret_cast<const f32x4*>(a.x + (row0 + rp) * a.ldx + rc);
+    acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;
+    *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + rc) = acc;
+  }
+}
+
+int choose_split(int frames, int HW, int* sps) {
+  const int tiles = HW / 32;
+  int ns = max(1, min(tiles / 4, 768 / max(frames, 1)));
+  *sps = (tiles + ns - 1) / ns;
+  return (tiles + *sps - 1) / *sps;
+}
+
+}  // namespace
+
+// floats of workspace vmm_linattn_block_bf16x3 needs (partials + context fragments)
+extern "C" int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW) {
+  int sps;
+  const int ns = choose_split(B * T, HW, &sps);
+  return (int64_t)B * T * ns * LH * PART + (int64_t)B * T * LH * 1024;
+}
+
+// Returns 1 (nothing launched) outside the envelope: C == 64, heads == 8, dim_head == 32, HW % 32 == 0.
+extern "C" int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                        const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                                        int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
+  if (C != LC || heads != LH || (HW % 32) || (ldx & 3) || (ldo & 3)) return 1;
+  if (B * T <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  LAArgs a;
+  a.x = x; a.ldx = ldx; a.gamma = gamma; a.eps = eps;
+  a.wqkv = reinterpret_cast<const uint4*>(wqkv_frag);
+  a.wout = reinterpret_cast<const uint4*>(wout_frag);
+  a.bias_out = bias_out;
+  a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0;
+  a.T = T; a.HW = HW;
+  a.nsplit = choose_split(B * T, HW, &a.sps);
+  a.part = workspace;
+  a.ctxfrag = reinterpret_cast<uint4*>(workspace + (long long)B * T * a.nsplit * LH * PART);
+  a.out = out; a.ldo = ldo;
+  a.q_scale = 1.0f / sqrtf((float)LD);
+  const unsigned blocks = (unsigned)(B * T * a.nsplit);
+  hipLaunchKernelGGL(linattn_ctx_kernel, dim3(blocks), dim3(512), 0, s, a);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(B * T * LH)), dim3(256), 0, s, a);
+  VMM_LAUNCH_CHECK();
+  const size_t shm = sizeof(float) * 2 * LH * 32 * LC;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linattn_apply_kernel, dim3(blocks), dim3(512), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

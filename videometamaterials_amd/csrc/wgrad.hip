@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
-  if (jb.fmt == 2) {
+  if (jb.fmt == 2 || jb.fmt == 3) {
     // split-bf16 operand in MFMA fragment order for conv3x3_bf16x3.hip / proj_bf16x3.hip: plane (column tile nt of 32, k16 step ks, hi|lo)
     // = 64 lanes x 8 bf16; lane l holds column nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +7.  K = (th, tw, c) padded to 32, N to 32.
+    // fmt 3: within every 32-block of k the contraction index follows the accumulator-register order of a preceding MFMA
+    // (linattn_block.hip): element e of half lk in step s <-> k = (e & 3) + 8 (2 s + (e >> 2)) + 4 lk.
     if (direction != 0) return;
     const int K = jb.TH * jb.TW * jb.Cp;
     const int KS = (K + 31) / 32 * 2;
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
       const int e = (int)(i & 7), l = (int)(i >> 3) & 63;
       const long long pl = i >> 9;  // nt*KS + ks
       const int ks = (int)(pl % KS), nt = (int)(pl / KS);
-      const int n = nt * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 + e;
+      const int n = nt * 32 + (l & 31);
+      const int k = jb.fmt == 2 ? ks * 16 + (l >> 5) * 8 + e : (ks >> 1) * 32 + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * (l >> 5);
       float v = 0.f;
       if (k < K && n < jb.N) {
         const int c = k % jb.Cp, t = k / jb.Cp;

@@ -303,9 +303,9 @@ class _Builder:
         frag = desc.pop("frag", False)
         if want_grad and self.x3 and not self.in_bwd:  # forward GEMM operand -> pre-split bf16 hi|lo
             kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
-            if frag:  # MFMA fragment order, read straight into registers (conv3x3_bf16x3.hip)
+            if frag:  # MFMA fragment order, read straight into registers (conv3x3_bf16x3.hip; 3 = permuted k, linattn_block.hip)
                 n_elems = (desc["N"] + 31) // 32 * 32 * kpad
-                desc = dict(desc, fmt=2)
+                desc = dict(desc, fmt=3 if frag == 3 else 2)
             else:     # [N][Kpad] planes, staged through LDS (igemm_bf16x3.hip)
                 n_elems = desc["N"] * kpad
                 desc = dict(desc, fmt=1)
@@ -348,11 +348,11 @@ class _Builder:
         return self.pack(name, kh * kw * co * nci, want_grad=False, TH=kh, TW=kw, C=co, Cp=co, N=nci, sn=kh * kw, sc=ci * kh * kw, sh=kw, sw=1, hs=1, ws=1,
                          src_off=ci0 * kh * kw)[0]
 
-    def pack_linear(self, name: str) -> Tuple[int, int]:
+    def pack_linear(self, name: str, frag=False) -> Tuple[int, int]:
         """(out, in[,1,1[,1]]) -> [in][out]"""
         shp = self.shapes[name]
         co, ci = shp[0], shp[1]
-        return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1)
+        return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1, frag=frag)
 
     def pack_linear_slice(self, name: str, ci0: int, nci: int) -> int:
         """torch (out, in) restricted to input columns [ci0, ci0+nci) as [out][nci]: the k-major operand of the data gradient."""
@@ -564,6 +564,22 @@ class _Builder:
         hid = 32 * heads
         HW = x.H * x.W
         rows = B * T * HW
+        if self.x3 and not self.training and x.C == 64 and heads == 8 and HW % 32 == 0 and getattr(self.m, "use_fused_linattn", True):
+            # full-resolution level: q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
+            wq, _ = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2)
+            wo, _ = self.pack_linear(name + ".fn.fn.to_out.weight", frag=3)
+            ws_n = int(self.lib.vmm_linattn_block_workspace(B, T, HW))
+            ws = self.alloc(ws_n)
+            ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
+            out = self.act(x.C, x.H, x.W)
+            flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * hid * 32
+            self.step(self.lib.vmm_linattn_block_bf16x3,
+                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(name + ".fn.fn.to_out.bias"), ek or None, ev or None,
+                       self.ntok if site else 0, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
+                      name + " fused block", flops=flops, nbytes=12.0 * x.n)
+            self.free(ws, ws_n)
+            self.plan.named[name] = out
+            return out
         y = self.layernorm(x, name + ".fn.norm.gamma")
         wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight")
         qkv = self.act(3 * hid, x.H, x.W)
