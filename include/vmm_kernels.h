@@ -47,14 +47,19 @@ typedef struct vmm_conv_desc {
   /* A-operand transform fused into the tile load (0 = none, 1 = GroupNorm+FiLM+SiLU of the producer:
    * silu(x*ga[b,c] + gb[b,c]), coefficients per (sample, channel) of source a1; vddp.py:279-285) */
   int32_t a_mode; const float* a_coef; int32_t a_imgs_per_sample; /* frames per sample (T) */
+  /* vmm_conv3x3_bf16x3 only: n_tickets zero-initialised ints that let few-row layers split the channel reduction over several
+   * workgroups per output tile; the partial sums are added in a fixed order (ticket = next split), so results are bit-reproducible.
+   * The kernel leaves them zero again.  NULL / too few: no split.  Launches sharing the array must be ordered on one stream. */
+  int32_t* split_tickets; int32_t n_tickets;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
  * ~1e-5 relative error): d->w must point to the fmt-1 output of vmm_pack_weights (pre-split, pre-transposed bf16 weights). */
 int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
-/* 3x3 / stride 1 / pad 1 specialisation of the above with an LDS-resident halo patch (each input element is staged once per
- * channel chunk instead of once per tap).  Needs C1, C2 multiples of 32, Cout >= 64, W <= 127; returns 1 (nothing launched) when the
- * descriptor is outside that envelope. */
+/* 3x3 / stride 1 / pad 1 specialisation of the above: LDS-resident halo patch (each input element is staged once per channel chunk
+ * instead of once per tap) and weights read straight into registers in MFMA fragment order -- d->w must point to the fmt-2 output of
+ * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
+ * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
 
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
@@ -117,9 +122,9 @@ int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, co
                              int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
 
 /* Fused temporal-attention BLOCK for the full-resolution level (vddp.py:615,630,680: x + to_out(attn(rotary(to_qkv(LayerNorm(x)))))):
- * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections on the split-bf16 matrix cores
- * (wqkv_packed / wout_packed = vmm_pack_weights fmt 1 of to_qkv (768,64) and to_out (64,256)), softmax in fp32 VALU.
- * Envelope: C == 64, heads == 8, dim_head == 32, T <= 12, HW % 16 == 0; returns 1 (nothing launched) otherwise. */
+ * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections, scores and value mix all run on the
+ * split-bf16 matrix cores (wqkv_packed = vmm_pack_weights fmt 2 of to_qkv (768,64), wout_packed = fmt 3 of to_out (64,256)).
+ * Envelope: C == 64, heads == 8, dim_head == 32, T <= 16, ntok <= 16, HW even; returns 1 (nothing launched) otherwise. */
 int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
                               const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                               const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,

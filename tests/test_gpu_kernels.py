@@ -162,9 +162,19 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
     d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, W, 1, Cout, 32, 1.0
     if fused:
         d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+    d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
     N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-5
+    # the split channel reduction of the few-row layers adds its partial sums in a fixed order: bit-reproducible, tickets left at zero
+    first = out.clone()
+    for _ in range(3):
+        out.fill_(7.0)
+        N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo")
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    assert int(tickets.abs().sum()) == 0
 
 
 def test_conv_concat_residual_and_fused_gn(gpu):

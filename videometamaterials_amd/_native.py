@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("rot_T", c_i32), ("rot_HW", c_i32), ("rot_ncols", c_i32), ("rot_dh", c_i32),
         ("q_scale", c_f32), ("q_ncols", c_i32),
         ("a_mode", c_i32), ("a_coef", c_ptr), ("a_imgs_per_sample", c_i32),
+        ("split_tickets", c_ptr), ("n_tickets", c_i32),
     ]
 
 

@@ -17,7 +17,7 @@
 //
 // Wave tile 64 rows x 64 columns (2 x 2 MFMA 32x32x16 tiles, 3 passes: lo*hi + hi*lo + hi*hi, see igemm_bf16x3.hip); workgroup =
 // 4 waves as 4 x 1 (256 pixels x 64 columns, Cout == 64) or 2 x 2 (128 pixels x 128 columns).  Few-row layers (12 x 12 level) split
-// the channel chunks over blockIdx.y and meet in fp32 atomics.  Fused input transform (GroupNorm * FiLM -> SiLU, a_mode 1), bias,
+// the channel chunks over blockIdx.y and add their partial sums in a fixed (ticketed) order.  Fused input transform (GroupNorm * FiLM -> SiLU, a_mode 1), bias,
 // two-source channel concat and the residual add are the same as in the generic kernel.
 #include "igemm_common.h"
 
@@ -273,9 +273,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     }
   }
 
-  // epilogue
+  // epilogue.  Split channel reduction (gridDim.y > 1): the splits of one output tile add their partial sums in split order, so the
+  // result does not depend on scheduling.  Split 0 writes through to memory; split y waits for ticket == y, adds with device-scope
+  // fp32 atomics (performed at the memory side, coherent across the XCDs' L2s without cache write-backs), waits for their
+  // completion and passes the ticket on (the last one resets it to 0).  Workgroups are dispatched y-major, i.e. split y - 1 is
+  // always resident before split y.
   const bool first = blockIdx.y == 0;
-  const bool atomic = gridDim.y > 1;
+  const bool split = gridDim.y > 1;
+  int* ticket = split ? p.split_tickets + blockIdx.x : nullptr;
+  if (split && !first) {
+    if (tid == 0)
+      while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -297,9 +307,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
           if (p.res) v += p.res[orow * p.ldres + col];
         }
         float* o = p.out + orow * p.ldo + col;
-        if (atomic) atomicAdd(o, v); else *o = v;
+        if (!split) *o = v;
+        else if (first) __hip_atomic_store(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+  }
+  if (split) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores / atomics have been performed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -358,18 +375,14 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   }
   if (a.PR > (wide ? 6 : 11) * 32) return 1;
   // few-row layers (12 x 12 level): split the channel chunks so that both workgroup slots of every CU are filled a few times over;
-  // the partial sums meet in fp32 atomics on a zeroed output
+  // the partial sums are added in a fixed order (tickets, see the kernel epilogue)
   const int nch = (d.C1 + d.C2) / CK;
   const long long blocks = (long long)mtiles * a.n_tiles;
   int ksplit = 1;
-  if (blocks < 1024 && d.ldo == d.Cout && d.res != d.out) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
+  if (blocks < 1024 && d.split_tickets && d.n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (ksplit > 1) {
-    hipError_t e = hipMemsetAsync(d.out, 0, sizeof(float) * (size_t)M * d.Cout, s);
-    if (e != hipSuccess) return (int)e;
-  }
   if (wide) return a.mode ? launch_c3<2, 2, 6, 1>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0>(a, mtiles, ksplit, s);
   return a.mode ? launch_c3<4, 1, 11, 1>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0>(a, mtiles, ksplit, s);
 }

@@ -1,18 +1,26 @@
-// Fused temporal-attention block for the full-resolution level (C = 64), split-bf16 MFMA + fp32 VALU softmax, gfx950.
+// Fused temporal-attention block for the C = 64 levels, everything on the split-bf16 matrix cores, gfx950.
 //
 //   out = x + to_out( softmax_attention( rotary(to_qkv( LayerNorm(x) )) ) )        (vddp.py:615,630,680: Residual(PreNorm(Attention)))
 //
-// The unfused path writes the 768-wide qkv rows (2.5 GB per site at batch 8) and the 256-wide attention output to HBM and
-// reads them back; this kernel keeps everything of a 16-pixel x 11-frame tile on chip: x is read once, out is written once.
-// One workgroup = 16 pixels x T frames (rows ordered frame-major: r = t*16 + pixel), 256 threads:
-//   phase 0  channel LayerNorm of the T*16 rows, split into bf16 hi/lo, into LDS (A operand of the projections)
-//   per head h (8x):
-//     phase 1  q,k,v = A (192x64) . Wqkv_h (64x96) on v_mfma_f32_32x32x16_bf16 (3 passes), weights straight from L2 as fragments;
-//              epilogue: q *= scale, interleaved-pair rotary on q,k by the frame index; q,k,v rows -> LDS (fp32)
-//     phase 2  one thread per (pixel, query frame): 22 keys (conditioning tokens from L1/L2 + 11 frames from LDS), online softmax,
-//              relative-position bias; the 32-wide output row is written back over the q slot as bf16 hi/lo
-//     phase 3  out_acc += O_h (192x32) . Wout_h (32x64)  (MFMA, accumulators persistent across heads)
-//   epilogue   out = out_acc + x  -> HBM
+// Attention runs along the frame axis of every pixel: T <= 16 frames plus <= 16 conditioning tokens per pixel and head.  The
+// unfused path writes the 768-wide qkv rows and the 256-wide attention output to HBM (2.5 GB + 0.8 GB per site at batch 8);
+// here x is read once and out written once, and -- unlike the first version of this kernel, which ran the 22-key softmax on the
+// vector ALU with one thread per row -- the scores and the value mix are matrix-core work too.
+//
+// Tile = 2 pixels x 16 frame slots = 32 rows (row m = pixel a * 16 + frame t; slots t >= T are zero rows).  One wave = one head
+// (512-thread workgroups), its q/k/v weight fragments stay in registers.  As in linattn_block.hip, every MFMA result is consumed as
+// an operand of the next MFMA straight from the accumulator registers (lane = column, registers = rows; both operands of the
+// next product enumerate the contraction index in register order), so nothing is transposed or staged:
+//   q^T, k^T [d][m]   = W_q,k (A, fragment-order weights) . y^T (B, LayerNorm rows as fragments); rotary + scale in registers
+//   v [m][d]          = y (A) . W_v^T (B)
+//   s^T [key][query]  = k (A <- k^T accumulators) . q^T (B <- q^T accumulators); 32 x 32, the two 16 x 16 diagonal blocks are used
+//   s_tok^T [tok][query] = ek (A, fragments built once per workgroup in LDS) . q^T
+//   softmax over the 8 + 8 register-resident scores of a lane and its lane ^ 32 partner; relative-position bias from LDS
+//   o^T [d][query]    = v^T (A <- v accumulators) . p^T (B <- s^T registers, zero outside the own pixel)  +  ev^T (A, LDS) . p_tok^T
+//   part [m][c]       = o (A <- o^T accumulators) . W_out,h^T (B, fmt-3 fragments)
+//   out               = sum over the 8 heads (LDS) + x
+// 75 MFMA 32x32x16 per tile and head (3 split-bf16 passes each); padded frame slots and the off-diagonal score blocks are the price
+// for needing no data movement between the products.
 #include "igemm_common.h"
 
 namespace {
@@ -21,16 +29,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TP = 16;            // pixels per workgroup
-constexpr int TC = 64;            // channels
-constexpr int TRP = 192;          // padded rows (6 MFMA row tiles) >= T*TP
-constexpr int XPITCH = TC + 8;    // bf16 per LDS row of the normalised input (144 B)
-constexpr int QPITCH = 100;       // floats per LDS row of q|k|v (400 B)
+constexpr int TC = 64;    // channels
+constexpr int HEADS = 8;  // = waves per workgroup
 constexpr int DHd = 32;
-constexpr int HEADS = 8;
 constexpr int HID = HEADS * DHd;
 
-__device__ __forceinline__ unsigned pack_hi(float a, float b, unsigned& lo) {
+struct TBArgs {
+  const float* x; int ldx;
+  const float* gamma;
+  const uint4* wqkv;  // fmt 2 fragments of to_qkv (768, 64)
+  const uint4* wout;  // fmt 3 fragments of to_out (64, 256)
+  const float* ek; const float* ev; int ntok;
+  const float* bias; int bias_on_cond;
+  const float* rot;   // [T][16][2] cos, sin
+  float* out; int ldo;
+  int T, HW, nsplit, tps;  // tps: pixel pairs per split
+  float q_scale, eps;
+};
+
+__device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) {
   const f32x2 v = {a, b};
   const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
   const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
@@ -38,287 +55,299 @@ __device__ __forceinline__ unsigned pack_hi(float a, float b, unsigned& lo) {
   return hi;
 }
 
-struct TBArgs {
-  const float* x; int ldx;
-  const float* gamma;
-  const unsigned short* wqkv;  // [768][64] hi plane | lo plane
-  const unsigned short* wout;  // [64][256] hi plane | lo plane
-  const float* ek; const float* ev; int ntok;
-  const float* bias; int bias_on_cond;
-  const float* rot;            // [T][16][2]
-  float* out; int ldo;
-  int T, HW; float q_scale; float eps; int dbg;  // dbg: ablation bits (1: skip phase 1, 2: skip phase 2, 4: skip phase 3), VMM_TB_DBG
-};
+__device__ __forceinline__ void split8(const f32x16& c, int r0, uint4& hi, uint4& lo) {
+  hi.x = pack_split(c[r0 + 0], c[r0 + 1], lo.x);
+  hi.y = pack_split(c[r0 + 2], c[r0 + 3], lo.y);
+  hi.z = pack_split(c[r0 + 4], c[r0 + 5], lo.z);
+  hi.w = pack_split(c[r0 + 6], c[r0 + 7], lo.w);
+}
 
-__global__ __launch_bounds__(256) void temporal_block_kernel(const TBArgs a) {
+__device__ __forceinline__ void split8v(const float (&v)[8], uint4& hi, uint4& lo) {
+  hi.x = pack_split(v[0], v[1], lo.x);
+  hi.y = pack_split(v[2], v[3], lo.y);
+  hi.z = pack_split(v[4], v[5], lo.z);
+  hi.w = pack_split(v[6], v[7], lo.w);
+}
+
+__device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  return c;
+}
+
+// index of the contraction / row slot that element j of lane half lk holds in k16 step s (accumulator register order)
+__device__ __forceinline__ int slot(int s, int lk, int j) { return (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * lk; }
+
+__global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned short* Xh = reinterpret_cast<unsigned short*>(smem_raw);
-  unsigned short* Xl = Xh + TRP * XPITCH;
-  float* QKV = reinterpret_cast<float*>(Xl + TRP * XPITCH);
-  float* rot_s = QKV + TRP * QPITCH;          // [T][16][2]
-  float* bias_s = rot_s + 12 * 32;            // [heads][T][T] (T <= 12)
+  float* red = reinterpret_cast<float*>(smem_raw);                     // [8 heads][32 rows][64 channels]
+  uint4* ekf = reinterpret_cast<uint4*>(red + HEADS * 32 * TC);        // [8 heads][2 steps][hi|lo][64 lanes]
+  uint4* evf = ekf + HEADS * 4 * 64;                                   // [8 heads][hi|lo][64 lanes]
+  float* biasf = reinterpret_cast<float*>(evf + HEADS * 2 * 64);       // [8 heads][2 halves][16 frames][8]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
+  const int pa = lrow >> 4, ft = lrow & 15;  // pixel of the pair, frame slot
   const int T = a.T, HW = a.HW;
-  const int tiles_per_sample = HW / TP;
-  const int b = blockIdx.x / tiles_per_sample;
-  const int pix0 = (blockIdx.x % tiles_per_sample) * TP;
-  const int R = T * TP;
-  const long long row_base = (long long)b * T * HW + pix0;  // + t*HW + pl
+  const int b = blockIdx.x / a.nsplit, split = blockIdx.x - b * a.nsplit;
+  const int pairs = HW / 2;
+  const int p_begin = split * a.tps, p_end = min(pairs, p_begin + a.tps);
+  const int ntok = a.ek ? a.ntok : 0;
 
-  // ---- phase 0: LayerNorm + split (thread per row), tables to LDS
-  for (int i = tid; i < T * 32; i += 256) rot_s[i] = a.rot[i];
-  for (int i = tid; i < HEADS * T * T; i += 256) bias_s[i] = a.bias[i];
-  if (tid < TRP) {
-    const int r = tid;
-    unsigned short* dh = Xh + r * XPITCH;
-    unsigned short* dl = Xl + r * XPITCH;
-    if (r < R) {
-      const int t = r / TP, pl = r % TP;
-      const float* xr = a.x + (row_base + (long long)t * HW + pl) * a.ldx;
-      f32x4 v[TC / 4];
+  // ---- per-workgroup tables in LDS
+  {
+    // conditioning keys as an A operand (rows = tokens, contraction = d), values as an A operand (rows = d, contraction = tokens)
+    uint4* eks = ekf + h * 4 * 64;
+    uint4* evs = evf + h * 2 * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = lrow < ntok ? a.ek[((long long)b * ntok + lrow) * HID + h * DHd + slot(s, lk, j)] : 0.f;
+      uint4 hi, lo;
+      split8v(v, hi, lo);
+      eks[(s * 2 + 0) * 64 + lane] = hi;
+      eks[(s * 2 + 1) * 64 + lane] = lo;
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      v[j] = tk < ntok ? a.ev[((long long)b * ntok + tk) * HID + h * DHd + lrow] : 0.f;
+    }
+    uint4 hi, lo;
+    split8v(v, hi, lo);
+    evs[lane] = hi;
+    evs[64 + lane] = lo;
+    // relative-position bias of query frame t against the 8 key frames a lane half holds: [h][lk][t][j]
+    for (int i = tid; i < HEADS * 2 * 16 * 8; i += 512) {
+      const int j = i & 7, t = (i >> 3) & 15, l2 = (i >> 7) & 1, hh = i >> 8;
+      const int tk = slot(0, l2, j);
+      biasf[i] = (t < T && tk < T) ? a.bias[(hh * T + t) * T + tk] : 0.f;
+    }
+  }
+
+  // ---- per-wave constants in registers
+  uint4 wqh[4], wql[4], wkh[4], wkl[4], wvh[4], wvl[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4* q = a.wqkv + (((long long)h * 4 + s) * 2) * 64 + lane;
+    const uint4* k = a.wqkv + (((long long)(HEADS + h) * 4 + s) * 2) * 64 + lane;
+    const uint4* v = a.wqkv + (((long long)(2 * HEADS + h) * 4 + s) * 2) * 64 + lane;
+    wqh[s] = q[0]; wql[s] = q[64];
+    wkh[s] = k[0]; wkl[s] = k[64];
+    wvh[s] = v[0]; wvl[s] = v[64];
+  }
+  const uint4* wo_l = a.wout + ((long long)2 * h * 2) * 64 + lane;  // to_out fragments are re-read per tile (8 KB per head, L2-resident)
+  // rotary factors of this lane's frame for the 8 (even, odd) feature pairs it holds: accumulator registers (2i, 2i+1)
+  float rc[8], rs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int d = slot(i >> 2, lk, (2 * i) & 7);  // feature index of register 2i
+    const float2 cs = ft < T ? *reinterpret_cast<const float2*>(a.rot + (ft * 16 + (d >> 1)) * 2) : make_float2(1.f, 0.f);
+    rc[i] = cs.x; rs[i] = cs.y;
+  }
+  auto rotate = [&](f32x16& v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e = v[2 * i], o = v[2 * i + 1];
+      v[2 * i] = e * rc[i] - o * rs[i];
+      v[2 * i + 1] = o * rc[i] + e * rs[i];
+    }
+  };
+  __syncthreads();
+
+  const bool row_ok = ft < T;
+  const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
+  // reduction role
+  const int rm = tid >> 4, rcol = (tid & 15) * 4;
+  const int rpa = rm >> 4, rft = rm & 15;
+
+  for (int pp = p_begin; pp < p_end; ++pp) {
+    // ---- LayerNorm of the 32 rows as fragments (lane = row, 8 channels per k16 step and lane half)
+    uint4 yh[4], yl[4];
+    {
+      f32x4 v[8];
+      if (row_ok) {
+        const float* xr = a.x + (((long long)b * T + ft) * HW + pp * 2 + pa) * a.ldx + lk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[2 * i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
+          v[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + i * 16 + 4);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       float s = 0.f;
 #pragma unroll
-      for (int c = 0; c < TC / 4; ++c) { v[c] = *reinterpret_cast<const f32x4*>(xr + c * 4); s += v[c].x + v[c].y + v[c].z + v[c].w; }
+      for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      s += __shfl_xor(s, 32, 64);
       const float mean = s * (1.0f / TC);
       float q = 0.f;
 #pragma unroll
-      for (int c = 0; c < TC / 4; ++c) {
-        v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
-        q += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+      for (int i = 0; i < 8; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
       }
+      q += __shfl_xor(q, 32, 64);
       const float rstd = 1.0f / sqrtf(q * (1.0f / TC) + a.eps);
 #pragma unroll
-      for (int c = 0; c < TC / 4; ++c) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
-        unsigned l0, l1;
-        const unsigned h0 = pack_hi(v[c].x * rstd * g.x, v[c].y * rstd * g.y, l0);
-        const unsigned h1 = pack_hi(v[c].z * rstd * g.z, v[c].w * rstd * g.w, l1);
-        *reinterpret_cast<uint2*>(dh + c * 4) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(dl + c * 4) = make_uint2(l0, l1);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < TC / 4; ++c) {
-        *reinterpret_cast<uint2*>(dh + c * 4) = make_uint2(0u, 0u);
-        *reinterpret_cast<uint2*>(dl + c * 4) = make_uint2(0u, 0u);
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8 + 4);
+        const f32x4 u = v[2 * i], w = v[2 * i + 1];
+        yh[i].x = pack_split(u.x * rstd * g0.x, u.y * rstd * g0.y, yl[i].x);
+        yh[i].y = pack_split(u.z * rstd * g0.z, u.w * rstd * g0.w, yl[i].y);
+        yh[i].z = pack_split(w.x * rstd * g1.x, w.y * rstd * g1.y, yl[i].z);
+        yh[i].w = pack_split(w.z * rstd * g1.z, w.w * rstd * g1.w, yl[i].w);
       }
     }
-  }
-  __syncthreads();
-
-  // row tiles of this wave: waves 0,1 own two of the six 32-row tiles, waves 2,3 one
-  const int n_mt = (wave < 2) ? 2 : 1;
-  const int mt0 = wave, mt1 = wave + 4;
-  f32x16 oacc[2][2];
+    // ---- projections
+    f32x16 qt = zero16(), kt = zero16(), vt = zero16();
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int s = 0; s < 4; ++s) {
+      qt = mfma3(wqh[s], wql[s], yh[s], yl[s], qt);  // [d][m]
+      kt = mfma3(wkh[s], wkl[s], yh[s], yl[s], kt);  // [d][m]
+      vt = mfma3(yh[s], yl[s], wvh[s], wvl[s], vt);  // [m][d]
+    }
+    rotate(qt);
+    rotate(kt);
+    uint4 qh[2], ql[2];
+    split8(qt, 0, qh[0], ql[0]);
+    split8(qt, 8, qh[1], ql[1]);
+    // ---- scores: keys x queries
+    f32x16 st = zero16(), sk = zero16();
+    const uint4* eks = ekf + h * 4 * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int s = 0; s < 2; ++s) {
+      uint4 kh, kl;
+      split8(kt, s * 8, kh, kl);
+      st = mfma3(kh, kl, qh[s], ql[s], st);
+      if (ntok) sk = mfma3(eks[(s * 2) * 64], eks[(s * 2 + 1) * 64], qh[s], ql[s], sk);
+    }
+    // ---- softmax over this query's 8 (+8) frame keys and 8 (+8) tokens: lane half lk holds slots {0-3, 8-11} + 4 lk
+    const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_l), bz1 = *reinterpret_cast<const f32x4*>(bias_l + 4);
+    const float bz[8] = {bz0.x, bz0.y, bz0.z, bz0.w, bz1.x, bz1.y, bz1.z, bz1.w};
+    float f[8], g[8];
+    float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][j][r] = 0.f;
-  const long long wq_plane = (long long)3 * HID * TC;
-  const long long wo_plane = (long long)TC * HID;
-
-  for (int h = 0; h < HEADS; ++h) {
-    // ---- phase 1: q,k,v of head h for this wave's row tiles
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      const float sv = pa ? st[8 + j] : st[j];
+      f[j] = tk < T ? sv * a.q_scale + bz[j] : -INFINITY;
+      g[j] = tk < ntok ? sk[j] * a.q_scale + (a.bias_on_cond ? bz[j] : 0.f) : -INFINITY;
+      mx = fmaxf(mx, fmaxf(f[j], g[j]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = __expf(f[j] - mx);
+      g[j] = __expf(g[j] - mx);
+      sum += f[j] + g[j];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float p0[8], p1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] *= inv;
+      g[j] *= inv;
+      p0[j] = pa ? 0.f : f[j];  // keys of pixel 0 <-> k16 step 0
+      p1[j] = pa ? f[j] : 0.f;  // keys of pixel 1 <-> k16 step 1
+    }
+    // ---- o^T = v^T . p^T (+ token values)
+    f32x16 ot = zero16();
     {
-      f32x16 acc[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < TC / 16; ++s) {
-        const int ko = s * 16 + lk * 8;
-        bf16x8 bh[3], bl[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const long long n = (long long)(j * HID + h * DHd + lrow);
-          bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a.wqkv + n * TC + ko));
-          bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a.wqkv + wq_plane + n * TC + ko));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (i < n_mt) {
-            const int row = (i == 0 ? mt0 : mt1) * 32 + lrow;
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + row * XPITCH + ko));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xl + row * XPITCH + ko));
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-            }
-          }
-        }
+      uint4 vh, vl, ph, pl;
+      split8(vt, 0, vh, vl);
+      split8v(p0, ph, pl);
+      ot = mfma3(vh, vl, ph, pl, ot);
+      split8(vt, 8, vh, vl);
+      split8v(p1, ph, pl);
+      ot = mfma3(vh, vl, ph, pl, ot);
+      if (ntok) {
+        const uint4* evs = evf + h * 2 * 64 + lane;
+        split8v(g, ph, pl);
+        ot = mfma3(evs[0], evs[64], ph, pl, ot);
       }
-      // epilogue: scale, rotary, to LDS.  C layout: col = lrow, row = (r&3) + 8*(r>>2) + 4*lk
+    }
+    // ---- this head's share of to_out
+    f32x16 pc[2] = {zero16(), zero16()};
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (i < n_mt) {
-          const int mt = (i == 0 ? mt0 : mt1);
+    for (int s = 0; s < 2; ++s) {
+      uint4 oh, ol;
+      split8(ot, s * 8, oh, ol);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const int t = min(row / TP, T - 1);
-            const float2 cs = *reinterpret_cast<const float2*>(rot_s + (t * 16 + (lrow >> 1)) * 2);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              float v = acc[i][j][r];
-              if (j == 0) v *= a.q_scale;
-              if (j < 2) {
-                const float partner = __shfl_xor(v, 1, 64);
-                v = v * cs.x + ((lrow & 1) ? partner : -partner) * cs.y;
-              }
-              QKV[row * QPITCH + j * DHd + lrow] = v;
-            }
-          }
-        }
+      for (int ct = 0; ct < 2; ++ct) {
+        const uint4* q = wo_l + ((ct * 16 + s) * 2) * 64;
+        pc[ct] = mfma3(oh, ol, q[0], q[64], pc[ct]);
       }
+    }
+    __syncthreads();  // the previous tile's head sum has been read by everyone
+    float* rb = red + (h * 32) * TC;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      rb[m * TC + lrow] = pc[0][r];
+      rb[m * TC + 32 + lrow] = pc[1][r];
     }
     __syncthreads();
-
-    // ---- phase 2: attention, thread per row (pixel pl = r % 16, query frame i = r / 16)
-    if (tid < R) {
-      const int r = tid, i = r / TP, pl = r % TP;
-      float q[DHd], acc[DHd];
+    if (rft < T) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d = 0; d < DHd / 4; ++d) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(QKV + r * QPITCH + d * 4);
-        q[d * 4] = v.x; q[d * 4 + 1] = v.y; q[d * 4 + 2] = v.z; q[d * 4 + 3] = v.w;
+      for (int w = 0; w < HEADS; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rm) * TC + rcol);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-#pragma unroll
-      for (int d = 0; d < DHd; ++d) acc[d] = 0.f;
-      float m = -INFINITY, l = 0.f;
-      const float* brow = bias_s + (h * T + i) * T;
-      auto step = [&](const float* kr, const float* vr, float bias_v) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-        for (int d = 0; d < DHd / 4; ++d) {
-          const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + d * 4);
-          s0 = fmaf(q[d * 4], kv.x, s0); s1 = fmaf(q[d * 4 + 1], kv.y, s1); s2 = fmaf(q[d * 4 + 2], kv.z, s2); s3 = fmaf(q[d * 4 + 3], kv.w, s3);
-        }
-        const float s = (s0 + s1) + (s2 + s3) + bias_v;
-        const float mn = fmaxf(m, s);
-        const float f = __expf(m - mn), p = __expf(s - mn);
-        l = l * f + p;
-#pragma unroll
-        for (int d = 0; d < DHd / 4; ++d) {
-          const f32x4 vv = *reinterpret_cast<const f32x4*>(vr + d * 4);
-          acc[d * 4] = fmaf(p, vv.x, acc[d * 4] * f); acc[d * 4 + 1] = fmaf(p, vv.y, acc[d * 4 + 1] * f);
-          acc[d * 4 + 2] = fmaf(p, vv.z, acc[d * 4 + 2] * f); acc[d * 4 + 3] = fmaf(p, vv.w, acc[d * 4 + 3] * f);
-        }
-        m = mn;
-      };
-      if (a.ek) {
-        for (int j = 0; j < a.ntok; ++j) {
-          const long long o = ((long long)b * a.ntok + j) * HID + h * DHd;
-          step(a.ek + o, a.ev + o, a.bias_on_cond ? brow[j] : 0.f);
-        }
-      }
-      for (int j = 0; j < T; ++j) {
-        const float* kr = QKV + (j * TP + pl) * QPITCH + DHd;
-        step(kr, kr + DHd, brow[j]);
-      }
-      const float inv = 1.0f / l;
-      // o row -> bf16 hi | lo over the q slot of this row (only this thread ever read it)
-      unsigned short* oh = reinterpret_cast<unsigned short*>(QKV + r * QPITCH);
-      unsigned short* ol = oh + DHd;
-#pragma unroll
-      for (int d = 0; d < DHd / 4; ++d) {
-        unsigned l0, l1;
-        const unsigned h0 = pack_hi(acc[d * 4] * inv, acc[d * 4 + 1] * inv, l0);
-        const unsigned h1 = pack_hi(acc[d * 4 + 2] * inv, acc[d * 4 + 3] * inv, l1);
-        *reinterpret_cast<uint2*>(oh + d * 4) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(ol + d * 4) = make_uint2(l0, l1);
-      }
-    } else if (tid < TRP) {  // padded rows: zero output operand
-      unsigned short* oh = reinterpret_cast<unsigned short*>(QKV + tid * QPITCH);
-#pragma unroll
-      for (int d = 0; d < 2 * DHd / 4; ++d) *reinterpret_cast<uint2*>(oh + d * 4) = make_uint2(0u, 0u);
-    }
-    __syncthreads();
-
-    // ---- phase 3: out_acc += O_h . Wout_h
-#pragma unroll
-    for (int s = 0; s < DHd / 16; ++s) {
-      const int ko = s * 16 + lk * 8;
-      bf16x8 bh[2], bl[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const long long n = j * 32 + lrow;
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a.wout + n * HID + h * DHd + ko));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a.wout + wo_plane + n * HID + h * DHd + ko));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (i < n_mt) {
-          const int row = (i == 0 ? mt0 : mt1) * 32 + lrow;
-          const unsigned short* orow = reinterpret_cast<const unsigned short*>(QKV + row * QPITCH);
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(orow + ko));
-          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(orow + DHd + ko));
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            oacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], oacc[i][j], 0, 0, 0);
-            oacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], oacc[i][j], 0, 0, 0);
-            oacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], oacc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();  // the next head overwrites QKV
-  }
-
-  // ---- epilogue: residual + store
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i < n_mt) {
-      const int mt = (i == 0 ? mt0 : mt1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < R) {
-          const int t = row / TP, pl = row % TP;
-          const long long g = row_base + (long long)t * HW + pl;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + lrow;
-            a.out[g * a.ldo + col] = oacc[i][j][r] + a.x[g * a.ldx + col];
-          }
-        }
-      }
+      const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
+      const f32x4 xr = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + rcol);
+      acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;
+      *reinterpret_cast<f32x4*>(a.out + row * a.ldo + rcol) = acc;
     }
   }
 }
 
 }  // namespace
 
-// Returns 1 (nothing launched) when the shape is outside the kernel's envelope: C == 64, heads == 8, dim_head == 32, T <= 12, HW % 16 == 0.
-extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
+// Weights: wqkv_frag = vmm_pack_weights fmt 2 of to_qkv (768, 64), wout_frag = fmt 3 of to_out (64, 256).
+// Returns 1 (nothing launched) when the shape is outside the kernel's envelope: C == 64, heads == 8, dim_head == 32, T <= 16,
+// ntok <= 16, HW even.
+extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
                                          const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                                          const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
                                          int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
-  if (C != TC || heads != HEADS || T * TP > TRP || T > 12 || (HW % TP) || (ldx & 3) || (ldo & 3)) return 1;
+  if (C != TC || heads != HEADS || T > 16 || T < 1 || (HW & 1) || (ldx & 3) || (ldo & 3) || (ek && ntok > 16)) return 1;
   if (bias_on_cond && ek && ntok != T) return -2;
+  if (B <= 0) return 0;
   TBArgs a;
   a.x = x; a.ldx = ldx; a.gamma = gamma;
-  a.wqkv = reinterpret_cast<const unsigned short*>(wqkv_packed);
-  a.wout = reinterpret_cast<const unsigned short*>(wout_packed);
+  a.wqkv = reinterpret_cast<const uint4*>(wqkv_frag);
+  a.wout = reinterpret_cast<const uint4*>(wout_frag);
   a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0;
   a.bias = bias; a.bias_on_cond = bias_on_cond; a.rot = rot_tab;
   a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.q_scale = q_scale; a.eps = eps;
-  { const char* e = getenv("VMM_TB_DBG"); a.dbg = e ? atoi(e) : 0; }
-  const size_t shm = sizeof(unsigned short) * 2 * TRP * XPITCH + sizeof(float) * (TRP * QPITCH + 12 * 32 + HEADS * 12 * 12);
+  const int pairs = HW / 2;
+  int ns = max(1, min(pairs, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
+  a.tps = (pairs + ns - 1) / ns;
+  a.nsplit = (pairs + a.tps - 1) / a.tps;
+  const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(B * (HW / TP))), dim3(256), shm, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(B * a.nsplit)), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -32,6 +32,7 @@ from . import hostmath
 
 ALIGN = 64  # floats (256 B)
 LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
+N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
 PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate", "fmt")
 
@@ -246,6 +247,7 @@ class _Builder:
         self.in_bwd = False
         self.job_uploads: List[Tuple[int, torch.Tensor]] = []
         self.raw_slots: Dict[str, int] = {}
+        self.tickets_ptr: Optional[int] = None
 
     # ---------------------------------------------------------------- memory
     def alloc(self, n: int) -> int:
@@ -409,6 +411,9 @@ class _Builder:
         d.rot_T, d.rot_HW, d.rot_ncols, d.rot_dh = self.T, a1.H * a1.W, rot_ncols, 32
         d.q_scale, d.q_ncols = q_scale, q_ncols
         d.a_mode, d.a_coef, d.a_imgs_per_sample = (1 if a_coef else 0), a_coef or None, self.T
+        if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
+            self.tickets_ptr = self.wslot(N_TICKETS)
+        d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
         self.plan.keepalive.append(d)
         return d
 
@@ -638,10 +643,11 @@ class _Builder:
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
-        if (temporal and self.x3 and x.C == 64 and heads == 8 and T <= 12 and HW % 16 == 0 and getattr(self.m, "use_fused_temporal", True)):
+        if (temporal and self.x3 and not self.training and x.C == 64 and heads == 8 and T <= 16 and HW % 2 == 0 and (not site or self.ntok <= 16)
+                and getattr(self.m, "use_fused_temporal", True)):
             # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
-            wq, _ = self.pack_linear(p + ".to_qkv.weight")
-            wo, _ = self.pack_linear(p + ".to_out.weight")
+            wq, _ = self.pack_linear(p + ".to_qkv.weight", frag=2)
+            wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             out = self.act(x.C, x.H, x.W)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + (self.ntok if site else 0))
