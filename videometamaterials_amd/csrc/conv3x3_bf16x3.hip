@@ -50,7 +50,7 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int WM, int WN, int MAXP, int MODE>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   constexpr int BM = WM * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -138,6 +138,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       preg[ps] = v;
     }
   };
+  // One item of the next chunk's patch.  vmcnt retires in order, so an HBM-latency load blocks every younger weight-fragment wait
+  // until it lands: the prefetch is issued one item per k16 step, AFTER that step's weight loads, which leaves it PFB + 1 steps to
+  // arrive before anything waits on it (all MAXP items at the chunk top parked the waves for ~40 % of their cycles).
+  auto load_patch_item = [&](int cc, int ps) {
+    const int c0 = cc * CK;
+    const bool src1 = c0 < p.C1;
+    const float* src = src1 ? p.a1 : p.a2;
+    const int ld = src1 ? p.lda1 : p.lda2;
+    const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int sr = src_row(ps);
+    if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
+    preg[ps] = v;
+  };
   auto store_patch = [&](int cc) {
     const int c0 = cc * CK;
     const bool xform = c0 < p.C1 && p.a_mode == 1;
@@ -215,29 +229,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
     const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
+    // Unsplit layers: the weights are the MFMA "A" (rows = output channels), the pixels the "B" (columns): a lane then holds 4 x 4
+    // CONSECUTIVE output channels of ONE pixel and the epilogue writes 16-byte pieces (4x fewer store instructions; the store tail
+    // was issue-bound).  Split layers keep pixels as rows: their epilogue is atomics, which want 32 lanes on one 128-byte line.
     // pass-major: consecutive MFMAs never share an accumulator
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
+    auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) {
+      if constexpr (SPLIT) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pix, wgt, c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0);
+    };
+    acc[0][0] = mm(al0, bh0, acc[0][0]);
+    acc[0][1] = mm(al0, bh1, acc[0][1]);
+    acc[1][0] = mm(al1, bh0, acc[1][0]);
+    acc[1][1] = mm(al1, bh1, acc[1][1]);
+    acc[0][0] = mm(ah0, bl0, acc[0][0]);
+    acc[0][1] = mm(ah0, bl1, acc[0][1]);
+    acc[1][0] = mm(ah1, bl0, acc[1][0]);
+    acc[1][1] = mm(ah1, bl1, acc[1][1]);
+    acc[0][0] = mm(ah0, bh0, acc[0][0]);
+    acc[0][1] = mm(ah0, bh1, acc[0][1]);
+    acc[1][0] = mm(ah1, bh0, acc[1][0]);
+    acc[1][1] = mm(ah1, bh1, acc[1][1]);
   };
 
-  // software pipeline over k16 steps q = (chunk, tap, half): operands of step q+1 are requested before the MFMAs of step q.
-  // sched_barrier pins that order (the scheduler otherwise sinks the loads next to their uses to save registers).
-  uint4 b0[4], b1[4], a0[4], a1[4];
+  // software pipeline over the 18 k16 steps q = 2 tap + half of a chunk: the weight fragments of step q + PFB and the patch fragments
+  // of step q + 1 are requested before the MFMAs of step q (PFB = 2 covers an L2 hit even when the sibling wave does not leave the
+  // line in L1).  sched_barrier pins that order (the scheduler otherwise sinks the loads next to their uses to save registers).
+  constexpr int NB = PFB + 1;
+  uint4 bb[NB][4], aa[2][4];
+  auto ks_of = [&](int cc, int q) { return (q >> 1) * cin16 + cc * 2 + (q & 1); };
   load_patch(c_begin);
-  load_b(b0, c_begin * 2);
+#pragma unroll
+  for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
   store_patch(c_begin);
   __syncthreads();
-  load_a(a0, 0, 0);
+  load_a(aa[0], 0, 0);
   for (int cc = c_begin; cc < c_end; ++cc) {
     const bool more = cc + 1 < c_end;
     // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
@@ -246,30 +271,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
-    if (more) load_patch(cc + 1);  // in flight during the nine taps
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ks = tap * cin16 + cc * 2;
-      load_b(b1, ks + 1);
-      load_a(a1, tap, 1);
+    for (int q = 0; q < 18; ++q) {
+      if (q + PFB < 18) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
+      else if (more) load_b(bb[(q + PFB) % NB], ks_of(cc + 1, q + PFB - 18));
+      if (q < MAXP && more) load_patch_item(cc + 1, q);
+      if (q + 1 < 18) load_a(aa[(q + 1) & 1], (q + 1) >> 1, (q + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_step(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap < 8) {
-        load_b(b0, ks + cin16);
-        load_a(a0, tap + 1, 0);
-      } else if (more) {
-        load_b(b0, cc * 2 + 2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(a1, b1);
+      mma_step(aa[q & 1], bb[q % NB]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
       __syncthreads();  // every wave is done reading the patch of chunk cc
       store_patch(cc + 1);
       __syncthreads();
-      load_a(a0, 0, 0);
+      load_a(aa[0], 0, 0);
     }
   }
 
@@ -278,19 +294,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   // fp32 atomics (performed at the memory side, coherent across the XCDs' L2s without cache write-backs), waits for their
   // completion and passes the ticket on (the last one resets it to 0).  Workgroups are dispatched y-major, i.e. split y - 1 is
   // always resident before split y.
-  const bool first = blockIdx.y == 0;
-  const bool split = gridDim.y > 1;
-  int* ticket = split ? p.split_tickets + blockIdx.x : nullptr;
-  if (split && !first) {
-    if (tid == 0)
-      while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
+  if constexpr (SPLIT) {
+    // acc[i][j]: rows = pixels (r & 3) + 8 (r >> 2) + 4 lk of row tile i, column = output channel j*32 + lrow
+    const bool first = blockIdx.y == 0;
+    int* ticket = p.split_tickets + blockIdx.x;
+    if (!first) {
+      if (tid == 0)
+        while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        long long orow;
+        if (MODE) {
+          orow = (long long)img * HW + (ty0 + (m >> 4)) * W + tx0 + (m & 15);
+        } else {
+          if (g0 + m >= a.total_rows) continue;
+          orow = g0 + m;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn * 64 + j * 32 + lrow;
+          float v = acc[i][j][r];
+          float* o = p.out + orow * p.ldo + col;
+          if (first) {
+            if (p.bias) v += p.bias[col];
+            if (p.res) v += p.res[orow * p.ldres + col];
+            __hip_atomic_store(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            __hip_atomic_fetch_add(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores / atomics have been performed
     __syncthreads();
-  }
+    if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    for (int i = 0; i < 2; ++i) {
+      const int m = wm * 64 + i * 32 + lrow;
       long long orow;
       if (MODE) {
         orow = (long long)img * HW + (ty0 + (m >> 4)) * W + tx0 + (m & 15);
@@ -300,35 +347,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + lrow;
-        float v = acc[i][j][r];
-        if (first) {
-          if (p.bias) v += p.bias[col];
-          if (p.res) v += p.res[orow * p.ldres + col];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * lk;
+          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (p.res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + col);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + col) = v;
         }
-        float* o = p.out + orow * p.ldo + col;
-        if (!split) *o = v;
-        else if (first) __hip_atomic_store(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-  if (split) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores / atomics have been performed
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
-template <int WM, int WN, int MAXP, int MODE>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE>), dim3((unsigned)(mtiles * a.n_tiles), ksplit), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT>), dim3((unsigned)(mtiles * a.n_tiles), ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -344,7 +390,7 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
                         d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 &&
                         d.rot_ncols == 0 && d.q_ncols == 0;
   const bool chan_ok = (d.C1 % CK == 0) && (d.C2 % CK == 0) && d.C1 > 0 && (d.Cout == 64 || d.Cout % 128 == 0) && (d.lda1 & 3) == 0 &&
-                       (!d.C2 || (d.lda2 & 3) == 0);
+                       (!d.C2 || (d.lda2 & 3) == 0) && (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
   if (!shape_ok || !chan_ok) return 1;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   const long long M = (long long)d.nimg * d.Hin * d.Win;
@@ -383,6 +429,10 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
   hipStream_t s = (hipStream_t)stream;
-  if (wide) return a.mode ? launch_c3<2, 2, 6, 1>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0>(a, mtiles, ksplit, s);
-  return a.mode ? launch_c3<4, 1, 11, 1>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0>(a, mtiles, ksplit, s);
+  if (ksplit > 1) {
+    if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true>(a, mtiles, ksplit, s);
+    return a.mode ? launch_c3<4, 1, 11, 1, 1, true>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true>(a, mtiles, ksplit, s);
+  }
+  if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false>(a, mtiles, 1, s);
+  return a.mode ? launch_c3<4, 1, 11, 1, 1, false>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, 1, false>(a, mtiles, 1, s);
 }
