@@ -33,6 +33,28 @@ B_PER_GPU, T, HW, TIMESTEPS, W_GUIDE = 4, 11, 96, 256, 5.0
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+# launcher (family) -> device kernel name prefix in rocprofv3 output
+KERNEL_OF = {"vmm_conv3x3_bf16x3": "conv3x3_x3_kernel", "vmm_conv_igemm_bf16x3": "igemm_bf16x3_kernel", "vmm_conv_igemm_f32": "igemm_f32_kernel",
+             "vmm_temporal_block_bf16x3": "temporal_block_kernel", "vmm_linattn_block_bf16x3": "linattn_"}
+
+
+def pmc_traffic(family: str):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/traffic_latest.json, made by
+    tools/profile_bench.sh on this same bench command: separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950's 128-byte requests).  None when the file or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    prefix = KERNEL_OF.get(family)
+    if not prefix or not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    tot, n = 0.0, 0
+    for k, v in tab.items():
+        if k.startswith(prefix) and "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+            ln = v.get("launches_FETCH_SIZE", 1)
+            tot += ln * (2.0 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+            n += ln
+    return round(tot / n) if n else None
+
 
 
 def usable_cores() -> int:
@@ -221,7 +243,8 @@ def main():
         # so its roof for ALGORITHMIC flops is the dense bf16 peak / 3
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach_tflops / peak, 4), "traffic": None,
+                    "frac": round(ach_tflops / peak, 4), "traffic": pmc_traffic(dom),
+                    "traffic_note": "HBM bytes per launch, mean over the family, from profiles/traffic_latest.json (rocprofv3 PMC passes of this command)",
                     "peak_note": "dense bf16 MFMA 2500 TFLOP/s / 3 passes (split-bf16 operands, fp32-class result)" if dom.endswith("bf16x3")
                     else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                     "launches_per_step": fam_n[dom] // reps, "avg_launch_ms": round(fam_ms[dom] / fam_n[dom], 4),
