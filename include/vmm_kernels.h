@@ -61,6 +61,13 @@ int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
  * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* 1x1 / Linear specialisation (to_qkv, to_out vddp.py:319,325,413,421; res_conv vddp.py:297): a workgroup stages its rows' full K
+ * extent once in LDS and sweeps all output columns, weights read straight into registers in MFMA fragment order (d->w = fmt-2 output
+ * of vmm_pack_weights), 16-byte epilogue stores; same epilogue options as vmm_conv_igemm_*.  ln_gamma != NULL: the rows pass through
+ * the channel LayerNorm of PreNorm (vddp.py:245-254; gamma [K], eps inside the sqrt) while they are staged, which replaces a
+ * separate vmm_channel_layernorm pass.  Envelope: KH = KW = 1, stride 1, identity row mapping, K = C1 + C2 padded to 32 in
+ * {32, 64, 128, 256}; returns 1 (nothing launched) otherwise. */
+int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
 
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
  * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer

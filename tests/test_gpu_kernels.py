@@ -364,6 +364,66 @@ def _pack_frag(N, lib, gpu, w2d, fmt):
     return packed
 
 
+@pytest.mark.parametrize("B,T,HW,C1,C2,Cout,ln,rot,res", [
+    (2, 3, 100, 128, 0, 768, True, True, False),   # temporal to_qkv: fused LayerNorm, q-scale, rotary; partial row tile
+    (1, 11, 144, 256, 0, 128, False, False, True),  # to_out: bias + residual, Cout < column chunk
+    (2, 2, 96 * 96, 64, 64, 64, False, False, False),  # res_conv on a skip concatenation, many row tiles
+    (1, 2, 36, 64, 0, 768, True, False, False),     # few rows: column chunks spread over blockIdx.y
+    (1, 3, 50, 16, 0, 48, True, False, True),       # K padded 16 -> 32
+    (1, 1, 40, 128, 128, 256, False, False, True)])
+def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, res):
+    """vmm_proj_bf16x3 against torch fp32: 1x1 projection with the row tile staged once (optional fused channel LayerNorm) and
+    fragment-order weights; epilogue bias / q-scale / rotary / residual."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(31)
+    M, K, hid = B * T * HW, C1 + C2, 256
+    x1 = torch.randn(M, C1, generator=g) * 1.5 + 0.3
+    x2 = torch.randn(M, C2, generator=g) if C2 else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    w = torch.randn(Cout, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(Cout, generator=g)
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    resid = torch.randn(M, Cout, generator=g)
+    a = xin
+    if ln:
+        a = (xin - xin.mean(1, keepdim=True)) / (xin.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * gamma
+    ref = a @ w.t() + bias
+    q_scale, rot_tab = 1.0, None
+    if rot:
+        q_scale = 32 ** -0.5
+        ref[:, :hid] *= q_scale
+        ang = torch.rand(T, 16, generator=g) * 6.28
+        rot_tab = torch.stack([ang.cos(), ang.sin()], -1).contiguous()  # [T][16][2]
+        t_of_row = (torch.arange(M) // HW) % T
+        cs = rot_tab[t_of_row]                                          # [M][16][2]
+        v = ref[:, :2 * hid].reshape(M, 2 * hid // 32, 16, 2)
+        e, o = v[..., 0].clone(), v[..., 1].clone()
+        v[..., 0] = e * cs[:, None, :, 0] - o * cs[:, None, :, 1]
+        v[..., 1] = o * cs[:, None, :, 0] + e * cs[:, None, :, 1]
+        ref[:, :2 * hid] = v.reshape(M, 2 * hid)
+    if res:
+        ref = ref + resid
+    wp = _pack_frag(N, lib, gpu, w, 2)
+    x1g, bg, gg, rg = x1.to(gpu), bias.to(gpu), gamma.to(gpu), resid.to(gpu)
+    x2g = x2.to(gpu) if C2 else None
+    rt = rot_tab.to(gpu) if rot else None
+    out = torch.full((M, Cout), 7.0, device=gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = x1g.data_ptr(), C1, C1, wp.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout
+    if C2:
+        d.a2, d.C2, d.lda2 = x2g.data_ptr(), C2, C2
+    if res:
+        d.res, d.ldres = rg.data_ptr(), Cout
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, HW, 1, HW, 1, 1
+    d.KH, d.KW, d.sgn_h, d.sgn_w = 1, 1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = HW, 1, 1, Cout, 32, q_scale
+    if rot:
+        d.rot_tab, d.rot_T, d.rot_HW, d.rot_ncols, d.q_ncols = rt.data_ptr(), T, HW, 2 * hid, hid
+    N.check(lib.vmm_proj_bf16x3(C.byref(d), gg.data_ptr() if ln else None, 1e-5, _s()), "proj")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 5e-5
+
+
 @pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 16, 16, 11), (1, 2, 96, 96, 0), (3, 1, 8, 12, 6)])
 def test_fused_linear_attention_block(gpu, B, T, H, W, ntok):
     """vmm_linattn_block_bf16x3 (LayerNorm -> to_qkv -> linear attention with stacked tokens -> to_out -> +x in three launches, q/k/v on chip)

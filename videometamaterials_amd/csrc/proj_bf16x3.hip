@@ -1,0 +1,297 @@
+// 1x1 convolution / Linear over rows with an A-stationary LDS tile and register-fed weights, split-bf16 MFMA, gfx950.
+//
+// The attention projections (to_qkv, to_out: vddp.py:319,325,413,421) and the ResnetBlock shortcut (res_conv, vddp.py:297) are
+// skinny-K GEMMs: K = 64 ... 256 input channels against up to 768 output columns.  They are bound by their OUTPUT traffic, and the
+// generic implicit-GEMM kernel (weights staged through LDS, one workgroup barrier per 32-k chunk, scalar epilogue stores) ran them
+// at 3-5x their HBM time.  Here a workgroup owns a tile of rows for ALL output columns:
+//   A  the rows' full K extent is staged ONCE in LDS as bf16 hi | lo -- optionally through the channel LayerNorm of PreNorm
+//      (vddp.py:245-254, a_mode 2: the rows are complete here, so the separate LayerNorm pass and its round trip disappear);
+//   B  weights in MFMA fragment order (vmm_pack_weights fmt 2) go straight from L2 into registers, one k16 step ahead;
+//   the workgroup then sweeps the output columns in chunks with no barrier at all; each chunk's accumulators (output channels as
+//   MFMA rows, so a lane owns 4 x 4 consecutive channels of one row) leave as 16-byte stores while the next chunk's MFMAs issue.
+// Epilogue: bias, q-scale, rotary (temporal to_qkv, vddp.py:449,456), residual -- as in igemm_common.h.
+// Wave tile 64 rows x 64 columns; workgroup 4 waves as 4x1 / 2x2 / 1x4 so that the LDS tile (rows x (4 K + 16) bytes) stays under
+// 80 KB and two workgroups share a CU (one stages / stores while the other computes).
+#include "igemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct PJArgs {
+  vmm_conv_desc p;
+  const float* gamma;  // a_mode 2: LayerNorm weight [K]
+  float eps;
+  int M;               // rows
+  int n_chunks;        // column chunks of WN*64
+  int chunks_per_y;    // column chunks per blockIdx.y
+};
+
+__device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) {
+  const f32x2 v = {a, b};
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  return hi;
+}
+
+// KS = k16 steps (K padded to 32 -> KS = Kpad / 16 in {2, 4, 8, 16})
+template <int WM, int WN, int KS>
+__global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int KP = KS * 16;         // padded K
+  constexpr int PITCH = 2 * KP + 8;   // bf16 per LDS row: hi[KP] | lo[KP] | pad  ((4 KP + 16) / 16 is odd: conflict-free ds_read_b128)
+  constexpr int IPL = (KP + 63) / 64; // float4 items per lane of a 16-lane row group
+  constexpr int PASSES = BM / 16;     // 256 threads = 16 rows per pass
+  extern __shared__ __attribute__((aligned(16))) unsigned short At[];
+  const vmm_conv_desc& p = a.p;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const int K = p.C1 + p.C2;
+  const int nc_begin = blockIdx.y * a.chunks_per_y, nc_end = min(a.n_chunks, nc_begin + a.chunks_per_y);
+  if (nc_begin >= nc_end) return;
+
+  // ---- stage the row tile: 16 lanes per row, lane l16 owns channels (l16 + 16 i) * 4 .. +3
+  {
+    const int l16 = tid & 15, r0 = tid >> 4;
+    f32x4 v[PASSES][IPL];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = m0 + ps * 16 + r0;
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) {
+        const int c = (l16 + 16 * i) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (m < a.M && c < K) {
+          t = c < p.C1 ? *reinterpret_cast<const f32x4*>(p.a1 + (long long)m * p.lda1 + c)
+                       : *reinterpret_cast<const f32x4*>(p.a2 + (long long)m * p.lda2 + (c - p.C1));
+        }
+        v[ps][i] = t;
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      if (p.a_mode == 2) {  // channel LayerNorm: (x - mean) / sqrt(var + eps) * gamma, biased variance
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) s += (v[ps][i].x + v[ps][i].y) + (v[ps][i].z + v[ps][i].w);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+          const int c = (l16 + 16 * i) * 4;
+          if (c < K) {
+            v[ps][i].x -= mean; v[ps][i].y -= mean; v[ps][i].z -= mean; v[ps][i].w -= mean;
+            q += (v[ps][i].x * v[ps][i].x + v[ps][i].y * v[ps][i].y) + (v[ps][i].z * v[ps][i].z + v[ps][i].w * v[ps][i].w);
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+          const int c = (l16 + 16 * i) * 4;
+          if (c < K) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c);
+            v[ps][i].x *= rstd * g.x; v[ps][i].y *= rstd * g.y; v[ps][i].z *= rstd * g.z; v[ps][i].w *= rstd * g.w;
+          }
+        }
+      }
+      unsigned short* row = At + (ps * 16 + r0) * PITCH;
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) {
+        const int c = (l16 + 16 * i) * 4;
+        if (c < KP) {
+          unsigned l0, l1;
+          const unsigned h0 = pj_split(v[ps][i].x, v[ps][i].y, l0);
+          const unsigned h1 = pj_split(v[ps][i].z, v[ps][i].w, l1);
+          *reinterpret_cast<uint2*>(row + c) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(row + KP + c) = make_uint2(l0, l1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- sweep the output columns
+  const uint4* wf = reinterpret_cast<const uint4*>(p.w);
+  auto load_b = [&](uint4 (&d)[4], int nc, int s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nt = (nc * BN + wn * 64) / 32 + j;
+      if (nt * 32 < p.Cout) {  // (wave-uniform) column tiles past Cout are not in the packed operand
+        const uint4* q = wf + ((long long)nt * KS + s) * 128 + lane;
+        d[2 * j] = q[0];
+        d[2 * j + 1] = q[64];
+      } else {
+        d[2 * j] = make_uint4(0u, 0u, 0u, 0u);
+        d[2 * j + 1] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  int abase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) abase[i] = (wm * 64 + i * 32 + lrow) * PITCH + lk * 8;
+  auto load_a = [&](uint4 (&d)[4], int s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* q = At + abase[i] + s * 16;
+      d[2 * i] = *reinterpret_cast<const uint4*>(q);
+      d[2 * i + 1] = *reinterpret_cast<const uint4*>(q + KP);
+    }
+  };
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
+    const bf16x8 ah0 = __builtin_bit_cast(bf16x8, av[0]), al0 = __builtin_bit_cast(bf16x8, av[1]);
+    const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
+    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
+    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
+    // weights = MFMA "A" (rows = output channels), rows of the tile = MFMA "B" (columns); pass-major order
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, al0, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al1, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, al1, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl0, ah0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl1, ah0, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl0, ah1, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl1, ah1, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah0, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah1, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah1, acc[1][1], 0, 0, 0);
+  };
+  const bool rotary = p.rot_ncols > 0;
+  auto store_chunk = [&](int nc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + lrow;
+      if (m >= a.M) continue;
+      const int t = rotary ? (m / p.rot_HW) % p.rot_T : 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = nc * BN + wn * 64 + j * 32 + 8 * g + 4 * lk;
+          if (col >= p.Cout) continue;
+          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (col < p.q_ncols) { v.x *= p.q_scale; v.y *= p.q_scale; v.z *= p.q_scale; v.w *= p.q_scale; }
+          if (col < p.rot_ncols) {  // interleaved pairs (2i, 2i+1) of each head's rot_dh features, angle by the row's frame index
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_tab + (t * (p.rot_dh >> 1) + ((col & (p.rot_dh - 1)) >> 1)) * 2);
+            const f32x4 u = v;
+            v.x = u.x * cs.x - u.y * cs.y; v.y = u.y * cs.x + u.x * cs.y;
+            v.z = u.z * cs.z - u.w * cs.w; v.w = u.w * cs.z + u.z * cs.w;
+          }
+          if (p.res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)m * p.ldres + col);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          *reinterpret_cast<f32x4*>(p.out + (long long)m * p.ldo + col) = v;
+        }
+      }
+    }
+  };
+
+  // software pipeline over the flattened (column chunk, k16 step) sequence: weights and tile fragments of the next step are
+  // requested before the MFMAs of the current one; KS is even, so the two register buffers alternate cleanly across chunks
+  uint4 bb[2][4], aa[2][4];
+  load_b(bb[0], nc_begin, 0);
+  load_a(aa[0], 0);
+  for (int nc = nc_begin; nc < nc_end; ++nc) {
+    const bool more = nc + 1 < nc_end;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(abase[i]));  // keep tile addresses base + immediate
+    zero_acc();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+        load_b(bb[(s + 1) & 1], nc, s + 1);
+        load_a(aa[(s + 1) & 1], s + 1);
+      } else if (more) {
+        load_b(bb[0], nc + 1, 0);
+        load_a(aa[0], 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(aa[s & 1], bb[s & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_chunk(nc);
+  }
+}
+
+template <int WM, int WN, int KS>
+int launch_pj(const PJArgs& a, hipStream_t s) {
+  constexpr int BM = WM * 64;
+  const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int mt = (int)cdiv(a.M, BM);
+  const int ny = (int)cdiv(a.n_chunks, a.chunks_per_y);
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// 1x1 / Linear projection.  d->w = vmm_pack_weights fmt 2 of the (Cout, K) weight.  ln_gamma != NULL: the rows pass through the
+// channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
+// identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 4; returns 1 (nothing launched) otherwise.
+extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
+                        d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
+  const int K = d.C1 + d.C2;
+  const bool chan_ok = (d.C1 & 3) == 0 && (d.C2 & 3) == 0 && d.C1 > 0 && K <= 256 && (d.Cout & 3) == 0 && (d.lda1 & 3) == 0 &&
+                       (!d.C2 || (d.lda2 & 3) == 0) && (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
+  if (!shape_ok || !chan_ok) return 1;
+  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)) || (d.rot_dh & 3) || (d.rot_ncols & 3) || d.rot_HW <= 0 || d.rot_T <= 0)) return -2;
+  if (d.q_ncols & 3) return -2;
+  const long long M = (long long)d.nimg * d.Hv * d.Wv;
+  if (M >= (1LL << 31)) return -4;
+  if (M <= 0 || d.Cout <= 0) return 0;
+  PJArgs a;
+  a.p = d;
+  a.p.a_mode = ln_gamma ? 2 : 0;
+  a.gamma = ln_gamma;
+  a.eps = ln_eps;
+  a.M = (int)M;
+  const int KP = (K + 31) / 32 * 32;
+  // workgroup shape: as many rows as fit 80 KB of LDS; column chunk = 256 / rows * 64
+  const int wm = KP <= 64 ? 4 : KP <= 128 ? 2 : 1, wn = 4 / wm;
+  a.n_chunks = (int)cdiv(d.Cout, wn * 64);
+  // few rows: spread the column chunks over blockIdx.y until ~1000 workgroups exist (the row tile is then staged once per y)
+  const long long mt = cdiv(M, wm * 64);
+  int ny = (int)max(1LL, min((long long)a.n_chunks, 1024 / max(mt, 1LL)));
+  a.chunks_per_y = (int)cdiv(a.n_chunks, ny);
+  hipStream_t s = (hipStream_t)stream;
+  if (KP == 32) return launch_pj<4, 1, 2>(a, s);
+  if (KP == 64) return launch_pj<4, 1, 4>(a, s);
+  if (KP <= 128) {
+    if (KP == 96) return 1;
+    return launch_pj<2, 2, 8>(a, s);
+  }
+  if (KP == 256) return launch_pj<1, 4, 16>(a, s);
+  return 1;
+}

@@ -417,12 +417,22 @@ class _Builder:
         self.plan.keepalive.append(d)
         return d
 
-    def conv(self, what: str = "conv", halo: bool = False, **kw) -> "N.ConvDesc":
+    def proj_ok(self, k: int, cout: int) -> bool:
+        """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
+        if not (self.x3 and not self.in_bwd and not self.training and getattr(self.m, "use_proj_kernel", True)):
+            return False
+        return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 4 == 0
+
+    def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
         # algorithmic work: every input element, weight and output element touched once
         nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
+        if proj:  # weights were packed in fragment order for it (proj_ok); ln_gamma: PreNorm LayerNorm fused into the row staging
+            self.step(self.lib.vmm_proj_bf16x3, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+            return d
+        assert not ln_gamma
         fn = self.lib.vmm_conv_igemm_f32
         if self.x3 and not self.in_bwd:
             fn = self.lib.vmm_conv_igemm_bf16x3
@@ -495,9 +505,11 @@ class _Builder:
         out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
         dr, gwr = None, 0
         if has_res:
-            wr, gwr = self.pack_linear(name + ".res_conv.weight")
+            pjr = self.proj_ok(x1.C + (x2.C if x2 is not None else 0), Cout)
+            wr, gwr = self.pack_linear(name + ".res_conv.weight", frag=2 if pjr else False)
             r = self.act(Cout, H, W)
-            dr = self.conv(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv")
+            dr = self.conv(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv",
+                           proj=pjr)
             res_ptr, ldres = r.ptr, Cout
         else:
             assert x2 is None and x1.C == Cout
@@ -585,11 +597,14 @@ class _Builder:
             self.free(ws, ws_n)
             self.plan.named[name] = out
             return out
-        y = self.layernorm(x, name + ".fn.norm.gamma")
-        wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight")
+        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel: the PreNorm LayerNorm runs while the rows are staged
+        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
+        wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
-        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv")
-        self.free_act(y)
+        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv", proj=pj,
+                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0)
+        if not pj:
+            self.free_act(y)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
         part_n, ctx_n = B * T * heads * nsplit * LA_PART, B * T * heads * 1024
         part, ctx = self.alloc(part_n), self.alloc(ctx_n)
@@ -603,10 +618,11 @@ class _Builder:
         self.free_act(qkv)
         self.free(part, part_n)
         self.free(ctx, ctx_n)
-        wo, gwo = self.pack_linear(name + ".fn.fn.to_out.weight")
+        pjo = self.proj_ok(hid, x.C)
+        wo, gwo = self.pack_linear(name + ".fn.fn.to_out.weight", frag=2 if pjo else False)
         out = self.act(x.C, x.H, x.W)
         do = self.conv(a1=o, w=wo, bias=self.wraw(name + ".fn.fn.to_out.bias"), Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld,
-                       what=name + " to_out")
+                       what=name + " to_out", proj=pjo)
         self.free_act(o)
         self.plan.named[name] = out
 
@@ -657,13 +673,16 @@ class _Builder:
                       name + " fused block", flops=flops, nbytes=8.0 * x.n)
             self.plan.named[name] = out
             return out
-        y = self.layernorm(x, name + ".fn.norm.gamma")
-        wq, gwq = self.pack_linear(p + ".to_qkv.weight")
+        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel: the PreNorm LayerNorm runs while the rows are staged
+        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
+        wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
         q_scale = 32 ** -0.5
         dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
-                       rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv")
-        self.free_act(y)
+                       rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
+                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0)
+        if not pj:
+            self.free_act(y)
         o = self.act(hid, x.H, x.W)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
         ntok = self.ntok if site else 0
@@ -676,9 +695,10 @@ class _Builder:
             self.step(self.lib.vmm_spatial_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, pfc, o.ptr, hid, B, T, HW, heads, 32, lse_ptr or None),
                       name + " core", nbytes=4.0 * rows * 4 * hid)
         self.free_act(qkv)
-        wo, gwo = self.pack_linear(p + ".to_out.weight")
+        pjo = self.proj_ok(hid, x.C)
+        wo, gwo = self.pack_linear(p + ".to_out.weight", frag=2 if pjo else False)
         out = self.act(x.C, x.H, x.W)
-        do = self.conv(a1=o, w=wo, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out")
+        do = self.conv(a1=o, w=wo, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out", proj=pjo)
         self.free_act(o)
         self.plan.named[name] = out
 
