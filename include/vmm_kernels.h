@@ -51,6 +51,10 @@ typedef struct vmm_conv_desc {
    * workgroups per output tile; the partial sums are added in a fixed order (ticket = next split), so results are bit-reproducible.
    * The kernel leaves them zero again.  NULL / too few: no split.  Launches sharing the array must be ordered on one stream. */
   int32_t* split_tickets; int32_t n_tickets;
+  /* vmm_conv3x3_bf16x3 only: when non-NULL and n = vmm_conv3x3_fuses_gn(d) > 0 the kernel also leaves GroupNorm partial sums of its
+   * output (+ bias) in gn_part[B * gn_groups][n][2] = n fp32 (sum x, sum x^2) pairs per (sample, group), every slot written exactly
+   * once (vddp.py:274-279; vmm_groupnorm_coef totals them in a fixed order); samples are runs of a_imgs_per_sample frames. */
+  float* gn_part; int32_t gn_groups;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
@@ -61,6 +65,9 @@ int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
  * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* host-only query: the number n of partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part
+ * (unsplit 2-D-tiled layers), or 0 when it will not produce them */
+int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
 /* 1x1 / Linear specialisation (to_qkv, to_out vddp.py:319,325,413,421; res_conv vddp.py:297): a workgroup stages its rows' full K
  * extent once in LDS and sweeps all output columns, weights read straight into registers in MFMA fragment order (d->w = fmt-2 output
  * of vmm_pack_weights), 16-byte epilogue stores; same epilogue options as vmm_conv_igemm_*.  ln_gamma != NULL: the rows pass through
@@ -97,10 +104,12 @@ int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per
                         double* sums /* [B*G*2], zeroed by the call */, vmm_stream_t stream);
 /* mean/rstd from the sums, then coef[b,c] = (a, b'):  y = silu(x*a + b')  with a = rstd*gamma*(scale+1),
  * b' = (beta - mean*rstd*gamma)*(scale+1)+shift;  film = [B][ldfilm] rows (scale | shift) or NULL (vddp.py:283,306).
- * stats_out [B*G*2] = (mean, rstd) is kept for the backward pass (may be NULL). */
+ * stats_out [B*G*2] = (mean, rstd) is kept for the backward pass (may be NULL).
+ * partials != NULL: the sums are instead the fixed-order total of n_contrib fp32 (sum x, sum x^2) pairs per (sample, group) that
+ * vmm_conv3x3_bf16x3 left in d->gn_part (sums is ignored). */
 int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
                        const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef /* [B][C][2] */,
-                       float* stats_out, vmm_stream_t stream);
+                       float* stats_out, const float* partials, int32_t n_contrib, vmm_stream_t stream);
 /* y = silu(x*a + b') (+ res) ; in place allowed (vddp.py:285,311). */
 int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y, int32_t ldy,
                     int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream);

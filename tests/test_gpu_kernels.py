@@ -175,6 +175,23 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
         torch.cuda.synchronize()
         assert torch.equal(out, first)
     assert int(tickets.abs().sum()) == 0
+    # GroupNorm sums of the output from the epilogue (unsplit 2-D-tiled layers without a residual)
+    G = 8
+    d.res, d.ldres = None, 0
+    d.split_tickets, d.n_tickets = None, 0  # (these small cases would otherwise split the channel reduction)
+    d.gn_part, d.gn_groups, d.a_imgs_per_sample = 1, G, T
+    n_part = lib.vmm_conv3x3_fuses_gn(C.byref(d))
+    if n_part:
+        part = torch.full((B * G, n_part, 2), float("nan"), device=gpu)
+        d.gn_part = part.data_ptr()
+        N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo + gn sums")
+        torch.cuda.synchronize()
+        y = (ref - res).reshape(B, T * H * W, G, Cout // G).double()
+        want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], -1)
+        assert relerr(out.cpu(), ref - res) < 5e-5
+        assert relerr(part.cpu().double().sum(1).reshape(B, G, 2), want) < 2e-5  # every slot written exactly once (no NaN left)
+    else:
+        assert not (W >= 32 and W % 16 == 0 and H % 16 == 0)
 
 
 def test_conv_concat_residual_and_fused_gn(gpu):
@@ -262,7 +279,7 @@ def test_groupnorm_film_silu(gpu, C_, G):
     gg, bg, fg, rg = gamma.to(gpu), beta.to(gpu), film.to(gpu), res.to(gpu)  # keep the device copies alive across the launches
     N.check(lib.vmm_groupnorm_stats(xr.data_ptr(), C_, B, rps, C_, G, sums.data_ptr(), _s()), "stats")
     N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(),
-                                   2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), _s()), "coef")
+                                   2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), None, 0, _s()), "coef")
     out = torch.empty_like(xr)
     N.check(lib.vmm_affine_silu(xr.data_ptr(), C_, coef.data_ptr(), rg.data_ptr(), C_, out.data_ptr(), C_, xr.shape[0], rps, C_, _s()), "apply")
     torch.cuda.synchronize()

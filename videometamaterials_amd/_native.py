@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("q_scale", c_f32), ("q_ncols", c_i32),
         ("a_mode", c_i32), ("a_coef", c_ptr), ("a_imgs_per_sample", c_i32),
         ("split_tickets", c_ptr), ("n_tickets", c_i32),
+        ("gn_part", c_ptr), ("gn_groups", c_i32),
     ]
 
 
@@ -76,6 +77,7 @@ SIGNATURES = {
     "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
@@ -97,7 +99,7 @@ SIGNATURES = {
     "vmm_adam_step": [c_ptr, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_ptr],
     "vmm_ema_step": [c_ptr, c_i32, c_i64, c_f32, c_i32, c_ptr],
     "vmm_groupnorm_stats": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
-    "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr],
     "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
     "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],
     "vmm_temporal_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],

@@ -363,6 +363,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
         }
       }
     }
+    if (MODE && p.gn_part) {
+      // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels
+      // the sum and the sum of squares over this wave's 64 pixels, combined over the workgroup's waves in LDS, then one fp64
+      // atomic per (run, moment) into sums[sample][group] -- the separate statistics pass over the output disappears.
+      float gs[2][4], gq[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * lk;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+            s1 += (v0 + v1) + (v2 + v3);
+            s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          }
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          gs[j][g] = s1;
+          gq[j][g] = s2;
+        }
+      }
+      __syncthreads();  // every wave is done with the patch: reuse its LDS
+      float* sc = reinterpret_cast<float*>(smem);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            sc[wave * 16 + (j * 4 + g) * 2] = gs[j][g];
+            sc[wave * 16 + (j * 4 + g) * 2 + 1] = gq[j][g];
+          }
+      }
+      __syncthreads();
+      if (tid < WN * 16) {
+        const int wn2 = tid >> 4, slot = tid & 15, run = slot >> 1;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) v += sc[(w2 * WN + wn2) * 16 + slot];
+        // slot of this (frame, tile, 8-channel run) among the contributions to its (sample, group): written exactly once, no atomics
+        const int cout0 = n0 + wn2 * 64 + (run >> 2) * 32 + (run & 3) * 8;
+        const int cpg = p.Cout / p.gn_groups, rpg = cpg >> 3;
+        const int grp = cout0 / cpg, rig = (cout0 - grp * cpg) >> 3;
+        const int smp = img / p.a_imgs_per_sample, fr = img - smp * p.a_imgs_per_sample;
+        const int n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * rpg;
+        const int k = (fr * a.tiles_per_frame + (mtile - img * a.tiles_per_frame)) * rpg + rig;
+        p.gn_part[(((long long)smp * p.gn_groups + grp) * n_contrib + k) * 2 + (slot & 1)] = v;
+      }
+    }
   }
 }
 
@@ -379,13 +434,8 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
-}  // namespace
-
-// Weights: vmm_pack_weights fmt 2 (MFMA fragment order).  Returns 1 (nothing launched) when the descriptor is outside this
-// kernel's envelope: 3x3 / stride 1 / pad 1, C1 % 32 == C2 % 32 == 0, Cout == 64 or Cout % 128 == 0, W <= 31 or (W % 16 == 0 and
-// H % 16 == 0) -- the caller then uses vmm_conv_igemm_bf16x3 with fmt-1 weights.
-extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
-  const vmm_conv_desc& d = *dp;
+// shape planning shared by the launcher and the query below; returns 0 and fills a / mtiles / ksplit / gn, or the launcher's status
+int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& gn) {
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 &&
                         d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 &&
                         d.rot_ncols == 0 && d.q_ncols == 0;
@@ -394,15 +444,13 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   if (!shape_ok || !chan_ok) return 1;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   const long long M = (long long)d.nimg * d.Hin * d.Win;
-  if (M >= (1LL << 31) || M <= 0) return M <= 0 ? 0 : -4;
+  if (M >= (1LL << 31)) return -4;
   const bool wide = d.Cout >= 128;  // 2 x 2 waves, 128 pixels x 128 columns; else 4 x 1 waves, 256 pixels x 64 columns
   const int BM = wide ? 128 : 256, TH = BM / 16;
-  C3Args a;
   a.p = d;
   a.n_tiles = wide ? d.Cout / 128 : 1;
   a.total_rows = (int)M;
   a.KS = 9 * (d.C1 + d.C2) / 16;
-  int mtiles;
   if (d.Win >= 32 && d.Win % 16 == 0 && d.Hin % TH == 0) {
     a.mode = 1;
     a.tiles_x = d.Win / 16;
@@ -424,10 +472,42 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   // the partial sums are added in a fixed order (tickets, see the kernel epilogue)
   const int nch = (d.C1 + d.C2) / CK;
   const long long blocks = (long long)mtiles * a.n_tiles;
-  int ksplit = 1;
+  ksplit = 1;
   if (blocks < 1024 && d.split_tickets && d.n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
+  // GroupNorm statistics of the output in the epilogue: unsplit 2-D tiles (one frame, hence one sample, per workgroup), groups of whole
+  // 8-channel runs, no residual in the output
+  gn = d.gn_part && d.gn_groups > 0 && a.mode == 1 && ksplit == 1 && !d.res && d.a_imgs_per_sample > 0 && d.Cout % d.gn_groups == 0 &&
+       (d.Cout / d.gn_groups) % 8 == 0 && d.nimg % d.a_imgs_per_sample == 0;
+  if (!gn) a.p.gn_part = nullptr;
+  return 0;
+}
+
+}  // namespace
+
+// Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
+// vmm_groupnorm_stats and hands them to vmm_groupnorm_coef), 0 when it will not.  Pure host logic.
+extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
+  C3Args a;
+  int mtiles, ksplit;
+  bool gn = false;
+  if (plan_c3(*dp, a, mtiles, ksplit, gn) != 0 || !gn) return 0;
+  return dp->a_imgs_per_sample * a.tiles_per_frame * ((dp->Cout / dp->gn_groups) >> 3);
+}
+
+// Weights: vmm_pack_weights fmt 2 (MFMA fragment order).  Returns 1 (nothing launched) when the descriptor is outside this
+// kernel's envelope: 3x3 / stride 1 / pad 1, C1 % 32 == C2 % 32 == 0, Cout == 64 or Cout % 128 == 0, W <= 31 or (W % 16 == 0 and
+// H % 16 == 0) -- the caller then uses vmm_conv_igemm_bf16x3 with fmt-1 weights.
+extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  C3Args a;
+  int mtiles, ksplit;
+  bool gn = false;
+  const int rc = plan_c3(d, a, mtiles, ksplit, gn);
+  if (rc != 0) return rc;
+  if (a.total_rows <= 0) return 0;
+  const bool wide = d.Cout >= 128;
   hipStream_t s = (hipStream_t)stream;
   if (ksplit > 1) {
     if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true>(a, mtiles, ksplit, s);

@@ -48,30 +48,50 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-// coef[b][c] = (a, b') ; one thread per (b, c)
-__global__ void gn_coef_kernel(const double* __restrict__ sums, double inv_count, float eps, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, int B, int C, int G,
-                               float* __restrict__ coef, float* __restrict__ stats_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  const int g = c / (C / G);
-  const double mean = sums[(b * G + g) * 2] * inv_count;
-  double var = sums[(b * G + g) * 2 + 1] * inv_count - mean * mean;
+// coef[b][c] = (a, b') ; one workgroup per (sample, group): the group's two moments (from the fp64 sums, or as the fixed-order total of
+// the per-workgroup fp32 partial sums the producing convolution left behind, conv3x3_bf16x3.hip), then one thread per channel
+__global__ __launch_bounds__(128) void gn_coef_kernel(const double* __restrict__ sums, double inv_count, float eps, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, int B, int C, int G,
+                                                      float* __restrict__ coef, float* __restrict__ stats_out, const float* __restrict__ partials,
+                                                      int n_contrib) {
+  __shared__ double red[2][128];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  if (partials) {
+    const float* pp = partials + (long long)(b * G + g) * n_contrib * 2;
+    for (int k = tid; k < n_contrib; k += 128) { s1 += (double)pp[2 * k]; s2 += (double)pp[2 * k + 1]; }
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    for (int o = 64; o >= 1; o >>= 1) {
+      if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+      __syncthreads();
+    }
+    s1 = red[0][0]; s2 = red[1][0];
+  } else {
+    s1 = sums[(b * G + g) * 2];
+    s2 = sums[(b * G + g) * 2 + 1];
+  }
+  const double mean = s1 * inv_count;
+  double var = s2 * inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
-  float a = rstd * gamma[c];
-  float bb = beta[c] - meanf * a;
-  if (film) {
-    const float sc = film[(long long)b * ldfilm + c] + 1.0f;
-    const float sh = film[(long long)b * ldfilm + C + c];
-    a *= sc;
-    bb = bb * sc + sh;
+  const int cpg = C / G;
+  for (int cl = tid; cl < cpg; cl += 128) {
+    const int c = g * cpg + cl;
+    float a = rstd * gamma[c];
+    float bb = beta[c] - meanf * a;
+    if (film) {
+      const float sc = film[(long long)b * ldfilm + c] + 1.0f;
+      const float sh = film[(long long)b * ldfilm + C + c];
+      a *= sc;
+      bb = bb * sc + sh;
+    }
+    coef[((long long)b * C + c) * 2 + 0] = a;
+    coef[((long long)b * C + c) * 2 + 1] = bb;
   }
-  coef[i * 2 + 0] = a;
-  coef[i * 2 + 1] = bb;
-  if (stats_out && c == g * (C / G)) {
+  if (stats_out && tid == 0) {
     stats_out[(b * G + g) * 2 + 0] = meanf;
     stats_out[(b * G + g) * 2 + 1] = rstd;
   }
@@ -173,11 +193,11 @@ extern "C" int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32
 
 extern "C" int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
                                   const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef,
-                                  float* stats_out, vmm_stream_t stream) {
+                                  float* stats_out, const float* partials, int32_t n_contrib, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (C % G) return -1;
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, sums, 1.0 / (double)count_per_group, eps, gamma,
-                     beta, film, ldfilm, B, C, G, coef, stats_out);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(B * G), dim3(128), 0, s, sums, 1.0 / (double)count_per_group, eps, gamma,
+                     beta, film, ldfilm, B, C, G, coef, stats_out, partials, n_contrib);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -414,6 +414,7 @@ class _Builder:
         if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
             self.tickets_ptr = self.wslot(N_TICKETS)
         d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
+        d.gn_part, d.gn_groups = None, self.G
         self.plan.keepalive.append(d)
         return d
 
@@ -455,18 +456,33 @@ class _Builder:
         if out_ptr:
             self.step(self.lib.vmm_colsum_accumulate, (x_ptr, ldx, rows, C_, out_ptr), what + " bias grad", nbytes=4.0 * rows * C_)
 
-    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int):
-        """GroupNorm statistics of h and the fused (scale, shift) coefficients; returns (coef_off, n, ptr, stats_ptr)."""
+    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int, conv_desc: Optional["N.ConvDesc"] = None):
+        """GroupNorm statistics of h and the fused (scale, shift) coefficients; returns (coef_off, n, ptr, stats_ptr).
+        conv_desc: descriptor of the vmm_conv3x3_bf16x3 launch that produced h -- where that kernel can, it leaves per-workgroup
+        partial sums of its output behind (conv3x3 epilogue) and the statistics pass over h is skipped."""
         B, G, C_ = self.B, self.G, h.C
         rows_ps = self.T * h.H * h.W
-        sums_off = self.alloc(B * G * 4)
+        n_part = 0
+        if conv_desc is not None:
+            conv_desc.gn_part, conv_desc.gn_groups = 1, G  # placeholder pointer for the host-side query
+            n_part = int(self.lib.vmm_conv3x3_fuses_gn(C.byref(conv_desc)))
+            conv_desc.gn_part = None
         coef_off = self.alloc(B * C_ * 2)
         stats_ptr = self.ptr(self.alloc(B * G * 2)) if self.training else 0
-        self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
-        self.step(self.lib.vmm_groupnorm_coef,
-                  (self.ptr(sums_off), rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
-                   film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None), prefix + ".norm coef")
-        self.free(sums_off, B * G * 4)
+        if n_part:
+            part_off = self.alloc(B * G * n_part * 2)
+            conv_desc.gn_part = self.ptr(part_off)
+            self.step(self.lib.vmm_groupnorm_coef,
+                      (None, rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
+                       film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None, self.ptr(part_off), n_part), prefix + ".norm coef")
+            self.free(part_off, B * G * n_part * 2)
+        else:
+            sums_off = self.alloc(B * G * 4)
+            self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
+            self.step(self.lib.vmm_groupnorm_coef,
+                      (self.ptr(sums_off), rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
+                       film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None, None, 0), prefix + ".norm coef")
+            self.free(sums_off, B * G * 4)
         return coef_off, B * C_ * 2, self.ptr(coef_off), stats_ptr
 
     def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
@@ -492,7 +508,7 @@ class _Builder:
         h1 = self.act(Cout, H, W)
         d1 = self.conv(a1=x1, a2=x2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
                        Wv=W, what=name + ".block1.proj", halo=halo1)
-        c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout)
+        c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout, conv_desc=d1 if halo1 else None)
         halo2 = self.halo_ok(Cout, 0, Cout, H, W)
         w2, gw2 = self.pack_conv(name + ".block2.proj.weight", frag=halo2)
         h2 = self.act(Cout, H, W)
@@ -500,7 +516,7 @@ class _Builder:
                        a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2)
         self.free_act(h1)
         self.free(c1_off, c1_n)
-        c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0)
+        c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0, conv_desc=d2 if halo2 else None)
         has_res = (name + ".res_conv.weight") in self.shapes
         out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
         dr, gwr = None, 0
