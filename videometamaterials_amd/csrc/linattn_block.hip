@@ -13,8 +13,8 @@
 //                                     partial to_out (MFMA) -> 8-head sum through LDS + bias + residual -> out
 // HBM traffic per site: x read twice (+ once more from L2 for the residual), out written once.
 //
-// One wave = one head (512-thread workgroups): its weight fragments stay in registers for the whole kernel (no LDS, no barrier in
-// pass A; one barrier per 32-pixel tile in pass B for the head sum).  The trick that removes every transposition: an MFMA 32x32
+// One wave = one head (512-thread workgroups): its weight fragments stay in registers for the whole kernel (one barrier per 32-pixel tile in
+// pass A for the shared LayerNorm tile, two in pass B: tile and head sum).  The trick that removes every transposition: an MFMA 32x32
 // accumulator holds, per lane, ONE column (lane & 31) and 16 rows; that is exactly an A or B operand of the next MFMA whose
 // contraction runs over those rows, provided both operands enumerate the contraction index in the same (register) order:
 //   k16 step s, lane half lk, element j  <->  row (j & 3) + 8 * (2 s + (j >> 2)) + 4 lk.
@@ -70,38 +70,37 @@ __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const 
   return c;
 }
 
-// LayerNorm of 32 pixel rows as operand fragments: lane (pixel = lane & 31, lk) owns channels s*16 + lk*8 .. +7 of its row for
-// the four k16 steps s.  The same registers serve as an A operand (rows = pixels) or a B operand (columns = pixels).
-__device__ __forceinline__ void load_norm_rows(const LAArgs& a, long long row, int lk, uint4 (&yh)[4], uint4 (&yl)[4]) {
-  const float* xr = a.x + row * a.ldx + lk * 8;
-  f32x4 v[8];
-  float s = 0.f;
+// The 32 x 64 input tile of a step is read ONCE per workgroup: thread (row tid >> 4, channels (tid & 15) * 4 .. +3) loads one float4 a
+// tile ahead (the HBM latency hides under the previous tile's MFMAs), the 16 lanes of a row normalise it (channel LayerNorm,
+// vddp.py:245-254) and the bf16 hi | lo rows go to LDS, where the eight head-waves pick up their operand fragments: lane
+// (pixel = lane & 31, lk) owns channels s*16 + lk*8 .. +7 for the four k16 steps s.  The same registers serve as an A operand
+// (rows = pixels) or a B operand (columns = pixels).
+constexpr int YPITCH = 2 * LC + 8;  // bf16 per LDS row: hi 64 | lo 64 | pad (272 bytes = 17 x 16: conflict-free ds_read_b128)
+
+__device__ __forceinline__ void stage_norm_row(const LAArgs& a, const f32x4& x, const f32x4& gam, unsigned short* ytile, int tid) {
+  float s = (x.x + x.y) + (x.z + x.w);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[2 * i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
-    v[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + i * 16 + 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  s += __shfl_xor(s, 32, 64);
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
   const float mean = s * (1.0f / LC);
-  float q = 0.f;
+  const f32x4 c = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
+  float q = (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-  }
-  q += __shfl_xor(q, 32, 64);
+  for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q * (1.0f / LC) + a.eps);
+  unsigned l0, l1;
+  const unsigned h0 = pack_split(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
+  const unsigned h1 = pack_split(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
+  unsigned short* row = ytile + (tid >> 4) * YPITCH + (tid & 15) * 4;
+  *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(row + LC) = make_uint2(l0, l1);
+}
+
+__device__ __forceinline__ void read_row_frags(const unsigned short* ytile, int lrow, int lk, uint4 (&yh)[4], uint4 (&yl)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8);
-    const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8 + 4);
-    const f32x4 u = v[2 * i], w = v[2 * i + 1];
-    yh[i].x = pack_split(u.x * rstd * g0.x, u.y * rstd * g0.y, yl[i].x);
-    yh[i].y = pack_split(u.z * rstd * g0.z, u.w * rstd * g0.w, yl[i].y);
-    yh[i].z = pack_split(w.x * rstd * g1.x, w.y * rstd * g1.y, yl[i].z);
-    yh[i].w = pack_split(w.z * rstd * g1.z, w.w * rstd * g1.w, yl[i].w);
+    const unsigned short* q = ytile + lrow * YPITCH + i * 16 + lk * 8;
+    yh[i] = *reinterpret_cast<const uint4*>(q);
+    yl[i] = *reinterpret_cast<const uint4*>(q + LC);
   }
 }
 
@@ -128,11 +127,24 @@ __global__ __launch_bounds__(512, 2) void linattn_ctx_kernel(const LAArgs a) {
     wkh[s] = qk[0]; wkl[s] = qk[64];
     wvh[s] = qv[0]; wvl[s] = qv[64];
   }
+  __shared__ __attribute__((aligned(16))) unsigned short ytile[2][32 * YPITCH];  // double buffer: one barrier per tile
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + (tid & 15) * 4);
+  auto load_x = [&](int t) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < t_end) v = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + (tid & 15) * 4);
+    return v;
+  };
   float m = -INFINITY, ssum = 0.f;
   f32x16 ctx = zero16();  // rows e, column d = lrow
+  f32x4 x_next = load_x(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    const f32x4 x_cur = x_next;
+    x_next = load_x(t + 1);
+    stage_norm_row(a, x_cur, gam, ytile[buf], tid);
+    __syncthreads();
     uint4 yh[4], yl[4];
-    load_norm_rows(a, (long long)frame * a.HW + t * 32 + lrow, lk, yh, yl);
+    read_row_frags(ytile[buf], lrow, lk, yh, yl);
     f32x16 kt = zero16(), vt = zero16();  // rows pixels, column d (resp. e) = lrow
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(256) void linattn_combine_kernel(const LAArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------- pass B
 __global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2 buffers][8 heads][32 pixels][64 channels]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [8 heads][32 pixels][64 channels], then the staged input tile
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(red + LH * 32 * LC);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
   const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
@@ -246,11 +259,21 @@ __global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
   const int rp = tid >> 4, rc = (tid & 15) * 4;
   const f32x4 bias = a.bias_out ? *reinterpret_cast<const f32x4*>(a.bias_out + rc) : f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int buf = 0;
-  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + rc);
+  auto load_x = [&](int t) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < t_end) v = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + rc);
+    return v;
+  };
+  f32x4 x_next = load_x(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
     const long long row0 = (long long)frame * a.HW + t * 32;
+    const f32x4 x_cur = x_next;
+    x_next = load_x(t + 1);
+    stage_norm_row(a, x_cur, gam, ytile, tid);
+    __syncthreads();  // tile rows visible; also: every wave has finished the previous tile's head sum (red is free again)
     uint4 yh[4], yl[4];
-    load_norm_rows(a, row0 + lrow, lk, yh, yl);
+    read_row_frags(ytile, lrow, lk, yh, yl);
     f32x16 qt = zero16();  // rows d, column pixel = lrow
 #pragma unroll
     for (int s = 0; s < 4; ++s) qt = mfma3(wqh[s], wql[s], yh[s], yl[s], qt);
@@ -280,22 +303,21 @@ __global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
     }
-    float* rb = red + ((buf * LH + h) * 32) * LC;
+    float* rb = red + (h * 32) * LC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int px = (r & 3) + 8 * (r >> 2) + 4 * lk;
       rb[px * LC + lrow] = pc[0][r];
       rb[px * LC + 32 + lrow] = pc[1][r];
     }
-    __syncthreads();  // (the other buffer is free again: its readers passed the previous barrier)
+    __syncthreads();
     f32x4 acc = bias;
 #pragma unroll
     for (int w = 0; w < LH; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((buf * LH + w) * 32 + rp) * LC + rc);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rp) * LC + rc);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    const f32x4 xr = *reinterpret_cast<const f32x4*>(a.x + (row0 + rp) * a.ldx + rc);
-    acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;
+    acc.x += x_cur.x; acc.y += x_cur.y; acc.z += x_cur.z; acc.w += x_cur.w;  // residual: the element this thread normalised
     *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + rc) = acc;
   }
 }
@@ -340,7 +362,7 @@ extern "C" int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float
   VMM_LAUNCH_CHECK();
   hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(B * T * LH)), dim3(256), 0, s, a);
   VMM_LAUNCH_CHECK();
-  const size_t shm = sizeof(float) * 2 * LH * 32 * LC;
+  const size_t shm = sizeof(float) * LH * 32 * LC + sizeof(unsigned short) * 32 * YPITCH;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

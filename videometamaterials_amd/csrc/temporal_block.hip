@@ -92,6 +92,8 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   uint4* ekf = reinterpret_cast<uint4*>(red + HEADS * 32 * TC);        // [8 heads][2 steps][hi|lo][64 lanes]
   uint4* evf = ekf + HEADS * 4 * 64;                                   // [8 heads][hi|lo][64 lanes]
   float* biasf = reinterpret_cast<float*>(evf + HEADS * 2 * 64);       // [8 heads][2 halves][16 frames][8]
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(biasf + HEADS * 2 * 16 * 8);  // [32 rows][hi 64 | lo 64 | pad 8]
+  constexpr int YPITCH = 2 * TC + 8;                                   // 272 bytes = 17 x 16: conflict-free ds_read_b128 over consecutive rows
 
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
@@ -172,45 +174,43 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   const int rm = tid >> 4, rcol = (tid & 15) * 4;
   const int rpa = rm >> 4, rft = rm & 15;
 
+  // The 32 x 64 input tile is read ONCE per workgroup: thread (row rm, channels rcol .. rcol+3) loads one float4 -- a tile ahead, so the
+  // HBM latency hides under the previous tile's MFMAs -- the 16 lanes of a row normalise it, and the bf16 hi|lo rows go to LDS where
+  // all eight head-waves pick up their fragments.  The same thread owns that element again in the head sum: x is never re-read.
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + rcol);
+  auto load_x = [&](int pp) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (rft < T && pp < p_end) v = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * T + rft) * HW + pp * 2 + rpa) * a.ldx + rcol);
+    return v;
+  };
+  f32x4 x_next = load_x(p_begin);
   for (int pp = p_begin; pp < p_end; ++pp) {
-    // ---- LayerNorm of the 32 rows as fragments (lane = row, 8 channels per k16 step and lane half)
-    uint4 yh[4], yl[4];
+    const f32x4 x_cur = x_next;
+    x_next = load_x(pp + 1);
+    // ---- LayerNorm of the 32 rows (16 lanes per row), rows to LDS as bf16 hi | lo
     {
-      f32x4 v[8];
-      if (row_ok) {
-        const float* xr = a.x + (((long long)b * T + ft) * HW + pp * 2 + pa) * a.ldx + lk * 8;
+      float s = (x_cur.x + x_cur.y) + (x_cur.z + x_cur.w);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[2 * i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
-          v[2 * i + 1] = *reinterpret_cast<const f32x4*>(xr + i * 16 + 4);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      s += __shfl_xor(s, 32, 64);
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
       const float mean = s * (1.0f / TC);
-      float q = 0.f;
+      const f32x4 c = {x_cur.x - mean, x_cur.y - mean, x_cur.z - mean, x_cur.w - mean};
+      float q = (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-      }
-      q += __shfl_xor(q, 32, 64);
+      for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
       const float rstd = 1.0f / sqrtf(q * (1.0f / TC) + a.eps);
+      unsigned l0, l1;
+      const unsigned h0 = pack_split(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
+      const unsigned h1 = pack_split(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
+      *reinterpret_cast<uint2*>(ytile + rm * YPITCH + rcol) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(ytile + rm * YPITCH + TC + rcol) = make_uint2(l0, l1);
+    }
+    __syncthreads();  // tile rows visible; also: every wave has finished the previous tile's head sum (red is free again)
+    uint4 yh[4], yl[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + i * 16 + lk * 8 + 4);
-        const f32x4 u = v[2 * i], w = v[2 * i + 1];
-        yh[i].x = pack_split(u.x * rstd * g0.x, u.y * rstd * g0.y, yl[i].x);
-        yh[i].y = pack_split(u.z * rstd * g0.z, u.w * rstd * g0.w, yl[i].y);
-        yh[i].z = pack_split(w.x * rstd * g1.x, w.y * rstd * g1.y, yl[i].z);
-        yh[i].w = pack_split(w.z * rstd * g1.z, w.w * rstd * g1.w, yl[i].w);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const unsigned short* q = ytile + lrow * YPITCH + i * 16 + lk * 8;
+      yh[i] = *reinterpret_cast<const uint4*>(q);
+      yl[i] = *reinterpret_cast<const uint4*>(q + TC);
     }
     // ---- projections
     f32x16 qt = zero16(), kt = zero16(), vt = zero16();
@@ -294,8 +294,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
         pc[ct] = mfma3(oh, ol, q[0], q[64], pc[ct]);
       }
     }
-    __syncthreads();  // the previous tile's head sum has been read by everyone
-    float* rb = red + (h * 32) * TC;
+    float* rb = red + (h * 32) * TC;  // (free: the barrier after the LayerNorm above came after everyone's previous head sum)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -311,8 +310,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
-      const f32x4 xr = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + rcol);
-      acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;
+      acc.x += x_cur.x; acc.y += x_cur.y; acc.z += x_cur.z; acc.w += x_cur.w;  // residual: the element this thread normalised
       *reinterpret_cast<f32x4*>(a.out + row * a.ldo + rcol) = acc;
     }
   }
@@ -341,7 +339,8 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
   int ns = max(1, min(pairs, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
   a.tps = (pairs + ns - 1) / ns;
   a.nsplit = (pairs + a.tps - 1) / a.tps;
-  const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8;
+  const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
+                     sizeof(unsigned short) * 32 * (2 * TC + 8);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
