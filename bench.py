@@ -106,11 +106,14 @@ def cpu_baseline(max_seconds: float = 30.0):
             "forward_s_b1": fwd}
 
 
-def bench_training(vm, model, diff, dev, dist, world, rank, steps: int):
+def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precision: str = "fp32"):
     """One data-parallel optimisation step = q_sample -> denoiser forward -> L1 loss -> hand-written backward -> bucketed RCCL
-    all-reduce overlapped with the backward -> multi-tensor Adam (+ EMA every 10 steps); per-GPU batch 4 (model.yaml:2)."""
+    all-reduce overlapped with the backward -> multi-tensor Adam (+ EMA every 10 steps); per-GPU batch 4 (model.yaml:2).
+    precision "fp32": exact-fp32 MFMA everywhere (the parity mode, gradients within 1e-3 of the reference);
+    "bf16x3": forward + data gradients on the split-bf16 matrix cores, weight gradients fp32."""
     from videometamaterials_amd.dp import DataParallelTrainer
     model.static_weights = False
+    model.train_precision = precision
     model.train()
     tr = DataParallelTrainer(diff, train_lr=1e-4)
     g = torch.Generator().manual_seed(100 + rank)
@@ -136,7 +139,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int):
     pl = tr._plan
     fl = sum(f for _, f, _ in pl.meta) + sum(f for _, f, _ in pl.bwd_meta)
     return {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
-            "batch_per_gpu": B_PER_GPU, "dtype": "f32", "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3),
+            "batch_per_gpu": B_PER_GPU, "dtype": "f32", "matrix_core_mode": precision, "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3),
             "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1), "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1)}
 
 
@@ -215,6 +218,8 @@ def main():
     if not args.no_train:
         try:
             train = bench_training(vm, model, diff, dev, dist, world, rank, steps=max(2, min(args.steps, 6)))
+            # same step with the forward and the data gradients on the split-bf16 matrix cores (extra information, not the parity mode)
+            train["split_bf16_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=max(2, min(args.steps, 6)), precision="bf16x3")
         except Exception as e:  # the sampling metric above stays valid; report the failure instead of hiding it
             train = {"error": f"{type(e).__name__}: {e}"}
 

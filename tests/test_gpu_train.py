@@ -100,6 +100,41 @@ def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_va
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
 
 
+@pytest.mark.parametrize("cfg_name", ["lagr16", "lagr64"])
+def test_split_bf16_training_gradients(gpu, cfg_name):
+    """train_precision = "bf16x3": forward and data gradients on the split-bf16 matrix cores (3x3 data gradients through the halo kernel
+    with reversed taps, 1x1 ones through the projection kernel), weight gradients exact fp32.  Checked with the smooth l2 loss: with l1 the
+    loss gradient is a sign, and a 1e-5 forward difference flips enough of them to dominate the comparison (hence fp32 stays the default)."""
+    import videometamaterials_amd as vm
+    from oracle import diffusion_oracle as do
+    from oracle import unet3d_oracle as uo
+    kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    sd = helpers.synth_state_dict(helpers.load_shapes(cfg_name))
+    model = vm.Unet3D(**kw)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    model.train_precision = "bf16x3"
+    diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=256, loss_type="l2", sampling_timesteps=256).to(gpu)
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.rand(x.shape, generator=g) * 2 - 1
+    noise = torch.randn(x.shape, generator=g)
+    cfg = uo.UnetCfg(**kw)
+    sdg = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
+    want_loss = do.p_losses(do.schedule_buffers(256), lambda a, b: uo.unet3d_forward(sdg, cfg, a, b, cond, torch.zeros(B, dtype=torch.bool)), x0, t, noise,
+                            loss_type="l2")
+    want_loss.backward()
+    want = {k: v.grad for k, v in sdg.items() if v.requires_grad}
+    loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
+    loss.backward()
+    assert abs(float(loss) - float(want_loss)) < 1e-4 * abs(float(want_loss))
+    bad = _report({k: p.grad for k, p in model.named_parameters()}, want)
+    assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
+    plan = model.get_plan(B, T, H, W, cond.shape[1], gpu, training=True)
+    used = {fn.__name__ for fn, _, _ in plan.bwd_steps}
+    assert "vmm_proj_bf16x3" in used and ("vmm_conv3x3_bf16x3" in used or cfg_name == "lagr16")
+
+
 def test_trainer_step_matches_torch_adam(gpu):
     """DataParallelTrainer (world 1): fused q_sample -> forward -> loss -> backward -> multi-tensor Adam -> EMA copy."""
     from videometamaterials_amd.dp import DataParallelTrainer

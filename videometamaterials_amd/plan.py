@@ -239,7 +239,8 @@ class _Builder:
         self.G = model.resnet_groups
         self.heads = model.attn_heads
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
-        self.x3 = (getattr(model, "precision", "fp32") == "bf16x3") and not training
+        # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
+        self.x3 = getattr(model, "train_precision" if training else "precision", "fp32") == "bf16x3"
         self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
         self.unpack_jobs: List[dict] = []
         self.gacts: Dict[int, Act] = {}  # activation offset -> gradient buffer
@@ -299,11 +300,14 @@ class _Builder:
         self.wtop += (n + ALIGN - 1) // ALIGN * ALIGN
         return self.wbase + off * 4
 
-    def pack(self, name: str, n_elems: int, want_grad: bool = True, **desc) -> Tuple[int, int]:
-        """Register an operand layout of parameter `name` (see vmm_pack_job); returns (packed ptr, packed-gradient ptr)."""
+    def pack(self, name: str, n_elems: int, want_grad: bool = True, gemm: Optional[bool] = None, **desc) -> Tuple[int, int]:
+        """Register an operand layout of parameter `name` (see vmm_pack_job); returns (packed ptr, packed-gradient ptr).
+        gemm: the layout is a GEMM operand (forward weights, or the transposed operand of a data gradient) and takes the
+        split-bf16 formats in bf16x3 mode; default = want_grad (raw parameter copies stay fp32)."""
         self._touch(name)
         frag = desc.pop("frag", False)
-        if want_grad and self.x3 and not self.in_bwd:  # forward GEMM operand -> pre-split bf16 hi|lo
+        n_fp32, fp32_desc = n_elems, desc
+        if (want_grad if gemm is None else gemm) and self.x3:  # GEMM operand -> pre-split bf16 hi|lo
             kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
             if frag:  # MFMA fragment order, read straight into registers (conv3x3_bf16x3.hip; 3 = permuted k, linattn_block.hip)
                 n_elems = (desc["N"] + 31) // 32 * 32 * kpad
@@ -316,8 +320,9 @@ class _Builder:
         self.plan.pack_jobs.append(job)
         gptr = 0
         if self.training and want_grad and name in self.trainable:
-            gptr = self.scratch(n_elems)
-            self.unpack_jobs.append(dict(job, packed=gptr, accumulate=1))
+            # weight gradients are always produced (vmm_conv_wgrad_f32) and scattered back in the fp32 k-major layout
+            gptr = self.scratch(n_fp32)
+            self.unpack_jobs.append(dict(name=name, packed=gptr, accumulate=1, **fp32_desc))
         return ptr, gptr
 
     def wraw(self, name: str) -> int:
@@ -335,7 +340,7 @@ class _Builder:
 
     def halo_ok(self, c1: int, c2: int, cout: int, H: int, W: int) -> bool:
         """Envelope of vmm_conv3x3_bf16x3 (LDS halo patch + register-fed fragment-order weights)."""
-        if not (self.x3 and not self.in_bwd and getattr(self.m, "use_halo_conv", True)):
+        if not (self.x3 and getattr(self.m, "use_halo_conv", True)):
             return False
         if c1 % 32 or c2 % 32 or not (cout == 64 or cout % 128 == 0):
             return False
@@ -344,11 +349,14 @@ class _Builder:
             return True
         return bm + 2 * (W + 1) <= (6 if cout >= 128 else 11) * 32
 
-    def pack_conv_dgrad(self, name: str, ci0: int, nci: int) -> int:
-        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, co)][ci0 : ci0+nci]  (data gradient of a stride-1 conv; the descriptor mirrors the taps)"""
+    def pack_conv_dgrad(self, name: str, ci0: int, nci: int, flip: bool = False, frag=False, gemm: bool = False) -> int:
+        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, co)][ci0 : ci0+nci]  (data gradient of a stride-1 conv).  flip = False: taps in forward
+        order, the descriptor mirrors them (off = +pad, sgn = -1); flip = True: taps reversed here, so that the data gradient is an
+        ordinary 'same' convolution of dY (what vmm_conv3x3_bf16x3 runs).  gemm: split-bf16 operand in bf16x3 mode."""
         co, ci, _, kh, kw = self.shapes[name]
-        return self.pack(name, kh * kw * co * nci, want_grad=False, TH=kh, TW=kw, C=co, Cp=co, N=nci, sn=kh * kw, sc=ci * kh * kw, sh=kw, sw=1, hs=1, ws=1,
-                         src_off=ci0 * kh * kw)[0]
+        geo = dict(h0=kh - 1, hs=-1, w0=kw - 1, ws=-1) if flip else dict(hs=1, ws=1)
+        return self.pack(name, kh * kw * co * nci, want_grad=False, gemm=gemm, TH=kh, TW=kw, C=co, Cp=co, N=nci, sn=kh * kw, sc=ci * kh * kw, sh=kw, sw=1,
+                         src_off=ci0 * kh * kw, frag=frag, **geo)[0]
 
     def pack_linear(self, name: str, frag=False) -> Tuple[int, int]:
         """(out, in[,1,1[,1]]) -> [in][out]"""
@@ -356,10 +364,30 @@ class _Builder:
         co, ci = shp[0], shp[1]
         return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1, frag=frag)
 
-    def pack_linear_slice(self, name: str, ci0: int, nci: int) -> int:
+    def pack_linear_slice(self, name: str, ci0: int, nci: int, frag=False, gemm: bool = False) -> int:
         """torch (out, in) restricted to input columns [ci0, ci0+nci) as [out][nci]: the k-major operand of the data gradient."""
         co, ci = self.shapes[name][0], self.shapes[name][1]
-        return self.pack(name, co * nci, want_grad=False, TH=1, TW=1, C=co, Cp=co, N=nci, sn=1, sc=ci, src_off=ci0)[0]
+        return self.pack(name, co * nci, want_grad=False, gemm=gemm, TH=1, TW=1, C=co, Cp=co, N=nci, sn=1, sc=ci, src_off=ci0, frag=frag)[0]
+
+    def dgrad_3x3(self, name: str, ci0: int, nci: int, what: str, **kw) -> None:
+        """dX[:, ci0:ci0+nci] (+)= data gradient of the 3x3 'same' conv with weight `name`: with the taps reversed it is itself a
+        3x3 'same' convolution of dY, so bf16x3 mode runs it on vmm_conv3x3_bf16x3 where the envelope fits."""
+        co = self.shapes[name][0]
+        a1 = kw["a1"]
+        if self.halo_ok(co, 0, nci, a1.H, a1.W):
+            w = self.pack_conv_dgrad(name, ci0, nci, flip=True, frag=True, gemm=True)
+            self.conv(w=w, Cout=nci, KH=3, KW=3, off=(-1, -1), what=what, halo=True, x3w=True, **kw)
+        else:
+            w = self.pack_conv_dgrad(name, ci0, nci, gemm=self.x3)
+            self.conv(w=w, Cout=nci, KH=3, KW=3, off=(1, 1), sgn=(-1, -1), what=what, x3w=self.x3, **kw)
+
+    def dgrad_1x1(self, name: str, ci0: int, nci: int, what: str, **kw) -> None:
+        """dX[:, ci0:ci0+nci] (+)= dY . W[:, ci0:ci0+nci] for a 1x1 conv / Linear weight `name` (out, in): split-bf16 projection kernel in
+        bf16x3 mode (K = out features), exact fp32 implicit GEMM otherwise."""
+        co = self.shapes[name][0]
+        pj = self.proj_ok(co, nci)
+        w = self.pack_linear_slice(name, ci0, nci, frag=2 if pj else False, gemm=self.x3)
+        self.conv(w=w, Cout=nci, what=what, proj=pj, x3w=self.x3, **kw)
 
     def step(self, fn, args: tuple, what: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
         if self.in_bwd:
@@ -420,11 +448,11 @@ class _Builder:
 
     def proj_ok(self, k: int, cout: int) -> bool:
         """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
-        if not (self.x3 and not self.in_bwd and not self.training and getattr(self.m, "use_proj_kernel", True)):
+        if not (self.x3 and getattr(self.m, "use_proj_kernel", True)):
             return False
         return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 4 == 0
 
-    def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, **kw) -> "N.ConvDesc":
+    def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
@@ -435,7 +463,7 @@ class _Builder:
             return d
         assert not ln_gamma
         fn = self.lib.vmm_conv_igemm_f32
-        if self.x3 and not self.in_bwd:
+        if self.x3 and (x3w or not self.in_bwd):  # x3w: a backward GEMM whose weight operand was packed split-bf16 (pack(..., gemm=True))
             fn = self.lib.vmm_conv_igemm_bf16x3
             if halo:  # weights were packed in fragment order for it (halo_ok)
                 fn = self.lib.vmm_conv3x3_bf16x3
@@ -544,8 +572,8 @@ class _Builder:
                 self.colsum(gout.ptr, Cout, rows, Cout, self.pg(name + ".res_conv.bias"), name + ".res_conv")
                 for xs, c0 in srcs:
                     gx, acc = self.grad_of(xs)
-                    self.conv(a1=gout, w=self.pack_linear_slice(name + ".res_conv.weight", c0, xs.C), Cout=xs.C, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
-                              res_ptr=gx.ptr if acc else 0, ldres=xs.C, what=name + ".res_conv dgrad")
+                    self.dgrad_1x1(name + ".res_conv.weight", c0, xs.C, name + ".res_conv dgrad", a1=gout, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
+                                   res_ptr=gx.ptr if acc else 0, ldres=xs.C)
             else:
                 self.add_into(x1, gout.ptr)
             # main branch: GN2+SiLU, conv2, GN1+FiLM+SiLU, conv1
@@ -554,16 +582,15 @@ class _Builder:
             self.wgrad(d2, dh2.ptr, Cout, gw2, name + ".block2.proj")
             self.colsum(dh2.ptr, Cout, rows, Cout, self.pg(name + ".block2.proj.bias"), name + ".block2.proj")
             da1 = self.act(Cout, H, W)
-            self.conv(a1=dh2, w=self.pack_conv_dgrad(name + ".block2.proj.weight", 0, Cout), Cout=Cout, KH=3, KW=3, off=(1, 1), sgn=(-1, -1), out_ptr=da1.ptr,
-                      ldo=Cout, Hv=H, Wv=W, what=name + ".block2.proj dgrad")
+            self.dgrad_3x3(name + ".block2.proj.weight", 0, Cout, name + ".block2.proj dgrad", a1=dh2, out_ptr=da1.ptr, ldo=Cout, Hv=H, Wv=W)
             self.tmp_free(dh2)
             self.gn_bwd(name + ".block1", da1.ptr, h1, c1_ptr, st1, film_ptr, 2 * Cout, da1.ptr, dfilm_ptr)  # in place: dh1 overwrites da1
             self.wgrad(d1, da1.ptr, Cout, gw1, name + ".block1.proj")
             self.colsum(da1.ptr, Cout, rows, Cout, self.pg(name + ".block1.proj.bias"), name + ".block1.proj")
             for xs, c0 in srcs:
                 gx, acc = self.grad_of(xs)
-                self.conv(a1=da1, w=self.pack_conv_dgrad(name + ".block1.proj.weight", c0, xs.C), Cout=xs.C, KH=3, KW=3, off=(1, 1), sgn=(-1, -1),
-                          out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W, res_ptr=gx.ptr if acc else 0, ldres=xs.C, what=name + ".block1.proj dgrad")
+                self.dgrad_3x3(name + ".block1.proj.weight", c0, xs.C, name + ".block1.proj dgrad", a1=da1, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
+                               res_ptr=gx.ptr if acc else 0, ldres=xs.C)
             self.tmp_free(da1)
         self.on_backward(bwd, pg_start, uj_start)
         return out
@@ -613,13 +640,14 @@ class _Builder:
             self.free(ws, ws_n)
             self.plan.named[name] = out
             return out
-        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel: the PreNorm LayerNorm runs while the rows are staged
-        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
+        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
+        fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
+        y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
         dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv", proj=pj,
-                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0)
-        if not pj:
+                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+        if not fuse_ln:
             self.free_act(y)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
         part_n, ctx_n = B * T * heads * nsplit * LA_PART, B * T * heads * 1024
@@ -648,7 +676,7 @@ class _Builder:
             self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
             self.colsum(gout.ptr, x.C, rows, x.C, self.pg(name + ".fn.fn.to_out.bias"), name + " to_out")
             go = self.act(hid, x.H, x.W)
-            self.conv(a1=gout, w=self.wraw(name + ".fn.fn.to_out.weight"), Cout=hid, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_out dgrad")
+            self.dgrad_1x1(name + ".fn.fn.to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
             gqkv = self.act(3 * hid, x.H, x.W)
             dctx = self.alloc(ctx_n)
             geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
@@ -658,7 +686,7 @@ class _Builder:
             self.tmp_free((dctx, ctx_n))
             self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
             gy = self.act(x.C, x.H, x.W)
-            self.conv(a1=gqkv, w=self.wraw(name + ".fn.fn.to_qkv.weight"), Cout=x.C, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W, what=name + " to_qkv dgrad")
+            self.dgrad_1x1(name + ".fn.fn.to_qkv.weight", 0, x.C, name + " to_qkv dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
             self.tmp_free(gqkv)
             self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
             self.tmp_free(gy)
@@ -689,15 +717,16 @@ class _Builder:
                       name + " fused block", flops=flops, nbytes=8.0 * x.n)
             self.plan.named[name] = out
             return out
-        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel: the PreNorm LayerNorm runs while the rows are staged
-        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
+        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
+        fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
+        y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
         q_scale = 32 ** -0.5
         dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
                        rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
-                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0)
-        if not pj:
+                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+        if not fuse_ln:
             self.free_act(y)
         o = self.act(hid, x.H, x.W)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
@@ -723,7 +752,7 @@ class _Builder:
             self.add_into(x, gout.ptr)
             self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
             go = self.act(hid, x.H, x.W)
-            self.conv(a1=gout, w=self.wraw(p + ".to_out.weight"), Cout=hid, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_out dgrad")
+            self.dgrad_1x1(p + ".to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
             gqkv = self.act(3 * hid, x.H, x.W)
             dbuf = self.alloc(rows * heads)
             geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
@@ -735,7 +764,7 @@ class _Builder:
             self.tmp_free((dbuf, rows * heads))
             self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
             gy = self.act(x.C, x.H, x.W)
-            self.conv(a1=gqkv, w=self.wraw(p + ".to_qkv.weight"), Cout=x.C, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W, what=name + " to_qkv dgrad")
+            self.dgrad_1x1(p + ".to_qkv.weight", 0, x.C, name + " to_qkv dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
             self.tmp_free(gqkv)
             self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
             self.tmp_free(gy)

@@ -107,9 +107,12 @@ class Unet3D(nn.Module):
         self._plans: Dict[tuple, "_plan.Plan"] = {}
         self._weights_version = None
         self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
-        # matrix-core arithmetic of the inference contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative,
-        # 5x the MFMA rate); "fp32" = exact fp32 MFMA (1e-6).  Training plans always use fp32.
+        # matrix-core arithmetic of the contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative, 5x the MFMA
+        # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
+        # (forward + data gradients; weight gradients are always exact fp32).  Training defaults to fp32: with the reference's l1 loss
+        # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3.
         self.precision = "bf16x3"
+        self.train_precision = "fp32"
 
     # ------------------------------------------------------------------ parameters (names = reference module tree)
     def _conv(self, name, cout, cin, k, bias=True):
@@ -231,7 +234,7 @@ class Unet3D(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> "_plan.Plan":
-        key = (B, T, H, W, cond_len, str(device), training, self.precision)
+        key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision)
         pl = self._plans.get(key)
         if pl is None:
             pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training)
