@@ -10,8 +10,9 @@ One "step" = one guided ancestral DDPM step p_sample(x_t, t) for the whole batch
 reference executes 256 times per sample() call (vddp.py:956-975).  Inputs are resident in HBM.
 value = sampled frames/s = n_gpus * B * 11 frames / (256 steps * step time).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel family (implicit-GEMM conv/projection, fp32 MFMA
-bound) from HIP-event timing of every launch, and `cpu_baseline` = the oracle (CPU restatement) timed on the host cores.
+Extra objects on the JSON line: `roofline` for the dominant kernel family (the 3x3 convolutions, split-bf16 MFMA bound) from
+HIP-event timing of every launch, `cpu_baseline` = the oracle (CPU restatement) timed on the host cores, and `training` = the
+data-parallel optimisation step (the other half of BASELINE.json's metric).
 """
 from __future__ import annotations
 

@@ -168,7 +168,6 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   };
   __syncthreads();
 
-  const bool row_ok = ft < T;
   const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
   // reduction role
   const int rm = tid >> 4, rcol = (tid & 15) * 4;
