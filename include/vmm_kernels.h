@@ -284,6 +284,15 @@ int vmm_adam_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, f
 /* m (EMA weights) = copy_only ? p : beta*m + (1-beta)*p */
 int vmm_ema_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float beta, int32_t copy_only, vmm_stream_t stream);
 
+/* ---- geometry extraction (INT, bit-exact): the topology rule of Trainer.save_preds (vddp.py:1890-1913) followed by
+ * clean_pred (src/utils.py:32-82), one workgroup per sample.  videos = the sampler's fp32 (N, C, T, P, P) output;
+ * out[n][x * P/2 + y] in {0, 1}, the rows of the reference's geometries.csv.  lagrangian != 0 and T > 1: a pixel of the mirrored
+ * upper-left quarter is void iff channel 1 (u_2) is within torch.isclose(atol = 0.02) of zero_u_2 in every frame; otherwise the
+ * bottom-left quarter of channel 0 / frame 0 binarised at 0.5.  Then: transpose, drop pixels whose four (existing) neighbours are
+ * empty, keep the largest 4-connected component (networkx's iteration order breaks ties).  P even, P <= 192. */
+int vmm_extract_geometry(const float* videos, int32_t N, int32_t C, int32_t T, int32_t P, int32_t lagrangian, float zero_u_2,
+                         int32_t* out, vmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

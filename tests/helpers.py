@@ -88,3 +88,37 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 def max_rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max |b|."""
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------- geometry extraction (SURVEY 8(f) f1)
+GEOMETRY_CASES = {  # name -> (seed, N, T, P, zero_u_2)
+    "lagr96": (11, 3, 11, 96, -0.2137),
+    "lagr32": (12, 8, 11, 32, 0.1),
+    "lagr32b": (13, 8, 5, 32, -0.6),
+    "single32": (14, 4, 1, 32, 0.0),  # num_frames == 1 -> the first-frame / first-channel rule even for 'lagrangian'
+}
+
+
+def synth_geometry_videos(seed: int, N: int, T: int, P: int, zero_u_2: float) -> torch.Tensor:
+    """Sampler-like output (N, 3, T, P, P) whose u_2 channel encodes a blobby material / void pattern with speckle, thin bridges and
+    equal-sized islands (ties), so that every rule of the extraction is exercised.  Deterministic in its arguments."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    v = torch.rand(N, 3, T, P, P, generator=g)
+    cells = max(2, P // 8)
+    mask = F.interpolate((torch.rand(N, 1, cells, cells, generator=g) > 0.45).float(), size=(P, P), mode="nearest")[:, 0].bool()
+    mask ^= torch.rand(N, P, P, generator=g) > 0.93            # speckle: isolated pixels and pin holes
+    mask[:, :: max(3, P // 6), :] |= torch.rand(N, 1, P, generator=g) > 0.5   # thin horizontal runs (components with axis-1 edges only)
+    if N > 1:  # sample 1: islands of identical size (tie between components) in both quarters the two rules look at
+        mask[1] = False
+        for r0 in (0, P // 2):
+            mask[1, r0 + 2:r0 + 4, 1:4] = True
+            mask[1, r0 + 9:r0 + 12, 9:11] = True
+            mask[1, r0 + 6, 13:15] = True
+    dev = (torch.rand(N, T, P, P, generator=g) - 0.5) * 0.03    # void: |u_2 - zero| < 0.015 in every frame
+    frame = torch.randint(0, T, (N, P, P), generator=g)
+    bump = (0.03 + 0.1 * torch.rand(N, P, P, generator=g)) * torch.where(torch.rand(N, P, P, generator=g) > 0.5, 1.0, -1.0)
+    onehot = F.one_hot(frame, T).permute(0, 3, 1, 2).float()
+    v[:, 1] = zero_u_2 + dev + mask[:, None].float() * onehot * bump[:, None]   # material: one frame leaves the band
+    v[:, 0, 0] = torch.where(mask, 0.55 + 0.4 * torch.rand(N, P, P, generator=g), 0.45 * torch.rand(N, P, P, generator=g))
+    return v

@@ -7,5 +7,6 @@ arithmetic in hand-written HIP (libvmm_hip.so, C ABI in include/vmm_kernels.h).
 from .unet3d import Unet3D  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from . import hostmath  # noqa: F401
+from .geometry import extract_geometries  # noqa: F401
 
-__all__ = ["Unet3D", "GaussianDiffusion", "hostmath"]
+__all__ = ["Unet3D", "GaussianDiffusion", "hostmath", "extract_geometries"]
