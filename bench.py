@@ -162,12 +162,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # one process per GPU over RCCL.  (VMM_DIST_BACKEND=gloo lets a single-GPU box rehearse the multi-rank control flow with
+        # several ranks sharing cuda:0 -- RCCL itself refuses duplicate devices; numbers from such a run are meaningless.)
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(os.environ.get("VMM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     import videometamaterials_amd as vm
     from videometamaterials_amd import hostmath
