@@ -105,11 +105,12 @@ int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per
 /* mean/rstd from the sums, then coef[b,c] = (a, b'):  y = silu(x*a + b')  with a = rstd*gamma*(scale+1),
  * b' = (beta - mean*rstd*gamma)*(scale+1)+shift;  film = [B][ldfilm] rows (scale | shift) or NULL (vddp.py:283,306).
  * stats_out [B*G*2] = (mean, rstd) is kept for the backward pass (may be NULL).
- * partials != NULL: the sums are instead the fixed-order total of n_contrib fp32 (sum x, sum x^2) pairs per (sample, group) that
- * vmm_conv3x3_bf16x3 left in d->gn_part (sums is ignored). */
+ * Source of the moments, in this order of precedence: partials != NULL: the fixed-order total of n_contrib fp32 (sum x, sum x^2)
+ * pairs per (sample, group) that vmm_conv3x3_bf16x3 left in d->gn_part; x != NULL: a direct fixed-order reduction of the group's
+ * slice of x (rows [B * count_per_group / (C/G)][ldx]; for small layers, saves the vmm_groupnorm_stats launch); else sums. */
 int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
                        const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef /* [B][C][2] */,
-                       float* stats_out, const float* partials, int32_t n_contrib, vmm_stream_t stream);
+                       float* stats_out, const float* partials, int32_t n_contrib, const float* x, int32_t ldx, vmm_stream_t stream);
 /* y = silu(x*a + b') (+ res) ; in place allowed (vddp.py:285,311). */
 int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y, int32_t ldy,
                     int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream);

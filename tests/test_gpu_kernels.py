@@ -279,7 +279,7 @@ def test_groupnorm_film_silu(gpu, C_, G):
     gg, bg, fg, rg = gamma.to(gpu), beta.to(gpu), film.to(gpu), res.to(gpu)  # keep the device copies alive across the launches
     N.check(lib.vmm_groupnorm_stats(xr.data_ptr(), C_, B, rps, C_, G, sums.data_ptr(), _s()), "stats")
     N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(),
-                                   2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), None, 0, _s()), "coef")
+                                   2 * C_, B, C_, G, coef.data_ptr(), stats.data_ptr(), None, 0, None, 0, _s()), "coef")
     out = torch.empty_like(xr)
     N.check(lib.vmm_affine_silu(xr.data_ptr(), C_, coef.data_ptr(), rg.data_ptr(), C_, out.data_ptr(), C_, xr.shape[0], rps, C_, _s()), "apply")
     torch.cuda.synchronize()
@@ -287,6 +287,12 @@ def test_groupnorm_film_silu(gpu, C_, G):
     xs = x.reshape(B, G, -1)
     assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 0], xs.mean(-1), atol=1e-5)
     assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 1], 1 / torch.sqrt(xs.var(-1, unbiased=False) + 1e-5), rtol=1e-5)
+    if (C_ // G) % 4 == 0:  # direct mode: the coefficient kernel reduces each (sample, group) slice of x itself, no statistics launch
+        coef2 = torch.full_like(coef, float("nan"))
+        N.check(lib.vmm_groupnorm_coef(None, rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(), 2 * C_, B, C_, G, coef2.data_ptr(), None,
+                                       None, 0, xr.data_ptr(), C_, _s()), "coef direct")
+        torch.cuda.synchronize()
+        assert relerr(coef2.cpu(), coef.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("C_", [16, 32, 64, 128, 512])

@@ -48,22 +48,42 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-// coef[b][c] = (a, b') ; one workgroup per (sample, group): the group's two moments (from the fp64 sums, or as the fixed-order total of
-// the per-workgroup fp32 partial sums the producing convolution left behind, conv3x3_bf16x3.hip), then one thread per channel
-__global__ __launch_bounds__(128) void gn_coef_kernel(const double* __restrict__ sums, double inv_count, float eps, const float* __restrict__ gamma,
+// coef[b][c] = (a, b') ; one workgroup per (sample, group): the group's two moments, then one thread per channel.  The moments come
+// from (in this order of precedence) the per-workgroup fp32 partial sums the producing convolution left behind (conv3x3_bf16x3.hip),
+// a direct fixed-order reduction of the group's slice of x (small layers: saves the statistics launch), or the fp64 sums of
+// vmm_groupnorm_stats.
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ sums, double inv_count, float eps, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, int B, int C, int G,
                                                       float* __restrict__ coef, float* __restrict__ stats_out, const float* __restrict__ partials,
-                                                      int n_contrib) {
-  __shared__ double red[2][128];
+                                                      int n_contrib, const float* __restrict__ x, int ldx, int rows_per_sample) {
+  __shared__ double red[2][256];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int tid = threadIdx.x;
+  const int cpg = C / G;
   double s1 = 0.0, s2 = 0.0;
-  if (partials) {
-    const float* pp = partials + (long long)(b * G + g) * n_contrib * 2;
-    for (int k = tid; k < n_contrib; k += 128) { s1 += (double)pp[2 * k]; s2 += (double)pp[2 * k + 1]; }
+  if (partials || x) {
+    if (partials) {
+      const float* pp = partials + (long long)(b * G + g) * n_contrib * 2;
+      for (int k = tid; k < n_contrib; k += 256) { s1 += (double)pp[2 * k]; s2 += (double)pp[2 * k + 1]; }
+    } else {
+      const int c4n = cpg >> 2;                       // float4 columns of the group
+      const int col4 = tid % c4n, rslot = tid / c4n, rslots = 256 / c4n;
+      if (rslot < rslots) {
+        const float* base = x + ((long long)b * rows_per_sample) * ldx + g * cpg + col4 * 4;
+        float a1 = 0.f, a2 = 0.f;
+        int run = 0;
+        for (int r = rslot; r < rows_per_sample; r += rslots) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)r * ldx);
+          a1 += (v.x + v.y) + (v.z + v.w);
+          a2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (++run == 64) { s1 += (double)a1; s2 += (double)a2; a1 = a2 = 0.f; run = 0; }  // bounded fp32 runs
+        }
+        s1 += (double)a1; s2 += (double)a2;
+      }
+    }
     red[0][tid] = s1; red[1][tid] = s2;
     __syncthreads();
-    for (int o = 64; o >= 1; o >>= 1) {
+    for (int o = 128; o >= 1; o >>= 1) {
       if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
       __syncthreads();
     }
@@ -77,8 +97,7 @@ __global__ __launch_bounds__(128) void gn_coef_kernel(const double* __restrict__
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
-  const int cpg = C / G;
-  for (int cl = tid; cl < cpg; cl += 128) {
+  for (int cl = tid; cl < cpg; cl += 256) {
     const int c = g * cpg + cl;
     float a = rstd * gamma[c];
     float bb = beta[c] - meanf * a;
@@ -193,11 +212,13 @@ extern "C" int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32
 
 extern "C" int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, const float* gamma, const float* beta,
                                   const float* film, int32_t ldfilm, int32_t B, int32_t C, int32_t G, float* coef,
-                                  float* stats_out, const float* partials, int32_t n_contrib, vmm_stream_t stream) {
+                                  float* stats_out, const float* partials, int32_t n_contrib, const float* x, int32_t ldx, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (C % G) return -1;
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(B * G), dim3(128), 0, s, sums, 1.0 / (double)count_per_group, eps, gamma,
-                     beta, film, ldfilm, B, C, G, coef, stats_out, partials, n_contrib);
+  const int cpg = C / G;
+  if (x && !partials && ((cpg & 3) || (ldx & 3) || (cpg >> 2) > 256 || count_per_group % cpg)) return -1;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(B * G), dim3(256), 0, s, sums, 1.0 / (double)count_per_group, eps, gamma,
+                     beta, film, ldfilm, B, C, G, coef, stats_out, partials, n_contrib, x, ldx, (int)(count_per_group / cpg));
   VMM_LAUNCH_CHECK();
   return 0;
 }

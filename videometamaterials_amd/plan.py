@@ -32,6 +32,10 @@ from . import hostmath
 
 ALIGN = 64  # floats (256 B)
 LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
+# elements per (sample, group) up to which vmm_groupnorm_coef reduces the slice itself; measured on MI355X: one workgroup streams a
+# 100-200 K-element slice in ~45 us, the two-launch path (statistics over many workgroups + coefficients) takes ~30 us, so only tiny
+# layers go direct
+GN_DIRECT_MAX = 1 << 14
 N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
 PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate", "fmt")
@@ -497,19 +501,20 @@ class _Builder:
             conv_desc.gn_part = None
         coef_off = self.alloc(B * C_ * 2)
         stats_ptr = self.ptr(self.alloc(B * G * 2)) if self.training else 0
+        coef_args = (rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"), film_ptr or None, ldfilm,
+                     B, C_, G, self.ptr(coef_off), stats_ptr or None)
         if n_part:
             part_off = self.alloc(B * G * n_part * 2)
             conv_desc.gn_part = self.ptr(part_off)
-            self.step(self.lib.vmm_groupnorm_coef,
-                      (None, rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
-                       film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None, self.ptr(part_off), n_part), prefix + ".norm coef")
+            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
             self.free(part_off, B * G * n_part * 2)
+        elif rows_ps * (C_ // G) <= GN_DIRECT_MAX and (C_ // G) % 4 == 0:
+            # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
+            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, None, 0, h.ptr, h.ld), prefix + ".norm stats+coef", nbytes=4.0 * h.n)
         else:
             sums_off = self.alloc(B * G * 4)
             self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
-            self.step(self.lib.vmm_groupnorm_coef,
-                      (self.ptr(sums_off), rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
-                       film_ptr or None, ldfilm, B, C_, G, self.ptr(coef_off), stats_ptr or None, None, 0), prefix + ".norm coef")
+            self.step(self.lib.vmm_groupnorm_coef, (self.ptr(sums_off), *coef_args, None, 0, None, 0), prefix + ".norm coef")
             self.free(sums_off, B * G * 4)
         return coef_off, B * C_ * 2, self.ptr(coef_off), stats_ptr
 
