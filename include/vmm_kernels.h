@@ -128,6 +128,15 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
                            int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
                            vmm_stream_t stream);
 
+/* Temporal attention core + to_out + residual for the levels whose to_qkv is a separate projection (C = 128, 256, 512;
+ * vddp.py:491-534, 421): out = x + to_out(attention(q, [ek|k], [ev|v])) with the scores and the value mix on the split-bf16 matrix
+ * cores; the qkv rows (vmm_proj_bf16x3 output: q pre-scaled, q / k pre-rotated) are read once, the attention output never touches HBM.
+ * wout_frag = vmm_pack_weights fmt 3 of to_out (C, 256).  Envelope: heads == 8, dim_head == 32, C % 128 == 0, T <= 16, ntok <= 16,
+ * HW even; returns 1 (nothing launched) otherwise. */
+int vmm_temporal_core_bf16x3(const float* qkv, int32_t ldqkv, const float* x, int32_t ldx, const float* wout_frag, const float* ek,
+                             const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B,
+                             int32_t T, int32_t HW, int32_t C, int32_t heads, vmm_stream_t stream);
+
 /* Fused spatial linear-attention BLOCK for the full-resolution level (vddp.py:313-378 inside Residual(PreNorm(.)), vddp.py:613/628):
  * out = x + to_out(linear_attention(to_qkv(LayerNorm(x)))) + bias with the conditioning tokens ek/ev [B][ntok][256] stacked onto k, v.
  * q, k, v never touch HBM (x read twice, out written once).  wqkv_frag = vmm_pack_weights fmt 2 of to_qkv (768,64), wout_frag = fmt 3

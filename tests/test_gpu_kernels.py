@@ -343,6 +343,39 @@ def test_temporal_attention_core(gpu, ntok, bias_on_cond):
     assert relerr(out.cpu(), ref) < 5e-6
 
 
+@pytest.mark.parametrize("Cc,T,HW,ntok,bias_on_cond", [(128, 11, 36, 11, 1), (256, 7, 10, 16, 0), (128, 16, 6, 0, 0), (512, 3, 144, 5, 0)])
+def test_temporal_core_with_to_out(gpu, Cc, T, HW, ntok, bias_on_cond):
+    """vmm_temporal_core_bf16x3: attention over frames (+ stacked tokens, relative-position bias) on the matrix cores, to_out and the
+    residual in the same kernel; several pixel splits, several 128-channel head-sum passes, padded frame slots."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(16)
+    B, heads, hid = 2, 8, 256
+    qkv = torch.randn(B, T, HW, 3, heads, 32, generator=g) * 0.7
+    bias = torch.randn(heads, T, T, generator=g)
+    wout = torch.randn(Cc, hid, generator=g) / 16
+    x = torch.randn(B * T * HW, Cc, generator=g)
+    q, k, v = (qkv[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))  # b hw h t d
+    bfull = bias[None, None]
+    ek = ev = None
+    if ntok:
+        ek, ev = torch.randn(B, ntok, heads, 32, generator=g), torch.randn(B, ntok, heads, 32, generator=g)
+        k = torch.cat([ek.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), k], dim=-2)
+        v = torch.cat([ev.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), v], dim=-2)
+        bfull = torch.cat([bias if bias_on_cond else torch.zeros(heads, T, ntok), bias], dim=-1)[None, None]
+    o = _attn_ref(q, k, v, bfull).permute(0, 3, 1, 2, 4).reshape(B * T * HW, hid)
+    branch = o @ wout.t()
+    wp = _pack_frag(N, lib, gpu, wout, 3)
+    qg, xg, bg = qkv.reshape(B * T * HW, 3 * hid).to(gpu), x.to(gpu), bias.to(gpu)
+    ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    out = torch.full_like(xg, 7.0)
+    N.check(lib.vmm_temporal_core_bf16x3(qg.data_ptr(), 3 * hid, xg.data_ptr(), Cc, wp.data_ptr(), ekg.data_ptr() if ntok else None,
+                                         evg.data_ptr() if ntok else None, ntok, bg.data_ptr(), bias_on_cond, out.data_ptr(), Cc, B, T, HW, Cc, heads,
+                                         _s()), "temporal core + to_out")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu() - x, branch) < 5e-5  # on the attention branch alone (the residual would mask errors)
+
+
 @pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0)])
 def test_spatial_attention_core(gpu, HW, ntok, per_frame):
     N, lib = _lib()

@@ -108,6 +108,8 @@ SIGNATURES = {
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_proj_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
     "vmm_extract_geometry": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr, c_ptr],
+    "vmm_temporal_core_bf16x3": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_ptr],
     "vmm_linattn_block_workspace": [c_i32, c_i32, c_i32],
     "vmm_linattn_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                  c_f32, c_ptr],

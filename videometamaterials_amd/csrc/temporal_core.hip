@@ -1,0 +1,288 @@
+// Temporal attention core + output projection + residual for the levels whose to_qkv runs as a separate projection
+// (C = 128, 256, 512), on the split-bf16 matrix cores, gfx950.
+//
+//   out = x + to_out( softmax_attention(q, [ek | k], [ev | v]) )      (vddp.py:491-534 and 421; q pre-scaled, q / k / ek pre-rotated)
+//
+// The fully fused block (temporal_block.hip) keeps the q/k/v weight fragments of a head in registers, which only fits C = 64.  Here
+// to_qkv stays the A-stationary projection kernel (proj_bf16x3.hip, with the LayerNorm, q-scale and rotary in its staging /
+// epilogue) and this kernel replaces the VALU attention core and the to_out GEMM: the 768-wide qkv rows are read exactly once, the
+// 256-wide attention output never exists in memory, x is read once and out written once.
+//
+// Same tile and the same accumulator-as-operand chaining as temporal_block.hip: tile = 2 pixels x 16 frame slots, wave = head.
+//   q^T, k  : 16 + 16 floats per lane straight from the qkv rows in the operand layout (lane = row, contraction index d in register
+//             order), split to bf16 hi | lo in registers
+//   v^T     : lane = feature d, elements = key rows -- 16 dword loads whose 32 lanes read one row's 128 contiguous bytes
+//   s^T = k . q^T, s_tok^T = ek . q^T -> softmax over the lane's 8 + 8 scores (+ lane ^ 32 partner) -> o^T = v^T . p^T + ev^T . p_tok^T
+//   part[m][c] = o . W_out,h^T for 128 output channels per pass -> sum over the 8 heads through LDS -> + x -> out
+// The next tile's q / k / v are requested before the current tile's MFMAs (48 registers; the q/k/v weights are gone).
+#include "igemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HEADS = 8;  // = waves per workgroup
+constexpr int DHd = 32;
+constexpr int HID = HEADS * DHd;
+constexpr int PC = 128;   // output channels per head-sum pass
+
+struct TCArgs {
+  const float* qkv; int ldqkv;
+  const float* x; int ldx;
+  const uint4* wout;  // fmt 3 fragments of to_out (C, 256)
+  const float* ek; const float* ev; int ntok;
+  const float* bias; int bias_on_cond;
+  float* out; int ldo;
+  int T, HW, C, nsplit, tps;
+};
+
+__device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) {
+  const f32x2 v = {a, b};
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  return hi;
+}
+
+__device__ __forceinline__ void split8(const f32x16& c, int r0, uint4& hi, uint4& lo) {
+  hi.x = pack_split(c[r0 + 0], c[r0 + 1], lo.x);
+  hi.y = pack_split(c[r0 + 2], c[r0 + 3], lo.y);
+  hi.z = pack_split(c[r0 + 4], c[r0 + 5], lo.z);
+  hi.w = pack_split(c[r0 + 6], c[r0 + 7], lo.w);
+}
+
+__device__ __forceinline__ void split8v(const float* v, uint4& hi, uint4& lo) {
+  hi.x = pack_split(v[0], v[1], lo.x);
+  hi.y = pack_split(v[2], v[3], lo.y);
+  hi.z = pack_split(v[4], v[5], lo.z);
+  hi.w = pack_split(v[6], v[7], lo.w);
+}
+
+__device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  return c;
+}
+
+// index of the contraction / row slot that element j of lane half lk holds in k16 step s (accumulator register order)
+__device__ __forceinline__ int slot(int s, int lk, int j) { return (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * lk; }
+
+struct QKV { float q[16], k[16], v[16]; };
+
+__global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);   // [8 heads][32 rows][128 channels]
+  float* biasf = red + HEADS * 32 * PC;              // [8 heads][2 halves][16 frames][8]
+
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int pa = lrow >> 4, ft = lrow & 15;  // pixel of the pair, frame slot
+  const int T = a.T, HW = a.HW;
+  const int b = blockIdx.x / a.nsplit, split = blockIdx.x - b * a.nsplit;
+  const int pairs = HW / 2;
+  const int p_begin = split * a.tps, p_end = min(pairs, p_begin + a.tps);
+  const int ntok = a.ek ? a.ntok : 0;
+
+  // relative-position bias of query frame t against the 8 key frames a lane half holds: [h][lk][t][j]
+  for (int i = tid; i < HEADS * 2 * 16 * 8; i += 512) {
+    const int j = i & 7, t = (i >> 3) & 15, l2 = (i >> 7) & 1, hh = i >> 8;
+    const int tk = slot(0, l2, j);
+    biasf[i] = (t < T && tk < T) ? a.bias[(hh * T + t) * T + tk] : 0.f;
+  }
+  // conditioning keys as an A operand (rows = tokens, contraction = d) and values (rows = d, contraction = tokens): per (sample, head),
+  // constant for the whole workgroup -> registers
+  uint4 ekh[2], ekl[2], evh, evl;
+  {
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = lrow < ntok ? a.ek[((long long)b * ntok + lrow) * HID + h * DHd + slot(s, lk, j)] : 0.f;
+      split8v(v, ekh[s], ekl[s]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      v[j] = tk < ntok ? a.ev[((long long)b * ntok + tk) * HID + h * DHd + lrow] : 0.f;
+    }
+    split8v(v, evh, evl);
+  }
+  __syncthreads();
+  const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
+
+  // this wave's slice of the qkv rows of one tile, in operand layout
+  auto load_tile = [&](int pp, QKV& d) {
+    const bool ok = pp < p_end && ft < T;
+    const float* row = a.qkv + (((long long)b * T + (ok ? ft : 0)) * HW + (ok ? pp * 2 + pa : 0)) * a.ldqkv + h * DHd + 4 * lk;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {  // elements j = 4g .. 4g+3 of step s: features 16 s + 8 g + 4 lk + 0..3
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4;
+        if (ok) {
+          q4 = *reinterpret_cast<const f32x4*>(row + 16 * s + 8 * g);
+          k4 = *reinterpret_cast<const f32x4*>(row + HID + 16 * s + 8 * g);
+        }
+        d.q[s * 8 + g * 4 + 0] = q4.x; d.q[s * 8 + g * 4 + 1] = q4.y; d.q[s * 8 + g * 4 + 2] = q4.z; d.q[s * 8 + g * 4 + 3] = q4.w;
+        d.k[s * 8 + g * 4 + 0] = k4.x; d.k[s * 8 + g * 4 + 1] = k4.y; d.k[s * 8 + g * 4 + 2] = k4.z; d.k[s * 8 + g * 4 + 3] = k4.w;
+      }
+    // v^T: lane = feature lrow, element (s, j) = key row slot(s, lk, j) = (pixel, frame) of the tile
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = slot(e >> 3, lk, e & 7), va = m >> 4, vt = m & 15;
+      float v = 0.f;
+      if (pp < p_end && vt < T) v = a.qkv[(((long long)b * T + vt) * HW + pp * 2 + va) * a.ldqkv + 2 * HID + h * DHd + lrow];
+      d.v[e] = v;
+    }
+  };
+
+  // reduction role: row rm of the tile, channels rcol .. rcol+3 and rcol+64 .. rcol+67 of each 128-channel pass
+  const int rm = tid >> 4, rcol = (tid & 15) * 4;
+  const int rpa = rm >> 4, rft = rm & 15;
+  const int passes = a.C / PC;
+
+  QKV nx;
+  load_tile(p_begin, nx);
+  for (int pp = p_begin; pp < p_end; ++pp) {
+    QKV cu = nx;
+    load_tile(pp + 1, nx);  // in flight under this tile's MFMAs
+    uint4 qh[2], ql[2];
+    split8v(cu.q, qh[0], ql[0]);
+    split8v(cu.q + 8, qh[1], ql[1]);
+    // ---- scores: keys x queries
+    f32x16 st = zero16(), sk = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 kh, kl;
+      split8v(cu.k + 8 * s, kh, kl);
+      st = mfma3(kh, kl, qh[s], ql[s], st);
+      if (ntok) sk = mfma3(ekh[s], ekl[s], qh[s], ql[s], sk);
+    }
+    // ---- softmax over this query's 8 (+8) frame keys and 8 (+8) tokens: lane half lk holds slots {0-3, 8-11} + 4 lk
+    const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_l), bz1 = *reinterpret_cast<const f32x4*>(bias_l + 4);
+    const float bz[8] = {bz0.x, bz0.y, bz0.z, bz0.w, bz1.x, bz1.y, bz1.z, bz1.w};
+    float f[8], g[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      const float sv = pa ? st[8 + j] : st[j];
+      f[j] = tk < T ? sv + bz[j] : -INFINITY;
+      g[j] = tk < ntok ? sk[j] + (a.bias_on_cond ? bz[j] : 0.f) : -INFINITY;
+      mx = fmaxf(mx, fmaxf(f[j], g[j]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = __expf(f[j] - mx);
+      g[j] = __expf(g[j] - mx);
+      sum += f[j] + g[j];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float p0[8], p1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] *= inv;
+      g[j] *= inv;
+      p0[j] = pa ? 0.f : f[j];  // keys of pixel 0 <-> k16 step 0
+      p1[j] = pa ? f[j] : 0.f;  // keys of pixel 1 <-> k16 step 1
+    }
+    // ---- o^T = v^T . p^T (+ token values)
+    f32x16 ot = zero16();
+    {
+      uint4 vh, vl, ph, pl;
+      split8v(cu.v, vh, vl);
+      split8v(p0, ph, pl);
+      ot = mfma3(vh, vl, ph, pl, ot);
+      split8v(cu.v + 8, vh, vl);
+      split8v(p1, ph, pl);
+      ot = mfma3(vh, vl, ph, pl, ot);
+      if (ntok) {
+        split8v(g, ph, pl);
+        ot = mfma3(evh, evl, ph, pl, ot);
+      }
+    }
+    uint4 oh[2], ol[2];
+    split8(ot, 0, oh[0], ol[0]);
+    split8(ot, 8, oh[1], ol[1]);
+    // ---- to_out, 128 output channels per pass: this head's share, sum over heads through LDS, residual, store
+    for (int ps = 0; ps < passes; ++ps) {
+      f32x16 pc[4] = {zero16(), zero16(), zero16(), zero16()};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const uint4* q = a.wout + (((long long)(ps * 4 + ct) * 16 + 2 * h + s) * 2) * 64 + lane;  // 16 KB per head and pass, L2-resident
+          pc[ct] = mfma3(oh[s], ol[s], q[0], q[64], pc[ct]);
+        }
+      __syncthreads();  // the previous head sum has been read by everyone
+      float* rb = red + (h * 32) * PC;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lk;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) rb[m * PC + ct * 32 + lrow] = pc[ct][r];
+      }
+      __syncthreads();
+      if (rft < T) {
+        const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int c = rcol + hf * 64;
+          f32x4 acc = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + ps * PC + c);
+#pragma unroll
+          for (int w = 0; w < HEADS; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rm) * PC + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
+          *reinterpret_cast<f32x4*>(a.out + row * a.ldo + ps * PC + c) = acc;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// qkv rows [(b,t,hw)][768] with q pre-scaled and q, k pre-rotated (the to_qkv projection's epilogue), ek / ev [B][ntok][256] (ek
+// pre-rotated when per-frame) or NULL, bias [heads][T][T], wout_frag = vmm_pack_weights fmt 3 of to_out (C, 256).
+// Returns 1 (nothing launched) outside the envelope: heads == 8, dim_head == 32, C a multiple of 128, T <= 16, ntok <= 16, HW even.
+extern "C" int vmm_temporal_core_bf16x3(const float* qkv, int32_t ldqkv, const float* x, int32_t ldx, const float* wout_frag,
+                                        const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                        float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
+                                        vmm_stream_t stream) {
+  if (heads != HEADS || C < PC || (C % PC) || T > 16 || T < 1 || (HW & 1) || (ldqkv & 3) || (ldx & 3) || (ldo & 3) || (ek && ntok > 16)) return 1;
+  if (bias_on_cond && ek && ntok != T) return -2;
+  if (B <= 0) return 0;
+  TCArgs a;
+  a.qkv = qkv; a.ldqkv = ldqkv; a.x = x; a.ldx = ldx;
+  a.wout = reinterpret_cast<const uint4*>(wout_frag);
+  a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0;
+  a.bias = bias; a.bias_on_cond = bias_on_cond;
+  a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.C = C;
+  const int pairs = HW / 2;
+  int ns = max(1, min(pairs, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
+  a.tps = (pairs + ns - 1) / ns;
+  a.nsplit = (pairs + a.tps - 1) / a.tps;
+  const size_t shm = sizeof(float) * HEADS * 32 * PC + sizeof(float) * HEADS * 2 * 16 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_core_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(temporal_core_kernel, dim3((unsigned)(B * a.nsplit)), dim3(512), shm, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

@@ -733,11 +733,22 @@ class _Builder:
                        ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
         if not fuse_ln:
             self.free_act(y)
-        o = self.act(hid, x.H, x.W)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
         ntok = self.ntok if site else 0
-        lse_ptr = self.ptr(self.alloc(rows * heads)) if self.training else 0
         pfc = 1 if self.m.per_frame_cond else 0
+        if (temporal and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
+                and getattr(self.m, "use_fused_temporal", True)):
+            # scores, value mix and to_out on the matrix cores in one kernel: qkv read once, the attention output never stored
+            wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
+            out = self.act(x.C, x.H, x.W)
+            self.step(self.lib.vmm_temporal_core_bf16x3,
+                      (qkv.ptr, 3 * hid, x.ptr, x.ld, wo, ek or None, ev or None, ntok, self.bias_ptr, pfc, out.ptr, out.ld, B, T, HW, x.C, heads),
+                      name + " core+to_out", flops=2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok), nbytes=4.0 * rows * (3 * hid + 2 * x.C))
+            self.free_act(qkv)
+            self.plan.named[name] = out
+            return out
+        o = self.act(hid, x.H, x.W)
+        lse_ptr = self.ptr(self.alloc(rows * heads)) if self.training else 0
         if temporal:
             self.step(self.lib.vmm_temporal_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
                                                         lse_ptr or None), name + " core", nbytes=4.0 * rows * 4 * hid)
