@@ -425,7 +425,7 @@ def _pack_frag(N, lib, gpu, w2d, fmt):
     (1, 11, 144, 256, 0, 128, False, False, True),  # to_out: bias + residual, Cout < column chunk
     (2, 2, 96 * 96, 64, 64, 64, False, False, False),  # res_conv on a skip concatenation, many row tiles
     (1, 2, 36, 64, 0, 768, True, False, False),     # few rows: column chunks spread over blockIdx.y
-    (1, 3, 50, 16, 0, 48, True, False, True),       # K padded 16 -> 32
+    (1, 3, 50, 16, 0, 96, True, False, True),       # K padded 16 -> 32, Cout not a multiple of the 64-column wave tile
     (1, 1, 40, 128, 128, 256, False, False, True)])
 def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, res):
     """vmm_proj_bf16x3 against torch fp32: 1x1 projection with the row tile staged once (optional fused channel LayerNorm) and

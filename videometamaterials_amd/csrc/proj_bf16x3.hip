@@ -175,36 +175,66 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah1, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah1, acc[1][1], 0, 0, 0);
   };
+  // Epilogue of one column chunk.  Everything a lane needs besides its accumulators is requested up front and consumed after a
+  // single wait: the rotary factors depend only on (row, column mod 32) and are loaded once per workgroup, the bias / residual
+  // pieces of the chunk are 16 independent 16-byte loads.  (The straightforward form -- load, wait, use, store per 16-byte piece,
+  // with per-lane column tests -- serialised 16 memory latencies per chunk and left the kernel 3x short of its MFMA time.)
+  // q_ncols, rot_ncols and Cout are multiples of 32 / 4, so the column tests are per 32-column tile and wave-uniform.
   const bool rotary = p.rot_ncols > 0;
+  int mrow[2];
+  f32x4 rot[2][4];  // [row tile i][g]: (cos, sin) of the two feature pairs at column offset 8 g + 4 lk of every 32-column head slice
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    mrow[i] = m0 + wm * 64 + i * 32 + lrow;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rot[i][g] = f32x4{1.f, 0.f, 1.f, 0.f};
+      if (rotary && mrow[i] < a.M) {
+        const int t = (mrow[i] / p.rot_HW) % p.rot_T;
+        rot[i][g] = *reinterpret_cast<const f32x4*>(p.rot_tab + (t * 16 + 4 * g + 2 * lk) * 2);
+      }
+    }
+  }
   auto store_chunk = [&](int nc) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + lrow;
-      if (m >= a.M) continue;
-      const int t = rotary ? (m / p.rot_HW) % p.rot_T : 0;
+      const int m = mrow[i];
+      if (m < a.M) {  // the only per-lane condition of the epilogue
+        const float* resrow = p.res ? p.res + (long long)m * p.ldres : nullptr;
+        float* outrow = p.out + (long long)m * p.ldo;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {
+          const int tile0 = nc * BN + wn * 64 + j * 32;  // wave-uniform, as is everything tested on it (Cout, q_ncols, rot_ncols are multiples of 32)
+          if (tile0 >= p.Cout) continue;
+          const float scale = tile0 < p.q_ncols ? p.q_scale : 1.0f;
+          const bool do_rot = tile0 < p.rot_ncols;
+          const int c0 = tile0 + 4 * lk;
+          f32x4 bv[4], rv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = nc * BN + wn * 64 + j * 32 + 8 * g + 4 * lk;
-          if (col >= p.Cout) continue;
-          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          for (int g = 0; g < 4; ++g) {
+            bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
           if (p.bias) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + c0 + 8 * g);
           }
-          if (col < p.q_ncols) { v.x *= p.q_scale; v.y *= p.q_scale; v.z *= p.q_scale; v.w *= p.q_scale; }
-          if (col < p.rot_ncols) {  // interleaved pairs (2i, 2i+1) of each head's rot_dh features, angle by the row's frame index
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rot_tab + (t * (p.rot_dh >> 1) + ((col & (p.rot_dh - 1)) >> 1)) * 2);
-            const f32x4 u = v;
-            v.x = u.x * cs.x - u.y * cs.y; v.y = u.y * cs.x + u.x * cs.y;
-            v.z = u.z * cs.z - u.w * cs.w; v.w = u.w * cs.z + u.z * cs.w;
+          if (resrow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const f32x4*>(resrow + c0 + 8 * g);
           }
-          if (p.res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (long long)m * p.ldres + col);
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            v.x = (v.x + bv[g].x) * scale; v.y = (v.y + bv[g].y) * scale; v.z = (v.z + bv[g].z) * scale; v.w = (v.w + bv[g].w) * scale;
+            if (do_rot) {  // interleaved pairs (2i, 2i+1) of each head's 32 features, angle by the row's frame index (vddp.py:449,456)
+              const f32x4 cs = rot[i][g], u = v;
+              v.x = u.x * cs.x - u.y * cs.y; v.y = u.y * cs.x + u.x * cs.y;
+              v.z = u.z * cs.z - u.w * cs.w; v.w = u.w * cs.z + u.z * cs.w;
+            }
+            v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
+            *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
           }
-          *reinterpret_cast<f32x4*>(p.out + (long long)m * p.ldo + col) = v;
         }
       }
     }
@@ -257,17 +287,17 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
 
 // 1x1 / Linear projection.  d->w = vmm_pack_weights fmt 2 of the (Cout, K) weight.  ln_gamma != NULL: the rows pass through the
 // channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
-// identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 4; returns 1 (nothing launched) otherwise.
+// identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 32; returns 1 (nothing launched) otherwise.
 extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
                         d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
   const int K = d.C1 + d.C2;
-  const bool chan_ok = (d.C1 & 3) == 0 && (d.C2 & 3) == 0 && d.C1 > 0 && K <= 256 && (d.Cout & 3) == 0 && (d.lda1 & 3) == 0 &&
+  const bool chan_ok = (d.C1 & 3) == 0 && (d.C2 & 3) == 0 && d.C1 > 0 && K <= 256 && (d.Cout & 31) == 0 && (d.lda1 & 3) == 0 &&
                        (!d.C2 || (d.lda2 & 3) == 0) && (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
   if (!shape_ok || !chan_ok) return 1;
-  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)) || (d.rot_dh & 3) || (d.rot_ncols & 3) || d.rot_HW <= 0 || d.rot_T <= 0)) return -2;
-  if (d.q_ncols & 3) return -2;
+  if (d.rot_ncols > 0 && (!d.rot_tab || d.rot_dh != 32 || (d.rot_ncols & 31) || d.rot_HW <= 0 || d.rot_T <= 0)) return -2;
+  if (d.q_ncols & 31) return -2;
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   if (M >= (1LL << 31)) return -4;
   if (M <= 0 || d.Cout <= 0) return 0;

@@ -454,7 +454,7 @@ class _Builder:
         """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
         if not (self.x3 and getattr(self.m, "use_proj_kernel", True)):
             return False
-        return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 4 == 0
+        return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
     def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
