@@ -334,7 +334,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave
+    // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave.
+    // The eight bias pieces of the lane are requested together and folded into the accumulators after ONE wait (a load -> wait ->
+    // add -> store chain per 16-byte piece serialised sixteen L2 latencies per tile); the residual pieces likewise per pixel.
+    {
+      f32x4 bv[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bv[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            acc[i][j][4 * g] += bv[j][g].x; acc[i][j][4 * g + 1] += bv[j][g].y; acc[i][j][4 * g + 2] += bv[j][g].z; acc[i][j][4 * g + 3] += bv[j][g].w;
+          }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = wm * 64 + i * 32 + lrow;
@@ -345,23 +363,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
         if (g0 + m >= a.total_rows) continue;
         orow = g0 + m;
       }
+      const int c0 = n0 + wn * 64 + 4 * lk;
+      f32x4 rv[2][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          rv[j][g] = p.res ? *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + c0 + j * 32 + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      float* orp = p.out + orow * p.ldo + c0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * lk;
-          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (p.bias) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-          }
-          if (p.res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + col);
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-          }
-          *reinterpret_cast<f32x4*>(p.out + orow * p.ldo + col) = v;
+          const f32x4 v = {acc[i][j][4 * g] + rv[j][g].x, acc[i][j][4 * g + 1] + rv[j][g].y, acc[i][j][4 * g + 2] + rv[j][g].z,
+                           acc[i][j][4 * g + 3] + rv[j][g].w};
+          *reinterpret_cast<f32x4*>(orp + j * 32 + 8 * g) = v;
         }
-      }
     }
     if (MODE && p.gn_part) {
       // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels
@@ -372,13 +389,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * lk;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-          float s1 = 0.f, s2 = 0.f;
+          float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+            const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
             s1 += (v0 + v1) + (v2 + v3);
             s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
           }
