@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     const int c0 = cc * CK;
     const bool xform = c0 < p.C1 && p.a_mode == 1;
     const int rows_per_sample = HW * p.a_imgs_per_sample;
+    // GroupNorm * FiLM coefficients of this thread's four channels: one sample per 2-D tile -> fetched once per chunk, not per item
+    f32x4 ca = {1.f, 0.f, 1.f, 0.f}, cb4 = ca;
+    if (MODE && xform) {
+      const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + c0 + k4 * 4) * 2;
+      ca = *reinterpret_cast<const f32x4*>(cf);
+      cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
+    }
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       const int r = (tid >> 3) + ps * 32;
@@ -163,9 +170,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
         f32x4 v = preg[ps];
         const int sr = xform ? src_row(ps) : -1;
         if (sr >= 0) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
-          const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
-          const f32x4 ca = *reinterpret_cast<const f32x4*>(cf);
-          const f32x4 cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
+          if (!MODE) {  // flat row tiles run across samples
+            const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
+            ca = *reinterpret_cast<const f32x4*>(cf);
+            cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
+          }
           v.x = igemm::silu_fast(v.x * ca.x + ca.y);
           v.y = igemm::silu_fast(v.y * ca.z + ca.w);
           v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
