@@ -60,6 +60,9 @@ int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
  * ~1e-5 relative error): d->w must point to the fmt-1 output of vmm_pack_weights (pre-split, pre-transposed bf16 weights). */
 int vmm_conv_igemm_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* n <= 4 problems of identical shape (rows, taps, channels, output columns) in ONE launch, e.g. the four output phases of
+ * ConvTranspose3d (1,4,4) stride 2 (vddp.py:155): descs[i] differ in weights / tap offsets / output phase only. */
+int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream);
 /* 3x3 / stride 1 / pad 1 specialisation of the above: LDS-resident halo patch (each input element is staged once per channel chunk
  * instead of once per tap) and weights read straight into registers in MFMA fragment order -- d->w must point to the fmt-2 output of
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);

@@ -110,7 +110,7 @@ def test_plan_construction_without_gpu():
     kw, (B, T, H, W), cl = helpers.CONFIGS["lagr16"]
     m = vm.Unet3D(**kw)
     pl = plan.build_plan(m, B, T, H, W, cl, "cpu")
-    assert len(pl.steps) == len(pl.meta) > 200
+    assert len(pl.steps) == len(pl.meta) > 150  # (fusions keep shrinking the launch list)
     conv_flops = sum(f for k, f, _ in pl.meta if k.startswith("vmm_conv_igemm"))
     assert conv_flops > 1e9
     assert not pl.bwd_steps

@@ -76,6 +76,7 @@ class OptimJob(C.Structure):
 SIGNATURES = {
     "vmm_conv_igemm_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_igemm_bf16x3_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],

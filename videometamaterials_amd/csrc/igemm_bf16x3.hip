@@ -31,8 +31,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
+struct DescBatch { vmm_conv_desc d[4]; };  // same-shaped problems launched together (blockIdx.y): the 4 output phases of a transposed conv
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const vmm_conv_desc p, int Kpad, int n_tiles) {
+__device__ __forceinline__ void igemm_bf16x3_body(const vmm_conv_desc& p, int Kpad, int n_tiles) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int A_PASSES = BM / 32;            // 32 rows x 8 float4 per pass of 256 threads
@@ -149,35 +151,76 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const vmm_conv_desc p
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_x3(const vmm_conv_desc& d, int Kpad, hipStream_t s) {
-  const long long M = (long long)d.nimg * d.Hv * d.Wv;
-  const int nt = cdiv(d.Cout, BN);
-  hipLaunchKernelGGL((igemm_bf16x3_kernel<BM, BN, WM, WN>), dim3((unsigned)(cdiv(M, BM) * (long long)nt)), dim3(256), 0, s, d, Kpad, nt);
+__global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const vmm_conv_desc p, int Kpad, int n_tiles) {
+  igemm_bf16x3_body<BM, BN, WM, WN>(p, Kpad, n_tiles);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_bf16x3_batch_kernel(const DescBatch b, int Kpad, int n_tiles) {
+  igemm_bf16x3_body<BM, BN, WM, WN>(b.d[blockIdx.y], Kpad, n_tiles);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_x3(const vmm_conv_desc* d, int n, int Kpad, hipStream_t s) {
+  const long long M = (long long)d->nimg * d->Hv * d->Wv;
+  const int nt = cdiv(d->Cout, BN);
+  const dim3 grid((unsigned)(cdiv(M, BM) * (long long)nt), (unsigned)n);
+  if (n == 1) {
+    hipLaunchKernelGGL((igemm_bf16x3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, *d, Kpad, nt);
+  } else {
+    DescBatch b;
+    for (int i = 0; i < 4; ++i) b.d[i] = d[i < n ? i : 0];
+    hipLaunchKernelGGL((igemm_bf16x3_batch_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, b, Kpad, nt);
+  }
   VMM_LAUNCH_CHECK();
   return 0;
 }
 
-}  // namespace
-
-extern "C" int vmm_conv_igemm_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
-  const vmm_conv_desc& d = *dp;
-  hipStream_t s = (hipStream_t)stream;
+int check_x3(const vmm_conv_desc& d) {
   if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 64) return -1;
   if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)))) return -2;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   if (M >= (1LL << 31) || (long long)d.nimg * d.Hin * d.Win >= (1LL << 31)) return -4;
+  return 0;
+}
+
+// n same-shaped problems (n = 1: the plain entry point); blocks = row tiles x column tiles x n
+int run_x3(const vmm_conv_desc* dp, int n, hipStream_t s) {
+  const vmm_conv_desc& d = *dp;
+  const long long M = (long long)d.nimg * d.Hv * d.Wv;
   if (M <= 0 || d.Cout <= 0) return 0;
   const int Ktot = d.KH * d.KW * (d.C1 + d.C2);
   const int Kpad = (Ktot + XK - 1) / XK * XK;  // must match vmm_pack_weights fmt 1
   if (d.Cout >= 128) {
-    const long long blocks = (long long)cdiv(M, 128) * cdiv(d.Cout, 128);
-    if (blocks >= 512) return launch_x3<128, 128, 2, 2>(d, Kpad, s);
-    return launch_x3<64, 128, 1, 4>(d, Kpad, s);
+    const long long blocks = (long long)cdiv(M, 128) * cdiv(d.Cout, 128) * n;
+    if (blocks >= 512) return launch_x3<128, 128, 2, 2>(dp, n, Kpad, s);
+    return launch_x3<64, 128, 1, 4>(dp, n, Kpad, s);
   }
   if (d.Cout > 32) {
-    if (cdiv(M, 128) >= 512) return launch_x3<128, 64, 2, 2>(d, Kpad, s);
-    return launch_x3<64, 64, 2, 2>(d, Kpad, s);
+    if (cdiv(M, 128) * n >= 512) return launch_x3<128, 64, 2, 2>(dp, n, Kpad, s);
+    return launch_x3<64, 64, 2, 2>(dp, n, Kpad, s);
   }
-  return launch_x3<128, 32, 4, 1>(d, Kpad, s);
+  return launch_x3<128, 32, 4, 1>(dp, n, Kpad, s);
+}
+
+}  // namespace
+
+extern "C" int vmm_conv_igemm_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const int rc = check_x3(*dp);
+  if (rc) return rc;
+  return run_x3(dp, 1, (hipStream_t)stream);
+}
+
+// descs[0 .. n) (n <= 4): problems of identical shape (rows, taps, channels, output columns) that differ in pointers / offsets, e.g. the
+// four output phases of ConvTranspose3d (1,4,4) stride 2 (vddp.py:155); one launch instead of n fills the chip for the small levels.
+extern "C" int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream) {
+  if (n < 1 || n > 4) return -1;
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_x3(descs[i]);
+    if (rc) return rc;
+    const vmm_conv_desc &a = descs[0], &b = descs[i];
+    if (a.nimg != b.nimg || a.Hv != b.Hv || a.Wv != b.Wv || a.KH != b.KH || a.KW != b.KW || a.C1 != b.C1 || a.C2 != b.C2 || a.Cout != b.Cout) return -5;
+  }
+  return run_x3(descs, n, (hipStream_t)stream);
 }

@@ -1097,14 +1097,22 @@ class _Builder:
                 ci_, co_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
                 u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
+                one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
                 for ph in range(2):
                     for pw in range(2):
                         # ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'
                         wp, gwp = self.pack(nm + ".weight", 4 * ci_ * co_, TH=2, TW=2, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, h0=1 - ph, hs=2,
                                             w0=1 - pw, ws=2)
-                        du = self.conv(a1=xs, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
-                                       Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw), what=nm + f" phase {ph}{pw}")
+                        kw_ = dict(a1=xs, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
+                                   Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw))
+                        du = self.conv_desc(**kw_) if one_launch else self.conv(what=nm + f" phase {ph}{pw}", **kw_)
                         phases.append((du, gwp))
+                if one_launch:
+                    arr = (N.ConvDesc * 4)(*[du for du, _ in phases])
+                    self.plan.keepalive.append(arr)
+                    rows_in = B * T * xs.H * xs.W
+                    self.step(lib.vmm_conv_igemm_bf16x3_batched, (arr, 4), nm + " (4 phases)", flops=4 * 2.0 * rows_in * 4 * ci_ * co_,
+                              nbytes=4.0 * (rows_in * ci_ + 16 * ci_ * co_ + 4 * rows_in * co_))
 
                 def up_bwd(nm=nm, xs=xs, u=u, phases=phases, ci_=ci_, co_=co_):
                     gu, _ = self.grad_of(u)
