@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   float* biasf = reinterpret_cast<float*>(evf + HEADS * 2 * 64);       // [8 heads][2 halves][16 frames][8]
   unsigned short* ytile = reinterpret_cast<unsigned short*>(biasf + HEADS * 2 * 16 * 8);  // [32 rows][hi 64 | lo 64 | pad 8]
   constexpr int YPITCH = 2 * TC + 8;                                   // 272 bytes = 17 x 16: conflict-free ds_read_b128 over consecutive rows
+  float* rotf = reinterpret_cast<float*>(ytile + 32 * YPITCH);          // [2 halves][16 frames][8 pairs][cos, sin]
 
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
@@ -150,20 +151,31 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
     wvh[s] = v[0]; wvl[s] = v[64];
   }
   const uint4* wo_l = a.wout + ((long long)2 * h * 2) * 64 + lane;  // to_out fragments are re-read per tile (8 KB per head, L2-resident)
-  // rotary factors of this lane's frame for the 8 (even, odd) feature pairs it holds: accumulator registers (2i, 2i+1)
-  float rc[8], rs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int d = slot(i >> 2, lk, (2 * i) & 7);  // feature index of register 2i
-    const float2 cs = ft < T ? *reinterpret_cast<const float2*>(a.rot + (ft * 16 + (d >> 1)) * 2) : make_float2(1.f, 0.f);
-    rc[i] = cs.x; rs[i] = cs.y;
+  // rotary factors of a (frame slot, lane half): (cos, sin) of the 8 (even, odd) feature pairs the lane holds in accumulator registers
+  // (2i, 2i+1).  Kept in LDS, not in 16 registers: the q/k/v weight fragments already take 96 and the kernel sits at the 256 limit.
+  for (int i = tid; i < 2 * 16 * 8; i += 512) {
+    const int pr = i & 7, t = (i >> 3) & 15, l2 = i >> 7;
+    const int d = slot(pr >> 2, l2, (2 * pr) & 7);  // feature index of register 2 pr
+    const float2 cs = t < T ? *reinterpret_cast<const float2*>(a.rot + (t * 16 + (d >> 1)) * 2) : make_float2(1.f, 0.f);
+    rotf[i * 2] = cs.x;
+    rotf[i * 2 + 1] = cs.y;
   }
-  auto rotate = [&](f32x16& v) {
+  const float* rot_l = rotf + ((lk * 16 + ft) * 8) * 2;
+  auto rotate2 = [&](f32x16& u, f32x16& v) {  // both q^T and k^T with one read of the factors
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float e = v[2 * i], o = v[2 * i + 1];
-      v[2 * i] = e * rc[i] - o * rs[i];
-      v[2 * i + 1] = o * rc[i] + e * rs[i];
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(rot_l + i4 * 4);  // pairs 2 i4, 2 i4 + 1
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = 2 * i4 + k;
+        const float c = k ? cs.z : cs.x, sn = k ? cs.w : cs.y;
+        float e = u[2 * i], o = u[2 * i + 1];
+        u[2 * i] = e * c - o * sn;
+        u[2 * i + 1] = o * c + e * sn;
+        e = v[2 * i]; o = v[2 * i + 1];
+        v[2 * i] = e * c - o * sn;
+        v[2 * i + 1] = o * c + e * sn;
+      }
     }
   };
   __syncthreads();
@@ -219,8 +231,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
       kt = mfma3(wkh[s], wkl[s], yh[s], yl[s], kt);  // [d][m]
       vt = mfma3(yh[s], yl[s], wvh[s], wvl[s], vt);  // [m][d]
     }
-    rotate(qt);
-    rotate(kt);
+    rotate2(qt, kt);
     uint4 qh[2], ql[2];
     split8(qt, 0, qh[0], ql[0]);
     split8(qt, 8, qh[1], ql[1]);
@@ -339,7 +350,7 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
   a.tps = (pairs + ns - 1) / ns;
   a.nsplit = (pairs + a.tps - 1) / a.tps;
   const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
-                     sizeof(unsigned short) * 32 * (2 * TC + 8);
+                     sizeof(unsigned short) * 32 * (2 * TC + 8) + sizeof(float) * 2 * 16 * 8 * 2;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
