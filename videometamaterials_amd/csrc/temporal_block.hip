@@ -245,6 +245,18 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
       st = mfma3(kh, kl, qh[s], ql[s], st);
       if (ntok) sk = mfma3(eks[(s * 2) * 64], eks[(s * 2 + 1) * 64], qh[s], ql[s], sk);
     }
+    // to_out fragments of this head (8 KB, L2-resident): requested here, a softmax / value phase before their use -- next to their use
+    // each (column tile, step) pair paid an L2 round trip of its own; earlier than here the registers do not exist (q/k/v tiles live)
+    uint4 woh[2][2], wol[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const uint4* q = wo_l + ((ct * 16 + s) * 2) * 64;
+        woh[ct][s] = q[0];
+        wol[ct][s] = q[64];
+      }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- softmax over this query's 8 (+8) frame keys and 8 (+8) tokens: lane half lk holds slots {0-3, 8-11} + 4 lk
     const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_l), bz1 = *reinterpret_cast<const f32x4*>(bias_l + 4);
     const float bz[8] = {bz0.x, bz0.y, bz0.z, bz0.w, bz1.x, bz1.y, bz1.z, bz1.w};
@@ -299,10 +311,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
       uint4 oh, ol;
       split8(ot, s * 8, oh, ol);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const uint4* q = wo_l + ((ct * 16 + s) * 2) * 64;
-        pc[ct] = mfma3(oh, ol, q[0], q[64], pc[ct]);
-      }
+      for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
     }
     float* rb = red + (h * 32) * TC;  // (free: the barrier after the LayerNorm above came after everyone's previous head sum)
 #pragma unroll
