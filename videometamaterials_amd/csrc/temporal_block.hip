@@ -260,12 +260,15 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
     // ---- softmax over this query's 8 (+8) frame keys and 8 (+8) tokens: lane half lk holds slots {0-3, 8-11} + 4 lk
     const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_l), bz1 = *reinterpret_cast<const f32x4*>(bias_l + 4);
     const float bz[8] = {bz0.x, bz0.y, bz0.z, bz0.w, bz1.x, bz1.y, bz1.z, bz1.w};
+    const unsigned pmask = pa ? 0xffffffffu : 0u;
     float f[8], g[8];
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tk = slot(0, lk, j);
-      const float sv = pa ? st[8 + j] : st[j];
+      // bit blend, NOT `pa ? st[8 + j] : st[j]`: the compiler turns that select into st[(pa ? 8 : 0) + j], a run-time index into the
+      // 16 accumulator registers, i.e. a 16-way compare / select cascade per element (~400 of the loop's ~700 VALU instructions)
+      const float sv = __uint_as_float((__float_as_uint(st[8 + j]) & pmask) | (__float_as_uint(st[j]) & ~pmask));
       f[j] = tk < T ? sv * a.q_scale + bz[j] : -INFINITY;
       g[j] = tk < ntok ? sk[j] * a.q_scale + (a.bias_on_cond ? bz[j] : 0.f) : -INFINITY;
       mx = fmaxf(mx, fmaxf(f[j], g[j]));
