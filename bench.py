@@ -174,7 +174,6 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     import videometamaterials_amd as vm
-    from videometamaterials_amd import hostmath
     torch.manual_seed(0)  # identical random-init weights on every rank
     model = vm.Unet3D(**LAGRANGIAN).to(dev).eval()
     diff = vm.GaussianDiffusion(model, image_size=HW, num_frames=T, channels=3, timesteps=TIMESTEPS, loss_type="l1", use_dynamic_thres=True,

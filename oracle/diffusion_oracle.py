@@ -10,8 +10,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it.
 """
 from __future__ import annotations
 
-import math
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Sequence
 
 import torch
 

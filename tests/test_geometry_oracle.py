@@ -4,7 +4,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 import helpers
 from oracle import geometry_oracle as go

@@ -9,7 +9,6 @@ x0 prediction, exact radix-select quantile, posterior update) with no host sync 
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch

@@ -14,8 +14,7 @@ One process per GPU; `torch.distributed` backend "nccl" IS RCCL on ROCm (gloo in
 from __future__ import annotations
 
 import copy
-import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
