@@ -1,0 +1,81 @@
+"""Size-independent properties at BASELINE's full configuration (Lagrangian widths, 3 x 11 x 96 x 96), where the oracle needs minutes per
+forward: batch independence (GroupNorm, attention and the quantile are per sample), the guidance identity, bit-reproducibility, and the
+agreement of the two arithmetic modes.  The golden-vector tests pin the same code paths at smaller frames."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LAGR = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+            per_frame_cond=True, cond_bias=True)
+
+
+# A different batch size changes tile / split decisions, i.e. the summation order inside the split-bf16 contractions: two valid evaluations
+# of the same sample differ by a fraction of that arithmetic's own error (1.5e-5 against the reference), not by fp32 round-off.
+TOL_ORDER = 3e-5
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.fixture(scope="module")
+def setup(gpu):
+    import videometamaterials_amd as vm
+    torch.manual_seed(0)
+    m = vm.Unet3D(**LAGR).to(gpu).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 11, 96, 96, generator=g).to(gpu)
+    t = torch.tensor([3, 250, 77, 128]).to(gpu)
+    cond = (torch.rand(4, 11, generator=g) * 2 - 1).to(gpu)
+    return vm, m, x, t, cond
+
+
+def test_batch_independence_and_reproducibility(setup):
+    vm, m, x, t, cond = setup
+    with torch.no_grad():
+        full = m(x, t, cond=cond, null_cond_prob=0.0).clone()
+        again = m(x, t, cond=cond, null_cond_prob=0.0).clone()
+        assert torch.equal(full, again)                                  # same launch list, ordered reductions: bit-identical
+        for i in (0, 3):
+            solo = m(x[i:i + 1], t[i:i + 1], cond=cond[i:i + 1], null_cond_prob=0.0)
+            assert _rel(solo, full[i:i + 1]) < TOL_ORDER                 # only the tiling / split decisions differ with the batch size
+        perm = torch.tensor([2, 0, 3, 1], device=x.device)
+        shuffled = m(x[perm], t[perm], cond=cond[perm], null_cond_prob=0.0)
+        assert _rel(shuffled, full[perm]) < TOL_ORDER
+
+
+def test_guidance_identity(setup):
+    vm, m, x, t, cond = setup
+    with torch.no_grad():
+        e_c = m(x, t, cond=cond, null_cond_prob=0.0).clone()
+        e_n = m(x, t, cond=cond, null_cond_prob=1.0).clone()
+        for w in (0.0, 1.0, 3.0, 5.0):
+            got = m.forward_with_guidance_scale(x, t, cond=cond, guidance_scale=w)
+            want = e_c if w == 1.0 else e_n + (e_c - e_n) * w              # vddp.py:715-728
+            assert _rel(got, want) < TOL_ORDER, w
+
+
+def test_arithmetic_modes_agree(setup):
+    vm, m, x, t, cond = setup
+    with torch.no_grad():
+        m.precision = "bf16x3"
+        a = m.forward_with_guidance_scale(x, t, cond=cond, guidance_scale=5.0).clone()
+        m.precision = "fp32"
+        b = m.forward_with_guidance_scale(x, t, cond=cond, guidance_scale=5.0).clone()
+        m.precision = "bf16x3"
+    assert _rel(a, b) < 1e-4  # (1.5e-5 .. 2.5e-5 against the reference at the golden sizes)
+
+
+def test_full_sampling_step_batch_independence(setup, gpu):
+    """p_sample at full size: the dynamic threshold (exact 0.9-quantile of |x0| per sample) and the posterior are per sample."""
+    vm, m, x, t, cond = setup
+    diff = vm.GaussianDiffusion(m, image_size=96, num_frames=11, channels=3, timesteps=256, use_dynamic_thres=True, sampling_timesteps=256).to(gpu)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(4, 3, 11, 96, 96, generator=g).to(gpu)
+    tt = torch.full((4,), 100, device=gpu, dtype=torch.long)
+    with torch.no_grad():
+        full = diff.p_sample(x, tt, cond=cond, guidance_scale=5.0, noise=z).clone()
+        solo = diff.p_sample(x[1:2], tt[1:2], cond=cond[1:2], guidance_scale=5.0, noise=z[1:2])
+    assert torch.isfinite(full).all()
+    assert _rel(solo, full[1:2]) < TOL_ORDER
