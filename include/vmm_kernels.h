@@ -68,6 +68,9 @@ int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_str
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
  * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* the same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32; the "fp32" arithmetic mode): d->w = fmt-4 output of
+ * vmm_pack_weights; same envelope, tickets and GroupNorm partials */
+int vmm_conv3x3_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* host-only query: the number n of partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part
  * (unsplit 2-D-tiled layers), or 0 when it will not produce them */
 int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
@@ -78,6 +81,8 @@ int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
  * separate vmm_channel_layernorm pass.  Envelope: KH = KW = 1, stride 1, identity row mapping, K = C1 + C2 padded to 32 in
  * {32, 64, 128, 256}; returns 1 (nothing launched) otherwise. */
 int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
+/* exact-fp32 variant (d->w = fmt-4 output of vmm_pack_weights) */
+int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
 
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
  * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer
@@ -97,7 +102,9 @@ typedef struct vmm_pack_job {
   int32_t fmt; /* 0: fp32 [K][N];  1: split bf16 for vmm_conv_igemm_bf16x3: [N][Kpad] hi plane, then lo plane (Kpad = K rounded up to 32);
                 * 2: split bf16 in MFMA fragment order for vmm_conv3x3_bf16x3 / vmm_linattn_block_bf16x3: [N/32][Kpad/16][hi|lo][64 lanes][8],
                 *    lane l = column (l & 31), k = step*16 + (l >> 5)*8 .. +7 (N and K padded to 32 with zeros);
-                * 3: as 2 with k permuted inside every 32-block to the accumulator-register order (linattn_block.hip).  1-3: direction 0 only. */
+                * 3: as 2 with k permuted inside every 32-block to the accumulator-register order (linattn_block.hip);
+                * 4: fp32 in the fragment order of 2 for vmm_conv3x3_f32 / vmm_proj_f32: [N/32][Kpad/16][e 0..3 | e 4..7][64 lanes][4].
+                *    1-4: direction 0 only. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 

@@ -119,10 +119,12 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 12, 12, 64, 0, 64, False), (2, 1, 24, 24, 32, 32, 128, False), (1, 2, 96, 96, 64, 0, 64, True),
                                                       (1, 1, 12, 12, 512, 512, 256, False), (2, 3, 10, 20, 64, 64, 128, True), (2, 1, 32, 32, 64, 0, 64, True),
                                                       (2, 1, 48, 48, 32, 32, 128, True), (1, 11, 12, 12, 256, 0, 512, False)])
-def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
-    """LDS halo-patch 3x3 kernel (weights in fragment order, fmt 2): image borders, flat row tiles running across frames and samples with a
+@pytest.mark.parametrize("exact", [False, True])
+def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
+    """LDS halo-patch 3x3 kernel (weights in fragment order, fmt 2; exact: its fp32-MFMA variant vmm_conv3x3_f32, fmt 4): image borders, flat row tiles running across frames and samples with a
     partial last tile, 2-D pixel tiles, two sources, fused per-sample GN+SiLU operand, residual, split channel chunks (atomics)."""
     N, lib = _lib()
+    kernel, tol = (lib.vmm_conv3x3_f32, 3e-6) if exact else (lib.vmm_conv3x3_bf16x3, 5e-5)
     g = torch.Generator().manual_seed(12)
     Cin = C1 + C2
     x1 = torch.randn(B, C1, T, H, W, generator=g)
@@ -145,7 +147,7 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
     j = job[0]
     j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
     j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
-    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 2
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 4 if exact else 2
     tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
     N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
     d = N.ConvDesc()
@@ -164,14 +166,14 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
         d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
     tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
     d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
-    N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo")
+    N.check(kernel(C.byref(d), _s()), "conv3x3 halo")
     torch.cuda.synchronize()
-    assert relerr(out.cpu(), ref) < 5e-5
+    assert relerr(out.cpu(), ref) < tol
     # the split channel reduction of the few-row layers adds its partial sums in a fixed order: bit-reproducible, tickets left at zero
     first = out.clone()
     for _ in range(3):
         out.fill_(7.0)
-        N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo")
+        N.check(kernel(C.byref(d), _s()), "conv3x3 halo")
         torch.cuda.synchronize()
         assert torch.equal(out, first)
     assert int(tickets.abs().sum()) == 0
@@ -184,11 +186,11 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
     if n_part:
         part = torch.full((B * G, n_part, 2), float("nan"), device=gpu)
         d.gn_part = part.data_ptr()
-        N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), _s()), "conv3x3 halo + gn sums")
+        N.check(kernel(C.byref(d), _s()), "conv3x3 halo + gn sums")
         torch.cuda.synchronize()
         y = (ref - res).reshape(B, T * H * W, G, Cout // G).double()
         want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], -1)
-        assert relerr(out.cpu(), ref - res) < 5e-5
+        assert relerr(out.cpu(), ref - res) < tol
         assert relerr(part.cpu().double().sum(1).reshape(B, G, 2), want) < 2e-5  # every slot written exactly once (no NaN left)
     else:
         assert not (W >= 32 and W % 16 == 0 and H % 16 == 0)
@@ -427,8 +429,9 @@ def _pack_frag(N, lib, gpu, w2d, fmt):
     (1, 2, 36, 64, 0, 768, True, False, False),     # few rows: column chunks spread over blockIdx.y
     (1, 3, 50, 16, 0, 96, True, False, True),       # K padded 16 -> 32, Cout not a multiple of the 64-column wave tile
     (1, 1, 40, 128, 128, 256, False, False, True)])
-def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, res):
-    """vmm_proj_bf16x3 against torch fp32: 1x1 projection with the row tile staged once (optional fused channel LayerNorm) and
+@pytest.mark.parametrize("exact", [False, True])
+def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, res, exact):
+    """vmm_proj_bf16x3 (exact: its fp32-MFMA variant vmm_proj_f32, fmt-4 weights) against torch fp32: 1x1 projection with the row tile staged once (optional fused channel LayerNorm) and
     fragment-order weights; epilogue bias / q-scale / rotary / residual."""
     N, lib = _lib()
     g = torch.Generator().manual_seed(31)
@@ -459,7 +462,7 @@ def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, re
         ref[:, :2 * hid] = v.reshape(M, 2 * hid)
     if res:
         ref = ref + resid
-    wp = _pack_frag(N, lib, gpu, w, 2)
+    wp = _pack_frag(N, lib, gpu, w, 4 if exact else 2)
     x1g, bg, gg, rg = x1.to(gpu), bias.to(gpu), gamma.to(gpu), resid.to(gpu)
     x2g = x2.to(gpu) if C2 else None
     rt = rot_tab.to(gpu) if rot else None
@@ -475,9 +478,9 @@ def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, re
     d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = HW, 1, 1, Cout, 32, q_scale
     if rot:
         d.rot_tab, d.rot_T, d.rot_HW, d.rot_ncols, d.q_ncols = rt.data_ptr(), T, HW, 2 * hid, hid
-    N.check(lib.vmm_proj_bf16x3(C.byref(d), gg.data_ptr() if ln else None, 1e-5, _s()), "proj")
+    N.check((lib.vmm_proj_f32 if exact else lib.vmm_proj_bf16x3)(C.byref(d), gg.data_ptr() if ln else None, 1e-5, _s()), "proj")
     torch.cuda.synchronize()
-    assert relerr(out.cpu(), ref) < 5e-5
+    assert relerr(out.cpu(), ref) < (3e-6 if exact else 5e-5)
 
 
 @pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 16, 16, 11), (1, 2, 96, 96, 0), (3, 1, 8, 12, 6)])

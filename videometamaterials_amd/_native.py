@@ -78,6 +78,7 @@ SIGNATURES = {
     "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_igemm_bf16x3_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
@@ -108,6 +109,7 @@ SIGNATURES = {
                                   c_i32, c_f32, c_f32, c_ptr],
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_proj_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
+    "vmm_proj_f32": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
     "vmm_extract_geometry": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr, c_ptr],
     "vmm_temporal_core_bf16x3": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                  c_ptr],

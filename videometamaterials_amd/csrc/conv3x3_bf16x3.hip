@@ -50,7 +50,7 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   constexpr int BM = WM * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -180,11 +180,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
           v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
           v.w = igemm::silu_fast(v.w * cb4.z + cb4.w);
         }
-        unsigned h0, l0, h1, l1;
-        split2c(v.x, v.y, h0, l0);
-        split2c(v.z, v.w, h1, l1);
-        *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
+        if constexpr (F32) {  // exact-fp32 variant: the patch row is 32 floats (the same 128 + 16 bytes as bf16 hi | lo)
+          *reinterpret_cast<f32x4*>(&Ph[r * CROW + k4 * 8]) = v;
+        } else {
+          unsigned h0, l0, h1, l1;
+          split2c(v.x, v.y, h0, l0);
+          split2c(v.z, v.w, h1, l1);
+          *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
+        }
       }
     }
   };
@@ -220,20 +224,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) abase[i][kh] = (prow[i] + (kh - 1) * pitch - 1) * CROW + lk * 8;
+    for (int kh = 0; kh < 3; ++kh) abase[i][kh] = (prow[i] + (kh - 1) * pitch - 1) * CROW + lk * (F32 ? 16 : 8);
   auto load_a = [&](uint4 (&d)[4], int tap, int s) {
     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned short* q = Ph + abase[i][kh] + (kw * CROW + s * 16);
+      // bf16x3: 8 hi then 8 lo values of channels s*16 + lk*8 .. +7;  fp32: those eight channels as two float4
+      const unsigned short* q = Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       uint4 vh = *reinterpret_cast<const uint4*>(q);
-      uint4 vl = *reinterpret_cast<const uint4*>(q + CK);
+      uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
       if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
       d[2 * i] = vh;
       d[2 * i + 1] = vl;
     }
   };
   auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
+    if constexpr (F32) {
+      // exact fp32: v_mfma_f32_32x32x2_f32, eight K = 2 products per k16 step (the lane halves hold channels lk*8 + e, e = 0..7 of both
+      // operands); e-major order keeps consecutive MFMAs on different accumulators
+      const float pa[2][8] = {{__uint_as_float(av[0].x), __uint_as_float(av[0].y), __uint_as_float(av[0].z), __uint_as_float(av[0].w),
+                               __uint_as_float(av[1].x), __uint_as_float(av[1].y), __uint_as_float(av[1].z), __uint_as_float(av[1].w)},
+                              {__uint_as_float(av[2].x), __uint_as_float(av[2].y), __uint_as_float(av[2].z), __uint_as_float(av[2].w),
+                               __uint_as_float(av[3].x), __uint_as_float(av[3].y), __uint_as_float(av[3].z), __uint_as_float(av[3].w)}};
+      const float wb[2][8] = {{__uint_as_float(b[0].x), __uint_as_float(b[0].y), __uint_as_float(b[0].z), __uint_as_float(b[0].w),
+                               __uint_as_float(b[1].x), __uint_as_float(b[1].y), __uint_as_float(b[1].z), __uint_as_float(b[1].w)},
+                              {__uint_as_float(b[2].x), __uint_as_float(b[2].y), __uint_as_float(b[2].z), __uint_as_float(b[2].w),
+                               __uint_as_float(b[3].x), __uint_as_float(b[3].y), __uint_as_float(b[3].z), __uint_as_float(b[3].w)}};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][e], wb[j][e], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j][e], pa[i][e], acc[i][j], 0, 0, 0);
+          }
+      return;
+    }
     const bf16x8 ah0 = __builtin_bit_cast(bf16x8, av[0]), al0 = __builtin_bit_cast(bf16x8, av[1]);
     const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
@@ -444,15 +471,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   }
 }
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT>), dim3((unsigned)(mtiles * a.n_tiles), ksplit), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3((unsigned)(mtiles * a.n_tiles), ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -509,6 +536,16 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
 
 }  // namespace
 
+template <bool F32>
+int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t s) {
+  if (ksplit > 1) {
+    if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32>(a, mtiles, ksplit, s);
+    return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32>(a, mtiles, ksplit, s);
+  }
+  if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32>(a, mtiles, 1, s);
+  return a.mode ? launch_c3<4, 1, 11, 1, 1, false, F32>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, 1, false, F32>(a, mtiles, 1, s);
+}
+
 // Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
 // vmm_groupnorm_stats and hands them to vmm_groupnorm_coef), 0 when it will not.  Pure host logic.
 extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
@@ -532,10 +569,18 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   if (a.total_rows <= 0) return 0;
   const bool wide = d.Cout >= 128;
   hipStream_t s = (hipStream_t)stream;
-  if (ksplit > 1) {
-    if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true>(a, mtiles, ksplit, s);
-    return a.mode ? launch_c3<4, 1, 11, 1, 1, true>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true>(a, mtiles, ksplit, s);
-  }
-  if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false>(a, mtiles, 1, s);
-  return a.mode ? launch_c3<4, 1, 11, 1, 1, false>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, 1, false>(a, mtiles, 1, s);
+  return dispatch_c3<false>(a, mtiles, ksplit, wide, s);
+}
+
+// The same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32, 1e-6 parity): weights = vmm_pack_weights fmt 4
+// (fragment order, fp32).  Used by the "fp32" arithmetic mode (training default) for the forward and the data-gradient 3x3 convolutions.
+extern "C" int vmm_conv3x3_f32(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  C3Args a;
+  int mtiles, ksplit;
+  bool gn = false;
+  const int rc = plan_c3(d, a, mtiles, ksplit, gn);
+  if (rc != 0) return rc;
+  if (a.total_rows <= 0) return 0;
+  return dispatch_c3<true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
 }

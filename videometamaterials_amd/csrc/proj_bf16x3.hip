@@ -38,7 +38,7 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) {
 }
 
 // KS = k16 steps (K padded to 32 -> KS = Kpad / 16 in {2, 4, 8, 16})
-template <int WM, int WN, int KS>
+template <int WM, int WN, int KS, bool F32>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int KP = KS * 16;         // padded K
@@ -109,11 +109,15 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       for (int i = 0; i < IPL; ++i) {
         const int c = (l16 + 16 * i) * 4;
         if (c < KP) {
-          unsigned l0, l1;
-          const unsigned h0 = pj_split(v[ps][i].x, v[ps][i].y, l0);
-          const unsigned h1 = pj_split(v[ps][i].z, v[ps][i].w, l1);
-          *reinterpret_cast<uint2*>(row + c) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(row + KP + c) = make_uint2(l0, l1);
+          if constexpr (F32) {  // exact-fp32 variant: the row is KP floats (the same bytes as hi | lo)
+            *reinterpret_cast<f32x4*>(row + 2 * c) = v[ps][i];
+          } else {
+            unsigned l0, l1;
+            const unsigned h0 = pj_split(v[ps][i].x, v[ps][i].y, l0);
+            const unsigned h1 = pj_split(v[ps][i].z, v[ps][i].w, l1);
+            *reinterpret_cast<uint2*>(row + c) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(row + KP + c) = make_uint2(l0, l1);
+          }
         }
       }
     }
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   };
   int abase[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) abase[i] = (wm * 64 + i * 32 + lrow) * PITCH + lk * 8;
+  for (int i = 0; i < 2; ++i) abase[i] = (wm * 64 + i * 32 + lrow) * PITCH + lk * (F32 ? 16 : 8);
   auto load_a = [&](uint4 (&d)[4], int s) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned short* q = At + abase[i] + s * 16;
+      const unsigned short* q = At + abase[i] + s * (F32 ? 32 : 16);
       d[2 * i] = *reinterpret_cast<const uint4*>(q);
-      d[2 * i + 1] = *reinterpret_cast<const uint4*>(q + KP);
+      d[2 * i + 1] = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : KP));
     }
   };
   f32x16 acc[2][2];
@@ -157,6 +161,23 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
   auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
+    if constexpr (F32) {  // exact fp32: eight K = 2 products per k16 step, e-major so consecutive MFMAs hit different accumulators
+      const float pa[2][8] = {{__uint_as_float(av[0].x), __uint_as_float(av[0].y), __uint_as_float(av[0].z), __uint_as_float(av[0].w),
+                               __uint_as_float(av[1].x), __uint_as_float(av[1].y), __uint_as_float(av[1].z), __uint_as_float(av[1].w)},
+                              {__uint_as_float(av[2].x), __uint_as_float(av[2].y), __uint_as_float(av[2].z), __uint_as_float(av[2].w),
+                               __uint_as_float(av[3].x), __uint_as_float(av[3].y), __uint_as_float(av[3].z), __uint_as_float(av[3].w)}};
+      const float wb[2][8] = {{__uint_as_float(b[0].x), __uint_as_float(b[0].y), __uint_as_float(b[0].z), __uint_as_float(b[0].w),
+                               __uint_as_float(b[1].x), __uint_as_float(b[1].y), __uint_as_float(b[1].z), __uint_as_float(b[1].w)},
+                              {__uint_as_float(b[2].x), __uint_as_float(b[2].y), __uint_as_float(b[2].z), __uint_as_float(b[2].w),
+                               __uint_as_float(b[3].x), __uint_as_float(b[3].y), __uint_as_float(b[3].z), __uint_as_float(b[3].w)}};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j][e], pa[i][e], acc[i][j], 0, 0, 0);
+      return;
+    }
     const bf16x8 ah0 = __builtin_bit_cast(bf16x8, av[0]), al0 = __builtin_bit_cast(bf16x8, av[1]);
     const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
@@ -267,18 +288,18 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   }
 }
 
-template <int WM, int WN, int KS>
+template <int WM, int WN, int KS, bool F32>
 int launch_pj(const PJArgs& a, hipStream_t s) {
   constexpr int BM = WM * 64;
   const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int mt = (int)cdiv(a.M, BM);
   const int ny = (int)cdiv(a.n_chunks, a.chunks_per_y);
-  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -288,8 +309,8 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
 // 1x1 / Linear projection.  d->w = vmm_pack_weights fmt 2 of the (Cout, K) weight.  ln_gamma != NULL: the rows pass through the
 // channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
 // identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 32; returns 1 (nothing launched) otherwise.
-extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
-  const vmm_conv_desc& d = *dp;
+template <bool F32>
+static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
                         d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
   const int K = d.C1 + d.C2;
@@ -316,12 +337,21 @@ extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, f
   int ny = (int)max(1LL, min((long long)a.n_chunks, 1024 / max(mt, 1LL)));
   a.chunks_per_y = (int)cdiv(a.n_chunks, ny);
   hipStream_t s = (hipStream_t)stream;
-  if (KP == 32) return launch_pj<4, 1, 2>(a, s);
-  if (KP == 64) return launch_pj<4, 1, 4>(a, s);
+  if (KP == 32) return launch_pj<4, 1, 2, F32>(a, s);
+  if (KP == 64) return launch_pj<4, 1, 4, F32>(a, s);
   if (KP <= 128) {
     if (KP == 96) return 1;
-    return launch_pj<2, 2, 8>(a, s);
+    return launch_pj<2, 2, 8, F32>(a, s);
   }
-  if (KP == 256) return launch_pj<1, 4, 16>(a, s);
+  if (KP == 256) return launch_pj<1, 4, 16, F32>(a, s);
   return 1;
+}
+
+extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
+  return run_proj<false>(*dp, ln_gamma, ln_eps, stream);
+}
+
+// The same kernel on the exact-fp32 matrix-core instruction (d->w = vmm_pack_weights fmt 4); the "fp32" arithmetic mode's projections.
+extern "C" int vmm_proj_f32(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
+  return run_proj<true>(*dp, ln_gamma, ln_eps, stream);
 }

@@ -163,11 +163,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
-  if (jb.fmt == 2 || jb.fmt == 3) {
+  if (jb.fmt == 2 || jb.fmt == 3 || jb.fmt == 4) {
     // split-bf16 operand in MFMA fragment order for conv3x3_bf16x3.hip / proj_bf16x3.hip: plane (column tile nt of 32, k16 step ks, hi|lo)
     // = 64 lanes x 8 bf16; lane l holds column nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +7.  K = (th, tw, c) padded to 32, N to 32.
     // fmt 3: within every 32-block of k the contraction index follows the accumulator-register order of a preceding MFMA
     // (linattn_block.hip): element e of half lk in step s <-> k = (e & 3) + 8 (2 s + (e >> 2)) + 4 lk.
+    // fmt 4: the same fragment order in fp32 for the exact variants (vmm_conv3x3_f32 / vmm_proj_f32): the two 1 KiB planes of a
+    // (nt, ks) pair hold elements 0..3 and 4..7 of every lane's eight k values as float4.
     if (direction != 0) return;
     const int K = jb.TH * jb.TW * jb.Cp;
     const int KS = (K + 31) / 32 * 2;
@@ -179,12 +181,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
       const long long pl = i >> 9;  // nt*KS + ks
       const int ks = (int)(pl % KS), nt = (int)(pl / KS);
       const int n = nt * 32 + (l & 31);
-      const int k = jb.fmt == 2 ? ks * 16 + (l >> 5) * 8 + e : (ks >> 1) * 32 + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * (l >> 5);
+      const int k = jb.fmt != 3 ? ks * 16 + (l >> 5) * 8 + e : (ks >> 1) * 32 + (e & 3) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * (l >> 5);
       float v = 0.f;
       if (k < K && n < jb.N) {
         const int c = k % jb.Cp, t = k / jb.Cp;
         const int tw = t % jb.TW, th = t / jb.TW;
         if (c < jb.C) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh + (long long)(jb.w0 + tw * jb.ws) * jb.sw];
+      }
+      if (jb.fmt == 4) {
+        jb.packed[pl * 512 + (e >> 2) * 256 + l * 4 + (e & 3)] = v;
+        continue;
       }
       const __bf16 h = (__bf16)v;
       const __bf16 lo = (__bf16)(v - (float)h);

@@ -245,6 +245,8 @@ class _Builder:
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
         self.x3 = getattr(model, "train_precision" if training else "precision", "fp32") == "bf16x3"
+        # exact-fp32 mode: the 3x3 and projection kernels run their v_mfma_f32_32x32x2_f32 variants on fp32 fragment-order weights (fmt 4)
+        self.f32frag = not self.x3 and getattr(model, "use_f32_frag_kernels", True)
         self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
         self.unpack_jobs: List[dict] = []
         self.gacts: Dict[int, Act] = {}  # activation offset -> gradient buffer
@@ -311,7 +313,12 @@ class _Builder:
         self._touch(name)
         frag = desc.pop("frag", False)
         n_fp32, fp32_desc = n_elems, desc
-        if (want_grad if gemm is None else gemm) and self.x3:  # GEMM operand -> pre-split bf16 hi|lo
+        if (want_grad if gemm is None else gemm) and self.f32frag and frag:  # fp32 fragment order (vmm_conv3x3_f32 / vmm_proj_f32)
+            assert frag != 3
+            kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
+            n_elems = (desc["N"] + 31) // 32 * 32 * kpad
+            desc = dict(desc, fmt=4)
+        elif (want_grad if gemm is None else gemm) and self.x3:  # GEMM operand -> pre-split bf16 hi|lo
             kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
             if frag:  # MFMA fragment order, read straight into registers (conv3x3_bf16x3.hip; 3 = permuted k, linattn_block.hip)
                 n_elems = (desc["N"] + 31) // 32 * 32 * kpad
@@ -344,7 +351,7 @@ class _Builder:
 
     def halo_ok(self, c1: int, c2: int, cout: int, H: int, W: int) -> bool:
         """Envelope of vmm_conv3x3_bf16x3 (LDS halo patch + register-fed fragment-order weights)."""
-        if not (self.x3 and getattr(self.m, "use_halo_conv", True)):
+        if not ((self.x3 or self.f32frag) and getattr(self.m, "use_halo_conv", True)):
             return False
         if c1 % 32 or c2 % 32 or not (cout == 64 or cout % 128 == 0):
             return False
@@ -390,7 +397,7 @@ class _Builder:
         bf16x3 mode (K = out features), exact fp32 implicit GEMM otherwise."""
         co = self.shapes[name][0]
         pj = self.proj_ok(co, nci)
-        w = self.pack_linear_slice(name, ci0, nci, frag=2 if pj else False, gemm=self.x3)
+        w = self.pack_linear_slice(name, ci0, nci, frag=2 if pj else False, gemm=self.x3 or pj)
         self.conv(w=w, Cout=nci, what=what, proj=pj, x3w=self.x3, **kw)
 
     def step(self, fn, args: tuple, what: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
@@ -452,7 +459,7 @@ class _Builder:
 
     def proj_ok(self, k: int, cout: int) -> bool:
         """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
-        if not (self.x3 and getattr(self.m, "use_proj_kernel", True)):
+        if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
             return False
         return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
@@ -463,10 +470,11 @@ class _Builder:
         # algorithmic work: every input element, weight and output element touched once
         nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
         if proj:  # weights were packed in fragment order for it (proj_ok); ln_gamma: PreNorm LayerNorm fused into the row staging
-            self.step(self.lib.vmm_proj_bf16x3, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+            fn = self.lib.vmm_proj_bf16x3 if self.x3 else self.lib.vmm_proj_f32
+            self.step(fn, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
             return d
         assert not ln_gamma
-        fn = self.lib.vmm_conv_igemm_f32
+        fn = self.lib.vmm_conv3x3_f32 if halo and not self.x3 else self.lib.vmm_conv_igemm_f32
         if self.x3 and (x3w or not self.in_bwd):  # x3w: a backward GEMM whose weight operand was packed split-bf16 (pack(..., gemm=True))
             fn = self.lib.vmm_conv_igemm_bf16x3
             if halo:  # weights were packed in fragment order for it (halo_ok)
