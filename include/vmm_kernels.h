@@ -270,6 +270,12 @@ int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, const float
                       int32_t tok_per_frame, const float* bias, int32_t bias_on_cond, const float* out, const float* dout, int32_t ldo,
                       const float* lse, const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias,
                       float* dbuf, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* mode-0 fast path that vmm_attention_bwd takes where it applies (heads = 8, dh = 32, T <= 16, ntok <= 16; returns 1 and launches
+ * nothing otherwise): one workgroup per pixel stages the T rows once in LDS -- every qkv / dout / out element is read once */
+int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,
+                               int32_t bias_on_cond, const float* out, const float* dout, int32_t ldo, const float* lse,
+                               const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias, int32_t B,
+                               int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* linear attention backward; ctx and kstat (per (frame, head): max[32] | 1/sum[32] of the key softmax) saved by the forward */
 int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* ctx,
                     const float* kstat, const float* dout, int32_t lddo, float* dctx /* [B*T*heads][32*32] scratch */, float* dqkv,

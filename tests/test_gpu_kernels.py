@@ -624,3 +624,70 @@ def test_diffusion_elementwise(gpu):
     mean, var, logvar = d.q_posterior(eps.to(gpu), x0.to(gpu), t.to(gpu))
     want_mean, want_logvar = do.q_posterior_mean_logvar(sch, eps, x0, t)
     assert torch.allclose(mean.cpu(), want_mean, rtol=1e-5, atol=1e-6) and torch.equal(logvar.cpu(), want_logvar)
+
+
+@pytest.mark.parametrize("B,T,HW,ntok,use_bias,bias_on_cond,rot", [(2, 11, 37, 11, True, 1, True), (1, 16, 9, 16, True, 0, True), (3, 5, 130, 0, False, 0, False),
+                                                             (1, 11, 700, 3, True, 0, True)])
+def test_temporal_attention_backward(gpu, B, T, HW, ntok, use_bias, bias_on_cond, rot):
+    """vmm_attention_bwd mode 0 (LDS-staged workgroup-per-pixel kernel, temporal_attn_bwd.hip) against torch autograd of the same
+    attention: softmax over [conditioning tokens | frames] per (pixel, head), q-scale + rotary in front, relative-position bias."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    heads, dh = 8, 32
+    hid = heads * dh
+    scale = dh ** -0.5
+    raw = torch.randn(B, T, HW, 3 * hid, generator=g, dtype=torch.float64, requires_grad=True)
+    ek = torch.randn(B, ntok, hid, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    ev = torch.randn(B, ntok, hid, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    bias = (torch.randn(heads, T, T, generator=g, dtype=torch.float64) * 0.5).requires_grad_(True) if use_bias else None
+    ang = torch.rand(T, dh // 2, generator=g, dtype=torch.float64) * 6.28
+    cs, sn = ang.cos(), ang.sin()
+
+    def rotate(x):  # x (B, T, HW, heads, dh), position = frame
+        if not rot:
+            return x
+        e, o = x[..., 0::2], x[..., 1::2]
+        c, s = cs[None, :, None, None, :], sn[None, :, None, None, :]
+        return torch.stack([e * c - o * s, o * c + e * s], -1).flatten(-2)
+
+    q = rotate(raw[..., :hid].reshape(B, T, HW, heads, dh) * scale)
+    k = rotate(raw[..., hid:2 * hid].reshape(B, T, HW, heads, dh))
+    v = raw[..., 2 * hid:].reshape(B, T, HW, heads, dh)
+    sim = torch.einsum("biphd,bjphd->bphij", q, k)
+    if use_bias:
+        sim = sim + bias[None, None]
+    if ntok:
+        simt = torch.einsum("biphd,bjhd->bphij", q, ek.reshape(B, ntok, heads, dh))
+        if use_bias and bias_on_cond:
+            simt = simt + bias[None, None, :, :, :ntok]
+        sim = torch.cat([simt, sim], -1)
+    lse = torch.logsumexp(sim, -1)                       # (B, HW, heads, T)
+    attn = (sim - lse[..., None]).exp()
+    out = torch.einsum("bphij,bjphd->biphd", attn[..., ntok:], v)
+    if ntok:
+        out = out + torch.einsum("bphij,bjhd->biphd", attn[..., :ntok], ev.reshape(B, ntok, heads, dh))
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    (out * dout).sum().backward()
+
+    f = lambda t: t.detach().float().contiguous().to(gpu)
+    qkv_g = f(torch.cat([q.flatten(-2), k.flatten(-2), v.flatten(-2)], -1).reshape(-1, 3 * hid))
+    out_g, dout_g = f(out.reshape(-1, hid)), f(dout.reshape(-1, hid))
+    lse_g = f(lse.permute(0, 3, 1, 2).reshape(-1, heads))  # rows (b, t, pix) x heads
+    tab = f(torch.stack([cs, sn], -1)) if rot else None
+    ek_g, ev_g = (f(ek), f(ev)) if ntok else (None, None)
+    bias_g = f(bias) if use_bias else None
+    rows = B * T * HW
+    dqkv = torch.full((rows, 3 * hid), float("nan"), device=gpu)
+    dek, dev_ = torch.zeros(B, max(ntok, 1), hid, device=gpu), torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    dbias = torch.zeros(heads, T, T, device=gpu)
+    dbuf = torch.zeros(rows * heads, device=gpu)
+    p = lambda t: t.data_ptr() if t is not None else None
+    N.check(lib.vmm_attention_bwd(0, p(qkv_g), 3 * hid, p(ek_g), p(ev_g), ntok, 0, p(bias_g), bias_on_cond, p(out_g), p(dout_g), hid, p(lse_g), p(tab),
+                                  scale, p(dqkv), p(dek), p(dev_), p(dbias), p(dbuf), B, T, HW, heads, dh, _s()), "attention bwd")
+    torch.cuda.synchronize()
+    assert relerr(dqkv.cpu(), raw.grad.reshape(rows, 3 * hid)) < 2e-5
+    if ntok:
+        assert relerr(dek.cpu(), ek.grad) < 2e-5
+        assert relerr(dev_.cpu(), ev.grad) < 2e-5
+    if use_bias:
+        assert relerr(dbias.cpu(), bias.grad) < 2e-5

@@ -1,0 +1,23 @@
+"""Training-step workload for rocprofv3 (per-kernel breakdown of one optimisation step of the Lagrangian configuration, batch 4):
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_train -o train -- \
+        python $GRAFT_REPO_ROOT/tools/profile_train.py [fp32|bf16x3] [steps]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import videometamaterials_amd as vm  # noqa: E402
+
+precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = vm.Unet3D(**bench.LAGRANGIAN).to(dev)
+diff = vm.GaussianDiffusion(model, image_size=bench.HW, num_frames=bench.T, channels=3, timesteps=bench.TIMESTEPS, loss_type="l1",
+                            use_dynamic_thres=True, sampling_timesteps=bench.TIMESTEPS).to(dev)
+print(bench.bench_training(vm, model, diff, dev, None, 1, 0, steps, precision))

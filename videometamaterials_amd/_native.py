@@ -88,6 +88,8 @@ SIGNATURES = {
     "vmm_channel_layernorm_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i32, c_f32, c_ptr],
     "vmm_attention_bwd": [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr,
                           c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_temporal_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                   c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_dense_bwd_batched": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
     "vmm_cond_tokens_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
