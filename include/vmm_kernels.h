@@ -265,7 +265,7 @@ int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const float* gamma, c
                               int32_t accumulate, float* dgamma, int64_t rows, int32_t C, float eps, vmm_stream_t stream);
 /* softmax attention backward (mode 0 temporal, 1 mid spatial); qkv/out/lse as saved by the forward (q scaled+rotated, k rotated);
  * writes dqkv (gradient of the raw to_qkv output: rotation and q-scale undone), accumulates dek/dev [B][ntok][heads*dh] and
- * dbias [heads][T][T] with atomics (caller zeroes them); dbuf = scratch [rows*heads]. */
+ * dbias [heads][T][T] (+=; caller zeroes them); dbuf = scratch of vmm_attention_bwd_scratch(...) floats. */
 int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                       int32_t tok_per_frame, const float* bias, int32_t bias_on_cond, const float* out, const float* dout, int32_t ldo,
                       const float* lse, const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias,
@@ -274,8 +274,10 @@ int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, const float
  * nothing otherwise): one workgroup per pixel stages the T rows once in LDS -- every qkv / dout / out element is read once */
 int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,
                                int32_t bias_on_cond, const float* out, const float* dout, int32_t ldo, const float* lse,
-                               const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias, int32_t B,
-                               int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+                               const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev, float* dbias, float* scratch,
+                               int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* floats of scratch (dbuf) vmm_attention_bwd needs: rows * heads, or the fast path's per-workgroup partials if that is larger */
+int64_t vmm_attention_bwd_scratch(int32_t mode, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t ntok);
 /* linear attention backward; ctx and kstat (per (frame, head): max[32] | 1/sum[32] of the key softmax) saved by the forward */
 int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* ctx,
                     const float* kstat, const float* dout, int32_t lddo, float* dctx /* [B*T*heads][32*32] scratch */, float* dqkv,

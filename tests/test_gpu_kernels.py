@@ -680,7 +680,7 @@ def test_temporal_attention_backward(gpu, B, T, HW, ntok, use_bias, bias_on_cond
     dqkv = torch.full((rows, 3 * hid), float("nan"), device=gpu)
     dek, dev_ = torch.zeros(B, max(ntok, 1), hid, device=gpu), torch.zeros(B, max(ntok, 1), hid, device=gpu)
     dbias = torch.zeros(heads, T, T, device=gpu)
-    dbuf = torch.zeros(rows * heads, device=gpu)
+    dbuf = torch.zeros(int(lib.vmm_attention_bwd_scratch(0, B, T, HW, heads, ntok)), device=gpu)
     p = lambda t: t.data_ptr() if t is not None else None
     N.check(lib.vmm_attention_bwd(0, p(qkv_g), 3 * hid, p(ek_g), p(ev_g), ntok, 0, p(bias_g), bias_on_cond, p(out_g), p(dout_g), hid, p(lse_g), p(tab),
                                   scale, p(dqkv), p(dek), p(dev_), p(dbias), p(dbuf), B, T, HW, heads, dh, _s()), "attention bwd")

@@ -89,7 +89,8 @@ SIGNATURES = {
     "vmm_attention_bwd": [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr,
                           c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_temporal_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
-                                   c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+                                   c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_dense_bwd_batched": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
     "vmm_cond_tokens_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -141,7 +142,7 @@ SIGNATURES = {
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
-RESTYPES = {"vmm_linattn_block_workspace": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

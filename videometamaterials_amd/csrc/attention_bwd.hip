@@ -380,7 +380,7 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
   if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
   if (mode == 0 && !tok_per_frame) {  // temporal attention: LDS-staged workgroup-per-pixel kernel (temporal_attn_bwd.hip) where it applies
     const int rc = vmm_temporal_attention_bwd(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, dout, ldo, lse, rot_tab, q_scale, dqkv, dek, dev,
-                                              dbias, B, T, HW, heads, dh, stream);
+                                              dbias, dbuf, B, T, HW, heads, dh, stream);
     if (rc != 1) return rc;
   }
   const int n = mode == 0 ? T : HW, ninner = mode == 0 ? HW : T;

@@ -778,14 +778,15 @@ class _Builder:
             go = self.act(hid, x.H, x.W)
             self.dgrad_1x1(p + ".to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
             gqkv = self.act(3 * hid, x.H, x.W)
-            dbuf = self.alloc(rows * heads)
+            ndbuf = int(self.lib.vmm_attention_bwd_scratch(0 if temporal else 1, B, T, HW, heads, ntok))
+            dbuf = self.alloc(ndbuf)
             geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
             self.step(self.lib.vmm_attention_bwd,
                       (0 if temporal else 1, qkv.ptr, 3 * hid, ek or None, ev or None, ntok, 0 if temporal else pfc, self.bias_ptr if temporal else None,
                        pfc if temporal else 0, o.ptr, go.ptr, hid, lse_ptr, self.rot_ptr if temporal else None, C.c_float(q_scale), gqkv.ptr, geo or None,
                        gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
             self.tmp_free(go)
-            self.tmp_free((dbuf, rows * heads))
+            self.tmp_free((dbuf, ndbuf))
             self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
             gy = self.act(x.C, x.H, x.W)
             self.dgrad_1x1(p + ".to_qkv.weight", 0, x.C, name + " to_qkv dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
