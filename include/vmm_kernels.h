@@ -87,9 +87,12 @@ int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vm
 /* ---- training: weight gradient of the same contraction (autograd of vddp.py:155,241,271,297,319,325,413,421,626,708).
  * dw_packed[(tap, ci)][co] += sum_m A[m shifted by tap, ci] * dy[orow(m), co]; `d` is the FORWARD descriptor of the layer
  * (out/res/bias/rot fields ignored), the reduction is split over `nsplit` row slices combined with fp32 atomics, so
- * dw_packed must be zeroed by the caller. */
-int vmm_conv_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit,
-                       vmm_stream_t stream);
+ * dw_packed must be zeroed by the caller.  dbias != NULL: dbias[co] += sum_m dy[orow(m), co] as well (the layer's bias gradient,
+ * from the dY tiles the kernel stages anyway: one partial row per row slice in bias_scratch [nsplit][Cout], then vmm_sum_partials). */
+int vmm_conv_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
+                       float* bias_scratch, vmm_stream_t stream);
+/* out[c] += sum_{k < n} part[k * ld + c], fixed order: second stage of the reductions that leave one partial row per workgroup */
+int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
 /* batched weight packing: packed[(th*TW + tw)*Cp + c][n] <-> torch[n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw];
@@ -261,8 +264,10 @@ int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, int32_t ldh
                       const float* gamma, const float* beta, const float* film, int32_t ldfilm, int32_t B, int32_t rows_per_sample,
                       int32_t C, int32_t G, float* scratch /* [B*C*2 + B*G*2] */, float* dh, int32_t lddh, int32_t accumulate,
                       float* dgamma, float* dbeta, float* dfilm, vmm_stream_t stream);
+/* scratch: NULL (dgamma by atomics) or VMM_LN_BWD_MAX_BLOCKS * C floats (one partial row per workgroup + vmm_sum_partials) */
+#define VMM_LN_BWD_MAX_BLOCKS 2048
 int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, float* dx, int32_t lddx,
-                              int32_t accumulate, float* dgamma, int64_t rows, int32_t C, float eps, vmm_stream_t stream);
+                              int32_t accumulate, float* dgamma, int64_t rows, int32_t C, float eps, float* scratch, vmm_stream_t stream);
 /* softmax attention backward (mode 0 temporal, 1 mid spatial); qkv/out/lse as saved by the forward (q scaled+rotated, k rotated);
  * writes dqkv (gradient of the raw to_qkv output: rotation and q-scale undone), accumulates dek/dev [B][ntok][heads*dh] and
  * dbias [heads][T][T] (+=; caller zeroes them); dbuf = scratch of vmm_attention_bwd_scratch(...) floats. */

@@ -80,12 +80,13 @@ SIGNATURES = {
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
-    "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
     "vmm_groupnorm_bwd": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32,
                           c_ptr, c_ptr, c_ptr, c_ptr],
-    "vmm_channel_layernorm_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i32, c_f32, c_ptr],
+    "vmm_channel_layernorm_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr],
     "vmm_attention_bwd": [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr,
                           c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_temporal_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,

@@ -123,18 +123,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
-// channel LayerNorm backward; GS lanes per row, block-level dgamma in LDS then one atomic per channel per block
-template <int GS>
+// channel LayerNorm backward; GS lanes per row; every thread keeps the dgamma of its own channels in registers across its rows,
+// then one LDS reduction and one atomic per channel per workgroup
+template <int GS, int MAXV>
 __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx,
-                                                          float* __restrict__ dgamma, long long rows, int C, float eps, int accumulate) {
+                                                          float* __restrict__ dgamma, long long rows, int C, float eps, int accumulate,
+                                                          float* __restrict__ dgamma_part) {
   extern __shared__ float dg_sh[];  // [C]
   const int tid = threadIdx.x;
   for (int c = tid; c < C; c += 256) dg_sh[c] = 0.f;
   __syncthreads();
-  const int sub = tid % GS;
-  constexpr int MAXV = 8;
+  const int sub = tid % GS;  // lane `sub` of a row owns channels (j * GS + sub) * 4 .. + 3, j < MAXV
   const long long rows_per_iter = (long long)gridDim.x * (256 / GS);
+  f32x4 dga[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) dga[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (long long row0 = (long long)blockIdx.x * (256 / GS); row0 < rows; row0 += rows_per_iter) {
     const long long row = row0 + tid / GS;
     const bool valid = row < rows;
@@ -193,14 +197,26 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const float* __restric
           *reinterpret_cast<f32x4*>(op) = o;
           // dgamma_c += dy_c * xhat_c
           const f32x4 d = *reinterpret_cast<const f32x4*>(gr + c);
-          atomicAdd(&dg_sh[c], d.x * v[j].x); atomicAdd(&dg_sh[c + 1], d.y * v[j].y);
-          atomicAdd(&dg_sh[c + 2], d.z * v[j].z); atomicAdd(&dg_sh[c + 3], d.w * v[j].w);
+          dga[j].x = fmaf(d.x, v[j].x, dga[j].x); dga[j].y = fmaf(d.y, v[j].y, dga[j].y);
+          dga[j].z = fmaf(d.z, v[j].z, dga[j].z); dga[j].w = fmaf(d.w, v[j].w, dga[j].w);
         }
       }
     }
   }
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int c = (j * GS + sub) * 4;
+    if (c < C) {
+      atomicAdd(&dg_sh[c], dga[j].x); atomicAdd(&dg_sh[c + 1], dga[j].y);
+      atomicAdd(&dg_sh[c + 2], dga[j].z); atomicAdd(&dg_sh[c + 3], dga[j].w);
+    }
+  }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) atomicAdd(&dgamma[c], dg_sh[c]);
+  if (dgamma_part) {  // one partial row per workgroup, summed by vmm_sum_partials
+    for (int c = tid; c < C; c += 256) dgamma_part[(long long)blockIdx.x * C + c] = dg_sh[c];
+  } else {
+    for (int c = tid; c < C; c += 256) atomicAdd(&dgamma[c], dg_sh[c]);
+  }
 }
 
 }  // namespace
@@ -235,7 +251,7 @@ extern "C" int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, 
 
 extern "C" int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, float* dx,
                                          int32_t lddx, int32_t accumulate, float* dgamma, int64_t rows, int32_t C, float eps,
-                                         vmm_stream_t stream) {
+                                         float* scratch, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || C > 2048) return -1;
   const int c4 = C >> 2;
@@ -245,11 +261,16 @@ extern "C" int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const floa
   const int blocks = (int)max(1LL, min(want, 2048LL));
 #define LNB_CASE(G)                                                                                                                  \
   case G:                                                                                                                            \
-    hipLaunchKernelGGL(chan_ln_bwd_kernel<G>, dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
-                       (long long)rows, C, eps, accumulate);                                                                          \
+    if (c4 <= G)                                                                                                                      \
+      hipLaunchKernelGGL((chan_ln_bwd_kernel<G, 1>), dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
+                         (long long)rows, C, eps, accumulate, scratch);                                                                       \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((chan_ln_bwd_kernel<G, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
+                         (long long)rows, C, eps, accumulate, scratch);                                                                       \
     break;
   switch (gs) { LNB_CASE(1) LNB_CASE(2) LNB_CASE(4) LNB_CASE(8) LNB_CASE(16) LNB_CASE(32) LNB_CASE(64) }
 #undef LNB_CASE
   VMM_LAUNCH_CHECK();
+  if (scratch) return vmm_sum_partials(scratch, blocks, C, C, dgamma, stream);
   return 0;
 }

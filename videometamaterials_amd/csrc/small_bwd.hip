@@ -216,6 +216,64 @@ __global__ __launch_bounds__(256) void pointwise_to_ncthw_bwd_kernel(const float
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) atomicAdd(&db[i], dba[i]);
 }
 
+// The same for Cout <= 4 and Cin / 4 a power of two <= 64 (the final 1x1 conv: 64 -> 3 channels): Cin / 4 lanes per row, each owning four
+// input channels -- 16-byte row loads / stores, the dw partial sums in registers; one LDS reduction and one set of atomics per workgroup.
+template <int CO>
+__global__ __launch_bounds__(256) void pointwise_to_ncthw_bwd_small_kernel(const float* __restrict__ rows, int ld, int Cin, const float* __restrict__ w,
+                                                                           const float* __restrict__ dout, int T, int HW,
+                                                                           float* __restrict__ drows, int lddr, float* __restrict__ dw,
+                                                                           float* __restrict__ db, long long nrows) {
+  __shared__ float red[256 * (4 * CO + 1)];
+  const int tpr = Cin >> 2, c4 = threadIdx.x % tpr, slot = threadIdx.x / tpr, nslots = 256 / tpr;
+  f32x4 wv[CO], dwa[CO];
+  float dba[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    wv[co] = *reinterpret_cast<const f32x4*>(w + co * Cin + c4 * 4);
+    dwa[co] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dba[co] = 0.f;
+  }
+  for (long long r = (long long)blockIdx.x * nslots + slot; r < nrows; r += (long long)gridDim.x * nslots) {
+    const int hw = (int)(r % HW);
+    const int t = (int)((r / HW) % T);
+    const long long b = r / ((long long)HW * T);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(rows + r * ld + c4 * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      const float g = dout[((b * CO + co) * T + t) * HW + hw];
+      acc.x = fmaf(g, wv[co].x, acc.x); acc.y = fmaf(g, wv[co].y, acc.y); acc.z = fmaf(g, wv[co].z, acc.z); acc.w = fmaf(g, wv[co].w, acc.w);
+      dwa[co].x = fmaf(g, x.x, dwa[co].x); dwa[co].y = fmaf(g, x.y, dwa[co].y); dwa[co].z = fmaf(g, x.z, dwa[co].z); dwa[co].w = fmaf(g, x.w, dwa[co].w);
+      dba[co] += g;
+    }
+    *reinterpret_cast<f32x4*>(drows + r * lddr + c4 * 4) = acc;
+  }
+  float* mine = red + threadIdx.x * (4 * CO + 1);
+#pragma unroll
+  for (int co = 0; co < CO; ++co) { mine[4 * co] = dwa[co].x; mine[4 * co + 1] = dwa[co].y; mine[4 * co + 2] = dwa[co].z; mine[4 * co + 3] = dwa[co].w; }
+  mine[4 * CO] = dba[0];
+  __syncthreads();
+  // thread e < CO * Cin: dw[co][ci] over the row slots
+  for (int e = threadIdx.x; e < CO * Cin; e += 256) {
+    const int co = e / Cin, ci = e - co * Cin;
+    float sum = 0.f;
+    for (int k = 0; k < nslots; ++k) sum += red[(k * tpr + (ci >> 2)) * (4 * CO + 1) + 4 * co + (ci & 3)];
+    atomicAdd(&dw[e], sum);
+  }
+  __syncthreads();
+  // db: every lane of a row saw the same g, take lane c4 == 0 of each slot
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    if (c4 == 0) red[slot * CO + co] = dba[co];
+  }
+  __syncthreads();
+  if (threadIdx.x < CO) {
+    float sum = 0.f;
+    for (int k = 0; k < nslots; ++k) sum += red[k * CO + threadIdx.x];
+    atomicAdd(&db[threadIdx.x], sum);
+  }
+}
+
 // d loss / d pred for mean |noise - pred| or mean (noise - pred)^2, times the upstream scalar gradient
 __global__ void loss_grad_kernel(const float* __restrict__ noise, const float* __restrict__ pred, long long n, int squared,
                                  const float* __restrict__ gscale, float* __restrict__ dpred) {
@@ -282,6 +340,17 @@ extern "C" int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t
                                           int32_t T, int32_t HW, float* drows, int32_t lddr, float* dw, float* db, vmm_stream_t stream) {
   if (Cout * Cin > 4096) return -1;
   const long long nrows = (long long)B * T * HW;
+  const int tpr = Cin / 4;
+  if (Cout <= 4 && (Cin & 3) == 0 && tpr >= 1 && tpr <= 64 && (tpr & (tpr - 1)) == 0 && (ld & 3) == 0 && (lddr & 3) == 0) {
+    const int nslots = 256 / tpr;
+    const int nb = (int)max(1LL, min((long long)cdiv(nrows, nslots), 2048LL));
+    hipStream_t s = (hipStream_t)stream;
+#define VMM_PW_SMALL(CO) hipLaunchKernelGGL(pointwise_to_ncthw_bwd_small_kernel<CO>, dim3(nb), dim3(256), 0, s, rows, ld, Cin, w, dout, T, HW, drows, lddr, dw, db, nrows)
+    if (Cout == 1) VMM_PW_SMALL(1); else if (Cout == 2) VMM_PW_SMALL(2); else if (Cout == 3) VMM_PW_SMALL(3); else VMM_PW_SMALL(4);
+#undef VMM_PW_SMALL
+    VMM_LAUNCH_CHECK();
+    return 0;
+  }
   const int blocks = (int)max(1LL, min((long long)cdiv(nrows, 256), 512LL));
   const size_t shm = sizeof(float) * (2 * Cout * Cin + Cout);
   hipLaunchKernelGGL(pointwise_to_ncthw_bwd_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, rows, ld, Cin, w, dout, Cout, T, HW, drows,

@@ -239,14 +239,17 @@ __global__ __launch_bounds__(2 * NTH) void temporal_attn_bwd_kernel(const TBArgs
   for (int e = tid; e < HEADS * T * T; e += nth) part[2 * ntok * HID + e] = Bacc[e];
 }
 
-// dek / dev [B][ntok][HID] += sum over the sample's workgroups, dbias [HEADS][T][T] += sum over all workgroups
+// dek / dev [B][ntok][HID] += sum over the sample's workgroups, dbias [HEADS][T][T] += sum over all workgroups.
+// Workgroup = 16 consecutive elements x 16 slices of the partials; fixed summation order.
 __global__ __launch_bounds__(256) void temporal_attn_bwd_reduce_kernel(const float* __restrict__ part, int pstride, int bps, int B, int ntok, int T,
                                                                       float* __restrict__ dek, float* __restrict__ dev, float* __restrict__ dbias) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[16][17];
+  const int e16 = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e16;
   const int ntk = ntok * HID, ntot = B * 2 * ntk;
-  const float* src;
-  float* dst;
-  int n;
+  const float* src = nullptr;
+  float* dst = nullptr;
+  int n = 0;
   if (idx < ntot) {
     const int b = idx / (2 * ntk), e = idx - b * 2 * ntk;
     src = part + (long long)b * bps * pstride + e;
@@ -256,19 +259,24 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_reduce_kernel(const flo
     src = part + 2 * ntk + (idx - ntot);
     n = B * bps;
     dst = dbias + (idx - ntot);
-  } else {
-    return;
   }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 4 <= n; k += 4) {
+  int k = kg;
+  for (; k + 48 < n; k += 64) {
     s0 += src[(long long)k * pstride];
-    s1 += src[(long long)(k + 1) * pstride];
-    s2 += src[(long long)(k + 2) * pstride];
-    s3 += src[(long long)(k + 3) * pstride];
+    s1 += src[(long long)(k + 16) * pstride];
+    s2 += src[(long long)(k + 32) * pstride];
+    s3 += src[(long long)(k + 48) * pstride];
   }
-  for (; k < n; ++k) s0 += src[(long long)k * pstride];
-  *dst += (s0 + s1) + (s2 + s3);
+  for (; k < n; k += 16) s0 += src[(long long)k * pstride];
+  red[kg][e16] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kg == 0 && dst) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][e16];
+    *dst += t;
+  }
 }
 
 int tb_blocks_per_sample(int B, int HW) { return (int)max(1LL, min((long long)HW, cdiv(1024, B))); }
@@ -310,7 +318,7 @@ extern "C" int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const
   VMM_LAUNCH_CHECK();
   const int nred = B * 2 * ntok * HID + (bias && dbias ? HEADS * T * T : 0);
   if (nred > 0) {
-    hipLaunchKernelGGL(temporal_attn_bwd_reduce_kernel, dim3((unsigned)cdiv(nred, 256)), dim3(256), 0, s, scratch, a.pstride, a.blocks_per_sample, B, ntok,
+    hipLaunchKernelGGL(temporal_attn_bwd_reduce_kernel, dim3((unsigned)cdiv(nred, 16)), dim3(256), 0, s, scratch, a.pstride, a.blocks_per_sample, B, ntok,
                        T, dek, dev, bias ? dbias : nullptr);
     VMM_LAUNCH_CHECK();
   }

@@ -17,7 +17,7 @@ constexpr int WK = 16;  // rows per K chunk
 constexpr int WI = 64, WJ = 64;
 
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, const float* __restrict__ dy, int lddy,
-                                                        float* __restrict__ dw, long long rows_per_split) {
+                                                        float* __restrict__ dw, long long rows_per_split, float* __restrict__ bias_part) {
   __shared__ __attribute__((aligned(16))) float As[2][WK][WI];
   __shared__ __attribute__((aligned(16))) float Bs[2][WK][WJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,14 +46,15 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
   const int hw = p.Hv * p.Wv;
 
   f32x4 areg, breg;
-  auto load_chunk = [&](int kc) {
-    const long long m = m_begin + (long long)kc * WK + lr;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // column sums of this thread's dY pieces (the bias gradient, taken by the blockIdx.x == 0 tiles)
+  // (img, a, b) of this thread's row of the next chunk, advanced by WK rows per chunk without divisions
+  long long m = m_begin + lr;
+  int img = (int)(m / hw);
+  int a = (int)(m - (long long)img * hw) / p.Wv, b = (int)(m - (long long)img * hw) - a * p.Wv;
+  auto load_chunk = [&](int) {
     areg = (f32x4){0.f, 0.f, 0.f, 0.f};
     breg = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m < m_end) {
-      const int img = (int)(m / hw);
-      const int rem = (int)(m - (long long)img * hw);
-      const int a = rem / p.Wv, b = rem - a * p.Wv;
       if (ivalid) {
         const int ih = a * p.stride + dh, iw = b * p.stride + dwo;
         if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
@@ -80,10 +81,17 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
         breg = *reinterpret_cast<const f32x4*>(dy + orow * lddy + jb);
       }
     }
+    m += WK;
+    b += WK;
+    while (b >= p.Wv) {
+      b -= p.Wv;
+      if (++a == p.Hv) { a = 0; ++img; }
+    }
   };
   auto store_chunk = [&](int buf) {
     *reinterpret_cast<f32x4*>(&As[buf][lr][l4 * 4]) = areg;
     *reinterpret_cast<f32x4*>(&Bs[buf][lr][l4 * 4]) = breg;
+    bsum += breg;  // (here, not next to the load: the prefetch must stay in flight across the MFMAs)
   };
 
   f32x16 acc;
@@ -111,6 +119,17 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
     const int j = j0 + wj * 32 + l31;
     if (i < Ktot && j < p.Cout) atomicAdd(&dw[(long long)i * p.Cout + j], acc[r]);
   }
+  if (bias_part && blockIdx.x == 0) {  // (workgroup-uniform) column sums of this row slice of dY -> bias_part[slice][co]
+    float* red = &As[0][0][0];         // [16 loader rows][64 columns]; the last chunk's barrier is behind us
+    *reinterpret_cast<f32x4*>(red + lr * WJ + l4 * 4) = bsum;
+    __syncthreads();
+    if (tid < WJ && j0 + tid < p.Cout) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k * WJ + tid];
+      bias_part[(long long)blockIdx.z * p.Cout + j0 + tid] = t;
+    }
+  }
 }
 
 // column sums: out[j] += sum_m x[m, j]   (bias gradients; also per-channel reductions elsewhere)
@@ -121,11 +140,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int col4 = tid % c4n, rl = tid / c4n, rslots = 256 / c4n;
   const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (rl < rslots)
-    for (long long r = r0 + rl; r < r1; r += rslots) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + col4 * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (rl < rslots) {
+    long long r = r0 + rl;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+    for (; r + 3 * rslots < r1; r += 4 * rslots) {  // four independent loads in flight
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * ldx + col4 * 4);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (r + rslots) * ldx + col4 * 4);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(x + (r + 2 * rslots) * ldx + col4 * 4);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(x + (r + 3 * rslots) * ldx + col4 * 4);
+      s += v0; s1 += v1; s2 += v2; s3 += v3;
     }
+    for (; r < r1; r += rslots) s += *reinterpret_cast<const f32x4*>(x + r * ldx + col4 * 4);
+    s += s1; s2 += s3; s += s2;
+  }
   __shared__ f32x4 sh[256];
   sh[tid] = s;
   __syncthreads();
@@ -134,6 +161,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (int k = 0; k < rslots; ++k) { const f32x4 v = sh[k * c4n + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     atomicAdd(&out[tid * 4 + 0], t.x); atomicAdd(&out[tid * 4 + 1], t.y);
     atomicAdd(&out[tid * 4 + 2], t.z); atomicAdd(&out[tid * 4 + 3], t.w);
+  }
+}
+
+// out[c] += sum_{k < n} part[k * ld + c]: the second stage of the reductions that leave one partial row per workgroup (same-address
+// global atomics cost ~100 ns each on this part, so a thousand workgroups adding into one vector serialise for ~100 us).
+// Workgroup = 16 columns x 16 slices of k; fixed summation order.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, int ld, int C, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* src = part + c;
+    int k = kg;
+    for (; k + 48 < n; k += 64) {
+      s0 += src[(long long)k * ld];
+      s1 += src[(long long)(k + 16) * ld];
+      s2 += src[(long long)(k + 32) * ld];
+      s3 += src[(long long)(k + 48) * ld];
+    }
+    for (; k < n; k += 16) s0 += src[(long long)k * ld];
+  }
+  red[kg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kg == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][e];
+    out[c] += t;
   }
 }
 
@@ -218,16 +274,24 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
 
 }  // namespace
 
-extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit,
-                                  vmm_stream_t stream) {
+extern "C" int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream) {
+  if (n <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, n, ld, C, out);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
+                                  float* bias_scratch, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
-  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || (lddy & 3) || nsplit < 1) return -1;
+  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || (lddy & 3) || nsplit < 1 || (dbias && !bias_scratch)) return -1;
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   const int Ktot = d.KH * d.KW * (d.C1 + d.C2);
   const long long rps = (cdiv(M, nsplit) + WK - 1) / WK * WK;
   dim3 grid(cdiv(Ktot, WI), cdiv(d.Cout, WJ), cdiv(M, rps));
-  hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dy, lddy, dw_packed, rps);
+  hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dy, lddy, dw_packed, rps, dbias ? bias_scratch : nullptr);
   VMM_LAUNCH_CHECK();
+  if (dbias) return vmm_sum_partials(bias_scratch, (int)grid.z, d.Cout, d.Cout, dbias, stream);
   return 0;
 }
 

@@ -482,15 +482,21 @@ class _Builder:
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
-    def wgrad(self, d: "N.ConvDesc", dy_ptr: int, lddy: int, gw_ptr: int, what: str) -> None:
+    def wgrad(self, d: "N.ConvDesc", dy_ptr: int, lddy: int, gw_ptr: int, what: str, gb_ptr: int = 0) -> None:
+        """Weight gradient of the layer with forward descriptor d; gb_ptr: its bias gradient (column sums of dY) from the same launch."""
         if not gw_ptr:
+            if gb_ptr and d.ooh == 0 and d.oow == 0:  # (one call per layer: phase (0, 0) of a transposed convolution covers all its rows)
+                self.colsum(dy_ptr, lddy, d.nimg * d.Hout * d.Wout, d.Cout, gb_ptr, what)
             return
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
         tiles = -(-K // 64) * -(-d.Cout // 64)
         nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
-        self.step(self.lib.vmm_conv_wgrad_f32, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit), what + " wgrad", flops=2.0 * M * K * d.Cout,
+        sc = self.alloc(nsplit * d.Cout) if gb_ptr else None  # one partial row of the bias gradient per row slice
+        self.step(self.lib.vmm_conv_wgrad_f32, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit, gb_ptr or None, self.ptr(sc) if gb_ptr else None), what + " wgrad", flops=2.0 * M * K * d.Cout,
                   nbytes=4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout))
+        if gb_ptr:
+            self.tmp_free((sc, nsplit * d.Cout))
 
     def colsum(self, x_ptr: int, ldx: int, rows: int, C_: int, out_ptr: int, what: str) -> None:
         if out_ptr:
@@ -581,8 +587,7 @@ class _Builder:
             gout, _ = self.grad_of(out)  # complete by now
             srcs = [(x1, 0)] + ([(x2, x1.C)] if x2 is not None else [])
             if has_res:  # residual branch through the 1x1 conv
-                self.wgrad(dr, gout.ptr, Cout, gwr, name + ".res_conv")
-                self.colsum(gout.ptr, Cout, rows, Cout, self.pg(name + ".res_conv.bias"), name + ".res_conv")
+                self.wgrad(dr, gout.ptr, Cout, gwr, name + ".res_conv", gb_ptr=self.pg(name + ".res_conv.bias"))
                 for xs, c0 in srcs:
                     gx, acc = self.grad_of(xs)
                     self.dgrad_1x1(name + ".res_conv.weight", c0, xs.C, name + ".res_conv dgrad", a1=gout, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
@@ -592,14 +597,12 @@ class _Builder:
             # main branch: GN2+SiLU, conv2, GN1+FiLM+SiLU, conv1
             dh2 = self.act(Cout, H, W)
             self.gn_bwd(name + ".block2", gout.ptr, h2, c2_ptr, st2, 0, 0, dh2.ptr, 0)
-            self.wgrad(d2, dh2.ptr, Cout, gw2, name + ".block2.proj")
-            self.colsum(dh2.ptr, Cout, rows, Cout, self.pg(name + ".block2.proj.bias"), name + ".block2.proj")
+            self.wgrad(d2, dh2.ptr, Cout, gw2, name + ".block2.proj", gb_ptr=self.pg(name + ".block2.proj.bias"))
             da1 = self.act(Cout, H, W)
             self.dgrad_3x3(name + ".block2.proj.weight", 0, Cout, name + ".block2.proj dgrad", a1=dh2, out_ptr=da1.ptr, ldo=Cout, Hv=H, Wv=W)
             self.tmp_free(dh2)
             self.gn_bwd(name + ".block1", da1.ptr, h1, c1_ptr, st1, film_ptr, 2 * Cout, da1.ptr, dfilm_ptr)  # in place: dh1 overwrites da1
-            self.wgrad(d1, da1.ptr, Cout, gw1, name + ".block1.proj")
-            self.colsum(da1.ptr, Cout, rows, Cout, self.pg(name + ".block1.proj.bias"), name + ".block1.proj")
+            self.wgrad(d1, da1.ptr, Cout, gw1, name + ".block1.proj", gb_ptr=self.pg(name + ".block1.proj.bias"))
             for xs, c0 in srcs:
                 gx, acc = self.grad_of(xs)
                 self.dgrad_3x3(name + ".block1.proj.weight", c0, xs.C, name + ".block1.proj dgrad", a1=da1, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
@@ -618,8 +621,10 @@ class _Builder:
         gx, acc = self.grad_of(x)
         rows = self.B * self.T * x.H * x.W
         gg = self.pg(gamma_name) or self.scratch(x.C)
-        self.step(self.lib.vmm_channel_layernorm_bwd, (x.ptr, x.ld, self.wraw(gamma_name), dy_ptr, x.C, gx.ptr, x.C, acc, gg, rows, x.C, C.c_float(1e-5)),
-                  gamma_name + " bwd", nbytes=16.0 * x.n)
+        sc = self.alloc(2048 * x.C)  # VMM_LN_BWD_MAX_BLOCKS partial rows of dgamma
+        self.step(self.lib.vmm_channel_layernorm_bwd, (x.ptr, x.ld, self.wraw(gamma_name), dy_ptr, x.C, gx.ptr, x.C, acc, gg, rows, x.C, C.c_float(1e-5),
+                                                       self.ptr(sc)), gamma_name + " bwd", nbytes=16.0 * x.n)
+        self.tmp_free((sc, 2048 * x.C))
 
     def token_kv_bwd(self, site: str) -> None:
         """d(ek), d(ev) of one attention site -> dense backward jobs (collected, launched with the embedding backward)."""
@@ -686,8 +691,7 @@ class _Builder:
         def bwd():
             gout, _ = self.grad_of(out)
             self.add_into(x, gout.ptr)  # residual
-            self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
-            self.colsum(gout.ptr, x.C, rows, x.C, self.pg(name + ".fn.fn.to_out.bias"), name + " to_out")
+            self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out", gb_ptr=self.pg(name + ".fn.fn.to_out.bias"))
             go = self.act(hid, x.H, x.W)
             self.dgrad_1x1(name + ".fn.fn.to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
             gqkv = self.act(3 * hid, x.H, x.W)
@@ -1032,8 +1036,7 @@ class _Builder:
 
         def init_bwd():
             g0, _ = self.grad_of(x0)
-            self.wgrad(dinit, g0.ptr, m.init_dim, gwi, "init_conv")
-            self.colsum(g0.ptr, m.init_dim, rows0, m.init_dim, self.pg("init_conv.bias"), "init_conv")
+            self.wgrad(dinit, g0.ptr, m.init_dim, gwi, "init_conv", gb_ptr=self.pg("init_conv.bias"))
         self.on_backward(init_bwd, pg_start, uj_start)
         x_new = self.softmax_attn_block("init_temporal_attn", x, None, temporal=True)
         self.free_act(x)
@@ -1075,8 +1078,7 @@ class _Builder:
 
                 def down_bwd(nm=nm, xs=xs, d=d, dd=dd, gwd=gwd):
                     gd, _ = self.grad_of(d)
-                    self.wgrad(dd, gd.ptr, xs.C, gwd, nm)
-                    self.colsum(gd.ptr, xs.C, B * T * d.H * d.W, xs.C, self.pg(nm + ".bias"), nm)
+                    self.wgrad(dd, gd.ptr, xs.C, gwd, nm, gb_ptr=self.pg(nm + ".bias"))
                     gx, acc = self.grad_of(xs)
                     co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
                     for ph in range(2):
@@ -1125,9 +1127,8 @@ class _Builder:
 
                 def up_bwd(nm=nm, xs=xs, u=u, phases=phases, ci_=ci_, co_=co_):
                     gu, _ = self.grad_of(u)
-                    for du, gwp in phases:
-                        self.wgrad(du, gu.ptr, co_, gwp, nm)
-                    self.colsum(gu.ptr, co_, B * T * u.H * u.W, co_, self.pg(nm + ".bias"), nm)
+                    for du, gwp in phases:  # every output row belongs to exactly one phase: the four launches together give the bias gradient
+                        self.wgrad(du, gu.ptr, co_, gwp, nm, gb_ptr=self.pg(nm + ".bias"))
                     gx, acc = self.grad_of(xs)
                     # dX[a][ci] = sum_{kh,kw,co} dU[2a-1+kh][co] W[ci][co][kh][kw]: a stride-2 conv over dU with [(kh,kw,co)][ci]
                     wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1, hs=1, ws=1)[0]
