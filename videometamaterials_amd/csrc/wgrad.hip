@@ -13,15 +13,21 @@
 
 namespace {
 
-constexpr int WK = 16;  // rows per K chunk
-constexpr int WI = 64, WJ = 64;
+constexpr int WK = 16;  // rows per K chunk (a multiple of 16: the loader walks groups of 16 rows)
 
+// Workgroup tile = (64 AI) x (64 AJ) of dWp, 2 x 2 waves of (32 AI) x (32 AJ) each.  Measured on the Lagrangian training step (MI355X):
+// 64 x 64 tiles with 16-row chunks (6 waves / SIMD) 18.6 ms, 128-wide tiles 19.8 ms, 128 x 128 with 32-row chunks 22.9 ms -- the
+// kernel is bound by the latency of its gathered loads, which more resident waves hide better than more MFMAs per wave do; the host
+// therefore launches <1, 1>.
+template <int AI, int AJ>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dw, long long rows_per_split, float* __restrict__ bias_part) {
-  __shared__ __attribute__((aligned(16))) float As[2][WK][WI];
-  __shared__ __attribute__((aligned(16))) float Bs[2][WK][WJ];
+  constexpr int WI = 64 * AI, WJ = 64 * AJ;
+  // rows padded by 32 floats: the two lane halves of an operand read (rows kk and kk + 1, same columns) land in different bank halves
+  __shared__ __attribute__((aligned(16))) float As[2][WK][WI + 32];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WK][WJ + 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const int wi = wave >> 1, wj = wave & 1;
   const int Cin = p.C1 + p.C2;
   const int Ktot = p.KH * p.KW * Cin;
   const int i0 = blockIdx.x * WI, j0 = blockIdx.y * WJ;
@@ -31,103 +37,145 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
   if (m_begin >= m_end) return;
   const int nk = (int)((m_end - m_begin + WK - 1) / WK);
 
-  // loader roles: 16 rows x 16 float4 for both tiles
+  // loader roles: 16 rows x 16 float4 per 64 columns of either tile
   const int lr = tid >> 4, l4 = tid & 15;
-  // A column (tap, ci) of this thread is fixed
-  const int ia = i0 + l4 * 4;
-  const bool ivalid = ia < Ktot;
-  int tap = ivalid ? ia / Cin : 0;
-  const int ci = ia - tap * Cin;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int dh = p.off_h + p.sgn_h * kh, dwo = p.off_w + p.sgn_w * kw;
-  const int jb = j0 + l4 * 4;
-  const bool jvalid = jb < p.Cout;
+  // the A columns (tap, ci) of this thread are fixed
+  bool ivalid[AI];
+  int ci[AI], dh[AI], dwo[AI];
+#pragma unroll
+  for (int u = 0; u < AI; ++u) {
+    const int ia = i0 + u * 64 + l4 * 4;
+    ivalid[u] = ia < Ktot;
+    const int tap = ivalid[u] ? ia / Cin : 0;
+    ci[u] = ia - tap * Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    dh[u] = p.off_h + p.sgn_h * kh;
+    dwo[u] = p.off_w + p.sgn_w * kw;
+  }
   const bool identity_rows = (p.oscale == 1 && p.Hout == p.Hv && p.Wout == p.Wv && p.ooh == 0 && p.oow == 0);
   const int hw = p.Hv * p.Wv;
 
-  f32x4 areg, breg;
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // column sums of this thread's dY pieces (the bias gradient, taken by the blockIdx.x == 0 tiles)
+  constexpr int NG = WK / 16;  // row groups per chunk (rows lr, lr + 16, ...)
+  f32x4 areg[NG][AI], breg[NG][AJ];
+  f32x4 bsum[AJ];  // column sums of this thread's dY pieces (the bias gradient, taken by the blockIdx.x == 0 tiles)
+#pragma unroll
+  for (int v = 0; v < AJ; ++v) bsum[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // (img, a, b) of this thread's row of the next chunk, advanced by WK rows per chunk without divisions
   long long m = m_begin + lr;
   int img = (int)(m / hw);
   int a = (int)(m - (long long)img * hw) / p.Wv, b = (int)(m - (long long)img * hw) - a * p.Wv;
-  auto load_chunk = [&](int) {
-    areg = (f32x4){0.f, 0.f, 0.f, 0.f};
-    breg = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto load_rows = [&](f32x4 (&areg)[AI], f32x4 (&breg)[AJ]) {
+#pragma unroll
+    for (int u = 0; u < AI; ++u) areg[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < AJ; ++v) breg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m < m_end) {
-      if (ivalid) {
-        const int ih = a * p.stride + dh, iw = b * p.stride + dwo;
+#pragma unroll
+      for (int u = 0; u < AI; ++u) {
+        if (!ivalid[u]) continue;
+        const int ih = a * p.stride + dh[u], iw = b * p.stride + dwo[u];
         if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
           const long long pix = ((long long)img * p.Hin + ih) * p.Win + iw;
-          if (ci < p.C1) {
-            areg = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci);
+          if (ci[u] < p.C1) {
+            areg[u] = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci[u]);
             if (p.a_mode == 1) {
-              const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + ci) * 2;
+              const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + ci[u]) * 2;
               const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
               const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
-              areg.x = silu_f(areg.x * c0.x + c0.y);
-              areg.y = silu_f(areg.y * c0.z + c0.w);
-              areg.z = silu_f(areg.z * c1.x + c1.y);
-              areg.w = silu_f(areg.w * c1.z + c1.w);
+              areg[u].x = silu_f(areg[u].x * c0.x + c0.y);
+              areg[u].y = silu_f(areg[u].y * c0.z + c0.w);
+              areg[u].z = silu_f(areg[u].z * c1.x + c1.y);
+              areg[u].w = silu_f(areg[u].w * c1.z + c1.w);
             }
           } else {
-            areg = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci - p.C1));
+            areg[u] = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci[u] - p.C1));
           }
         }
       }
-      if (jvalid) {
-        long long orow = m;
-        if (!identity_rows) orow = ((long long)img * p.Hout + a * p.oscale + p.ooh) * p.Wout + b * p.oscale + p.oow;
-        breg = *reinterpret_cast<const f32x4*>(dy + orow * lddy + jb);
+      long long orow = m;
+      if (!identity_rows) orow = ((long long)img * p.Hout + a * p.oscale + p.ooh) * p.Wout + b * p.oscale + p.oow;
+#pragma unroll
+      for (int v = 0; v < AJ; ++v) {
+        const int jb = j0 + v * 64 + l4 * 4;
+        if (jb < p.Cout) breg[v] = *reinterpret_cast<const f32x4*>(dy + orow * lddy + jb);
       }
     }
-    m += WK;
-    b += WK;
+    m += 16;
+    b += 16;
     while (b >= p.Wv) {
       b -= p.Wv;
       if (++a == p.Hv) { a = 0; ++img; }
     }
   };
+  auto load_chunk = [&]() {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_rows(areg[g], breg[g]);
+  };
   auto store_chunk = [&](int buf) {
-    *reinterpret_cast<f32x4*>(&As[buf][lr][l4 * 4]) = areg;
-    *reinterpret_cast<f32x4*>(&Bs[buf][lr][l4 * 4]) = breg;
-    bsum += breg;  // (here, not next to the load: the prefetch must stay in flight across the MFMAs)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int u = 0; u < AI; ++u) *reinterpret_cast<f32x4*>(&As[buf][g * 16 + lr][u * 64 + l4 * 4]) = areg[g][u];
+#pragma unroll
+      for (int v = 0; v < AJ; ++v) {
+        *reinterpret_cast<f32x4*>(&Bs[buf][g * 16 + lr][v * 64 + l4 * 4]) = breg[g][v];
+        bsum[v] += breg[g][v];  // (here, not next to the load: the prefetch must stay in flight across the MFMAs)
+      }
+    }
   };
 
-  f32x16 acc;
+  f32x16 acc[AI][AJ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  load_chunk(0);
+  for (int u = 0; u < AI; ++u)
+#pragma unroll
+    for (int v = 0; v < AJ; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+  load_chunk();
   store_chunk(0);
   __syncthreads();
   const int l31 = lane & 31, lk = lane >> 5;
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
-    if (kc + 1 < nk) load_chunk(kc + 1);
+    if (kc + 1 < nk) load_chunk();
 #pragma unroll
     for (int kk = 0; kk < WK; kk += 2) {
-      const float av = As[buf][kk + lk][wi * 32 + l31];
-      const float bv = Bs[buf][kk + lk][wj * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      float av[AI], bv[AJ];
+#pragma unroll
+      for (int u = 0; u < AI; ++u) av[u] = As[buf][kk + lk][(wi * AI + u) * 32 + l31];
+#pragma unroll
+      for (int v = 0; v < AJ; ++v) bv[v] = Bs[buf][kk + lk][(wj * AJ + v) * 32 + l31];
+#pragma unroll
+      for (int u = 0; u < AI; ++u)
+#pragma unroll
+        for (int v = 0; v < AJ; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[v], acc[u][v], 0, 0, 0);
     }
     if (kc + 1 < nk) store_chunk(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-    const int j = j0 + wj * 32 + l31;
-    if (i < Ktot && j < p.Cout) atomicAdd(&dw[(long long)i * p.Cout + j], acc[r]);
-  }
-  if (bias_part && blockIdx.x == 0) {  // (workgroup-uniform) column sums of this row slice of dY -> bias_part[slice][co]
-    float* red = &As[0][0][0];         // [16 loader rows][64 columns]; the last chunk's barrier is behind us
-    *reinterpret_cast<f32x4*>(red + lr * WJ + l4 * 4) = bsum;
-    __syncthreads();
-    if (tid < WJ && j0 + tid < p.Cout) {
-      float t = 0.f;
+  for (int u = 0; u < AI; ++u)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k * WJ + tid];
-      bias_part[(long long)blockIdx.z * p.Cout + j0 + tid] = t;
+    for (int v = 0; v < AJ; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (wi * AI + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int j = j0 + (wj * AJ + v) * 32 + l31;
+        if (i < Ktot && j < p.Cout) atomicAdd(&dw[(long long)i * p.Cout + j], acc[u][v][r]);
+      }
+  if (bias_part && blockIdx.x == 0) {  // (workgroup-uniform) column sums of this row slice of dY -> bias_part[slice][co]
+    float* red = &As[0][0][0];         // [16 loader rows][64 columns] per 64-column group; the last chunk's barrier is behind us
+#pragma unroll
+    for (int v = 0; v < AJ; ++v) {
+      if (v) __syncthreads();
+      *reinterpret_cast<f32x4*>(red + lr * 64 + l4 * 4) = bsum[v];
+      __syncthreads();
+      if (tid < 64 && j0 + v * 64 + tid < p.Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 64 + tid];
+        bias_part[(long long)blockIdx.z * p.Cout + j0 + v * 64 + tid] = t;
+      }
     }
   }
 }
@@ -288,8 +336,14 @@ extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int3
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   const int Ktot = d.KH * d.KW * (d.C1 + d.C2);
   const long long rps = (cdiv(M, nsplit) + WK - 1) / WK * WK;
-  dim3 grid(cdiv(Ktot, WI), cdiv(d.Cout, WJ), cdiv(M, rps));
-  hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dy, lddy, dw_packed, rps, dbias ? bias_scratch : nullptr);
+  const int ai = 1, aj = 1;  // (see the note at the kernel)
+  dim3 grid(cdiv(Ktot, 64 * ai), cdiv(d.Cout, 64 * aj), cdiv(M, rps));
+  float* bp = dbias ? bias_scratch : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (ai == 2 && aj == 2) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2>), grid, dim3(256), 0, s, d, dy, lddy, dw_packed, rps, bp);
+  else if (ai == 2) hipLaunchKernelGGL((wgrad_f32_kernel<2, 1>), grid, dim3(256), 0, s, d, dy, lddy, dw_packed, rps, bp);
+  else if (aj == 2) hipLaunchKernelGGL((wgrad_f32_kernel<1, 2>), grid, dim3(256), 0, s, d, dy, lddy, dw_packed, rps, bp);
+  else hipLaunchKernelGGL((wgrad_f32_kernel<1, 1>), grid, dim3(256), 0, s, d, dy, lddy, dw_packed, rps, bp);
   VMM_LAUNCH_CHECK();
   if (dbias) return vmm_sum_partials(bias_scratch, (int)grid.z, d.Cout, d.Cout, dbias, stream);
   return 0;

@@ -490,7 +490,7 @@ class _Builder:
             return
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
-        tiles = -(-K // 64) * -(-d.Cout // 64)
+        tiles = -(-K // 64) * -(-d.Cout // 64)  # 64 x 64 workgroup tiles of vmm_conv_wgrad_f32
         nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
         sc = self.alloc(nsplit * d.Cout) if gb_ptr else None  # one partial row of the bias gradient per row slice
         self.step(self.lib.vmm_conv_wgrad_f32, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit, gb_ptr or None, self.ptr(sc) if gb_ptr else None), what + " wgrad", flops=2.0 * M * K * d.Cout,
