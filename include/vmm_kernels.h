@@ -91,6 +91,10 @@ int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vm
  * from the dY tiles the kernel stages anyway: one partial row per row slice in bias_scratch [nsplit][Cout], then vmm_sum_partials). */
 int vmm_conv_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
                        float* bias_scratch, vmm_stream_t stream);
+/* the same contraction with split-bf16 (hi + lo) operands on the bf16 matrix cores, three passes per product: the "bf16x3" training
+ * mode's weight gradient; same alignment requirements */
+int vmm_conv_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
+                          float* bias_scratch, vmm_stream_t stream);
 /* out[c] += sum_{k < n} part[k * ld + c], fixed order: second stage of the reductions that leave one partial row per workgroup */
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */

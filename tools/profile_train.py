@@ -20,4 +20,6 @@ torch.manual_seed(0)
 model = vm.Unet3D(**bench.LAGRANGIAN).to(dev)
 diff = vm.GaussianDiffusion(model, image_size=bench.HW, num_frames=bench.T, channels=3, timesteps=bench.TIMESTEPS, loss_type="l1",
                             use_dynamic_thres=True, sampling_timesteps=bench.TIMESTEPS).to(dev)
+if os.environ.get("VMM_X3_WGRAD"):
+    model.use_x3_wgrad = True  # opt-in split-bf16 weight-gradient kernel (default: the exact-fp32 one in both modes)
 print(bench.bench_training(vm, model, diff, dev, None, 1, 0, steps, precision))

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
   long long m = m_begin + lr;
   int img = (int)(m / hw);
   int a = (int)(m - (long long)img * hw) / p.Wv, b = (int)(m - (long long)img * hw) - a * p.Wv;
-  auto load_rows = [&](f32x4 (&areg)[AI], f32x4 (&breg)[AJ]) {
+  // fused GroupNorm + SiLU of the producer: applied in store_chunk, not next to the load (the prefetch must stay in flight across the MFMAs)
+  f32x4 fc0[NG][AI], fc1[NG][AI];
+  unsigned fmask = 0;
+  auto load_rows = [&](f32x4 (&areg)[AI], f32x4 (&breg)[AJ], int g) {
 #pragma unroll
     for (int u = 0; u < AI; ++u) areg[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -78,14 +81,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
           const long long pix = ((long long)img * p.Hin + ih) * p.Win + iw;
           if (ci[u] < p.C1) {
             areg[u] = *reinterpret_cast<const f32x4*>(p.a1 + pix * p.lda1 + ci[u]);
-            if (p.a_mode == 1) {
+            if (p.a_mode == 1) {  // coefficients fetched with the row, applied when it is consumed (store_chunk)
               const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + ci[u]) * 2;
-              const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
-              const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
-              areg[u].x = silu_f(areg[u].x * c0.x + c0.y);
-              areg[u].y = silu_f(areg[u].y * c0.z + c0.w);
-              areg[u].z = silu_f(areg[u].z * c1.x + c1.y);
-              areg[u].w = silu_f(areg[u].w * c1.z + c1.w);
+              fc0[g][u] = *reinterpret_cast<const f32x4*>(cf);
+              fc1[g][u] = *reinterpret_cast<const f32x4*>(cf + 4);
+              fmask |= 1u << (g * AI + u);
             }
           } else {
             areg[u] = *reinterpret_cast<const f32x4*>(p.a2 + pix * p.lda2 + (ci[u] - p.C1));
@@ -108,14 +108,24 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
     }
   };
   auto load_chunk = [&]() {
+    fmask = 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) load_rows(areg[g], breg[g]);
+    for (int g = 0; g < NG; ++g) load_rows(areg[g], breg[g], g);
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int u = 0; u < AI; ++u) *reinterpret_cast<f32x4*>(&As[buf][g * 16 + lr][u * 64 + l4 * 4]) = areg[g][u];
+      for (int u = 0; u < AI; ++u) {
+        if (fmask >> (g * AI + u) & 1) {
+          const f32x4 c0 = fc0[g][u], c1 = fc1[g][u];
+          areg[g][u].x = silu_f(areg[g][u].x * c0.x + c0.y);
+          areg[g][u].y = silu_f(areg[g][u].y * c0.z + c0.w);
+          areg[g][u].z = silu_f(areg[g][u].z * c1.x + c1.y);
+          areg[g][u].w = silu_f(areg[g][u].w * c1.z + c1.w);
+        }
+        *reinterpret_cast<f32x4*>(&As[buf][g * 16 + lr][u * 64 + l4 * 4]) = areg[g][u];
+      }
 #pragma unroll
       for (int v = 0; v < AJ; ++v) {
         *reinterpret_cast<f32x4*>(&Bs[buf][g * 16 + lr][v * 64 + l4 * 4]) = breg[g][v];

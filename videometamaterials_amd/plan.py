@@ -490,10 +490,16 @@ class _Builder:
             return
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
-        tiles = -(-K // 64) * -(-d.Cout // 64)  # 64 x 64 workgroup tiles of vmm_conv_wgrad_f32
-        nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
+        if self.x3 and getattr(self.m, "use_x3_wgrad", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
+            fn = self.lib.vmm_conv_wgrad_bf16x3
+            tiles = -(-K // 128) * -(-d.Cout // 128)
+            nsplit = max(1, min(-(-1024 // tiles), max(1, M // 512)))
+        else:                                                  # 64 x 64 workgroup tiles, exact fp32
+            fn = self.lib.vmm_conv_wgrad_f32
+            tiles = -(-K // 64) * -(-d.Cout // 64)
+            nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
         sc = self.alloc(nsplit * d.Cout) if gb_ptr else None  # one partial row of the bias gradient per row slice
-        self.step(self.lib.vmm_conv_wgrad_f32, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit, gb_ptr or None, self.ptr(sc) if gb_ptr else None), what + " wgrad", flops=2.0 * M * K * d.Cout,
+        self.step(fn, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit, gb_ptr or None, self.ptr(sc) if gb_ptr else None), what + " wgrad", flops=2.0 * M * K * d.Cout,
                   nbytes=4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout))
         if gb_ptr:
             self.tmp_free((sc, nsplit * d.Cout))
