@@ -372,7 +372,9 @@ extern "C" int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, 
 
 extern "C" int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream) {
   if (njobs <= 0) return 0;
-  const int bx = (int)max(1LL, min((long long)cdiv(max_elems, 256 * 4), 64LL));
+  // few jobs (the per-bucket gradient scatters of the backward pass): more workgroups per job so that the launch still fills the chip
+  const long long cap = max(64LL, 2048LL / njobs);
+  const int bx = (int)max(1LL, min((long long)cdiv(max_elems, 256 * 4), cap));
   hipLaunchKernelGGL(pack_kernel, dim3(bx, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, direction);
   VMM_LAUNCH_CHECK();
   return 0;
