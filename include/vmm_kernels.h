@@ -144,6 +144,11 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
                            const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
                            int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
                            vmm_stream_t stream);
+/* the path vmm_temporal_attention takes where it applies (heads = 8, dh = 32, T <= 16, ntok <= 16; returns 1 and launches nothing
+ * otherwise): one workgroup per pixel, the T rows of k | v staged once in LDS */
+int vmm_temporal_attention_staged(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,
+                                  int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads,
+                                  int32_t dh, float* lse, vmm_stream_t stream);
 
 /* Temporal attention core + to_out + residual for the levels whose to_qkv is a separate projection (C = 128, 256, 512;
  * vddp.py:491-534, 421): out = x + to_out(attention(q, [ek|k], [ev|v])) with the scores and the value mix on the split-bf16 matrix

@@ -279,6 +279,10 @@ extern "C" int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const flo
                                       int32_t HW, int32_t heads, int32_t dh, float* lse, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
   if (bias_on_cond && ek && ntok != T) return -2;  // the reference's in-place add needs tokens == frames
+  {  // LDS-staged workgroup-per-pixel kernel (temporal_attn_fwd.hip) where it applies
+    const int rc = vmm_temporal_attention_staged(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, ldo, B, T, HW, heads, dh, lse, stream);
+    if (rc != 1) return rc;
+  }
   const long long total = (long long)B * HW * heads * T;
   hipLaunchKernelGGL(temporal_attn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, ldqkv, ek, ev, ntok,
                      bias, bias_on_cond, out, ldo, B, T, HW, heads, lse);
