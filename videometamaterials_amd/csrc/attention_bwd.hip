@@ -203,6 +203,67 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, const floa
   if (bias && dbias && (!is_tok || g.bias_on_cond) && lane < n) atomicAdd(&dbias[((long long)head * n + lane) * n + (is_tok ? j : jj)], bias_acc);
 }
 
+// ---------------------------------------------------------------- pass B for the mid spatial attention (mode 1, HW <= 256 keys per frame)
+// The generic pass B maps lanes to the inner index, which here is the frame (T = 11 of 64 lanes busy, one wave per key).  This
+// one takes a workgroup per (sample, frame, head): q, dO, logsumexp and D of the frame's HW queries are staged once in LDS, thread j
+// = key j (thread HW = the frame's conditioning token) sweeps the queries with its k_j / v_j in registers.
+__global__ __launch_bounds__(256) void spatial_attn_bwd_kv_kernel(AttnGeom g, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
+                                                                  const float* __restrict__ ev, const float* __restrict__ dO, int ldo,
+                                                                  const float* __restrict__ lse, const float* __restrict__ Dbuf,
+                                                                  float* __restrict__ dqkv, float* __restrict__ dek, float* __restrict__ dev) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // Q[HW][32] | G[HW][32] | L[HW] | D[HW]
+  const int HW = g.HW, hid = g.heads * DH;
+  float* Qs = sm;
+  float* Gs = Qs + HW * DH;
+  float* Ls = Gs + HW * DH;
+  float* Dsh = Ls + HW;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % g.heads;
+  const int bt = blockIdx.x / g.heads, t = bt % g.T, b = bt / g.T;
+  const long long row0 = (long long)bt * HW;
+  for (int e = tid; e < HW * (DH / 4); e += 256) {
+    const int r = e >> 3, c = (e & 7) * 4;
+    *reinterpret_cast<f32x4*>(Qs + r * DH + c) = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ldqkv + head * DH + c);
+    *reinterpret_cast<f32x4*>(Gs + r * DH + c) = *reinterpret_cast<const f32x4*>(dO + (row0 + r) * ldo + head * DH + c);
+  }
+  for (int r = tid; r < HW; r += 256) {
+    Ls[r] = lse[(row0 + r) * g.heads + head];
+    Dsh[r] = Dbuf[(row0 + r) * g.heads + head];
+  }
+  __syncthreads();
+  const bool is_tok = tid == HW && g.ntok > 0;
+  if (tid >= HW && !is_tok) return;
+  float kk[DH], vv[DH], dk[DH], dv[DH];
+  if (is_tok) {
+    ld32(kk, ek + ((long long)b * g.ntok + t) * hid + head * DH);
+    ld32(vv, ev + ((long long)b * g.ntok + t) * hid + head * DH);
+  } else {
+    ld32(kk, qkv + (row0 + tid) * ldqkv + hid + head * DH);
+    ld32(vv, qkv + (row0 + tid) * ldqkv + 2 * hid + head * DH);
+  }
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int i = 0; i < HW; ++i) {
+    float q[DH], go[DH];
+    ld32(q, Qs + i * DH);  // (uniform address: LDS broadcast)
+    ld32(go, Gs + i * DH);
+    const float p = __expf(dot32r(q, kk) - Ls[i]);
+    const float ds = p * (dot32r(go, vv) - Dsh[i]);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { dk[d] = fmaf(ds, q[d], dk[d]); dv[d] = fmaf(p, go[d], dv[d]); }
+  }
+  if (is_tok) {  // one writer per (sample, frame, head)
+    float* kd = dek + ((long long)b * g.ntok + t) * hid + head * DH;
+    float* vd = dev + ((long long)b * g.ntok + t) * hid + head * DH;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { kd[d] += dk[d]; vd[d] += dv[d]; }
+  } else {
+    float* o = dqkv + (row0 + tid) * ldqkv + head * DH;
+    st32(o + hid, dk);
+    st32(o + 2 * hid, dv);
+  }
+}
+
 // ================================================================ linear attention backward
 // forward: kt = softmax_n(k), ctx[d,e] = sum_n kt[d,n] v[e,n] / HW, qt = softmax_d(q)*scale, out[n,e] = sum_d ctx[d,e] qt[n,d]
 // dctx[d,e] = sum_n qt[n,d] dout[n,e]                                       (kernel 1, reduction over rows, atomics)
@@ -391,6 +452,18 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, out, dout, ldo, lse, rot_tab, q_scale,
                      dqkv, dbuf);
   VMM_LAUNCH_CHECK();
+  if (mode == 1 && HW < 256 && !bias && !rot_tab && (g.ntok == 0 || (tok_per_frame && g.ntok == T))) {  // mid spatial attention
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+    }
+    const size_t shm = sizeof(float) * (size_t)HW * (2 * DH + 2);
+    hipLaunchKernelGGL(spatial_attn_bwd_kv_kernel, dim3((unsigned)(B * T * heads)), dim3(256), shm, s, g, qkv, ldqkv, ek, ev, dout, ldo, lse, dbuf, dqkv, dek,
+                       dev);
+    VMM_LAUNCH_CHECK();
+    return 0;
+  }
   const int nchunks = (ninner + 63) / 64, ngroups = (nchunks + CHUNKS_PER_WAVE - 1) / CHUNKS_PER_WAVE;
   const long long nwaves = (long long)B * heads * (g.ntok + n) * ngroups;
   hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, dout, ldo, lse, dbuf, rot_tab, dqkv,
