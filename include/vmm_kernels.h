@@ -296,6 +296,10 @@ int64_t vmm_attention_bwd_scratch(int32_t mode, int32_t B, int32_t T, int32_t HW
 int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* ctx,
                     const float* kstat, const float* dout, int32_t lddo, float* dctx /* [B*T*heads][32*32] scratch */, float* dqkv,
                     float* dek, float* dev, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* row pass of vmm_linattn_bwd on the fp32 matrix cores (heads % 4 == 0; returns 1 and launches nothing otherwise): dqkv rows from the
+ * saved qkv, dout, the frame's ctx / dctx [frames*heads][32*32] and kstat */
+int vmm_linattn_bwd_rows_mfma(const float* qkv, int32_t ldqkv, const float* dout, int32_t lddo, const float* ctx, const float* dctx,
+                              const float* kstat, float* dqkv, int32_t frames, int32_t HW, int32_t heads, float scale, vmm_stream_t stream);
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
 typedef struct vmm_dense_bwd_job {
   const float* x; const float* w; const float* b; float* dy; float* dx; float* dw; float* db;

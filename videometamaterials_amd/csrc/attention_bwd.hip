@@ -486,12 +486,17 @@ extern "C" int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek,
   const int rps = cdiv(cdiv(HW, nsplit), LB_TILE) * LB_TILE;
   hipLaunchKernelGGL(linattn_bwd_dctx_kernel, dim3(cdiv(HW, rps), nfh), dim3(256), 0, s, qkv, ldqkv, dout, lddo, HW, heads, rps, scale, dctx);
   VMM_LAUNCH_CHECK();
+  // row pass: fp32 matrix-core kernel (linattn_bwd_rows.hip) where it applies, else the thread-per-(row, head) kernel below
+  int rc_rows = vmm_linattn_bwd_rows_mfma(qkv, ldqkv, dout, lddo, ctx, dctx, kstat, dqkv, B * T, HW, heads, scale, stream);
+  if (rc_rows < 0 || rc_rows > 1) return rc_rows;
   const int hpb = (heads % 4 == 0) ? 4 : ((heads % 2 == 0) ? 2 : 1);
   const int rows_per_block = 256 / hpb;
   const size_t shm = sizeof(float) * (2 * hpb * (DH * DH + 4) + hpb * DH);
-  hipLaunchKernelGGL(linattn_bwd_rows_kernel, dim3(cdiv(HW, rows_per_block), B * T, heads / hpb), dim3(256), shm, s, qkv, ldqkv, dout, lddo, ctx, dctx,
-                     kstat, HW, heads, hpb, scale, dqkv);
-  VMM_LAUNCH_CHECK();
+  if (rc_rows == 1) {
+    hipLaunchKernelGGL(linattn_bwd_rows_kernel, dim3(cdiv(HW, rows_per_block), B * T, heads / hpb), dim3(256), shm, s, qkv, ldqkv, dout, lddo, ctx, dctx,
+                       kstat, HW, heads, hpb, scale, dqkv);
+    VMM_LAUNCH_CHECK();
+  }
   if (ek && ntok > 0) {
     const long long tot = (long long)nfh * ntok * DH;
     hipLaunchKernelGGL(linattn_bwd_tokens_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, s, ek, ev, ntok, ctx, dctx, kstat, T, HW, heads, nfh, dek, dev);
