@@ -17,6 +17,13 @@
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
+#include <cstdlib>
+
+// the matrix-core version (temporal_attn_bwd_mfma.hip); same partial-buffer layout, reduced by the kernel at the end of this file
+int vmm_temporal_attention_bwd_mfma_launch(const float* qkv, int ldqkv, const float* ek, const float* ev, int ntok, const float* bias, int bias_on_cond,
+                                           const float* out, const float* dout, int ldo, const float* lse, const float* rot_tab, float q_scale,
+                                           float* dqkv, float* scratch, int B, int T, int HW, int blocks_per_sample, int pstride, hipStream_t s);
+
 namespace {
 constexpr int DH = 32, HEADS = 8, HID = HEADS * DH, NTH = HEADS * 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -314,8 +321,15 @@ extern "C" int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(temporal_attn_bwd_kernel, dim3((unsigned)(B * a.blocks_per_sample)), dim3(ntok > 0 ? 2 * NTH : NTH), shm, s, a);
-  VMM_LAUNCH_CHECK();
+  static const bool use_valu = getenv("VMM_TEMPORAL_BWD_VALU") != nullptr;  // A/B switch: the VALU / LDS kernel of this file
+  if (!use_valu) {
+    const int rc = vmm_temporal_attention_bwd_mfma_launch(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, dout, ldo, lse, rot_tab, q_scale, dqkv, scratch,
+                                                          B, T, HW, a.blocks_per_sample, a.pstride, s);
+    if (rc != 0) return rc;
+  } else {
+    hipLaunchKernelGGL(temporal_attn_bwd_kernel, dim3((unsigned)(B * a.blocks_per_sample)), dim3(ntok > 0 ? 2 * NTH : NTH), shm, s, a);
+    VMM_LAUNCH_CHECK();
+  }
   const int nred = B * 2 * ntok * HID + (bias && dbias ? HEADS * T * T : 0);
   if (nred > 0) {
     hipLaunchKernelGGL(temporal_attn_bwd_reduce_kernel, dim3((unsigned)cdiv(nred, 16)), dim3(256), 0, s, scratch, a.pstride, a.blocks_per_sample, B, ntok,

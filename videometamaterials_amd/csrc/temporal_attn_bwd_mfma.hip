@@ -1,0 +1,202 @@
+// Backward of the temporal attention core on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
+// heads = 8, dim_head = 32, T <= 16 frames, <= 16 conditioning tokens.  Same contract as temporal_attn_bwd.hip (its VALU / LDS
+// predecessor, kept as the fallback): dqkv = gradient of the raw to_qkv output (rotation and q-scale undone), token-key / value
+// and bias gradients as one partial per workgroup for the fixed-order reduce kernel.
+//
+// A wave owns one head and walks the workgroup's pixels; a pixel's T x T problem is one 16 x 16 MFMA tile per product:
+//   S  = Q K^T, dP = dO V^T                 operands straight from global memory in "row" layout (lane = frame, 8 channels per lane group)
+//   p = exp(S + bias - L), dS = p (dP - D)  on the accumulator layout (registers = query i, lanes = key j)
+//   dK = dS^T Q, dV = p^T dO                the accumulators ARE the "A" operand (lane = key, contraction = query): no data movement
+//   dQ = dS K                               needs dS with lane = query: one 16 x 16 transpose through a wave-private LDS tile
+// and the same seven products against the sample's conditioning tokens (their dK / dV accumulate across the pixels in the MFMA
+// accumulators themselves).  No workgroup barriers, no LDS operand staging: 80 MFMAs and ~40 global load instructions per pixel
+// and head, where the VALU version spends ~3 500 packed FMAs fed by LDS broadcasts.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+constexpr int DH = 32, HEADS = 8, HID = HEADS * DH;
+
+struct TMArgs {
+  const float *qkv, *ek, *ev, *bias, *O, *dO, *lse, *rot;
+  float *dqkv, *part;
+  int ldqkv, ldo, B, T, HW, ntok, bias_on_cond, blocks_per_sample, pstride;
+  float q_scale;
+};
+
+__device__ __forceinline__ f32x4 mm(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// row layout of one 32-float head slice: lane (row c, group g) holds channels 8 g .. 8 g + 7
+__device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool ok) {
+  f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = u;
+  if (ok) {
+    u = *reinterpret_cast<const f32x4*>(p);
+    w = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
+  dst[4] = w.x; dst[5] = w.y; dst[6] = w.z; dst[7] = w.w;
+}
+
+__global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArgs a) {
+  __shared__ float xp[HEADS][2][16][17];  // wave-private transpose tiles: dS and dS(tokens)
+  const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int T = a.T, ntok = a.ntok;
+  const int b = blockIdx.x / a.blocks_per_sample, blk = blockIdx.x % a.blocks_per_sample;
+  const bool tok_bias = a.bias && a.bias_on_cond;
+  const bool cT = c < T, cN = c < ntok;
+
+  // bias in accumulator layout: register r <-> query i = 4 g + r, lane <-> key j = c
+  float bA[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * g + r;
+    bA[r] = (a.bias && i < T && cT) ? a.bias[((long long)head * T + i) * T + c] : 0.f;
+  }
+  // the sample's conditioning keys / values: row layout (lane = token) and, for dQ, column layout (lane = channel, register = token 4 g + r)
+  float ekr[8], evr[8], ekc[2][4];
+  {
+    const float* er = a.ek + ((long long)b * ntok + c) * HID + head * DH + 8 * g;
+    const float* vr = a.ev + ((long long)b * ntok + c) * HID + head * DH + 8 * g;
+    load_row8(ekr, er, cN);
+    load_row8(evr, vr, cN);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ekc[h][r] = (4 * g + r < ntok) ? a.ek[((long long)b * ntok + 4 * g + r) * HID + head * DH + c + 16 * h] : 0.f;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dEK[2] = {zero4, zero4}, dEV[2] = {zero4, zero4}, bacc = zero4;
+  float(*tile)[16][17] = xp[head];
+
+  for (int pix = blk; pix < a.HW; pix += a.blocks_per_sample) {
+    const long long row0 = (long long)b * T * a.HW + pix;  // row of frame t = row0 + t * HW
+    const long long rc = row0 + (long long)c * a.HW;       // this lane's row in the row layouts
+    const float* qrow = a.qkv + rc * a.ldqkv + head * DH + 8 * g;
+    float qr[8], kr[8], vr[8], gr[8], orr[8];
+    load_row8(qr, qrow, cT);
+    load_row8(kr, qrow + HID, cT);
+    load_row8(vr, qrow + 2 * HID, cT);
+    load_row8(gr, a.dO + rc * a.ldo + head * DH + 8 * g, cT);
+    load_row8(orr, a.O + rc * a.ldo + head * DH + 8 * g, cT);
+    const float Lq = cT ? a.lse[rc * HEADS + head] : 0.f;
+    // column layouts (lane = channel c + 16 h, register = frame 4 g + r) of k (for dQ), q (for dK) and dO (for dV)
+    float kc[2][4], qc[2][4], gc[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 4 * g + r;
+      const bool ok = t < T;
+      const long long rt = row0 + (long long)t * a.HW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        qc[h][r] = ok ? a.qkv[rt * a.ldqkv + head * DH + c + 16 * h] : 0.f;
+        kc[h][r] = ok ? a.qkv[rt * a.ldqkv + HID + head * DH + c + 16 * h] : 0.f;
+        gc[h][r] = ok ? a.dO[rt * a.ldo + head * DH + c + 16 * h] : 0.f;
+      }
+    }
+    // D_i = dO_i . O_i: this lane's 8 channels, then across the 4 lane groups
+    float Dq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) Dq = fmaf(gr[s], orr[s], Dq);
+    Dq += __shfl_xor(Dq, 16, 64);
+    Dq += __shfl_xor(Dq, 32, 64);
+    float LA[4], DA[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      LA[r] = __shfl(Lq, 4 * g + r, 64);  // lanes 0..15 hold the values of queries 0..15
+      DA[r] = __shfl(Dq, 4 * g + r, 64);
+    }
+    // ---- scores and dP against the frame keys and the token keys (accumulator layout: register = query 4 g + r, lane = key c)
+    f32x4 S = zero4, dP = zero4, St = zero4, dPt = zero4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      S = mm(qr[s], kr[s], S);
+      dP = mm(gr[s], vr[s], dP);
+      St = mm(qr[s], ekr[s], St);
+      dPt = mm(gr[s], evr[s], dPt);
+    }
+    float p[4], ds[4], pt[4], dst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool qok = 4 * g + r < T;
+      p[r] = (qok && cT) ? __expf(S[r] + bA[r] - LA[r]) : 0.f;
+      ds[r] = p[r] * (dP[r] - DA[r]);
+      pt[r] = (qok && cN) ? __expf(St[r] + (tok_bias ? bA[r] : 0.f) - LA[r]) : 0.f;
+      dst[r] = pt[r] * (dPt[r] - DA[r]);
+      bacc[r] += ds[r] + (tok_bias ? dst[r] : 0.f);
+      tile[0][4 * g + r][c] = ds[r];
+      tile[1][4 * g + r][c] = dst[r];
+    }
+    __syncthreads();  // (the tiles are wave-private; this orders the wave's own writes before its reads)
+    float dsB[4], dstB[4];  // lane = query c, register = key 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dsB[r] = tile[0][c][4 * g + r];
+      dstB[r] = tile[1][c][4 * g + r];
+    }
+    __syncthreads();  // reads done before the next pixel overwrites
+    // ---- gradients: per 16-channel half h
+    f32x4 dQ[2] = {zero4, zero4}, dK[2] = {zero4, zero4}, dV[2] = {zero4, zero4};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dK[h] = mm(ds[r], qc[h][r], dK[h]);     // dK[j][d] = sum_i dS[i][j] Q[i][d]
+        dV[h] = mm(p[r], gc[h][r], dV[h]);      // dV[j][d] = sum_i p[i][j] dO[i][d]
+        dQ[h] = mm(dsB[r], kc[h][r], dQ[h]);    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        dQ[h] = mm(dstB[r], ekc[h][r], dQ[h]);  //          + sum_t dS[i][t] EK[t][d]
+        dEK[h] = mm(dst[r], qc[h][r], dEK[h]);  // accumulated over the workgroup's pixels
+        dEV[h] = mm(pt[r], gc[h][r], dEV[h]);
+      }
+    // ---- store: register r <-> frame 4 g + r, lane <-> channel c + 16 h; undo the interleaved-pair rotation (pairs = adjacent lanes)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 4 * g + r;
+        float q = dQ[h][r], k = dK[h][r];
+        const float qp = __shfl_xor(q, 1, 64), kp = __shfl_xor(k, 1, 64);
+        if (t < T) {
+          const int d = c + 16 * h;
+          if (a.rot) {
+            const float cs = a.rot[(t * (DH / 2) + (d >> 1)) * 2], sn = a.rot[(t * (DH / 2) + (d >> 1)) * 2 + 1];
+            const float sg = (d & 1) ? -sn : sn;  // even: a c + b s, odd: b c - a s
+            q = q * cs + qp * sg;
+            k = k * cs + kp * sg;
+          }
+          float* o = a.dqkv + (row0 + (long long)t * a.HW) * a.ldqkv + head * DH + d;
+          o[0] = q * a.q_scale;
+          o[HID] = k;
+          o[2 * HID] = dV[h][r];
+        }
+      }
+  }
+  // ---- per-workgroup partials of the gradients shared by its pixels (summed by temporal_attn_bwd_reduce_kernel)
+  float* part = a.part + (long long)blockIdx.x * a.pstride;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 4 * g + r;
+      if (t < ntok) {
+        part[t * HID + head * DH + c + 16 * h] = dEK[h][r];
+        part[ntok * HID + t * HID + head * DH + c + 16 * h] = dEV[h][r];
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * g + r;
+    if (i < T && cT) part[2 * ntok * HID + (head * T + i) * T + c] = bacc[r];
+  }
+}
+
+}  // namespace
+
+// launched by vmm_temporal_attention_bwd (temporal_attn_bwd.hip), which owns the scratch sizing and the reduce kernel
+int vmm_temporal_attention_bwd_mfma_launch(const float* qkv, int ldqkv, const float* ek, const float* ev, int ntok, const float* bias, int bias_on_cond,
+                                           const float* out, const float* dout, int ldo, const float* lse, const float* rot_tab, float q_scale,
+                                           float* dqkv, float* scratch, int B, int T, int HW, int blocks_per_sample, int pstride, hipStream_t s) {
+  TMArgs a{qkv, ek, ev, bias, out, dout, lse, rot_tab, dqkv, scratch, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, blocks_per_sample, pstride, q_scale};
+  hipLaunchKernelGGL(temporal_attn_bwd_mfma_kernel, dim3((unsigned)(B * blocks_per_sample)), dim3(512), 0, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
