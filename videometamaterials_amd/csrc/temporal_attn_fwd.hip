@@ -8,6 +8,12 @@
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
+#include <cstdlib>
+
+// the matrix-core version (temporal_attn_fwd_mfma.hip)
+int vmm_temporal_attention_fwd_mfma_launch(const float* qkv, int ldqkv, const float* ek, const float* ev, int ntok, const float* bias, int bias_on_cond,
+                                           float* out, int ldo, float* lse, int B, int T, int HW, hipStream_t s);
+
 namespace {
 constexpr int DH = 32, HEADS = 8, HID = HEADS * DH, NTH = HEADS * 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -121,6 +127,8 @@ extern "C" int vmm_temporal_attention_staged(const float* qkv, int32_t ldqkv, co
   if (heads != HEADS || dh != DH || T > 16 || T < 1 || ntok > 16 || (ldqkv & 3) || (ldo & 3)) return 1;
   if (bias && bias_on_cond && ntok > T) return 1;
   if (B <= 0 || HW <= 0) return 0;
+  static const bool use_valu = getenv("VMM_TEMPORAL_FWD_VALU") != nullptr;  // A/B switch: the VALU / LDS kernel of this file
+  if (!use_valu) return vmm_temporal_attention_fwd_mfma_launch(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, ldo, lse, B, T, HW, (hipStream_t)stream);
   TFArgs a{qkv, ek, ev, bias, out, lse, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, 0};
   a.blocks_per_sample = (int)max(1LL, min((long long)HW, cdiv(1536, B)));
   const size_t shm = sizeof(float) * (size_t)(2 * HEADS * T * DH + 2 * HEADS * ntok * DH + HEADS * T * T);
