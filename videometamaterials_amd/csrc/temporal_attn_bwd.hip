@@ -1,249 +1,193 @@
-// Backward of the temporal attention core (training path, vddp.py:397-466 under autograd), gfx950.  heads = 8, dim_head = 32,
-// T <= 16 frames, <= 16 conditioning tokens.
+// Backward of the temporal attention core on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
+// heads = 8, dim_head = 32, T <= 16 frames, <= 16 conditioning tokens (vddp.py:397-466 under autograd).  dqkv = gradient of the raw
+// to_qkv output (the projection epilogue's rotation and q-scale are undone on the way out); token-key / value and bias gradients
+// leave as one partial per workgroup and are summed in a fixed order by the reduce kernel below (no atomics).
 //
-// One workgroup = one pixel at a time; two waves = 8 heads x 16 lanes for the frames, two more for the conditioning tokens; lane i of a
-// head group is key i in pass 1 and query i in pass 2:
-//   staging   the pixel's T rows of q, k, dO and O are read once, coalesced, into LDS; D_i = dO_i . O_i is reduced while staging
-//             (8 lanes per head slice); v_j goes straight into its key lane's registers
-//   pass 1    lane = key j (own k_j, v_j in registers; q_i, dO_i: LDS broadcast), one sweep over the queries:
-//             p_ij = exp(q_i . k_j + bias_ij - L_i),  ds_ij = p_ij (dO_i . v_j - D_i),  dk_j += ds_ij q_i,  dv_j += p_ij dO_i
-//   pass 2    lane = query i:  dq_i = sum_j ds_ij k_j   (k_j: LDS broadcast, ds through a T x (ntok + T) LDS tile per head)
-// The conditioning tokens are keys of pass 1 as well (lane = token, keys from global memory, shared by every pixel of the sample);
-// their key / value gradients stay in registers across the workgroup's pixels and leave as one partial per workgroup, the bias
-// gradient likewise through an LDS tile; a small second kernel sums the partials in a fixed order (no atomics).
-// Every element of qkv / dO / O is read from HBM once and every element of dqkv written once (the thread-per-query / wave-per-key
-// kernels of attention_bwd.hip re-read each row T times); the rotary rotation and q-scale of the projection epilogue are undone
-// on the way out, so dqkv is the gradient of the raw to_qkv output.
+// A wave owns one head and walks the workgroup's pixels; a pixel's T x T problem is one 16 x 16 MFMA tile per product:
+//   S  = Q K^T, dP = dO V^T                 operands straight from global memory in "row" layout (lane = frame, 8 channels per lane group)
+//   p = exp(S + bias - L), dS = p (dP - D)  on the accumulator layout (registers = query i, lanes = key j)
+//   dK = dS^T Q, dV = p^T dO                the accumulators ARE the "A" operand (lane = key, contraction = query): no data movement
+//   dQ = dS K                               needs dS with lane = query: one 16 x 16 transpose through a wave-private LDS tile
+// and the same seven products against the sample's conditioning tokens (their dK / dV accumulate across the pixels in the MFMA
+// accumulators themselves).  No workgroup barriers, no LDS operand staging: 80 MFMAs and ~40 global load instructions per pixel
+// and head.  History (ms per training step over the 10 sites): thread-per-query / wave-per-key kernels (attention_bwd.hip, still the
+// fallback outside the envelope) 18.9; LDS-staged workgroup-per-pixel kernel on packed fp32 FMAs 6.2; this one 3.7.
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
-#include <cstdlib>
-
-// the matrix-core version (temporal_attn_bwd_mfma.hip); same partial-buffer layout, reduced by the kernel at the end of this file
-int vmm_temporal_attention_bwd_mfma_launch(const float* qkv, int ldqkv, const float* ek, const float* ev, int ntok, const float* bias, int bias_on_cond,
-                                           const float* out, const float* dout, int ldo, const float* lse, const float* rot_tab, float q_scale,
-                                           float* dqkv, float* scratch, int B, int T, int HW, int blocks_per_sample, int pstride, hipStream_t s);
-
 namespace {
-constexpr int DH = 32, HEADS = 8, HID = HEADS * DH, NTH = HEADS * 16;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int DH = 32, HEADS = 8, HID = HEADS * DH;
 
-struct TBArgs {
+struct TMArgs {
   const float *qkv, *ek, *ev, *bias, *O, *dO, *lse, *rot;
   float *dqkv, *part;
   int ldqkv, ldo, B, T, HW, ntok, bias_on_cond, blocks_per_sample, pstride;
   float q_scale;
 };
 
-// rows of 32 floats, 16-byte chunk c of row r stored at chunk c ^ (r & 7): own-row reads of the 16 lanes of a group spread over the banks
-__device__ __forceinline__ int sw(int r, int c) { return r * DH + ((c ^ (r & 7)) << 2); }
+__device__ __forceinline__ f32x4 mm(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// a row as 16 float pairs: the dot products and axpys below are written on pairs so that they compile to v_pk_fma_f32
-__device__ __forceinline__ void lds_row(f32x2 (&dst)[16], const float* base, int r) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(base + sw(r, c));
-    dst[2 * c] = (f32x2){v.x, v.y};
-    dst[2 * c + 1] = (f32x2){v.z, v.w};
+// row layout of one 32-float head slice: lane (row c, group g) holds channels 8 g .. 8 g + 7
+__device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool ok) {
+  f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = u;
+  if (ok) {
+    u = *reinterpret_cast<const f32x4*>(p);
+    w = *reinterpret_cast<const f32x4*>(p + 4);
   }
-}
-__device__ __forceinline__ void glb_row(f32x2 (&dst)[16], const float* src) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c * 4);
-    dst[2 * c] = (f32x2){v.x, v.y};
-    dst[2 * c + 1] = (f32x2){v.z, v.w};
-  }
-}
-__device__ __forceinline__ float dot32(const f32x2 (&a)[16], const f32x2 (&b)[16]) {
-  f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < 16; c += 2) { s0 = a[c] * b[c] + s0; s1 = a[c + 1] * b[c + 1] + s1; }
-  s0 += s1;
-  return s0.x + s0.y;
-}
-__device__ __forceinline__ void axpy32(f32x2 (&acc)[16], float w, const f32x2 (&x)[16]) {
-  const f32x2 w2 = {w, w};
-#pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = w2 * x[c] + acc[c];
-}
-__device__ __forceinline__ void zero32(f32x2 (&x)[16]) {
-#pragma unroll
-  for (int c = 0; c < 16; ++c) x[c] = (f32x2){0.f, 0.f};
-}
-// transpose of the interleaved-pair rotation by position pos, then scale; 128-byte row store
-__device__ __forceinline__ void unrotate_store(float* dst, const f32x2 (&g)[16], const float* __restrict__ tab, int pos, float scale) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    f32x4 o = {g[2 * c].x, g[2 * c].y, g[2 * c + 1].x, g[2 * c + 1].y};
-    if (tab) {
-      const f32x4 cs = *reinterpret_cast<const f32x4*>(tab + (pos * (DH / 2) + c * 2) * 2);  // cos0 sin0 cos1 sin1
-      o = (f32x4){g[2 * c].x * cs.x + g[2 * c].y * cs.y, g[2 * c].y * cs.x - g[2 * c].x * cs.y,
-                  g[2 * c + 1].x * cs.z + g[2 * c + 1].y * cs.w, g[2 * c + 1].y * cs.z - g[2 * c + 1].x * cs.w};
-    }
-    o.x *= scale; o.y *= scale; o.z *= scale; o.w *= scale;
-    *reinterpret_cast<f32x4*>(dst + c * 4) = o;
-  }
-}
-__device__ __forceinline__ void store32(float* dst, const f32x2 (&g)[16]) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(dst + c * 4) = (f32x4){g[2 * c].x, g[2 * c].y, g[2 * c + 1].x, g[2 * c + 1].y};
+  dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
+  dst[4] = w.x; dst[5] = w.y; dst[6] = w.z; dst[7] = w.w;
 }
 
-__global__ __launch_bounds__(2 * NTH) void temporal_attn_bwd_kernel(const TBArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int T = a.T, ntok = a.ntok, NK = ntok + T;
-  float* Qs = smem;                       // [HEADS][T][32] (swizzled chunks); after pass 1: the token part of dq
-  float* Ks = Qs + HEADS * T * DH;
-  float* Gs = Ks + HEADS * T * DH;        // dO
-  float* DSm = Gs + HEADS * T * DH;       // ds [HEADS][T queries][ntok + T keys]
-  float* Bacc = DSm + HEADS * T * NK;     // bias-gradient accumulator [HEADS][T][T]
-  float* Bs = Bacc + HEADS * T * T;       // bias [HEADS][T][T]
-  float* Ls = Bs + HEADS * T * T;         // logsumexp [HEADS][16]
-  float* Dsum = Ls + HEADS * 16;          // D = dO . O [HEADS][16]
-  // waves 0-1: frame keys (and the final dq); waves 2-3 (launched only when there are conditioning tokens): token keys
-  const int tid = threadIdx.x, nth = blockDim.x, role = tid >> 7, head = (tid >> 4) & 7, i = tid & 15;
+__global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArgs a) {
+  __shared__ float xp[HEADS][2][16][17];  // wave-private transpose tiles: dS and dS(tokens)
+  const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int T = a.T, ntok = a.ntok;
   const int b = blockIdx.x / a.blocks_per_sample, blk = blockIdx.x % a.blocks_per_sample;
-  const bool act = i < T, tact = role == 1 && i < ntok;
   const bool tok_bias = a.bias && a.bias_on_cond;
-  for (int e = tid; e < HEADS * T * T; e += nth) {
-    Bacc[e] = 0.f;
-    Bs[e] = a.bias ? a.bias[e] : 0.f;
-  }
-  const float* Bh = Bs + head * T * T;
-  float* Bah = Bacc + head * T * T;
-  float* DSh = DSm + head * T * NK;
-  auto stage = [&](long long row0) {
-    // ---- q | k (v is only ever needed by its own key lane: read straight into registers)
-#pragma unroll 4
-    for (int e = tid; e < T * 128; e += nth) {
-      const int t = e >> 7, c4 = e & 127;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.qkv + (row0 + (long long)t * a.HW) * a.ldqkv + c4 * 4);
-      *reinterpret_cast<f32x4*>((c4 < 64 ? Qs : Ks) + sw(((c4 >> 3) & 7) * T + t, c4 & 7)) = v;
-    }
-    // ---- dO, D = dO . O
-#pragma unroll 2
-    for (int e = tid; e < T * (HID / 4); e += nth) {
-      const int t = e >> 6, c4 = e & 63, h = c4 >> 3;
-      const long long off = (row0 + (long long)t * a.HW) * a.ldo + c4 * 4;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(a.dO + off);
-      const f32x4 o = *reinterpret_cast<const f32x4*>(a.O + off);
-      *reinterpret_cast<f32x4*>(Gs + sw(h * T + t, c4 & 7)) = g;
-      float s = (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if ((c4 & 7) == 0) Dsum[h * 16 + t] = s;
-    }
-  };
-  // The two roles run the same sequence of barriers per pixel (stage | pass 1 | pass 2 | hand-over of the token part of dq).
-  if (role == 1) {
-    // ================= token waves: lane = (head, token i) in pass 1, (head, query i) in pass 2
-    f32x2 ekk[16], evv[16], kacc[16], vacc[16];  // own key / value (the same for every pixel), gradients summed over this workgroup's pixels
-    zero32(kacc);
-    zero32(vacc);
-    if (tact) {
-      glb_row(ekk, a.ek + ((long long)b * ntok + i) * HID + head * DH);
-      glb_row(evv, a.ev + ((long long)b * ntok + i) * HID + head * DH);
-    }
-    for (int pix = blk; pix < a.HW; pix += a.blocks_per_sample) {
-      const long long row0 = (long long)b * T * a.HW + pix;  // row of frame t = row0 + t * HW
-      __syncthreads();  // the previous pixel is done with the tiles
-      stage(row0);
-      __syncthreads();
-      if (tact) {
-        for (int ii = 0; ii < T; ++ii) {
-          f32x2 r[16], g[16];
-          lds_row(r, Qs, head * T + ii);
-          float s = dot32(r, ekk);
-          if (tok_bias) s += Bh[ii * T + i];
-          const float p = __expf(s - Ls[head * 16 + ii]);
-          lds_row(g, Gs, head * T + ii);
-          const float ds = p * (dot32(g, evv) - Dsum[head * 16 + ii]);
-          axpy32(kacc, ds, r);
-          axpy32(vacc, p, g);
-          DSh[ii * NK + i] = ds;
-        }
-      }
-      __syncthreads();
-      if (act) {  // token part of dq_i, left in the (now free) q tile
-        f32x2 dq[16];
-        zero32(dq);
-        for (int j = 0; j < ntok; ++j) {
-          f32x2 r[16];
-          glb_row(r, a.ek + ((long long)b * ntok + j) * HID + head * DH);
-          axpy32(dq, DSh[i * NK + j], r);
-        }
+  const bool cT = c < T, cN = c < ntok;
+
+  // bias in accumulator layout: register r <-> query i = 4 g + r, lane <-> key j = c
+  float bA[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(Qs + sw(head * T + i, c)) = (f32x4){dq[2 * c].x, dq[2 * c].y, dq[2 * c + 1].x, dq[2 * c + 1].y};
-      }
-      __syncthreads();
-    }
-    // gradients shared by the workgroup's pixels: one partial per workgroup, summed in a fixed order by the reduce kernel below
-    if (tact) {
-      float* part = a.part + (long long)blockIdx.x * a.pstride;
-      store32(part + i * HID + head * DH, kacc);
-      store32(part + ntok * HID + i * HID + head * DH, vacc);
-    }
-  } else {
-    // ================= frame waves: lane = (head, frame i): key i in pass 1, query i in pass 2
-    for (int pix = blk; pix < a.HW; pix += a.blocks_per_sample) {
-      const long long row0 = (long long)b * T * a.HW + pix;
-      __syncthreads();
-      stage(row0);
-      if (act) Ls[head * 16 + i] = a.lse[(row0 + (long long)i * a.HW) * HEADS + head];
-      __syncthreads();
-      // pass 1: s, p, ds against every query (q_i, dO_i: LDS broadcast) and the key's own gradients in one sweep
-      if (act) {
-        f32x2 kk[16], vv[16], dk[16], dv[16];
-        lds_row(kk, Ks, head * T + i);
-        float* orow = a.dqkv + (row0 + (long long)i * a.HW) * a.ldqkv + head * DH;
-        glb_row(vv, a.qkv + (row0 + (long long)i * a.HW) * a.ldqkv + 2 * HID + head * DH);
-        zero32(dk);
-        zero32(dv);
-        for (int ii = 0; ii < T; ++ii) {
-          f32x2 r[16], g[16];
-          lds_row(r, Qs, head * T + ii);
-          float s = dot32(r, kk);
-          if (a.bias) s += Bh[ii * T + i];
-          const float p = __expf(s - Ls[head * 16 + ii]);
-          lds_row(g, Gs, head * T + ii);
-          const float ds = p * (dot32(g, vv) - Dsum[head * 16 + ii]);
-          axpy32(dk, ds, r);
-          axpy32(dv, p, g);
-          DSh[ii * NK + ntok + i] = ds;
-        }
-        unrotate_store(orow + HID, dk, a.rot, i, 1.0f);
-        store32(orow + 2 * HID, dv);
-      }
-      __syncthreads();
-      // pass 2: dq_i = sum_j ds_ij k_j over the frame keys (LDS broadcast), plus the bias gradient of row i
-      f32x2 dq[16];
-      zero32(dq);
-      if (act) {
-        for (int j = 0; j < T; ++j) {
-          f32x2 r[16];
-          lds_row(r, Ks, head * T + j);
-          const float ds = DSh[i * NK + ntok + j];
-          axpy32(dq, ds, r);
-          if (a.bias) Bah[i * T + j] += ds + (tok_bias && j < ntok ? DSh[i * NK + j] : 0.f);
-        }
-      }
-      if (ntok > 0) __syncthreads();
-      if (act) {
-        if (ntok > 0) {
-          f32x2 r[16];
-          lds_row(r, Qs, head * T + i);
-#pragma unroll
-          for (int c = 0; c < 16; ++c) dq[c] += r[c];
-        }
-        unrotate_store(a.dqkv + (row0 + (long long)i * a.HW) * a.ldqkv + head * DH, dq, a.rot, i, a.q_scale);
-      }
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * g + r;
+    bA[r] = (a.bias && i < T && cT) ? a.bias[((long long)head * T + i) * T + c] : 0.f;
   }
-  __syncthreads();
+  // the sample's conditioning keys / values: row layout (lane = token) and, for dQ, column layout (lane = channel, register = token 4 g + r)
+  float ekr[8], evr[8], ekc[2][4];
+  {
+    const float* er = a.ek + ((long long)b * ntok + c) * HID + head * DH + 8 * g;
+    const float* vr = a.ev + ((long long)b * ntok + c) * HID + head * DH + 8 * g;
+    load_row8(ekr, er, cN);
+    load_row8(evr, vr, cN);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ekc[h][r] = (4 * g + r < ntok) ? a.ek[((long long)b * ntok + 4 * g + r) * HID + head * DH + c + 16 * h] : 0.f;
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dEK[2] = {zero4, zero4}, dEV[2] = {zero4, zero4}, bacc = zero4;
+  float(*tile)[16][17] = xp[head];
+
+  for (int pix = blk; pix < a.HW; pix += a.blocks_per_sample) {
+    const long long row0 = (long long)b * T * a.HW + pix;  // row of frame t = row0 + t * HW
+    const long long rc = row0 + (long long)c * a.HW;       // this lane's row in the row layouts
+    const float* qrow = a.qkv + rc * a.ldqkv + head * DH + 8 * g;
+    float qr[8], kr[8], vr[8], gr[8], orr[8];
+    load_row8(qr, qrow, cT);
+    load_row8(kr, qrow + HID, cT);
+    load_row8(vr, qrow + 2 * HID, cT);
+    load_row8(gr, a.dO + rc * a.ldo + head * DH + 8 * g, cT);
+    load_row8(orr, a.O + rc * a.ldo + head * DH + 8 * g, cT);
+    const float Lq = cT ? a.lse[rc * HEADS + head] : 0.f;
+    // column layouts (lane = channel c + 16 h, register = frame 4 g + r) of k (for dQ), q (for dK) and dO (for dV)
+    float kc[2][4], qc[2][4], gc[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 4 * g + r;
+      const bool ok = t < T;
+      const long long rt = row0 + (long long)t * a.HW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        qc[h][r] = ok ? a.qkv[rt * a.ldqkv + head * DH + c + 16 * h] : 0.f;
+        kc[h][r] = ok ? a.qkv[rt * a.ldqkv + HID + head * DH + c + 16 * h] : 0.f;
+        gc[h][r] = ok ? a.dO[rt * a.ldo + head * DH + c + 16 * h] : 0.f;
+      }
+    }
+    // D_i = dO_i . O_i: this lane's 8 channels, then across the 4 lane groups
+    float Dq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) Dq = fmaf(gr[s], orr[s], Dq);
+    Dq += __shfl_xor(Dq, 16, 64);
+    Dq += __shfl_xor(Dq, 32, 64);
+    float LA[4], DA[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      LA[r] = __shfl(Lq, 4 * g + r, 64);  // lanes 0..15 hold the values of queries 0..15
+      DA[r] = __shfl(Dq, 4 * g + r, 64);
+    }
+    // ---- scores and dP against the frame keys and the token keys (accumulator layout: register = query 4 g + r, lane = key c)
+    f32x4 S = zero4, dP = zero4, St = zero4, dPt = zero4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      S = mm(qr[s], kr[s], S);
+      dP = mm(gr[s], vr[s], dP);
+      St = mm(qr[s], ekr[s], St);
+      dPt = mm(gr[s], evr[s], dPt);
+    }
+    float p[4], ds[4], pt[4], dst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool qok = 4 * g + r < T;
+      p[r] = (qok && cT) ? __expf(S[r] + bA[r] - LA[r]) : 0.f;
+      ds[r] = p[r] * (dP[r] - DA[r]);
+      pt[r] = (qok && cN) ? __expf(St[r] + (tok_bias ? bA[r] : 0.f) - LA[r]) : 0.f;
+      dst[r] = pt[r] * (dPt[r] - DA[r]);
+      bacc[r] += ds[r] + (tok_bias ? dst[r] : 0.f);
+      tile[0][4 * g + r][c] = ds[r];
+      tile[1][4 * g + r][c] = dst[r];
+    }
+    __syncthreads();  // (the tiles are wave-private; this orders the wave's own writes before its reads)
+    float dsB[4], dstB[4];  // lane = query c, register = key 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dsB[r] = tile[0][c][4 * g + r];
+      dstB[r] = tile[1][c][4 * g + r];
+    }
+    __syncthreads();  // reads done before the next pixel overwrites
+    // ---- gradients: per 16-channel half h
+    f32x4 dQ[2] = {zero4, zero4}, dK[2] = {zero4, zero4}, dV[2] = {zero4, zero4};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dK[h] = mm(ds[r], qc[h][r], dK[h]);     // dK[j][d] = sum_i dS[i][j] Q[i][d]
+        dV[h] = mm(p[r], gc[h][r], dV[h]);      // dV[j][d] = sum_i p[i][j] dO[i][d]
+        dQ[h] = mm(dsB[r], kc[h][r], dQ[h]);    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        dQ[h] = mm(dstB[r], ekc[h][r], dQ[h]);  //          + sum_t dS[i][t] EK[t][d]
+        dEK[h] = mm(dst[r], qc[h][r], dEK[h]);  // accumulated over the workgroup's pixels
+        dEV[h] = mm(pt[r], gc[h][r], dEV[h]);
+      }
+    // ---- store: register r <-> frame 4 g + r, lane <-> channel c + 16 h; undo the interleaved-pair rotation (pairs = adjacent lanes)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 4 * g + r;
+        float q = dQ[h][r], k = dK[h][r];
+        const float qp = __shfl_xor(q, 1, 64), kp = __shfl_xor(k, 1, 64);
+        if (t < T) {
+          const int d = c + 16 * h;
+          if (a.rot) {
+            const float cs = a.rot[(t * (DH / 2) + (d >> 1)) * 2], sn = a.rot[(t * (DH / 2) + (d >> 1)) * 2 + 1];
+            const float sg = (d & 1) ? -sn : sn;  // even: a c + b s, odd: b c - a s
+            q = q * cs + qp * sg;
+            k = k * cs + kp * sg;
+          }
+          float* o = a.dqkv + (row0 + (long long)t * a.HW) * a.ldqkv + head * DH + d;
+          o[0] = q * a.q_scale;
+          o[HID] = k;
+          o[2 * HID] = dV[h][r];
+        }
+      }
+  }
+  // ---- per-workgroup partials of the gradients shared by its pixels (summed by temporal_attn_bwd_reduce_kernel)
   float* part = a.part + (long long)blockIdx.x * a.pstride;
-  for (int e = tid; e < HEADS * T * T; e += nth) part[2 * ntok * HID + e] = Bacc[e];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 4 * g + r;
+      if (t < ntok) {
+        part[t * HID + head * DH + c + 16 * h] = dEK[h][r];
+        part[ntok * HID + t * HID + head * DH + c + 16 * h] = dEV[h][r];
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * g + r;
+    if (i < T && cT) part[2 * ntok * HID + (head * T + i) * T + c] = bacc[r];
+  }
 }
 
 // dek / dev [B][ntok][HID] += sum over the sample's workgroups, dbias [HEADS][T][T] += sum over all workgroups.
@@ -311,29 +255,15 @@ extern "C" int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const
   if (bias && bias_on_cond && ntok > T) return 1;
   if (ntok > 0 && (!dek || !dev)) return -1;
   if (B <= 0 || HW <= 0) return 0;
-  TBArgs a{qkv, ek, ev, bias, out, dout, lse, rot_tab, dqkv, scratch, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, 0, 0, q_scale};
-  a.blocks_per_sample = tb_blocks_per_sample(B, HW);
-  a.pstride = tb_pstride(ntok, T);
-  const size_t shm = sizeof(float) * (size_t)(3 * HEADS * T * DH + HEADS * T * (ntok + T) + 2 * HEADS * T * T + 2 * HEADS * 16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  const int bps = tb_blocks_per_sample(B, HW), pstride = tb_pstride(ntok, T);
+  TMArgs a{qkv, ek, ev, bias, out, dout, lse, rot_tab, dqkv, scratch, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, bps, pstride, q_scale};
   hipStream_t s = (hipStream_t)stream;
-  static const bool use_valu = getenv("VMM_TEMPORAL_BWD_VALU") != nullptr;  // A/B switch: the VALU / LDS kernel of this file
-  if (!use_valu) {
-    const int rc = vmm_temporal_attention_bwd_mfma_launch(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, dout, ldo, lse, rot_tab, q_scale, dqkv, scratch,
-                                                          B, T, HW, a.blocks_per_sample, a.pstride, s);
-    if (rc != 0) return rc;
-  } else {
-    hipLaunchKernelGGL(temporal_attn_bwd_kernel, dim3((unsigned)(B * a.blocks_per_sample)), dim3(ntok > 0 ? 2 * NTH : NTH), shm, s, a);
-    VMM_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(temporal_attn_bwd_mfma_kernel, dim3((unsigned)(B * bps)), dim3(512), 0, s, a);
+  VMM_LAUNCH_CHECK();
   const int nred = B * 2 * ntok * HID + (bias && dbias ? HEADS * T * T : 0);
   if (nred > 0) {
-    hipLaunchKernelGGL(temporal_attn_bwd_reduce_kernel, dim3((unsigned)cdiv(nred, 16)), dim3(256), 0, s, scratch, a.pstride, a.blocks_per_sample, B, ntok,
-                       T, dek, dev, bias ? dbias : nullptr);
+    hipLaunchKernelGGL(temporal_attn_bwd_reduce_kernel, dim3((unsigned)cdiv(nred, 16)), dim3(256), 0, s, scratch, pstride, bps, B, ntok, T, dek, dev,
+                       bias ? dbias : nullptr);
     VMM_LAUNCH_CHECK();
   }
   return 0;
