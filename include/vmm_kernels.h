@@ -192,6 +192,10 @@ int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const 
                         vmm_stream_t stream);
 int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                       int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* the path vmm_linattn_apply takes for heads % 4 == 0 (returns 1 and launches nothing otherwise): out rows = softmax_d(q) scale . ctx on
+ * the fp32 matrix cores, ctx^T resident as the MFMA "A" operand */
+int vmm_linattn_apply_mfma(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t frames, int32_t HW,
+                           int32_t heads, float scale, vmm_stream_t stream);
 
 /* ---- K15: batched tiny dense layers (time_mlp, sign_emb, cond_token_to_hidden, ResnetBlock.mlp, to_k/to_v on tokens;
  * vddp.py:290-293,322-323,416-417,637-661).  One launch runs `njobs` independent jobs:

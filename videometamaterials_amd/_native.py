@@ -94,6 +94,7 @@ SIGNATURES = {
                                    c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_linattn_apply_mfma": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr],
     "vmm_linattn_bwd_rows_mfma": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr],
     "vmm_dense_bwd_batched": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
     "vmm_cond_tokens_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],

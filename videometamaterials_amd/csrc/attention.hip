@@ -318,6 +318,10 @@ extern "C" int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float*
 extern "C" int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                                  int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || (ldo & 3) || heads > 64 || 256 % heads) return -1;
+  {  // fp32 matrix-core row pass (linattn_rows.hip) where it applies
+    const int rc = vmm_linattn_apply_mfma(qkv, ldqkv, ctx, out, ldo, B * T, HW, heads, 0.17677669529663687f /* 32^-0.5, vddp.py:316 */, stream);
+    if (rc != 1) return rc;
+  }
   const int rows_per_block = 256 / heads;
   const size_t shm = sizeof(float) * heads * (DH * DH + 4);
   hipLaunchKernelGGL(linattn_apply_kernel, dim3(cdiv(HW, rows_per_block), B * T), dim3(256), shm, (hipStream_t)stream, qkv, ldqkv,

@@ -486,7 +486,7 @@ extern "C" int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek,
   const int rps = cdiv(cdiv(HW, nsplit), LB_TILE) * LB_TILE;
   hipLaunchKernelGGL(linattn_bwd_dctx_kernel, dim3(cdiv(HW, rps), nfh), dim3(256), 0, s, qkv, ldqkv, dout, lddo, HW, heads, rps, scale, dctx);
   VMM_LAUNCH_CHECK();
-  // row pass: fp32 matrix-core kernel (linattn_bwd_rows.hip) where it applies, else the thread-per-(row, head) kernel below
+  // row pass: fp32 matrix-core kernel (linattn_rows.hip) where it applies, else the thread-per-(row, head) kernel below
   int rc_rows = vmm_linattn_bwd_rows_mfma(qkv, ldqkv, dout, lddo, ctx, dctx, kstat, dqkv, B * T, HW, heads, scale, stream);
   if (rc_rows < 0 || rc_rows > 1) return rc_rows;
   const int hpb = (heads % 4 == 0) ? 4 : ((heads % 2 == 0) ? 2 : 1);

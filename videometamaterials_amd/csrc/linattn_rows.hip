@@ -1,4 +1,5 @@
-// Row pass of the linear-attention backward (vddp.py:313-378 under autograd) on the fp32 matrix cores, gfx950.  dim_head = 32.
+// Row passes of linear attention (vddp.py:313-378; forward apply and the backward row pass) on the fp32 matrix cores, gfx950.
+// dim_head = 32.  Backward:
 //
 // Per (frame, head) the three per-row products are [rows x 32] . [32 x 32] GEMMs against the frame's ctx / dctx:
 //   G^T   = ctx  . dout^T      dq[n,d] = scale p[n,d] (G[n,d] - sum_d p G),  p = softmax_d(q[n,:])
@@ -173,7 +174,67 @@ __global__ __launch_bounds__(256) void linattn_bwd_rows_mfma_kernel(const LBArgs
   }
 }
 
+// ---------------------------------------------------------------- forward row pass (vmm_linattn_apply)
+// out[n, e] = sum_d ctx[d][e] softmax_d(q[n, :])[d] scale  as  O^T = ctx^T . qt^T: ctx^T resident as the "A" operand, a lane's half row of
+// q is its "B" operand after the row softmax (the other half row sits in the partner lane: one shuffle per reduction); no LDS.
+__global__ __launch_bounds__(256) void linattn_apply_mfma_kernel(const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ctx,
+                                                                 float* __restrict__ out, int ldo, int HW, int heads, int rows_per_block, float scale) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lk = lane >> 5;
+  const long long frame = blockIdx.y;
+  const int head = blockIdx.z * 4 + wave;
+  const float* C = ctx + (frame * heads + head) * DH * DH;
+  float cT[16];  // ctx^T: row e = l31, contraction d = 16 lk + s
+#pragma unroll
+  for (int s = 0; s < 16; ++s) cT[s] = C[(16 * lk + s) * DH + l31];
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(n_begin + rows_per_block, HW);
+  for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+    const int n = n0 + l31;
+    const bool valid = n < n_end;
+    float q[16];
+    const float* src = qkv + (frame * HW + (valid ? n : n_begin)) * ldqkv + head * DH + 16 * lk;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * c);
+      q[4 * c] = v.x; q[4 * c + 1] = v.y; q[4 * c + 2] = v.z; q[4 * c + 3] = v.w;
+    }
+    float mx = q[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) mx = fmaxf(mx, q[s]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { q[s] = __expf(q[s] - mx); sum += q[s]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float sc = scale / sum;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cT[s], q[s] * sc, acc, 0, 0, 0);
+    if (valid) {  // register r = 4 c + j <-> channel e = 4 (2 c + lk) + j of row n
+      float* op = out + (frame * HW + n) * ldo + head * DH;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<f32x4*>(op + 4 * (2 * c + lk)) = (f32x4){acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+    }
+  }
+}
+
 }  // namespace
+
+// Row pass of vmm_linattn_apply for heads % 4 == 0 (returns 1 and launches nothing otherwise).
+extern "C" int vmm_linattn_apply_mfma(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t frames, int32_t HW,
+                                      int32_t heads, float scale, vmm_stream_t stream) {
+  if (heads % 4 || (ldqkv & 3) || (ldo & 3)) return 1;
+  if (frames <= 0 || HW <= 0) return 0;
+  const long long groups = (long long)frames * (heads / 4);
+  const long long chunks = max(1LL, min((long long)cdiv(HW, 32), cdiv(4096, groups)));
+  const int rows_per_block = (int)(cdiv(cdiv(HW, chunks), 32) * 32);
+  hipLaunchKernelGGL(linattn_apply_mfma_kernel, dim3((unsigned)cdiv(HW, rows_per_block), (unsigned)frames, (unsigned)(heads / 4)), dim3(256), 0,
+                     (hipStream_t)stream, qkv, ldqkv, ctx, out, ldo, HW, heads, rows_per_block, scale);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
 
 // Row pass of vmm_linattn_bwd for heads % 4 == 0 (returns 1 and launches nothing otherwise): dqkv rows from qkv, dout, ctx, dctx, kstat.
 extern "C" int vmm_linattn_bwd_rows_mfma(const float* qkv, int32_t ldqkv, const float* dout, int32_t lddo, const float* ctx, const float* dctx,
