@@ -691,3 +691,49 @@ def test_temporal_attention_backward(gpu, B, T, HW, ntok, use_bias, bias_on_cond
         assert relerr(dev_.cpu(), ev.grad) < 2e-5
     if use_bias:
         assert relerr(dbias.cpu(), bias.grad) < 2e-5
+
+
+@pytest.mark.parametrize("HW,ntok", [(144, 11), (100, 0), (2304, 5)])
+def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
+    """heads = 8 takes the fp32 matrix-core row passes (linattn_rows.hip): vmm_linattn_apply forward and the row pass of
+    vmm_linattn_bwd, both against torch (forward formula of vddp.py:313-378, gradients from autograd in float64)."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(21)
+    B, T, heads = 1, 2, 8
+    hid, scale = heads * 32, 32 ** -0.5
+    raw = (torch.randn(B * T, HW, 3, heads, 32, generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+    ek = torch.randn(B, ntok, heads, 32, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    ev = torch.randn(B, ntok, heads, 32, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    q, k, v = (raw[:, :, i].permute(0, 2, 3, 1) for i in range(3))  # (bt, h, d, n)
+    if ntok:
+        ekf = ek.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        evf = ev.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        k, v = torch.cat([ekf, k], -1), torch.cat([evf, v], -1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(-1), v / HW)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q.softmax(-2) * scale).permute(0, 3, 1, 2).reshape(B * T * HW, hid)
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    (out * dout).sum().backward()
+
+    f = lambda t: t.detach().float().contiguous().to(gpu)
+    qg = f(raw.reshape(B * T * HW, 3 * hid))
+    ekg, evg = (f(ek.reshape(B, ntok, hid)), f(ev.reshape(B, ntok, hid))) if ntok else (None, None)
+    p = lambda t: t.data_ptr() if t is not None else None
+    nsplit = 3
+    part = torch.empty(B * T * heads * nsplit * (1024 + 64), device=gpu)
+    ctxg = torch.empty(B * T * heads * 1024, device=gpu)
+    kstat = torch.empty(B * T * heads * 64, device=gpu)
+    og = torch.full((B * T * HW, hid), float("nan"), device=gpu)
+    N.check(lib.vmm_linattn_context(p(qg), 3 * hid, p(ekg), p(evg), ntok, B, T, HW, heads, 32, nsplit, p(part), p(ctxg), p(kstat), _s()), "ctx")
+    N.check(lib.vmm_linattn_apply(p(qg), 3 * hid, p(ctxg), p(og), hid, B, T, HW, heads, 32, _s()), "apply")
+    torch.cuda.synchronize()
+    assert relerr(og.cpu(), out.detach()) < 5e-6
+    dctx = torch.empty(B * T * heads * 1024, device=gpu)
+    dqkv = torch.full((B * T * HW, 3 * hid), float("nan"), device=gpu)
+    dek, dev_ = torch.zeros(B, max(ntok, 1), hid, device=gpu), torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    N.check(lib.vmm_linattn_bwd(p(qg), 3 * hid, p(ekg), p(evg), ntok, p(ctxg), p(kstat), p(f(dout)), hid, p(dctx), p(dqkv), p(dek), p(dev_), B, T, HW,
+                                heads, 32, _s()), "linattn bwd")
+    torch.cuda.synchronize()
+    assert relerr(dqkv.cpu(), raw.grad.reshape(B * T * HW, 3 * hid)) < 2e-5
+    if ntok:
+        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 2e-5
+        assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
