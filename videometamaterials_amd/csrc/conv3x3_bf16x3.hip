@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels
       // the sum and the sum of squares over this wave's 64 pixels, combined over the workgroup's waves in LDS, then one fp64
       // atomic per (run, moment) into sums[sample][group] -- the separate statistics pass over the output disappears.
-      float gs[2][4], gq[2][4];
+      // 16 values per lane: (sum, sum of squares) x 8 runs; wave totals by a reduce-scatter butterfly -- every exchange halves the
+      // values a lane still carries (8 + 4 + 2 + 1 shuffles), two plain steps finish: 17 shuffles instead of 96
+      float gv[16];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -432,26 +434,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
             s1 += (v0 + v1) + (v2 + v3);
             s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
           }
-#pragma unroll
-          for (int o = 32; o >= 1; o >>= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-          }
-          gs[j][g] = s1;
-          gq[j][g] = s2;
+          gv[(j * 4 + g) * 2] = s1;
+          gv[(j * 4 + g) * 2 + 1] = s2;
         }
       }
+#pragma unroll
+      for (int bit = 5, n = 8; bit >= 2; --bit, n >>= 1) {
+        const bool hi = (lane >> bit) & 1;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+          const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
+          gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+        }
+      }
+      gv[0] += __shfl_xor(gv[0], 2, 64);
+      gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
       __syncthreads();  // every wave is done with the patch: reuse its LDS
       float* sc = reinterpret_cast<float*>(smem);
-      if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            sc[wave * 16 + (j * 4 + g) * 2] = gs[j][g];
-            sc[wave * 16 + (j * 4 + g) * 2 + 1] = gq[j][g];
-          }
-      }
+      if ((lane & 3) == 0) sc[wave * 16 + (lane >> 2)] = gv[0];
       __syncthreads();
       if (tid < WN * 16) {
         const int wn2 = tid >> 4, slot = tid & 15, run = slot >> 1;
