@@ -124,7 +124,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     return s;
   };
   f32x4 preg[MAXP];
+  // GroupNorm * FiLM coefficients of this thread's four channels for the chunk in flight (2-D tiles: one sample per tile).  Requested with
+  // the chunk's patch loads, not when the patch is stored: a dependent L2 round trip would otherwise sit on the critical path.
+  f32x4 cfa = {1.f, 0.f, 1.f, 0.f}, cfb = cfa;
+  auto load_coef = [&](int cc) {
+    const int c0 = cc * CK;
+    if (MODE && p.a_mode == 1 && c0 < p.C1) {
+      const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + c0 + k4 * 4) * 2;
+      cfa = *reinterpret_cast<const f32x4*>(cf);
+      cfb = *reinterpret_cast<const f32x4*>(cf + 4);
+    }
+  };
   auto load_patch = [&](int cc) {  // raw loads only, so that they stay in flight under the MFMAs; the operand transform runs at store time
+    load_coef(cc);
     const int c0 = cc * CK;
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
@@ -157,12 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     const bool xform = c0 < p.C1 && p.a_mode == 1;
     const int rows_per_sample = HW * p.a_imgs_per_sample;
     // GroupNorm * FiLM coefficients of this thread's four channels: one sample per 2-D tile -> fetched once per chunk, not per item
-    f32x4 ca = {1.f, 0.f, 1.f, 0.f}, cb4 = ca;
-    if (MODE && xform) {
-      const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + c0 + k4 * 4) * 2;
-      ca = *reinterpret_cast<const f32x4*>(cf);
-      cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
-    }
+    f32x4 ca = cfa, cb4 = cfb;
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       const int r = (tid >> 3) + ps * 32;
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     for (int q = 0; q < 18; ++q) {
       if (q + PFB < 18) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
       else if (more) load_b(bb[(q + PFB) % NB], ks_of(cc + 1, q + PFB - 18));
+      if (q == 0 && more) load_coef(cc + 1);
       if (q < MAXP && more) load_patch_item(cc + 1, q);
       if (q + 1 < 18) load_a(aa[(q + 1) & 1], (q + 1) >> 1, (q + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
