@@ -428,7 +428,9 @@ def _pack_frag(N, lib, gpu, w2d, fmt):
     (2, 2, 96 * 96, 64, 64, 64, False, False, False),  # res_conv on a skip concatenation, many row tiles
     (1, 2, 36, 64, 0, 768, True, False, False),     # few rows: column chunks spread over blockIdx.y
     (1, 3, 50, 16, 0, 96, True, False, True),       # K padded 16 -> 32, Cout not a multiple of the 64-column wave tile
-    (1, 1, 40, 128, 128, 256, False, False, True)])
+    (1, 1, 40, 128, 128, 256, False, False, True),
+    (2, 3, 50, 256, 0, 64, False, False, True),      # K = 256 with one 64-column slice: the four waves split the k16 steps
+    (1, 2, 77, 128, 128, 32, True, False, False)])
 @pytest.mark.parametrize("exact", [False, True])
 def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, res, exact):
     """vmm_proj_bf16x3 (exact: its fp32-MFMA variant vmm_proj_f32, fmt-4 weights) against torch fp32: 1x1 projection with the row tile staged once (optional fused channel LayerNorm) and

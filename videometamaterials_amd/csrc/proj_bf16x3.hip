@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   const vmm_conv_desc& p = a.p;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave / WN, wn_id = wave % WN;
   const int lrow = lane & 31, lk = lane >> 5;
   const int m0 = blockIdx.x * BM;
   const int K = p.C1 + p.C2;
@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
 
   // ---- sweep the output columns
   const uint4* wf = reinterpret_cast<const uint4*>(p.w);
+  // Cout <= 64 under the 1 x 4 wave arrangement (K = 256: a 64-row tile is all the LDS holds) leaves one column slice: the four waves then
+  // split the k16 steps of that slice instead of three of them idling, and wave 0 sums the partial accumulators through LDS.
+  const bool ksplit4 = WN == 4 && p.Cout <= 64;
+  const int wn = ksplit4 ? 0 : wn_id;
   auto load_b = [&](uint4 (&d)[4], int nc, int s) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -264,6 +268,48 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   // software pipeline over the flattened (column chunk, k16 step) sequence: weights and tile fragments of the next step are
   // requested before the MFMAs of the current one; KS is even, so the two register buffers alternate cleanly across chunks
   uint4 bb[2][4], aa[2][4];
+  if (ksplit4) {
+    if constexpr (WN == 4 && KS % 4 == 0) {
+      const int s_begin = wave * (KS / 4);
+      zero_acc();
+      load_b(bb[0], nc_begin, s_begin);
+      load_a(aa[0], s_begin);
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        if (q + 1 < KS / 4) {
+          load_b(bb[(q + 1) & 1], nc_begin, s_begin + q + 1);
+          load_a(aa[(q + 1) & 1], s_begin + q + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(aa[q & 1], bb[q & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // partial accumulators of waves 1..3 -> LDS (the row tile is no longer needed), summed by wave 0, which runs the epilogue
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(At);
+      if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave - 1) * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((w * 4 + i * 2 + j) * 16 + r) * 64 + lane];
+        store_chunk(nc_begin);
+      }
+    }
+    return;
+  }
   load_b(bb[0], nc_begin, 0);
   load_a(aa[0], 0);
   for (int nc = nc_begin; nc < nc_end; ++nc) {

@@ -461,7 +461,10 @@ class _Builder:
         """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
         if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
             return False
-        return (k + 31) // 32 * 32 in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
+        kp = (k + 31) // 32 * 32
+        if kp == 256 and cout <= 64:  # one 64-row tile per CU and a single column slice: the streaming implicit GEMM is faster (measured)
+            return False
+        return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
     def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
