@@ -23,3 +23,16 @@ diff = vm.GaussianDiffusion(model, image_size=bench.HW, num_frames=bench.T, chan
 if os.environ.get("VMM_X3_WGRAD"):
     model.use_x3_wgrad = True  # opt-in split-bf16 weight-gradient kernel (default: the exact-fp32 one in both modes)
 print(bench.bench_training(vm, model, diff, dev, None, 1, 0, steps, precision))
+
+if os.environ.get("VMM_TRAIN_DETAIL"):
+    # per-launch table of one forward + backward of the training plan (HIP events around every launch; eager replay)
+    pl = model.get_plan(bench.B_PER_GPU, bench.T, bench.HW, bench.HW, 11, dev, training=True)
+    pl.launch()
+    pl.pgrad.zero_(); pl.gscratch.zero_()
+    for name, steps, meta in (("fwd", pl.steps, pl.meta), ("bwd", pl.bwd_steps, pl.bwd_meta)):
+        ms = pl.launch_timed(steps)
+        rows = sorted(zip(ms, steps, meta), key=lambda r: -r[0])
+        print(f"== {name}: {sum(ms):.2f} ms over {len(ms)} launches", file=sys.stderr)
+        for t, (fn, _, what), (_, fl, nb) in rows[:60]:
+            print(f"{t:8.3f} ms {fl / t / 1e9 if t > 0 else 0:8.1f} TFLOP/s {nb / t / 1e6 if t > 0 else 0:8.1f} GB/s  {fn.__name__:32s} {what}", file=sys.stderr)
+

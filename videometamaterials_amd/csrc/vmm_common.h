@@ -43,6 +43,8 @@ __device__ __forceinline__ float group_max(float v, int width) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// the same with the hardware reciprocal (1 ulp) instead of an IEEE division: operand transforms inside GEMM loaders
+__device__ __forceinline__ float silu_rcp(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -119,10 +119,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
       for (int u = 0; u < AI; ++u) {
         if (fmask >> (g * AI + u) & 1) {
           const f32x4 c0 = fc0[g][u], c1 = fc1[g][u];
-          areg[g][u].x = silu_f(areg[g][u].x * c0.x + c0.y);
-          areg[g][u].y = silu_f(areg[g][u].y * c0.z + c0.w);
-          areg[g][u].z = silu_f(areg[g][u].z * c1.x + c1.y);
-          areg[g][u].w = silu_f(areg[g][u].w * c1.z + c1.w);
+          areg[g][u].x = silu_rcp(areg[g][u].x * c0.x + c0.y);
+          areg[g][u].y = silu_rcp(areg[g][u].y * c0.z + c0.w);
+          areg[g][u].z = silu_rcp(areg[g][u].z * c1.x + c1.y);
+          areg[g][u].w = silu_rcp(areg[g][u].w * c1.z + c1.w);
         }
         *reinterpret_cast<f32x4*>(&As[buf][g * 16 + lr][u * 64 + l4 * 4]) = areg[g][u];
       }

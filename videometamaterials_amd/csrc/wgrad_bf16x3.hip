@@ -129,10 +129,10 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const vmm_conv_desc p, co
         if (vmask >> r & 1) {
           const int k = smask >> r & 1;
           const f32x4 c0 = k ? cf0[1] : cf0[0], c1 = k ? cf1[1] : cf1[0];
-          rv[r].x = silu_f(rv[r].x * c0.x + c0.y);
-          rv[r].y = silu_f(rv[r].y * c0.z + c0.w);
-          rv[r].z = silu_f(rv[r].z * c1.x + c1.y);
-          rv[r].w = silu_f(rv[r].w * c1.z + c1.w);
+          rv[r].x = silu_rcp(rv[r].x * c0.x + c0.y);
+          rv[r].y = silu_rcp(rv[r].y * c0.z + c0.w);
+          rv[r].z = silu_rcp(rv[r].z * c1.x + c1.y);
+          rv[r].w = silu_rcp(rv[r].w * c1.z + c1.w);
         }
       }
     }
