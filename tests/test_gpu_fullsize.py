@@ -79,3 +79,25 @@ def test_full_sampling_step_batch_independence(setup, gpu):
         solo = diff.p_sample(x[1:2], tt[1:2], cond=cond[1:2], guidance_scale=5.0, noise=z[1:2])
     assert torch.isfinite(full).all()
     assert _rel(solo, full[1:2]) < TOL_ORDER
+
+
+def test_graph_replays_across_samples_stay_finite(setup, gpu):
+    """Regression: the captured sampling step reused for a second full 256-step sample (new noise and conditioning written between
+    replays, no host sync and no other kernels inside the loop -- the failure was timing dependent).  With the GroupNorm sums zeroed by
+    a hipMemsetAsync NODE of the captured graph, the first replay of the second sample ran the memset unordered with the statistics
+    kernel in ~3 of 4 runs: non-finite denoiser output, which the x0 clamp turns into -1, i.e. an all-zero video."""
+    vm, m, x, t, cond = setup
+    from videometamaterials_amd.diffusion import _GraphedStep
+    diff = vm.GaussianDiffusion(m, image_size=96, num_frames=11, channels=3, timesteps=256, loss_type="l1", use_dynamic_thres=True,
+                                sampling_timesteps=256).to(gpu)
+    shape = (4, 3, 11, 96, 96)
+    st = _GraphedStep(diff, shape, 11, 5.0)
+    with torch.inference_mode():
+        for sample in range(2):
+            st.set_cond((torch.rand(4, 11, device=gpu) * 2 - 1))
+            img = torch.randn(shape, device=gpu)
+            for i in reversed(range(256)):
+                img = st(img, i)
+            out = (img + 1) * 0.5
+            assert bool(torch.isfinite(out).all())
+            assert 0.2 < float(out.mean()) < 0.8, f"sample {sample}: mean {float(out.mean()):.4f} (0 = every pixel clamped to -1)"

@@ -479,8 +479,7 @@ extern "C" int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek,
   if (dh != DH || (ldqkv & 3) || (lddo & 3)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int nfh = B * T * heads;
-  hipError_t e = hipMemsetAsync(dctx, 0, sizeof(float) * nfh * DH * DH, s);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = vmm_zero_async(dctx, sizeof(float) * nfh * DH * DH, s)) return rc;
   const float scale = 0.17677669529663687f;
   const int nsplit = max(1, min((HW + LB_TILE - 1) / LB_TILE, cdiv(2048, nfh)));
   const int rps = cdiv(cdiv(HW, nsplit), LB_TILE) * LB_TILE;

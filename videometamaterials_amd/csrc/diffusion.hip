@@ -239,8 +239,7 @@ extern "C" int vmm_lincomb(const float* x, const float* y, const float* z, float
 extern "C" int vmm_loss_reduce(const float* a, const float* b, int64_t n, int32_t squared, double* acc, float* out_mean,
                                vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), s);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = vmm_zero_async(acc, sizeof(double), s)) return rc;
   const int blocks = (int)min((long long)cdiv(n, 256 * 8), 1024LL);
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(max(blocks, 1)), dim3(256), 0, s, a, b, (long long)n, squared, acc);
   VMM_LAUNCH_CHECK();

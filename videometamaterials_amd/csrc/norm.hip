@@ -198,8 +198,7 @@ extern "C" int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32
                                    double* sums, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) || C > 1024 || C % G || G > 256 || (ldx & 3)) return -1;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * B * G * 2, s);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = vmm_zero_async(sums, sizeof(double) * B * G * 2, s)) return rc;  // (a kernel, not a memset node: see vmm_common.h)
   const int rslots = 256 / (C >> 2);
   // enough blocks to fill the chip (>= ~2048 in total) while keeping >= 8 rows per thread slot
   int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));

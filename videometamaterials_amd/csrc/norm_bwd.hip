@@ -229,8 +229,7 @@ extern "C" int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, 
   if ((C & 3) || C > 1024 || C % G || (lddz & 3) || (ldh & 3) || (lddh & 3)) return -1;
   float* P = scratch;
   float* m12 = scratch + (long long)B * C * 2;
-  hipError_t e = hipMemsetAsync(P, 0, sizeof(float) * B * C * 2, s);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = vmm_zero_async(P, sizeof(float) * B * C * 2, s)) return rc;
   const int rslots = 256 / (C >> 2);
   int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));
   const int rpb = cdiv(rows_per_sample, blocks);

@@ -49,3 +49,19 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Zero-fill on a stream as a KERNEL.  The library never uses hipMemsetAsync: captured into a hipGraph its memset node was observed
+// (ROCm 7.2, MI355X) to run unordered with the kernel nodes around it -- accumulators zeroed after contributions had landed
+// (tools/repro_graph_memset.py).  `words` 4-byte words at a 4-byte aligned address.
+static __global__ void vmm_zero_words_kernel(unsigned* __restrict__ p, long long words) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline int vmm_zero_async(void* p, size_t bytes, hipStream_t s) {
+  const long long words = (long long)(bytes / 4);
+  if (words <= 0) return 0;
+  const long long want = (words + 255) / 256;
+  const int blocks = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(vmm_zero_words_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<unsigned*>(p), words);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
