@@ -277,10 +277,13 @@ class _GraphedStep:
     def _body(self):
         d, lib, B = self.diff, N.lib(), self.B
         pl = self.plan
-        pl.x_in[:B].copy_(self.img)
-        pl.x_in[B:].copy_(self.img)
-        pl.time_in[:B].copy_(self.t)
-        pl.time_in[B:].copy_(self.t)
+        # elementwise kernels, not copy_(): a same-dtype contiguous copy_ is a hipMemcpyAsync, i.e. a memcpy NODE once captured, and a
+        # memset node of this graph was observed to run unordered with its neighbouring kernels -- the captured
+        # step consists of kernel nodes only
+        torch.add(self.img, 0, out=pl.x_in[:B])
+        torch.add(self.img, 0, out=pl.x_in[B:])
+        torch.add(self.t, 0, out=pl.time_in[:B])
+        torch.add(self.t, 0, out=pl.time_in[B:])
         pl.launch()
         n = self.img.numel() // B
         dyn = d.use_dynamic_thres
