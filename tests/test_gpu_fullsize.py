@@ -101,3 +101,34 @@ def test_graph_replays_across_samples_stay_finite(setup, gpu):
             out = (img + 1) * 0.5
             assert bool(torch.isfinite(out).all())
             assert 0.2 < float(out.mean()) < 0.8, f"sample {sample}: mean {float(out.mean()):.4f} (0 = every pixel clamped to -1)"
+
+
+def test_captured_step_equals_eager_launch_list(setup, gpu):
+    """The denoiser output of a replayed hipGraph step is bit-identical to the eager launch list on the same inputs (the kernels are
+    deterministic): guards against graph-only ordering faults such as the memset-node one above.  Replays run back to back without a
+    host sync; only the inputs of the last replay are kept."""
+    vm, m, x, t, cond = setup
+    from videometamaterials_amd.diffusion import _GraphedStep
+    diff = vm.GaussianDiffusion(m, image_size=96, num_frames=11, channels=3, timesteps=256, loss_type="l1", use_dynamic_thres=True,
+                                sampling_timesteps=256).to(gpu)
+    shape = (4, 3, 11, 96, 96)
+    st = _GraphedStep(diff, shape, 11, 5.0)
+    pl = st.plan
+    with torch.inference_mode():
+        for trial, nsteps in enumerate((3, 17)):
+            st.set_cond(torch.rand(4, 11, device=gpu) * 2 - 1)
+            img = torch.randn(shape, device=gpu)
+            ts = list(reversed(range(256)))[:nsteps]
+            for i in ts[:-1]:
+                img = st(img, i)
+            prev = st.img.clone()
+            st(img, ts[-1])
+            got = pl.out.clone()
+            torch.cuda.synchronize()
+            assert st.graph is not None, "hipGraph capture failed: the sampler would silently run eagerly"
+            pl.x_in[:4].copy_(prev)
+            pl.x_in[4:].copy_(prev)
+            pl.time_in.fill_(ts[-1])
+            pl.launch()
+            torch.cuda.synchronize()
+            assert torch.equal(got, pl.out), f"trial {trial}: replayed step differs from the eager launch list"
