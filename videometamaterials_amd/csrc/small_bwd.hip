@@ -68,9 +68,18 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const vmm_dense_bwd_jo
   if (unit >= jb.rows * kchunks) return;
   const int r = unit / kchunks, k = (unit % kchunks) * 64 + lane;
   if (k >= jb.K) return;
-  float acc = 0.f;
-  for (int o = 0; o < jb.N; ++o) acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
-  atomicAdd(&jb.dx[(long long)r * jb.lddx + k], acc * act_grad(jb.x[(long long)r * jb.ldx + k], jb.act_in));
+  // blockIdx.z = slice of 128 output features: these layers have a handful of rows (the batch), so the reduction over N is what there
+  // is to parallelise; dx is accumulated with atomics anyway
+  const int o0 = blockIdx.z * 128, o1 = min(jb.N, o0 + 128);
+  if (o0 >= o1) return;
+  float acc = 0.f, acc2 = 0.f;
+  int o = o0;
+  for (; o + 1 < o1; o += 2) {
+    acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
+    acc2 = fmaf(jb.dy[(long long)r * jb.lddy + o + 1], jb.w[(long long)(o + 1) * jb.K + k], acc2);
+  }
+  if (o < o1) acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
+  atomicAdd(&jb.dx[(long long)r * jb.lddx + k], (acc + acc2) * act_grad(jb.x[(long long)r * jb.ldx + k], jb.act_in));
 }
 
 // tokens[b,f,d] = cond[b,f]*w[d] + bias[d] (or null token), pooled = mean_f of the un-dropped tokens; thread per d
@@ -292,7 +301,7 @@ extern "C" int vmm_dense_bwd_batched(const vmm_dense_bwd_job* jobs_dev, int32_t 
   hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(max_N, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   VMM_LAUNCH_CHECK();
   if (max_xunits > 0) {
-    hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(max_xunits, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(max_xunits, 4), njobs, cdiv(max_N, 128)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
     VMM_LAUNCH_CHECK();
   }
   return 0;
