@@ -119,6 +119,11 @@ int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_el
 /* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */
 int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G,
                         double* sums /* [B*G*2], zeroed by the call */, vmm_stream_t stream);
+/* the same statistics as per-workgroup fp32 (sum, sum of squares) slots part[B*G][n][2], n = vmm_groupnorm_stats_slots(B, rows_per_sample, C);
+ * vmm_groupnorm_coef(sums = NULL, partials = part, n_contrib = n) adds them in a fixed order (bit-reproducible; no zero-fill, no atomics) */
+int vmm_groupnorm_stats_slots(int32_t B, int32_t rows_per_sample, int32_t C);
+int vmm_groupnorm_stats_partials(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G, float* part,
+                                 vmm_stream_t stream);
 /* mean/rstd from the sums, then coef[b,c] = (a, b'):  y = silu(x*a + b')  with a = rstd*gamma*(scale+1),
  * b' = (beta - mean*rstd*gamma)*(scale+1)+shift;  film = [B][ldfilm] rows (scale | shift) or NULL (vddp.py:283,306).
  * stats_out [B*G*2] = (mean, rstd) is kept for the backward pass (may be NULL).

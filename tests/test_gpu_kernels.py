@@ -289,6 +289,18 @@ def test_groupnorm_film_silu(gpu, C_, G):
     xs = x.reshape(B, G, -1)
     assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 0], xs.mean(-1), atol=1e-5)
     assert torch.allclose(stats.cpu().reshape(B, G, 2)[..., 1], 1 / torch.sqrt(xs.var(-1, unbiased=False) + 1e-5), rtol=1e-5)
+    # slot mode: the statistics pass leaves one (sum, sum of squares) pair per workgroup, the coefficient kernel adds them in fixed order
+    nslots = int(lib.vmm_groupnorm_stats_slots(B, rps, C_))
+    part = torch.full((B * G * nslots * 2,), float("nan"), device=gpu)
+    coef3 = torch.full_like(coef, float("nan"))
+    for _ in range(2):  # twice: bit-reproducible
+        N.check(lib.vmm_groupnorm_stats_partials(xr.data_ptr(), C_, B, rps, C_, G, part.data_ptr(), _s()), "stats slots")
+        N.check(lib.vmm_groupnorm_coef(None, rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(), 2 * C_, B, C_, G, coef3.data_ptr(), None,
+                                       part.data_ptr(), nslots, None, 0, _s()), "coef from slots")
+        torch.cuda.synchronize()
+        assert relerr(coef3.cpu(), coef.cpu()) < 1e-6
+        again = coef3.clone() if _ == 0 else again
+    assert torch.equal(coef3, again)
     if (C_ // G) % 4 == 0:  # direct mode: the coefficient kernel reduces each (sample, group) slice of x itself, no statistics launch
         coef2 = torch.full_like(coef, float("nan"))
         N.check(lib.vmm_groupnorm_coef(None, rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fg.data_ptr(), 2 * C_, B, C_, G, coef2.data_ptr(), None,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "vmm_adam_step": [c_ptr, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_ptr],
     "vmm_ema_step": [c_ptr, c_i32, c_i64, c_f32, c_i32, c_ptr],
     "vmm_groupnorm_stats": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_groupnorm_stats_slots": [c_i32, c_i32, c_i32],
+    "vmm_groupnorm_stats_partials": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
     "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],

@@ -9,7 +9,7 @@ namespace {
 // ---------------------------------------------------------------- GroupNorm statistics
 // grid = (blocks_per_sample, B); block = 256 threads; each thread owns one float4 column group and strides over rows.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, int rows_per_sample, int C, int G,
-                                                        int rows_per_block, double* __restrict__ sums) {
+                                                        int rows_per_block, double* __restrict__ sums, float* __restrict__ part) {
   const int b = blockIdx.y;
   const int c4n = C >> 2;                 // float4 columns per row
   const int tid = threadIdx.x;
@@ -43,8 +43,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         dq += (double)sh_q[(rl * c4n + c4) * 4 + j];
       }
     }
-    atomicAdd(&sums[(b * G + tid) * 2 + 0], ds);
-    atomicAdd(&sums[(b * G + tid) * 2 + 1], dq);
+    if (part) {  // one (sum, sum of squares) slot per workgroup: summed in fixed order by gn_coef_kernel (no zero-fill, no atomics)
+      float* pp = part + (((long long)(b * G + tid)) * gridDim.x + blockIdx.x) * 2;
+      pp[0] = (float)ds;
+      pp[1] = (float)dq;
+    } else {
+      atomicAdd(&sums[(b * G + tid) * 2 + 0], ds);
+      atomicAdd(&sums[(b * G + tid) * 2 + 1], dq);
+    }
   }
 }
 
@@ -194,17 +200,37 @@ __global__ __launch_bounds__(256) void chan_ln_kernel(const float* __restrict__ 
 
 }  // namespace
 
+static int gn_stats_blocks(int rows_per_sample, int C, int B) {
+  const int rslots = 256 / (C >> 2);
+  // enough blocks to fill the chip (>= ~2048 in total) while keeping >= 8 rows per thread slot
+  int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));
+  const int rows_per_block = cdiv(rows_per_sample, blocks);
+  return cdiv(rows_per_sample, rows_per_block);
+}
+
 extern "C" int vmm_groupnorm_stats(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G,
                                    double* sums, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) || C > 1024 || C % G || G > 256 || (ldx & 3)) return -1;
   if (int rc = vmm_zero_async(sums, sizeof(double) * B * G * 2, s)) return rc;  // (a kernel, not a memset node: see vmm_common.h)
-  const int rslots = 256 / (C >> 2);
-  // enough blocks to fill the chip (>= ~2048 in total) while keeping >= 8 rows per thread slot
-  int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));
-  const int rows_per_block = cdiv(rows_per_sample, blocks);
-  blocks = cdiv(rows_per_sample, rows_per_block);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks, B), dim3(256), 0, s, x, ldx, rows_per_sample, C, G, rows_per_block, sums);
+  const int blocks = gn_stats_blocks(rows_per_sample, C, B);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks, B), dim3(256), 0, s, x, ldx, rows_per_sample, C, G, cdiv(rows_per_sample, blocks), sums, nullptr);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same pass leaving one fp32 (sum, sum of squares) pair per workgroup in part[B*G][n][2], n = vmm_groupnorm_stats_slots(...):
+// vmm_groupnorm_coef(partials = part, n_contrib = n) then adds them in a fixed order -- bit-reproducible, no zero-fill, no atomics.
+extern "C" int vmm_groupnorm_stats_slots(int32_t B, int32_t rows_per_sample, int32_t C) {
+  if ((C & 3) || C > 1024 || rows_per_sample <= 0) return 0;
+  return gn_stats_blocks(rows_per_sample, C, B);
+}
+extern "C" int vmm_groupnorm_stats_partials(const float* x, int32_t ldx, int32_t B, int32_t rows_per_sample, int32_t C, int32_t G, float* part,
+                                            vmm_stream_t stream) {
+  if ((C & 3) || C > 1024 || C % G || G > 256 || (ldx & 3)) return -1;
+  const int blocks = gn_stats_blocks(rows_per_sample, C, B);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, x, ldx, rows_per_sample, C, G, cdiv(rows_per_sample, blocks),
+                     nullptr, part);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -535,10 +535,11 @@ class _Builder:
             # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
             self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, None, 0, h.ptr, h.ld), prefix + ".norm stats+coef", nbytes=4.0 * h.n)
         else:
-            sums_off = self.alloc(B * G * 4)
-            self.step(self.lib.vmm_groupnorm_stats, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(sums_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
-            self.step(self.lib.vmm_groupnorm_coef, (self.ptr(sums_off), *coef_args, None, 0, None, 0), prefix + ".norm coef")
-            self.free(sums_off, B * G * 4)
+            nslots = int(self.lib.vmm_groupnorm_stats_slots(B, rows_ps, C_))  # one (sum, sum of squares) slot per workgroup of the statistics pass
+            part_off = self.alloc(B * G * nslots * 2)
+            self.step(self.lib.vmm_groupnorm_stats_partials, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(part_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
+            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), nslots, None, 0), prefix + ".norm coef")
+            self.free(part_off, B * G * nslots * 2)
         return coef_off, B * C_ * 2, self.ptr(coef_off), stats_ptr
 
     def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
