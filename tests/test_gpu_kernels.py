@@ -329,11 +329,13 @@ def _attn_ref(q, k, v, bias=None):
     return torch.einsum("...ij,...jd->...id", sim.softmax(-1), v)
 
 
-@pytest.mark.parametrize("ntok,bias_on_cond", [(0, 0), (7, 1), (16, 0)])
-def test_temporal_attention_core(gpu, ntok, bias_on_cond):
+@pytest.mark.parametrize("heads,T,ntok,bias_on_cond", [(4, 7, 0, 0), (4, 7, 7, 1), (4, 7, 16, 0),              # thread-per-query kernel
+                                                       (8, 11, 11, 1), (8, 16, 16, 0), (8, 5, 0, 0),           # fp32 matrix-core kernel, one frame tile
+                                                       (8, 22, 16, 0), (8, 32, 5, 0), (8, 17, 0, 0)])  # two frame tiles
+def test_temporal_attention_core(gpu, heads, T, ntok, bias_on_cond):
     N, lib = _lib()
     g = torch.Generator().manual_seed(6)
-    B, T, HW, heads = 2, 7, 10, 4
+    B, HW = 2, 10
     hid = heads * 32
     qkv = torch.randn(B, T, HW, 3, heads, 32, generator=g)
     bias = torch.randn(heads, T, T, generator=g)
@@ -346,15 +348,19 @@ def test_temporal_attention_core(gpu, ntok, bias_on_cond):
         v = torch.cat([ev.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), v], dim=-2)
         bfull = torch.cat([bias if bias_on_cond else torch.zeros(heads, T, ntok), bias], dim=-1)[None, None]
     ref = _attn_ref(q, k, v, bfull).permute(0, 3, 1, 2, 4).reshape(B * T * HW, hid)
+    sim = torch.einsum("...id,...jd->...ij", q, k) + bfull
+    lse_ref = torch.logsumexp(sim, -1).permute(0, 3, 1, 2).reshape(B * T * HW, heads)  # rows (b, t, pix) x heads
     qg = qkv.reshape(B * T * HW, 3 * hid).to(gpu)
-    out = torch.empty(B * T * HW, hid, device=gpu)
+    out = torch.full((B * T * HW, hid), float("nan"), device=gpu)
+    lse = torch.full((B * T * HW, heads), float("nan"), device=gpu)
     ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
     bg = bias.to(gpu)
     N.check(lib.vmm_temporal_attention(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok,
-                                       bg.data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, None, _s()), "temporal")
+                                       bg.data_ptr(), bias_on_cond, out.data_ptr(), hid, B, T, HW, heads, 32, lse.data_ptr(), _s()), "temporal")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
+    assert relerr(lse.cpu(), lse_ref) < 5e-6
 
 
 @pytest.mark.parametrize("Cc,T,HW,ntok,bias_on_cond", [(128, 11, 36, 11, 1), (256, 7, 10, 16, 0), (128, 16, 6, 0, 0), (512, 3, 144, 5, 0)])
