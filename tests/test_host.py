@@ -128,3 +128,88 @@ def test_plan_construction_without_gpu():
     assert offs == sorted(offs, reverse=True) and offs[-1] == 0
     spans = sorted(keep.param_slices.values())
     assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _diffusion_ckpt_variants(ref_sd):
+    """The key variants a reference checkpoint can come in: rotary freqs present or not (package version), keys
+    bare or behind DDP's `module.` -- at the wrapped GaussianDiffusion or at the denoiser."""
+    no_freqs = {k: v for k, v in ref_sd.items() if ".rotary_emb." not in k}
+    yield "as saved", dict(ref_sd)
+    yield "no rotary freqs", no_freqs
+    yield "module. prefix", {"module." + k: v for k, v in ref_sd.items()}
+    yield "module. prefix, no rotary freqs", {"module." + k: v for k, v in no_freqs.items()}
+    yield "denoise_fn.module.", {(k.replace("denoise_fn.", "denoise_fn.module.", 1)): v for k, v in ref_sd.items()}
+    newer = dict(ref_sd)
+    newer["denoise_fn.downs.0.3.fn.fn.fn.rotary_emb.cached_freqs"] = torch.zeros(11, 32)  # tables newer rotary packages may persist
+    yield "extra rotary tables", newer
+
+
+def test_reference_checkpoint_loads_at_the_gaussian_diffusion_level():
+    """Trainer.load (vddp.py:1563-1592) calls model.load_state_dict(data['model']) and ema_model.load_state_dict(data['ema']) on the
+    GaussianDiffusion objects, strict.  Key list = the real reference's GaussianDiffusion.state_dict() (make_golden_ckpt.py)."""
+    import videometamaterials_amd as vm
+    kw, (B, T, H, W), _ = helpers.CONFIGS["lagr16"]
+    with open(os.path.join(helpers.GOLDEN_DIR, "shapes_diffusion_lagr16.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    diff = vm.GaussianDiffusion(vm.Unet3D(**kw), image_size=H, num_frames=T, channels=3, timesteps=256, loss_type="l1", use_dynamic_thres=True,
+                                sampling_timesteps=256)
+    own = diff.state_dict()
+    assert set(own) == set(shapes) and all(tuple(own[k].shape) == shapes[k] for k in shapes)
+    ref_sd = {k: (helpers.synth_tensor(k[len("denoise_fn."):], s, 3) if k.startswith("denoise_fn.") else own[k].clone()) for k, s in shapes.items()}
+    ema = copy.deepcopy(diff)  # vddp.py:1453
+    for what, sd in _diffusion_ckpt_variants(ref_sd):
+        for target in (diff, ema):
+            for p in target.parameters():
+                p.data.zero_()
+            gen = target.denoise_fn._generation
+            res = target.load_state_dict(sd)  # strict
+            assert not res.missing_keys and not res.unexpected_keys, what
+            assert target.denoise_fn._generation > gen, what  # cached plans will re-pack
+            got = target.state_dict()
+            for k in ("denoise_fn.init_conv.weight", "denoise_fn.ups.3.3.fn.fn.fn.to_out.weight", "denoise_fn.null_text_token"):
+                assert torch.equal(got[k], ref_sd[k]), (what, k)
+            assert torch.equal(got["betas"], own["betas"])
+    with pytest.raises(RuntimeError):  # strictness is kept for everything that is not one of the tolerated variants
+        diff.load_state_dict({k: v for k, v in ref_sd.items() if k != "denoise_fn.init_conv.weight"})
+    with pytest.raises(RuntimeError):
+        diff.load_state_dict(dict(ref_sd, **{"denoise_fn.bogus.weight": torch.zeros(1)}))
+    pickle.loads(pickle.dumps(diff)).load_state_dict(ref_sd)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """sizeof / offsetof of every struct in include/vmm_kernels.h, as gcc lays them out, against the ctypes Structures the host binds
+    them with (and against the listing in INTEGRATION.md)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from videometamaterials_amd import _native as N
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"vmm_conv_desc": N.ConvDesc, "vmm_dense_job": N.DenseJob, "vmm_pack_job": N.PackJob, "vmm_dense_bwd_job": N.DenseBwdJob,
+             "vmm_optim_job": N.OptimJob}
+    hdr = open(os.path.join(ROOT, "include", "vmm_kernels.h")).read()
+    assert set(re.findall(r"typedef struct (\w+)", hdr)) == set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vmm_kernels.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+        # every member of the C struct is bound: the field count of the header's struct body equals the ctypes one
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        members = [m for decl in body.split(";") for m in decl.split(",") if m.strip()]
+        assert len(members) == len(cls._fields_), (cname, len(members), len(cls._fields_))
+    # INTEGRATION.md shows the same vmm_conv_desc binding
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for fname, _ in N.ConvDesc._fields_:
+        assert re.search(r'\("%s"' % fname, doc), f"INTEGRATION.md's vmm_conv_desc listing lacks {fname}"

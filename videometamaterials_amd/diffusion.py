@@ -69,6 +69,15 @@ class GaussianDiffusion(nn.Module):
         self.ddim_sampling_eta = ddim_sampling_eta
         self._graph_cache = {}
         self.use_graph = True
+        self.register_load_state_dict_pre_hook(GaussianDiffusion._ckpt_pre_hook)
+
+    @staticmethod
+    def _ckpt_pre_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """A checkpoint written from the DDP / Accelerate-wrapped model carries `module.` in front of every key
+        (`module.betas`, `module.denoise_fn...`); Trainer.load (vddp.py:1577,1587) hands it to this class unchanged."""
+        wrapped = prefix + "module."
+        for k in [k for k in state_dict if k.startswith(wrapped)]:
+            state_dict[prefix + k[len(wrapped):]] = state_dict.pop(k)
 
     def __getstate__(self):
         st = self.__dict__.copy()
@@ -161,6 +170,9 @@ class GaussianDiffusion(nn.Module):
             cond = cond.to(device).contiguous()
         stepper = None
         was_static = getattr(self.denoise_fn, "static_weights", False)
+        # the optimiser, an EMA update or load_state_dict may have changed the parameters since the last sample(): re-pack the
+        # cached plans' operand layouts ONCE (static addresses, so captured graphs stay valid), then skip the per-step scan
+        self.denoise_fn.refresh_plans()
         self.denoise_fn.static_weights = True  # weights cannot change inside the sampling loop
         try:
             if self.use_graph and noises is None and cond is not None and guidance_scale != 1:
@@ -187,8 +199,8 @@ class GaussianDiffusion(nn.Module):
         batch, device, eta = shape[0], self.betas.device, self.ddim_sampling_eta
         pairs = hostmath.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).clone()
-        acp = self.alphas_cumprod.double().cpu()
         from .plan import cfg_combine
+        acp = self.alphas_cumprod.cpu()  # one transfer; the per-step scalars below are evaluated on 0-d fp32 host tensors
         for j, (time, time_next) in enumerate(pairs):
             tt = torch.full((batch,), time, device=device, dtype=torch.long)
             eps_c, eps_n = self._eps_pair(img, tt, cond, guidance_scale)
@@ -198,7 +210,7 @@ class GaussianDiffusion(nn.Module):
                 img = x0
                 continue
             # scalar coefficients evaluated like the reference (fp32 0-d tensors, vddp.py:1006-1010)
-            a, an = self.alphas_cumprod[time].cpu(), self.alphas_cumprod[time_next].cpu()
+            a, an = acp[time], acp[time_next]
             sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
             c = (1 - an - sigma ** 2).sqrt()
             noise = torch.randn_like(img) if noises is None else noises[j].to(device)
@@ -211,11 +223,14 @@ class GaussianDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ hipGraph-captured guided sampling step
     def _graphed_step(self, shape, cond, w):
-        key = (shape, w, cond.shape[-1], str(cond.device))
+        # everything the captured launch list bakes in: shapes, guidance weight, thresholding mode / rank, the denoiser's arithmetic
+        key = (shape, w, cond.shape[-1], str(cond.device), bool(self.use_dynamic_thres), float(self.dynamic_thres_percentile),
+               self.denoise_fn.precision)
         st = self._graph_cache.get(key)
         if st is None:
             st = _GraphedStep(self, shape, cond.shape[-1], w)
             self._graph_cache[key] = st
+        st.refresh_weights()
         st.set_cond(cond)
         return st
 
@@ -268,6 +283,12 @@ class _GraphedStep:
         self.graph = None
         self.captured = False
 
+    def refresh_weights(self):
+        """Re-pack the plan's operand layouts if the parameters changed since they were packed (the packed buffers have static
+        addresses, so a captured graph stays valid)."""
+        _, _, T, H, W = self.shape
+        self.plan = self.diff.denoise_fn.get_plan(2 * self.B, T, H, W, self.cond2.shape[1], self.img.device)
+
     def set_cond(self, cond):
         self.cond2[: self.B].copy_(cond)
         self.cond2[self.B:].copy_(cond)
@@ -313,10 +334,7 @@ class _GraphedStep:
         self.t.fill_(i)
         if not self.captured:
             saved = self.img.clone()
-            try:
-                self._capture()
-            except Exception:  # capture unsupported: stay on the eager HIP path (same kernels)
-                self.graph = None
+            self._capture()  # a capture failure is an error, not a reason to go eager silently (use_graph = False is the opt-out)
             self.captured = True
             self.img.copy_(saved)
             self.t.fill_(i)

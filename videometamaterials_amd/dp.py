@@ -103,34 +103,59 @@ class DataParallelTrainer:
         self.ema_model.load_state_dict(self.model.state_dict())
 
     # ------------------------------------------------------------------ setup for one input shape
+    def _pointer_signature(self) -> tuple:
+        return tuple(p.data_ptr() for p in self.unet.parameters()) + tuple(p.data_ptr() for p in self.ema_model.denoise_fn.parameters())
+
+    def _moments_for(self, pl, dev):
+        """Adam's first / second moments live per PARAMETER NAME and survive a change of training plan (another batch shape, e.g.
+        the short last batch of an epoch -- the reference's DataLoader has no drop_last): only the job tables are rebuilt."""
+        if not hasattr(self, "_moments"):
+            self._moments = {}
+        missing = [(name, n) for name, (_, n) in pl.param_slices.items() if name not in self._moments]
+        if missing:
+            flat = torch.zeros(2 * sum((n + 3) // 4 * 4 for _, n in missing), dtype=torch.float32, device=dev)
+            o = 0
+            for name, n in missing:
+                npad = (n + 3) // 4 * 4
+                self._moments[name] = (flat[o:o + n], flat[o + npad:o + npad + n])
+                o += 2 * npad
+        return self._moments
+
+    def _build_tables(self, pl, dev) -> None:
+        params = dict(self.unet.named_parameters())
+        ema_params = dict(self.ema_model.denoise_fn.named_parameters())
+        moments = self._moments_for(pl, dev)
+        jobs = (N.OptimJob * len(pl.param_slices))()
+        ejobs = (N.OptimJob * len(params))()
+        self._max_n = 0
+        for i, (name, (off, n)) in enumerate(pl.param_slices.items()):
+            j = jobs[i]
+            m, v = moments[name]
+            j.p, j.g = params[name].data_ptr(), pl.pgrad.data_ptr() + 4 * off
+            j.m, j.v, j.n = m.data_ptr(), v.data_ptr(), n
+            self._max_n = max(self._max_n, n)
+        for i, (name, p) in enumerate(params.items()):  # EMA covers every parameter (vddp.py:121-124)
+            j = ejobs[i]
+            j.p, j.m, j.n = p.data_ptr(), ema_params[name].data_ptr(), p.numel()
+            self._max_n = max(self._max_n, p.numel())
+        self._adam_table = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), len(jobs))
+        self._ema_table = (torch.frombuffer(bytearray(bytes(ejobs)), dtype=torch.uint8).to(dev), len(ejobs))
+        self._ptr_sig = self._pointer_signature()
+
     def _prepare(self, x, cond):
         B, _, T, H, W = x.shape
         pl = self.unet.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True)
+        dev = x.device
         if pl is not self._plan:
             self._plan = pl
-            dev = x.device
-            self.m_buf = torch.zeros_like(pl.pgrad)
-            self.v_buf = torch.zeros_like(pl.pgrad)
-            params = dict(self.unet.named_parameters())
-            ema_params = dict(self.ema_model.denoise_fn.named_parameters())
-            jobs = (N.OptimJob * len(pl.param_slices))()
-            ejobs = (N.OptimJob * len(params))()
-            self._max_n = 0
-            for i, (name, (off, n)) in enumerate(pl.param_slices.items()):
-                j = jobs[i]
-                j.p, j.g = params[name].data_ptr(), pl.pgrad.data_ptr() + 4 * off
-                j.m, j.v, j.n = self.m_buf.data_ptr() + 4 * off, self.v_buf.data_ptr() + 4 * off, n
-                self._max_n = max(self._max_n, n)
-            for i, (name, p) in enumerate(params.items()):  # EMA covers every parameter (vddp.py:121-124)
-                j = ejobs[i]
-                j.p, j.m, j.n = p.data_ptr(), ema_params[name].data_ptr(), p.numel()
-                self._max_n = max(self._max_n, p.numel())
-            self._adam_table = (torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev), len(jobs))
-            self._ema_table = (torch.frombuffer(bytearray(bytes(ejobs)), dtype=torch.uint8).to(dev), len(ejobs))
-            self._ptr_sig = tuple(p.data_ptr() for p in params.values()) + tuple(p.data_ptr() for p in ema_params.values())
+            self._build_tables(pl, dev)
             self._reducer = BucketedAllReduce(pl.pgrad, pl.pgrad_floats, self.bucket_floats, self.group)
             self._acc = torch.empty(1, dtype=torch.float64, device=dev)
             self._loss = torch.empty((), dtype=torch.float32, device=dev)
+        elif self._ptr_sig != self._pointer_signature():
+            # parameters were re-homed (.to(), `.data =` as in the reference EMA, load_state_dict(assign=True)): the device job
+            # tables hold raw pointers the Adam / EMA kernels write through
+            self._build_tables(pl, dev)
         return pl
 
     # ------------------------------------------------------------------ one optimisation step
@@ -152,8 +177,8 @@ class DataParallelTrainer:
         pl.time_in.copy_(t)
         pl.cond_in.copy_(cond)
         pl.mask_in.copy_(mask)
-        # the plan re-packs its operand layouts from the live parameters (one launch) -- they changed in the last optimiser step
-        pl.refresh_weights(self.unet._params_flat())
+        # (_prepare -> get_plan re-packed the operand layouts from the live parameters, one launch: the last optimiser step bumped the
+        # model's generation)
         pl.launch()
         sq = 1 if d.loss_type == "l2" else 0
         N.check(lib.vmm_loss_reduce(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, self._acc.data_ptr(), self._loss.data_ptr(), _stream()), "loss")
@@ -164,9 +189,11 @@ class DataParallelTrainer:
         b1, b2 = self.betas
         tab, n = self._adam_table
         N.check(lib.vmm_adam_step(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, self.step, 1.0 / self.world, _stream()), "vmm_adam_step")
+        self.unet.bump_generation()  # written through raw pointers: autograd's version counters did not move
         if self.step % self.update_ema_every == 0:  # vddp.py:1637-1639, 1500-1504
             tab, n = self._ema_table
             N.check(lib.vmm_ema_step(tab.data_ptr(), n, self._max_n, self.ema_decay, 1 if self.step < self.step_start_ema else 0, _stream()), "vmm_ema_step")
+            self.ema_model.denoise_fn.bump_generation()
         return self._loss
 
     # ------------------------------------------------------------------ sharded sampling (vddp.py:1506-1532, 1816-1845)

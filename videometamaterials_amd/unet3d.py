@@ -105,7 +105,8 @@ class Unet3D(nn.Module):
 
         self._build_parameters()
         self._plans: Dict[tuple, "_plan.Plan"] = {}
-        self._weights_version = None
+        self._generation = 0
+        self.register_load_state_dict_pre_hook(Unet3D._ckpt_pre_hook)
         self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
         # matrix-core arithmetic of the contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative, 5x the MFMA
         # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
@@ -205,24 +206,35 @@ class Unet3D(nn.Module):
         _attach(self, "null_text_token", torch.randn(1, self.cond_attention_tokens, cd))
         _attach(self, "null_text_hidden", torch.randn(1, td))
 
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        """Accept checkpoints with or without the `...rotary_emb.freqs` entries (their presence depends on the
-        rotary_embedding_torch version) and with a DDP `module.` prefix."""
-        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-        own = super().state_dict()
-        for k in own:
-            if k.endswith("rotary_emb.freqs") and k not in sd:
-                sd[k] = own[k]
-        sd = {k: v for k, v in sd.items() if not (k.endswith("rotary_emb.freqs") and k not in own)}
-        out = super().load_state_dict(sd, strict=strict, assign=assign)
-        self._weights_version = None
-        return out
+    @staticmethod
+    def _ckpt_pre_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoint tolerances, applied wherever this module sits in the tree being loaded -- the reference loads at the
+        GaussianDiffusion level (Trainer.load -> model.load_state_dict / ema_model.load_state_dict, vddp.py:1577,1587), where
+        nn.Module recursion reaches children through _load_from_state_dict only:
+        * a DDP / Accelerate `module.` level in front of the denoiser's keys is stripped;
+        * `...rotary_emb.*` entries are optional both ways: whether `freqs` (and newer versions' cached tables) appear in a
+          checkpoint depends on the rotary_embedding_torch version -- missing ones keep the constructor's table,
+          extra ones are dropped."""
+        wrapped = prefix + "module."
+        for k in [k for k in state_dict if k.startswith(wrapped)]:
+            state_dict[prefix + k[len(wrapped):]] = state_dict.pop(k)
+        own = {prefix + k: v for k, v in module.state_dict().items() if ".rotary_emb." in k}
+        for k in [k for k in state_dict if k.startswith(prefix) and ".rotary_emb." in k and k not in own]:
+            del state_dict[k]
+        for k, v in own.items():
+            state_dict.setdefault(k, v)
+        module.bump_generation()
+
+    def bump_generation(self) -> None:
+        """Parameters were (or are about to be) rewritten through a path autograd's version counters cannot see -- raw-pointer
+        HIP launches (vmm_adam_step / vmm_ema_step), load_state_dict, `.data` re-homing: every cached plan re-packs its operand
+        layouts on next use."""
+        self._generation += 1
 
     # ------------------------------------------------------------------ execution
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_plans"] = {}  # plans hold ctypes descriptors and device arenas: rebuilt on demand
-        st["_weights_version"] = None
         return st
 
     def _params_flat(self) -> Dict[str, torch.Tensor]:
@@ -231,7 +243,19 @@ class Unet3D(nn.Module):
         return d
 
     def _version_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self._generation,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def refresh_plans(self) -> None:
+        """Bring the packed weights of every cached inference plan up to date with the live parameters (one pack launch per stale
+        plan).  Sampling loops call this once and then run with `static_weights` (no per-step version scan)."""
+        ver = None
+        for pl in self._plans.values():
+            if pl.training:
+                continue  # training plans re-pack at every step anyway (dp.py / get_plan)
+            ver = self._version_key() if ver is None else ver
+            if pl.weights_version != ver:
+                pl.refresh_weights(self._params_flat())
+                pl.weights_version = ver
 
     def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> "_plan.Plan":
         key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision)
