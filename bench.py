@@ -1,24 +1,31 @@
 #!/usr/bin/env python
 """Benchmark of the hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): Lagrangian model.yaml denoiser (dim 64, mults 1-2-4-8, 39.5 M parameters,
-random-init), 3 x 11 x 96 x 96 video, batch 4 per GPU, classifier-free guidance w = 5, dynamic thresholding.
-One "step" = one guided ancestral DDPM step p_sample(x_t, t) for the whole batch: the denoiser at batch 2B
-(conditional + unconditional branch), x0 prediction, exact 0.9-quantile, posterior update -- exactly what the
-reference executes 256 times per sample() call (vddp.py:956-975).  Inputs are resident in HBM.
-value = sampled frames/s = n_gpus * B * 11 frames / (256 steps * step time).
+N > 1: one rank per GPU over RCCL.  When the launcher's environment (WORLD_SIZE) is absent, bench.py starts the N ranks itself by
+re-executing under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`; every rank asserts that the process group
+really has N members and rank 0 puts `rccl_ranks` on the JSON line.
 
-Extra objects on the JSON line: `roofline` for the dominant kernel family (the 3x3 convolutions, split-bf16 MFMA bound) from
-HIP-event timing of every launch, `cpu_baseline` = the oracle (CPU restatement) timed on the host cores, and `training` = the
-data-parallel optimisation step (the other half of BASELINE.json's metric).
+Workload (BASELINE.json configs[1]): Lagrangian model.yaml denoiser (dim 64, mults 1-2-4-8, 39.5 M parameters, random-init),
+3 x 11 x 96 x 96 video, batch 4 per GPU, classifier-free guidance w = 5, dynamic thresholding.
+One "step" = one guided ancestral DDPM step p_sample(x_t, t) for the whole batch: the denoiser at batch 2B (conditional +
+unconditional branch), x0 prediction, exact 0.9-quantile, posterior update -- what the reference executes 256 times per sample()
+call (vddp.py:956-975).  Inputs are resident in HBM.  The default K = 256 steps t = 255 .. 0 is one full sample(); value = sampled
+frames/s = n_gpus * B * 11 frames * (K / 256) / elapsed.  `full_sample` repeats the measurement through the public
+GaussianDiffusion.sample() call (SURVEY 8(d)'s definition).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel family of the sampling step, `attention` (the attention kernel
+families against the matrix-core roof), `fp32_exact` (the same sampler in exact-fp32 arithmetic), `training` = the data-parallel
+optimisation step (the other half of BASELINE.json's metric) with its own `roofline_training`, and `cpu_baseline` = the oracle (CPU
+restatement of the reference) timed on the host cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,18 +43,25 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (AMD's 5 PF headline includes 2:1 sparsi
 PEAK_HBM_GBS = 8000.0
 # launcher (family) -> device kernel name prefix in rocprofv3 output
 KERNEL_OF = {"vmm_conv3x3_bf16x3": "conv3x3_x3_kernel", "vmm_conv_igemm_bf16x3": "igemm_bf16x3_kernel", "vmm_conv_igemm_f32": "igemm_f32_kernel",
-             "vmm_temporal_block_bf16x3": "temporal_block_kernel", "vmm_linattn_block_bf16x3": "linattn_"}
+             "vmm_temporal_block_bf16x3": "temporal_block_kernel", "vmm_linattn_block_bf16x3": "linattn_", "vmm_temporal_core_bf16x3": "temporal_core_kernel",
+             "vmm_proj_bf16x3": "proj_x3_kernel", "vmm_conv_wgrad_f32": "wgrad_f32_kernel", "vmm_conv3x3_f32": "conv3x3_x3_kernel",
+             "vmm_proj_f32": "proj_x3_kernel"}
+ATTENTION_FAMILIES = ("vmm_temporal_block_bf16x3", "vmm_temporal_core_bf16x3", "vmm_linattn_block_bf16x3", "vmm_spatial_attention", "vmm_linattn_context",
+                      "vmm_linattn_apply", "vmm_temporal_attention")
+
+
+def _committed(name: str):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
 
 
 def pmc_traffic(family: str):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/traffic_latest.json, made by
     tools/profile_bench.sh on this same bench command: separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950's 128-byte requests).  None when the file or the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    prefix = KERNEL_OF.get(family)
-    if not prefix or not os.path.exists(path):
+    prefix, tab = KERNEL_OF.get(family), _committed("traffic_latest.json")
+    if not prefix or tab is None:
         return None
-    tab = json.load(open(path))
     tot, n = 0.0, 0
     for k, v in tab.items():
         if k.startswith(prefix) and "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
@@ -56,6 +70,19 @@ def pmc_traffic(family: str):
             n += ln
     return round(tot / n) if n else None
 
+
+def pmc_mfma_util(family: str):
+    """Matrix-pipe utilisation of a kernel family from the committed SQ counter pass (profiles/sq_latest.json, tools/pmc_kernels.sh +
+    tools/summarize_sq.py on this bench command): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), launch-weighted."""
+    prefix, tab = KERNEL_OF.get(family), _committed("sq_latest.json")
+    if not prefix or tab is None:
+        return None
+    busy = act = 0.0
+    for k, v in tab.items():
+        if k.startswith(prefix) and v.get("GRBM_GUI_ACTIVE"):
+            busy += v["launches"] * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            act += v["launches"] * v["GRBM_GUI_ACTIVE"] * 1024.0
+    return round(busy / act, 4) if act else None
 
 
 def usable_cores() -> int:
@@ -76,38 +103,80 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(max_seconds: float = 30.0):
-    """Oracle (oracle/unet3d_oracle.py, parity-pinned CPU restatement of the reference) on the host cores."""
+def cpu_baseline(full: bool = False):
+    """Oracle (oracle/unet3d_oracle.py + diffusion_oracle.py, the parity-pinned CPU restatement of the reference) on the host cores, fp32,
+    torch CPU with every usable core.  Default = a bounded sample (about a minute): one warm-up forward, then the median of 3 guided
+    p_sample steps and one optimisation step (forward + backward + Adam), all at batch 1 -- every op of the path is per sample, so
+    batch 4 costs 4x (3.9 s at B = 1, 17.9 s at B = 4 for the reference itself).  full = SURVEY 8(d)'s protocol: forward, guided step and
+    training step at batch 4, median of 3 after a warm-up (about 10 minutes)."""
+    from oracle import diffusion_oracle as do
     from oracle import unet3d_oracle as uo
-    torch.manual_seed(0)
     import videometamaterials_amd as vm
+    torch.manual_seed(0)
     model = vm.Unet3D(**LAGRANGIAN)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     cfg = uo.UnetCfg(**{k: v for k, v in LAGRANGIAN.items()})
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(1, 3, T, HW, HW, generator=g)
-    t = torch.randint(0, TIMESTEPS, (1,), generator=g)
-    cond = torch.rand(1, 11, generator=g) * 2 - 1
     nthreads = usable_cores()
     torch.set_num_threads(nthreads)
-    times = []
-    with torch.no_grad():
-        t_begin = time.perf_counter()
-        for i in range(4):
+    b = B_PER_GPU if full else 1
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, 3, T, HW, HW, generator=g)
+    t = torch.randint(0, TIMESTEPS, (b,), generator=g)
+    cond = torch.rand(b, 11, generator=g) * 2 - 1
+    noise = torch.randn(b, 3, T, HW, HW, generator=g)
+    sch = do.schedule_buffers(TIMESTEPS)
+    zeros = torch.zeros(b, dtype=torch.bool)
+
+    def timed(fn, n):
+        out = []
+        for _ in range(n):
             t0 = time.perf_counter()
-            uo.unet3d_forward(sd, cfg, x, t, cond, torch.zeros(1, dtype=torch.bool))
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_begin > max_seconds:
-                break
-    fwd = min(times[1:]) if len(times) > 1 else times[0]
-    step_s = fwd * 2 * B_PER_GPU  # guided step at batch 4 = 8 single-sample forwards
-    return {"value": B_PER_GPU * T / (TIMESTEPS * step_s), "unit": "frames/s", "cores": nthreads, "kind": "port",
-            "sample": f"{len(times)} oracle Unet3D forwards (B=1, 11x96x96, Lagrangian widths, fp32, torch CPU {nthreads} threads); "
-                      f"best {fwd:.2f} s/forward, extrapolated x8 forwards per guided step (B=4) x 256 steps",
-            "forward_s_b1": fwd}
+            fn()
+            out.append(time.perf_counter() - t0)
+        return out
+
+    with torch.no_grad():
+        timed(lambda: uo.unet3d_forward(sd, cfg, x, t, cond, zeros), 1)  # warm-up (thread pool, allocator)
+        fwd = timed(lambda: uo.unet3d_forward(sd, cfg, x, t, cond, zeros), 3) if full else None
+        step = timed(lambda: do.p_sample_step(sch, lambda a, c: uo.unet3d_guided(sd, cfg, a, c, cond, W_GUIDE), x, t, noise), 3)
+    sdg = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
+    params = [v for v in sdg.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        loss = do.p_losses(sch, lambda a, c: uo.unet3d_forward(sdg, cfg, a, c, cond, zeros), x.clamp(-1, 1), t, noise)
+        loss.backward()
+        opt.step()
+
+    train = timed(train_step, 3 if full else 1)
+    step_s, train_s = statistics.median(step), statistics.median(train)
+    scale = B_PER_GPU / b  # per-sample cost is batch independent
+    out = {"value": round(B_PER_GPU * T / (TIMESTEPS * step_s * scale), 6), "unit": "frames/s", "cores": nthreads, "kind": "port",
+           "sample": (f"oracle (torch CPU fp32, {nthreads} threads), Lagrangian widths, 11x96x96, batch {b}: 1 warm-up forward, median of {len(step)} guided "
+                      f"p_sample steps (w=5, two denoiser passes + x0 / quantile / posterior) = {step_s:.2f} s, {len(train)} optimisation step(s) "
+                      f"(forward + backward + Adam) = {train_s:.2f} s" + ("" if full else f"; scaled x{int(scale)} to batch {B_PER_GPU} (per-sample cost is batch "
+                      "independent), x256 steps for a full sample")),
+           "guided_step_s": round(step_s * scale, 3), "guided_step_s_samples": [round(v, 3) for v in step], "batch_measured": b,
+           "train_step_s": round(train_s * scale, 3), "train_denoising_steps_per_sec": round(B_PER_GPU / (train_s * scale), 5)}
+    if fwd:
+        out["forward_s"] = round(statistics.median(fwd), 3)
+    return out
 
 
-def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precision: str = "fp32"):
+def _family_times(meta, ms_lists):
+    fam = {}
+    for ms in ms_lists:
+        for (name, fl, by), t_ms in zip(meta, ms):
+            f = fam.setdefault(name, [0.0, 0.0, 0.0, 0])
+            f[0] += t_ms
+            f[1] += fl
+            f[2] += by
+            f[3] += 1
+    return fam
+
+
+def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precision: str = "fp32", want_roofline: bool = False):
     """One data-parallel optimisation step = q_sample -> denoiser forward -> L1 loss -> hand-written backward -> bucketed RCCL
     all-reduce overlapped with the backward -> multi-tensor Adam (+ EMA every 10 steps); per-GPU batch 4 (model.yaml:2).
     precision "fp32": exact-fp32 MFMA everywhere (the parity mode, gradients within 1e-3 of the reference);
@@ -117,6 +186,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     model.train_precision = precision
     model.train()
     tr = DataParallelTrainer(diff, train_lr=1e-4)
+    assert tr.world == world
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(B_PER_GPU, 3, T, HW, HW, generator=g).to(dev)
     cond = (torch.rand(B_PER_GPU, 11, generator=g) * 2 - 1).to(dev)
@@ -139,34 +209,79 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     ms = el / steps * 1e3
     pl = tr._plan
     fl = sum(f for _, f, _ in pl.meta) + sum(f for _, f, _ in pl.bwd_meta)
-    return {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
-            "batch_per_gpu": B_PER_GPU, "dtype": "f32", "matrix_core_mode": precision, "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3),
-            "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1), "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1)}
+    out = {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
+           "batch_per_gpu": B_PER_GPU, "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3 forward + data gradients, fp32 weight gradients",
+           "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
+           "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if world > 1 else 0}
+    if want_roofline and rank == 0:
+        # per-launch HIP events over one forward + backward of the training plan (same stream as the launches)
+        fwd_ms, bwd_ms = pl.launch_timed(), pl.backward_timed()
+        fam = _family_times(pl.meta, [fwd_ms])
+        for k, v in _family_times(pl.bwd_meta, [bwd_ms]).items():
+            a = fam.setdefault(k, [0.0, 0.0, 0.0, 0])
+            for i in range(4):
+                a[i] += v[i]
+        dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
+        objs = {}
+        for k in {dom, "vmm_conv_wgrad_f32", "vmm_conv3x3_f32" if precision == "fp32" else "vmm_conv3x3_bf16x3"} & set(fam):
+            t_ms, flops, nbytes, n = fam[k]
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if k.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
+            ach = flops / (t_ms * 1e-3) / 1e12
+            objs[k] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                       "launches_per_step": n, "ms_per_step": round(t_ms, 3), "avg_launch_ms": round(t_ms / n, 4), "algorithmic_GFLOP_per_step": round(flops / 1e9, 1),
+                       "algorithmic_GB_per_step": round(nbytes / 1e9, 2)}
+        out["roofline_training"] = {"dominant": dom, "kernels": objs, "event_ms_forward": round(sum(fwd_ms), 2), "event_ms_backward": round(sum(bwd_ms), 2),
+                                    "ms_by_kernel_family": {k: round(v[0], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]},
+                                    "peak_note": "fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32); split-bf16 kernels: 2500 / 3"}
+    return out
+
+
+def _respawn_under_torchrun(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    os.execv(sys.executable, cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=TIMESTEPS, help="guided p_sample steps in the timed region (256 = one full sample)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY 8(d) protocol on the CPU: batch 4, median of 3 (about 10 minutes)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step (profiling passes)")
     ap.add_argument("--detail", action="store_true", help="per-launch timing table on stderr")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sample() call and the exact-fp32 sampler (profiling passes)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: one rank per GPU, both must agree")
+    backend = os.environ.get("VMM_DIST_BACKEND", "nccl")
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        ndev = torch.cuda.device_count()
         # one process per GPU over RCCL.  (VMM_DIST_BACKEND=gloo lets a single-GPU box rehearse the multi-rank control flow with
         # several ranks sharing cuda:0 -- RCCL itself refuses duplicate devices; numbers from such a run are meaningless.)
-        dev_index = local_rank % torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {ndev}): one RCCL rank per GPU")
+        dev_index = local_rank % ndev
         torch.cuda.set_device(dev_index)
-        dist.init_process_group(os.environ.get("VMM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     else:
         dist = None
         dev_index = 0
@@ -182,72 +297,97 @@ def main():
     # rows of data/target_responses.csv are min-max normalised to [-1, 1] by the reference; synthetic stand-in of that range
     cond = (torch.rand(B_PER_GPU, 11, generator=g) * 2 - 1).to(dev)
     shape = (B_PER_GPU, 3, T, HW, HW)
-    img = torch.randn(shape, generator=g).to(dev)
+    x_T = torch.randn(shape, generator=g).to(dev)
 
-    model.static_weights = True
-    from videometamaterials_amd.diffusion import _GraphedStep
-    stepper = _GraphedStep(diff, shape, 11, W_GUIDE)
-    stepper.set_cond(cond)
-    if args.no_graph:
-        stepper.captured = True  # stay eager
-    ts = list(reversed(range(TIMESTEPS)))
+    def timed_region(fn):
+        """barrier + synchronize on both sides; MAX over ranks."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            et = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            el = float(et.item())
+        return el
 
-    def run_steps(n, offset=0):
-        nonlocal img
-        for j in range(n):
-            img = stepper(img, ts[(offset + j) % TIMESTEPS])
+    def sampler_leg(steps, warmup):
+        """K guided p_sample steps t = 255, 254, ... on the sampler's own captured step (GaussianDiffusion._graphed_step)."""
+        model.refresh_plans()
+        model.static_weights = True
+        diff.use_graph = not args.no_graph
+        stepper = diff._graphed_step(shape, cond, W_GUIDE)
+        if args.no_graph:
+            stepper.captured = True  # stay eager
+        ts = list(reversed(range(TIMESTEPS)))
+        state = {"img": x_T.clone()}
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps, args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+        def run(n, offset):
+            for j in range(n):
+                state["img"] = stepper(state["img"], ts[(offset + j) % TIMESTEPS])
+        with torch.inference_mode():
+            run(warmup, 0)
+            state["img"] = x_T.clone()  # the timed steps start from pure noise at t = 255, like sample()
+            el = timed_region(lambda: run(steps, 0))
+        if not args.no_graph and stepper.graph is None:
+            raise SystemExit("hipGraph capture of the sampling step failed: refusing to report an eager number as the graphed one")
+        model.static_weights = False
+        return el, stepper, state["img"]
+
+    elapsed, stepper, img = sampler_leg(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
-    frames_per_s = world * B_PER_GPU * T / (TIMESTEPS * ms_per_step * 1e-3)
+    frames_per_s = world * B_PER_GPU * T * (args.steps / TIMESTEPS) / elapsed
     finite = bool(torch.isfinite(img).all().item())
+
+    full_sample = fp32_exact = None
+    if not args.no_extras:
+        # the public call: GaussianDiffusion.sample() = 256 steps + unnormalise, draws its own x_T (vddp.py:965-984)
+        diff.use_graph = not args.no_graph
+        out_holder = {}
+        el = timed_region(lambda: out_holder.__setitem__("v", diff.sample(cond=cond, guidance_scale=W_GUIDE)))
+        v = out_holder["v"]
+        full_sample = {"seconds": round(el, 3), "frames_per_sec": round(world * B_PER_GPU * T / el, 4), "output_shape": list(v.shape),
+                       "output_finite": bool(torch.isfinite(v).all().item()), "output_mean": round(float(v.mean()), 4)}
+        # the same sampler in exact-fp32 arithmetic (v_mfma_f32_32x32x2_f32 everywhere), a shorter run
+        model.precision = "fp32"
+        n32 = max(2, min(args.steps, 16))
+        el32, st32, _ = sampler_leg(n32, 2)
+        model.precision = "bf16x3"
+        fp32_exact = {"ms_per_step": round(el32 / n32 * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (TIMESTEPS * el32 / n32), 4), "steps": n32,
+                      "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1e-6 parity", "hipgraph": st32.graph is not None}
 
     # ---- second half of BASELINE.json's metric: training denoising steps/s (configs[2]: per-GPU batch 4, fp32, Adam, RCCL all-reduce)
     train = None
     if not args.no_train:
-        try:
-            train = bench_training(vm, model, diff, dev, dist, world, rank, steps=max(2, min(args.steps, 6)))
-            # same step with the forward and the data gradients on the split-bf16 matrix cores (extra information, not the parity mode)
-            train["split_bf16_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=max(2, min(args.steps, 6)), precision="bf16x3")
-        except Exception as e:  # the sampling metric above stays valid; report the failure instead of hiding it
-            train = {"error": f"{type(e).__name__}: {e}"}
+        nst = max(2, min(args.steps, 6))
+        train = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, want_roofline=True)
+        # same step with the forward and the data gradients on the split-bf16 matrix cores (extra information, not the parity mode)
+        train["split_bf16_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="bf16x3")
+        model.eval()
 
-    out = None
     if rank == 0:
         # ---- per-kernel-family timing with HIP events on the launch stream (separate, un-timed pass)
         pl = stepper.plan
-        fam_ms, fam_fl, fam_by, fam_n = {}, {}, {}, {}
+        model.refresh_plans()
         reps = 3
-        for _ in range(reps):
-            for (name, fl, by), ms in zip(pl.meta, pl.launch_timed()):
-                fam_ms[name] = fam_ms.get(name, 0.0) + ms
-                fam_fl[name] = fam_fl.get(name, 0.0) + fl
-                fam_by[name] = fam_by.get(name, 0.0) + by
-                fam_n[name] = fam_n.get(name, 0) + 1
+        fam = _family_times(pl.meta, [pl.launch_timed() for _ in range(reps)])
         if args.detail:
             ms = pl.launch_timed()
-            rows_ = sorted(zip(ms, pl.steps, pl.meta), key=lambda r: -r[0])
-            for t_ms, (_, _, what), (fam, fl, by) in rows_:
+            for t_ms, (_, _, what), (f_, fl, by) in sorted(zip(ms, pl.steps, pl.meta), key=lambda r: -r[0]):
                 print(f"  {t_ms:8.3f} ms  {fl / max(t_ms, 1e-9) / 1e9:8.1f} TFLOP/s  {by / max(t_ms, 1e-9) / 1e6:8.1f} GB/s  {what}", file=sys.stderr)
-        fwd_ms = sum(fam_ms.values()) / reps
-        dom = max(fam_ms, key=fam_ms.get)
-        ach_tflops = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
-        ach_gbs = fam_by[dom] / (fam_ms[dom] * 1e-3) / 1e9
+        total_ms = sum(v[0] for v in fam.values())
+        fwd_ms = total_ms / reps
+        dom = max(fam, key=lambda k: fam[k][0])
+        d_ms, d_fl, d_by, d_n = fam[dom]
+        ach_tflops = d_fl / (d_ms * 1e-3) / 1e12
+        ach_gbs = d_by / (d_ms * 1e-3) / 1e9
         # fp32 MFMA peak for the exact kernel; for the split-bf16 kernel every algorithmic flop costs three bf16 MFMA flops,
         # so its roof for ALGORITHMIC flops is the dense bf16 peak / 3
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
@@ -256,27 +396,41 @@ def main():
                     "traffic_note": "HBM bytes per launch, mean over the family, from profiles/traffic_latest.json (rocprofv3 PMC passes of this command)",
                     "peak_note": "dense bf16 MFMA 2500 TFLOP/s / 3 passes (split-bf16 operands, fp32-class result)" if dom.endswith("bf16x3")
                     else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                    "launches_per_step": fam_n[dom] // reps, "avg_launch_ms": round(fam_ms[dom] / fam_n[dom], 4),
-                    "algorithmic_GFLOP_per_step": round(fam_fl[dom] / reps / 1e9, 1), "algorithmic_GB_per_step": round(fam_by[dom] / reps / 1e9, 2),
-                    "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
-                    "share_of_denoiser_time": round(fam_ms[dom] / sum(fam_ms.values()), 3)}
-        families = {k: round(v / reps, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
+                    "launches_per_step": d_n // reps, "avg_launch_ms": round(d_ms / d_n, 4),
+                    "algorithmic_GFLOP_per_step": round(d_fl / reps / 1e9, 1), "algorithmic_GB_per_step": round(d_by / reps / 1e9, 2),
+                    "algorithmic_bytes_per_launch": round(d_by / d_n), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
+                    "mfma_pipe_util": pmc_mfma_util(dom), "share_of_denoiser_time": round(d_ms / total_ms, 3)}
+        attention = {}
+        for k in ATTENTION_FAMILIES:
+            if k in fam and fam[k][0] > 0:
+                a_ms, a_fl, a_by, a_n = fam[k]
+                attention[k] = {"ms_per_step": round(a_ms / reps, 3), "launches_per_step": a_n // reps,
+                                "achieved_TFLOPs": round(a_fl / (a_ms * 1e-3) / 1e12, 1) if a_fl else None,
+                                "frac_of_bf16x3_roof": round(a_fl / (a_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4) if a_fl else None,
+                                "achieved_GBs": round(a_by / (a_ms * 1e-3) / 1e9, 1), "mfma_pipe_util": pmc_mfma_util(k)}
+        families = {k: round(v[0] / reps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
         cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(full=args.cpu_baseline_full)
         out = {
             "metric": "sampled frames/sec (guided DDPM sampling, 11x96x96 video)", "value": round(frames_per_s, 4), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_gpus": world, "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0), "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
+            "arithmetic": "split-bf16 MFMA: fp32 operands as bf16 hi + lo, products hi*hi + hi*lo + lo*hi accumulated in fp32 (1.5e-5 relative to the "
+                          "reference, inside north_star's 1e-3); activations and weights fp32 in HBM; `fp32_exact` = the exact-fp32 sampler",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: Lagrangian model.yaml Unet3D (dim 64, 39.5M params, random init), 3x11x96x96, batch 4 per GPU, "
                                    "guidance w=5, 256-step ancestral DDPM with dynamic thresholding; step = one guided p_sample over the batch "
-                                   "(denoiser at batch 8 + x0/quantile/posterior)",
+                                   "(denoiser at batch 8 + x0/quantile/posterior); 256 steps = one sample()",
                        "batch_per_gpu": B_PER_GPU, "frames": T, "image": HW, "timesteps": TIMESTEPS, "guidance_scale": W_GUIDE,
-                       "hipgraph": stepper.graph is not None, "parallelism": f"independent sampling shards x{world} (no data-path collective)"},
+                       "hipgraph": stepper.graph is not None, "launches_per_step": len(pl.steps),
+                       "parallelism": f"independent sampling shards x{world} (no data-path collective)" + ("" if backend == "nccl" or world == 1
+                                                                                                           else f" [{backend} rehearsal, not RCCL]")},
             "denoising_sample_steps_per_sec": round(world * B_PER_GPU / (ms_per_step * 1e-3), 3),
-            "full_sample_seconds": round(TIMESTEPS * ms_per_step * 1e-3, 2),
+            "full_sample": full_sample, "fp32_exact": fp32_exact,
             "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
-            "training": train, "roofline": roofline, "cpu_baseline": cpu,
+            "training": train, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,105 @@
+"""The data-parallel engine with more than one rank ON THE GPU: two ranks share cuda:0 and talk over gloo (RCCL refuses duplicate
+devices, so on a one-GPU box gloo carries the same bucketed tail-slice all-reduce; the RCCL path differs only in the backend string).
+Each rank runs DataParallelTrainer.train_step on its own half of a batch; the reduced gradients and the updated weights must equal ONE
+process stepping on the concatenated batch (integration row; main.py:31-34, vddp.py:1449,1629)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CFG = "lagr16"
+STEPS = 3
+
+
+def _inputs(step):
+    """Batch of 2 x B samples for optimisation step `step`: data in [0,1], conditioning, timesteps, noise, CFG mask."""
+    kw, (B, T, H, W), cl = helpers.CONFIGS[CFG]
+    g = torch.Generator().manual_seed(40 + step)
+    n = 2 * B
+    x = torch.rand(n, 3, T, H, W, generator=g)
+    cond = torch.rand(n, cl, generator=g) * 2 - 1
+    t = torch.randint(0, 256, (n,), generator=g)
+    noise = torch.randn(n, 3, T, H, W, generator=g)
+    mask = (torch.rand(n, generator=g) < 0.25).to(torch.uint8)
+    return x, cond, t, noise, mask
+
+
+def _trainer(dev, **kw_tr):
+    import videometamaterials_amd as vm
+    from videometamaterials_amd.dp import DataParallelTrainer
+    kw, (B, T, H, W), _ = helpers.CONFIGS[CFG]
+    model = vm.Unet3D(**kw)
+    model.load_state_dict(helpers.synth_state_dict(helpers.load_shapes(CFG)))
+    diff = vm.GaussianDiffusion(model.to(dev), image_size=H, num_frames=T, channels=3, timesteps=256, loss_type="l2", use_dynamic_thres=True,
+                                sampling_timesteps=256).to(dev)
+    return DataParallelTrainer(diff, train_lr=1e-3, update_ema_every=2, step_start_ema=2, **kw_tr)
+
+
+def _run(tr, dev, sl):
+    losses, grads = [], None
+    for step in range(STEPS):
+        x, cond, t, noise, mask = (a[sl].to(dev) for a in _inputs(step))
+        losses.append(float(tr.train_step(x, cond, t=t, noise=noise, mask=mask)))
+        if step == 0:
+            pl = tr._plan
+            grads = {k: pl.pgrad[o:o + n].clone().cpu() for k, (o, n) in pl.param_slices.items()}
+    torch.cuda.synchronize()
+    return dict(losses=losses, grads=grads, weights={k: v.detach().cpu() for k, v in tr.unet.state_dict().items()},
+                ema={k: v.detach().cpu() for k, v in tr.ema_model.denoise_fn.state_dict().items()},
+                buckets=list(tr._reducer.launched), host_staged=tr._reducer.host_staged)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        B = helpers.CONFIGS[CFG][1][0]
+        tr = _trainer(dev, bucket_floats=200_000)  # several buckets per backward at this model size
+        assert tr.world == world
+        res = _run(tr, dev, slice(rank * B, (rank + 1) * B))
+        torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_one_process_on_the_concatenated_batch(gpu, tmp_path):
+    ctx = mp.get_context("spawn")
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    # meanwhile: the single-process answer on the whole batch (this process has no process group: world 1)
+    one = _run(_trainer(gpu), gpu, slice(None))
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    ranks = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2)]
+    # every rank holds the same reduced gradients = world x the gradient of the mean loss over the concatenated batch
+    assert len(ranks[0]["buckets"]) >= 3, ranks[0]["buckets"]  # the reduction really ran as several tail slices
+    for k, g1 in one["grads"].items():
+        g2 = ranks[0]["grads"][k] * 0.5
+        assert torch.equal(ranks[0]["grads"][k], ranks[1]["grads"][k]), k
+        scale = float(g1.abs().max())
+        assert float((g2 - g1).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((g2 - g1).abs().max()), scale)
+    # ... and after three optimiser steps (Adam; EMA copy after the first, EMA decay after the third) the replicas agree bit for bit with each other and closely with
+    # the single process (Adam's m / sqrt(v) amplifies last-bit gradient differences where |g| is tiny: absolute tolerance in lr units)
+    for k, w1 in one["weights"].items():
+        assert torch.equal(ranks[0]["weights"][k], ranks[1]["weights"][k]), k
+        assert torch.equal(ranks[0]["ema"][k], ranks[1]["ema"][k]), k
+        d = (ranks[0]["weights"][k] - w1).abs()
+        assert float(d.max()) <= 2.0 * STEPS * 1e-3, k          # never further than a few lr-sized steps
+        assert float(d.mean()) <= 1e-4, (k, float(d.mean()))   # and identical almost everywhere (a stale / unreduced replica is off by ~lr everywhere)
+    mean_loss = [(a + b) / 2 for a, b in zip(ranks[0]["losses"], ranks[1]["losses"])]
+    for a, b in zip(mean_loss, one["losses"]):
+        assert abs(a - b) < 1e-4 * abs(b)

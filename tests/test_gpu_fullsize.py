@@ -132,3 +132,71 @@ def test_captured_step_equals_eager_launch_list(setup, gpu):
             pl.launch()
             torch.cuda.synchronize()
             assert torch.equal(got, pl.out), f"trial {trial}: replayed step differs from the eager launch list"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Once per run the full-width, full-frame path also meets the oracle itself (about 10 s + 60 s of CPU): a shared indexing fault of
+# the kernel templates at 96 x 96 (6 x 6 tile grids, 9216-pixel attention, 36-tile halo patches) would pass every self-consistency check above.
+def _oracle_cfg():
+    from oracle import unet3d_oracle as uo
+    return uo.UnetCfg(**LAGR)
+
+
+def test_full_size_forward_matches_oracle(setup):
+    from oracle import unet3d_oracle as uo
+    vm, m, x, t, cond = setup
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    i = 1
+    with torch.no_grad():
+        want_c = uo.unet3d_forward(sd, _oracle_cfg(), x[i:i + 1].cpu(), t[i:i + 1].cpu(), cond[i:i + 1].cpu(), torch.zeros(1, dtype=torch.bool))
+        want_n = uo.unet3d_forward(sd, _oracle_cfg(), x[i:i + 1].cpu(), t[i:i + 1].cpu(), cond[i:i + 1].cpu(), torch.ones(1, dtype=torch.bool))
+        for prec, tol in (("bf16x3", 2e-4), ("fp32", 2e-5)):
+            m.precision = prec
+            got_c = m(x, t, cond=cond, null_cond_prob=0.0)[i:i + 1].cpu()         # sample 1 of the batch of 4 (tile grid of the full batch)
+            got_n = m(x[i:i + 1], t[i:i + 1], cond=cond[i:i + 1], null_cond_prob=1.0).cpu()
+            assert _rel(got_c, want_c) < tol, (prec, _rel(got_c, want_c))
+            assert _rel(got_n, want_n) < tol, (prec, _rel(got_n, want_n))
+        m.precision = "bf16x3"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_full_size_training_gradients_match_oracle_autograd(setup, gpu, prec):
+    """cfgL widths, 3 x 11 x 96 x 96, B = 1: loss and a spread of parameter gradients (every kernel family of the backward list:
+    3x3 / 1x1 / 4x4 / 7x7 weight gradients, GroupNorm, LayerNorm, both attention flavours, token k/v, embeddings) against autograd
+    through the oracle.  l2 loss: with l1 the gradient is a sign pattern, see test_gpu_train.py."""
+    from oracle import diffusion_oracle as do
+    from oracle import unet3d_oracle as uo
+    vm, m, x, t, cond = setup
+    names = ["init_conv.weight", "downs.0.0.block1.proj.weight", "downs.0.0.block2.norm.weight", "downs.0.1.mlp.1.weight",
+             "downs.0.2.fn.fn.to_qkv.weight", "downs.0.2.fn.fn.to_k.weight", "downs.0.3.fn.fn.fn.to_qkv.weight", "downs.0.3.fn.norm.gamma",
+             "downs.0.4.weight", "downs.1.0.res_conv.weight", "downs.2.1.block2.proj.weight", "downs.3.3.fn.fn.fn.to_out.weight",
+             "mid_spatial_attn.fn.fn.fn.to_qkv.weight", "mid_temporal_attn.fn.fn.fn.to_v.weight", "ups.0.0.block1.proj.weight", "ups.1.4.weight",
+             "ups.3.1.block1.proj.bias", "ups.3.2.fn.fn.to_out.weight", "final_conv.0.block1.proj.weight", "final_conv.1.weight",
+             "time_mlp.1.weight", "sign_emb.weight", "null_text_token", "time_rel_pos_bias.relative_attention_bias.weight"]
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(31)
+    x0 = torch.rand(1, 3, 11, 96, 96, generator=g) * 2 - 1
+    noise = torch.randn(1, 3, 11, 96, 96, generator=g)
+    tt, cc = t[2:3].cpu(), cond[2:3].cpu()
+    sdg = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    want_loss = do.p_losses(do.schedule_buffers(256), lambda a, b: uo.unet3d_forward(sdg, _oracle_cfg(), a, b, cc, torch.zeros(1, dtype=torch.bool)),
+                            x0, tt, noise, loss_type="l2")
+    want_loss.backward()
+    diff = vm.GaussianDiffusion(m, image_size=96, num_frames=11, channels=3, timesteps=256, loss_type="l2", sampling_timesteps=256).to(gpu)
+    m.train_precision = prec
+    m.zero_grad()
+    try:
+        loss = diff.p_losses(x0.to(gpu), tt.to(gpu), cond=cc.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
+        loss.backward()
+        assert abs(float(loss) - float(want_loss)) < 1e-4 * float(want_loss)
+        live = dict(m.named_parameters())
+        bad = []
+        for k in names:
+            err = _rel(live[k].grad.cpu(), sdg[k].grad)
+            if err > 1e-3:
+                bad.append((k, err))
+        assert not bad, bad
+    finally:
+        m.train_precision = "fp32"
+        m.zero_grad(set_to_none=True)
+        m._plans = {k: v for k, v in m._plans.items() if not v.training}  # the keep-all training arenas are GBs: drop them for the tests that follow

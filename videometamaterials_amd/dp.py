@@ -40,6 +40,16 @@ class BucketedAllReduce:
         self.hi = n_valid
         self.works = []
         self.launched: List[Tuple[int, int]] = []
+        # RCCL reduces device buffers in place.  The gloo rehearsal backend (several ranks sharing one GPU on a single-GPU box; CPU
+        # tests) may lack device-tensor support in this build: then slices are staged through pinned host memory on the side stream.
+        self.host_staged = False
+        if self.cuda and self.world > 1 and dist.get_backend(group) == "gloo":
+            try:
+                probe = torch.zeros(4, device=flat.device)
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+            except RuntimeError:
+                self.host_staged = True
 
     def start(self) -> None:
         self.hi = self.n
@@ -55,7 +65,15 @@ class BucketedAllReduce:
             ev.record()  # everything enqueued so far on the compute stream produced flat[lo:hi]
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.host_staged:
+                    host = torch.empty(hi - lo, dtype=sl.dtype, pin_memory=True)
+                    host.copy_(sl, non_blocking=True)
+                    self.comm_stream.synchronize()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    sl.copy_(host, non_blocking=True)
+                    self._pinned = getattr(self, "_pinned", []) + [host]  # alive until finish()
+                else:
+                    self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -68,10 +86,17 @@ class BucketedAllReduce:
     def finish(self) -> None:
         self._reduce(0, self.hi)
         self.hi = 0
-        for w in self.works:
-            w.wait()
         if self.comm_stream is not None:
+            with torch.cuda.stream(self.comm_stream):
+                for w in self.works:
+                    w.wait()  # (device collectives: orders the side stream behind the collective, does not block the host)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.host_staged:
+                self.comm_stream.synchronize()
+                self._pinned = []
+        else:
+            for w in self.works:
+                w.wait()
 
 
 class DataParallelTrainer:
@@ -190,9 +215,10 @@ class DataParallelTrainer:
         tab, n = self._adam_table
         N.check(lib.vmm_adam_step(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, self.step, 1.0 / self.world, _stream()), "vmm_adam_step")
         self.unet.bump_generation()  # written through raw pointers: autograd's version counters did not move
-        if self.step % self.update_ema_every == 0:  # vddp.py:1637-1639, 1500-1504
+        ref_step = self.step - 1  # Trainer.step while this optimiser step runs: the reference counts from 0 (vddp.py:1612-1640)
+        if ref_step % self.update_ema_every == 0:  # vddp.py:1637-1639, 1500-1504
             tab, n = self._ema_table
-            N.check(lib.vmm_ema_step(tab.data_ptr(), n, self._max_n, self.ema_decay, 1 if self.step < self.step_start_ema else 0, _stream()), "vmm_ema_step")
+            N.check(lib.vmm_ema_step(tab.data_ptr(), n, self._max_n, self.ema_decay, 1 if ref_step < self.step_start_ema else 0, _stream()), "vmm_ema_step")
             self.ema_model.denoise_fn.bump_generation()
         return self._loss
 

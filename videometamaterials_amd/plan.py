@@ -208,6 +208,13 @@ class Plan:
                 on_mark(marks[i])
         return self.pgrad
 
+    def backward_timed(self) -> List[float]:
+        """The backward launch list with a HIP event pair around every launch (bench.py's training roofline); ms per step."""
+        assert self.training
+        self.pgrad.zero_()
+        self.gscratch.zero_()
+        return self.launch_timed(self.bwd_steps)
+
     def grad_views(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         return {k: self.pgrad[o:o + n].view(params[k].shape) for k, (o, n) in self.param_slices.items() if k in params}
 
