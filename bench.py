@@ -73,16 +73,17 @@ def pmc_traffic(family: str):
 
 def pmc_mfma_util(family: str):
     """Matrix-pipe utilisation of a kernel family from the committed SQ counter pass (profiles/sq_latest.json, tools/pmc_kernels.sh +
-    tools/summarize_sq.py on this bench command): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), launch-weighted."""
+    tools/summarize_sq.py on this bench command): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x un-profiled kernel duration x 2.4 GHz),
+    launch-weighted -- the share of the matrix pipes' nominal issue capacity the family keeps busy, padded products included."""
     prefix, tab = KERNEL_OF.get(family), _committed("sq_latest.json")
     if not prefix or tab is None:
         return None
-    busy = act = 0.0
+    busy = cap = 0.0
     for k, v in tab.items():
-        if k.startswith(prefix) and v.get("GRBM_GUI_ACTIVE"):
+        if k.startswith(prefix) and v.get("avg_ns_unprofiled"):
             busy += v["launches"] * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-            act += v["launches"] * v["GRBM_GUI_ACTIVE"] * 1024.0
-    return round(busy / act, 4) if act else None
+            cap += v["launches"] * 1024.0 * v["avg_ns_unprofiled"] * 2.4
+    return round(busy / cap, 4) if cap else None
 
 
 def usable_cores() -> int:

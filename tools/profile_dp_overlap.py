@@ -2,7 +2,7 @@
 shows the gradient reduction of the deep layers running while the backward of the shallow layers is still executing:
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_dp -o dp -- \
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_dp -o dp_%pid% -- \
         python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
         $GRAFT_REPO_ROOT/tools/profile_dp_overlap.py
     python tools/profile_dp_overlap.py summarize gpurun_out/prof_dp > profiles/r02_dp_overlap.txt
@@ -58,15 +58,15 @@ def summarize(root):
         for r in ks:
             r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         ks.sort(key=lambda r: r["s"])
+        lg = [i for i, r in enumerate(ks) if "loss_grad" in r["Kernel_Name"]]
         adam = [i for i, r in enumerate(ks) if "adam" in r["Kernel_Name"]]
-        if len(adam) < 2:
+        if not lg or not adam or adam[-1] < lg[-1]:
             continue
-        lo, hi = adam[-2] + 1, adam[-1]          # kernels of the last optimisation step
-        step = ks[lo:hi + 1]
-        first_bwd = next(i for i, r in enumerate(step) if "loss_grad" in r["Kernel_Name"])
-        bwd = step[first_bwd:]
+        bwd = ks[lg[-1]:adam[-1] + 1]            # backward of the last optimisation step: loss_grad .. adam
         t0, t1 = bwd[0]["s"], bwd[-1]["e"]
-        comm = [r for r in bwd if any(s in r["Kernel_Name"].lower() for s in ("nccl", "rccl", "allreduce", "all_reduce"))]
+        # communication: RCCL kernels, or (gloo rehearsal) the blit kernels that move a bucket between HBM and gloo's pinned host buffers
+        comm = [r for r in bwd if any(s in r["Kernel_Name"].lower() for s in ("nccl", "rccl", "allreduce", "all_reduce"))
+                or ("copyBuffer" in r["Kernel_Name"] and r["e"] - r["s"] > 20_000)]
         copies = []
         if os.path.exists(mc):
             for r in csv.DictReader(open(mc)):
@@ -83,7 +83,7 @@ def summarize(root):
                 a, b = max(s, r["s"]), min(e, r["e"])
                 if b > a:
                     tot += b - a
-                    names.append(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:40])
+                    names.append(r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:40])
             return tot, names
         events = [(r["s"], r["e"], "comm kernel " + r["Kernel_Name"][:40]) for r in comm] + [(s, e, "copy " + d) for s, e, d in copies]
         events.sort()

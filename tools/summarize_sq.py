@@ -1,8 +1,12 @@
-"""Aggregate a rocprofv3 --pmc pass (SQ_* and GRBM_GUI_ACTIVE) per kernel into JSON for profiles/sq_latest.json and print the derived
-figures: matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); share of wave cycles parked at
-s_waitcnt / barriers = SQ_WAIT_ANY / SQ_WAVE_CYCLES; issue stalls = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots).
+"""Aggregate a rocprofv3 --pmc pass (SQ_*) per kernel into JSON for profiles/sq_latest.json and print the derived figures:
+matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES (pipe-busy cycles summed over every SIMD: 32 per v_mfma_f32_32x32x16_bf16) /
+(1024 SIMDs x kernel duration x 2.4 GHz), the duration being the average of the SAME kernel in the un-profiled --kernel-trace --stats
+pass of the same command (counter passes serialise and slow the kernels; GRBM_GUI_ACTIVE under the profiler includes the dispatch
+overhead) -- i.e. the fraction of the matrix pipes' peak issue capacity at the nominal clock, padded and transposed products included;
+share of wave cycles parked at s_waitcnt / barriers = SQ_WAIT_ANY / SQ_WAVE_CYCLES; issue stalls = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+(MI355X_MICROARCH.md, PMC slots).
 
-    python tools/summarize_sq.py gpurun_out/prof_<tag>/pmc_sq out.json
+    python tools/summarize_sq.py gpurun_out/prof_<tag>/pmc_sq out.json [kernel_stats.csv]
 """
 import csv
 import glob
@@ -22,6 +26,16 @@ for r in csv.DictReader(open(f[0])):
     k = re.sub(r"\(.*$", "", k)[:90]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     disp[k].add(r.get("Dispatch_Id"))
+
+def short(name):
+    k = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", k)[:90]
+
+
+avg_ns = {}
+if len(sys.argv) > 3 and os.path.exists(sys.argv[3]):
+    for r in csv.DictReader(open(sys.argv[3])):
+        avg_ns[short(r.get("Name", ""))] = float(r.get("AverageNs", 0) or 0)
 table = {}
 print(f"{'kernel':70s} {'launches':>8s} {'mfma_util':>9s} {'parked':>7s} {'stall':>7s} {'active':>7s}")
 for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
@@ -29,8 +43,9 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0.0)):
     row = {c: v / n for c, v in agg[k].items()}
     row["launches"] = n
     wc, gui = row.get("SQ_WAVE_CYCLES", 0.0), row.get("GRBM_GUI_ACTIVE", 0.0)
-    if gui:
-        row["mfma_pipe_util"] = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0)
+    if avg_ns.get(k):
+        row["avg_ns_unprofiled"] = avg_ns[k]
+        row["mfma_pipe_util"] = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * avg_ns[k] * 2.4)
     if wc:
         row["parked_share"] = row.get("SQ_WAIT_ANY", 0.0) / wc
         row["issue_stall_share"] = row.get("SQ_WAIT_INST_ANY", 0.0) / wc

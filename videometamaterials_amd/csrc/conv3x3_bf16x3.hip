@@ -19,6 +19,9 @@
 // 4 waves as 4 x 1 (256 pixels x 64 columns, Cout == 64) or 2 x 2 (128 pixels x 128 columns).  Few-row layers (12 x 12 level) split
 // the channel chunks over blockIdx.y and add their partial sums in a fixed (ticketed) order.  Fused input transform (GroupNorm * FiLM -> SiLU, a_mode 1), bias,
 // two-source channel concat and the residual add are the same as in the generic kernel.
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "igemm_common.h"
 
 namespace {
@@ -479,6 +482,728 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent, wave-specialised variant of the same contraction (unsplit layers).  One workgroup of EIGHT waves per CU walks a list of
+// 256-pixel x 64-column output tiles in 16-channel chunks (nine k16 steps, one per tap):
+//   waves 0-3  "matrix" waves, one per SIMD: a 64 x 64 output tile each.  Both operands come from LDS (eight ds_read_b128 per twelve
+//              MFMAs); the only vector-memory instructions they ever issue are the epilogue's -- nothing can sit in front of an
+//              operand on vmcnt (in the kernel above the weight fragments of four waves went through the L1 / texture path, 16 KB per
+//              k16 step and CU, behind the patch prefetch: every layer sat at 260-340 TFLOP/s whatever its shape).
+//   waves 4-6  "patch" waves: global loads of the NEXT-BUT-ONE chunk's patch rows into registers, then GroupNorm * FiLM -> SiLU, the
+//              bf16 hi | lo split and the LDS stores of the NEXT chunk -- VALU, LDS-store and VMEM pipes, beside the MFMAs.
+//   wave  7    "weight" wave: the next chunk's 36 fragment planes (64 columns x nine k16 steps, hi | lo, 1 KB each, contiguous in the
+//              fmt-2 packing) by LDS-DMA (global_load_lds_dwordx4): once per workgroup instead of once per wave, no registers.
+// Patch and weight stage are double-buffered in LDS; ONE s_barrier per chunk (about 3.5k cycles of MFMAs) is the only synchronisation
+// and also carries the workgroup from tile to tile: the first chunk of tile n + 1 is staged while the last chunk of tile n is
+// multiplied, the epilogue's stores drain under the next tile's MFMAs, there is no prologue latency after the first tile.  Workgroup b
+// takes tiles from the contiguous range of XCD b % 8 (dispatch order, MI355X_MICROARCH.md), column tiles of one row tile adjacent, so
+// that halo rows and the row tile's re-reads by its column tiles are served by that XCD's L2.
+constexpr int CK2 = 16;                    // channels per chunk
+constexpr int CROW2 = 40;                  // patch row pitch in 2-byte units: 16 hi | 16 lo | 8 pad = 80 bytes
+constexpr int PW_MAXP = 7;                 // patch items per patch-wave thread: 192 threads x 4 channels = 48 rows per pass
+constexpr bool PW_KEEP_SD = false;        // keep the drained halves' store-data registers untouched for a whole tile (64 VGPRs: spills)
+constexpr int PW_STAGE = 9 * 4 * 1024;     // bytes of one weight stage: nine k16 steps x (2 column tiles x hi | lo) planes of 1 KB
+
+struct PWArgs {
+  vmm_conv_desc p;
+  int n_tiles;                   // 64-column tiles
+  int mode, tiles_x, tiles_per_frame, PR, pitch, halo, KS, total_rows, n_units;
+  int patch_bytes;               // one patch buffer, rounded up to 1 KB
+  int dbg;                       // measurement knobs (VMM_PW_DBG): 2 no patch work, 4 no weight DMA, 8 no epilogue, 32 no output stores, 64 no GroupNorm sums
+  int stagger;                   // cycles between the start of consecutive workgroup quarters (0 = all together)
+  unsigned long long* trace;     // VMM_PW_TRACE: workgroup 0 stamps s_memtime at every barrier (arrive, leave) per wave
+};
+
+template <int MODE, bool F32>
+__global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
+  constexpr int BM = 256;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_b[];
+  // a private copy of the arguments: the barriers and the hand-placed loads below are asm statements with a "memory" clobber, after each
+  // of which the compiler would re-read every argument it needs from the kernel-argument segment (an s_load + wait of ~200 cycles per
+  // dependent round; the patch waves spent 3.7k cycles per phase "issuing" nine loads)
+  const PWArgs a = a_in;
+  const vmm_conv_desc& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = p.Win, H = p.Hin, HW = H * W;
+  const int Cin = p.C1 + p.C2;
+  const int nchunks = Cin / CK2;
+  const int cin16 = Cin / 16;
+  unsigned char* const wstage = smem_b + 2 * a.patch_bytes;
+
+  // this workgroup's tiles: u = first + i * J, i < cnt; u = mtile * n_tiles + ntile
+  const int J = gridDim.x >> 3, xcd = blockIdx.x & 7, j_in = blockIdx.x >> 3;
+  const int upx = (a.n_units + 7) >> 3;
+  const int u_lo = xcd * upx, u_hi = min(a.n_units, u_lo + upx);
+  const int first = u_lo + j_in;
+  const int cnt = first < u_hi ? (u_hi - first + J - 1) / J : 0;
+  if (cnt == 0) return;           // (the whole workgroup: no wave skips a barrier the others wait at)
+  const int P = cnt * nchunks;    // phases = (tile, chunk) pairs; every wave executes exactly 1 + P barriers
+
+  struct Geo { int img, ty0, tx0, g0, n0, mtile; };
+  auto geo_of = [&](int i) -> Geo {
+    const int u = first + i * J;
+    Geo g;
+    g.mtile = u / a.n_tiles;
+    g.n0 = (u - g.mtile * a.n_tiles) * 64;
+    g.img = g.ty0 = g.tx0 = g.g0 = 0;
+    if (MODE) {
+      g.img = g.mtile / a.tiles_per_frame;
+      const int t = g.mtile - g.img * a.tiles_per_frame;
+      const int tyi = t / a.tiles_x;
+      g.ty0 = tyi * 16;
+      g.tx0 = (t - tyi * a.tiles_x) * 16;
+    } else {
+      g.g0 = g.mtile * BM;
+    }
+    return g;
+  };
+  // barriers are raw: what each role must have retired before it arrives differs (LDS stores / LDS-DMA / LDS reads), and a
+  // matrix wave must NOT wait for its epilogue stores (vmcnt counts stores on gfx9)
+  int tr_n = 0;
+  const bool tracing = a.trace && blockIdx.x == 0 && lane == 0;
+  auto stamp = [&](int which) {
+    if (tracing && tr_n < 128) {
+      a.trace[(tr_n * 8 + wave) * 2 + which] = __builtin_readcyclecounter();
+      if (which) ++tr_n;
+    }
+  };
+#define PW_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(0); asm volatile("s_barrier" ::: "memory"); stamp(1); } while (0)
+#define PW_BARRIER_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); asm volatile("s_barrier" ::: "memory"); stamp(1); } while (0)
+
+  // Epilogue: the matrix waves never store to global memory.  vmcnt counts stores, and a register a store has not read yet cannot be
+  // re-used: with every CU finishing a tile at the same moment (16.8 MB of output queued chip-wide) the matrix waves sat ~8k cycles
+  // behind their own stores at the start of every tile.  They transpose a 32-pixel half of their tile through LDS instead
+  // (4 waves x 32 rows x (256 + 16 pad) bytes behind the weight stages -- that is all the LDS left, hence the two halves and the two
+  // extra barriers per tile) and the four producer waves write it out: a store instruction covers four whole 256-byte rows (an
+  // accumulator lane holds 4 x 4 channels of ONE pixel: stored directly, 64 requests of 16 bytes per instruction), from registers that
+  // nothing touches again before the next tile ends, so the write burst drains in the background of the next tile's MFMAs.
+  constexpr int EP_PITCH = 272, EP_WAVE = 32 * EP_PITCH;
+  const int ep_base = 2 * a.patch_bytes + 2 * PW_STAGE;
+  const int dt = tid - 256;  // producer waves: 0 .. 255
+  f32x4 sd0[8], sd1[8];      // store data of half 0 / half 1 (kept alive until that half's next turn)
+  auto drain_read = [&](f32x4 (&sd)[8]) {
+    if (PW_KEEP_SD && MODE) {  // naming the registers here keeps the compiler from re-using them since the previous drain of this half
+      asm volatile("" ::"v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]), "v"(sd[4]), "v"(sd[5]), "v"(sd[6]), "v"(sd[7]));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int px = (dt >> 4) + 16 * k;  // pixel slot 0 .. 127 of the half: matrix wave px >> 5, MFMA column px & 31
+      sd[k] = *reinterpret_cast<const f32x4*>(smem_b + ep_base + (px >> 5) * EP_WAVE + (px & 31) * EP_PITCH + (dt & 15) * 16);
+    }
+  };
+  // Output addressing of the drains: a per-thread byte offset per piece that does not depend on the tile (computed once) on top of a
+  // per-tile scalar base -- one store instruction per piece, no vector address arithmetic (a producer wave issues roughly one
+  // instruction per four cycles at best: its instruction count per phase, not any unit's bandwidth, is what it is short of).
+  unsigned doff[8];
+  if (wave >= 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int px = (dt >> 4) + 16 * k, wmm = px >> 5, r = px & 31;
+      const int rel = MODE ? (wmm * 4 + (r >> 4)) * W + (r < 16 ? r : ((r - 2) & 15)) : wmm * 64 + r;  // pixel row relative to the tile's first
+      doff[k] = ((unsigned)rel * (unsigned)p.ldo + (dt & 15) * 4) * 4u;
+    }
+  }
+  auto drain_store = [&](f32x4 (&sd)[8], int h, const Geo& gg) {
+    // first output row of half h of the tile (2-D: the half's pixel rows start 2 h image rows down; flat: 32 h rows)
+    const long long row0 = MODE ? (long long)gg.img * HW + (gg.ty0 + 2 * h) * W + gg.tx0 : (long long)gg.g0 + 32 * h;
+    char* obase = reinterpret_cast<char*>(p.out + row0 * p.ldo + gg.n0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int px = (dt >> 4) + 16 * k;
+      bool ok = true;
+      if (!MODE) ok = gg.g0 + (px >> 5) * 64 + h * 32 + (px & 31) < a.total_rows;
+      if (ok) {
+        f32x4 v = sd[k];
+        if (p.res) {  // (gradient accumulation of the training path; same row layout)
+          const long long rel = doff[k] / 4u / (unsigned)p.ldo;
+          v += *reinterpret_cast<const f32x4*>(p.res + (row0 + rel) * p.ldres + gg.n0 + (dt & 15) * 4);
+        }
+        if (!(a.dbg & 32)) *reinterpret_cast<f32x4*>(obase + doff[k]) = v;
+      }
+    }
+  };
+
+  if (wave >= 4 && (a.dbg & 256)) __builtin_amdgcn_s_setprio(2);
+  if (wave == 7) {
+    // ======================================================================================================== weight wave
+    const uint4* wf = reinterpret_cast<const uint4*>(p.w);
+    auto stage = [&](const Geo& g, int cc, unsigned char* dst) {
+      const uint4* base = wf + (long long)(g.n0 / 32) * a.KS * 128 + lane;
+#pragma unroll
+      for (int idx = 0; idx < 36; ++idx) {
+        const int t = idx >> 2, j = (idx >> 1) & 1, hl = idx & 1;
+        const uint4* src = base + ((long long)j * a.KS + t * cin16 + cc) * 128 + hl * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + idx * 1024), 16, 0, 0);
+      }
+    };
+    // (the stage must have landed before the barrier; loads and stores retire independently of each other, so "everything" is the only
+    // count that guarantees it once this wave also has drain stores in flight)
+#define PW_BARRIER_DMA_N(n) PW_BARRIER_DMA()
+    Geo g = geo_of(0);   // tile being STAGED (one phase ahead)
+    int si = 0, sc = 0;
+    stage(g, 0, wstage);
+    if (a.stagger > 0) {
+      // Workgroups start a quarter of a tile apart (everybody else waits at the first barrier): left alone, all 256 CUs finish their
+      // tiles at the same moment and the output of a whole round (16.8 MB) hits the memory system as one burst -- the producer waves
+      // then sat thousands of cycles in the issue of their stores and of the next patch requests.
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      const unsigned long long d = (unsigned long long)(j_in & 3) * a.stagger;
+      while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+    PW_BARRIER_DMA();
+    int ph = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const Geo gt = geo_of(i);  // tile being MULTIPLIED
+      for (int cc = 0; cc < nchunks; ++cc, ++ph) {
+        if (ph + 1 < P) {
+          if (++sc == nchunks) { sc = 0; ++si; g = geo_of(si); }
+          if (!(a.dbg & 4)) stage(g, sc, wstage + ((ph + 1) & 1) * PW_STAGE);
+        }
+        bool drained = false;
+        if (cc == 0 && i > 0) {  // second half of the previous tile (written between its Y and R barriers)
+          const Geo gp = geo_of(i - 1);
+          drain_read(sd1);
+          drain_store(sd1, 1, gp);
+          drained = true;
+        }
+        if (cc + 1 == nchunks) {
+          PW_BARRIER_LDS();      // X: half 0 of this tile is staged
+          drain_read(sd0);
+          PW_BARRIER_LDS();      // Y: ... and has been read
+          drain_store(sd0, 0, gt);
+          drained = true;
+        }
+        PW_BARRIER_DMA_N(drained);
+      }
+    }
+    drain_read(sd1);
+    drain_store(sd1, 1, geo_of(cnt - 1));
+    return;
+  }
+
+  if (wave >= 4) {
+    // ======================================================================================================== patch waves
+    const int pt = tid - 256;  // 0 .. 191
+    const int k4 = pt & 3;
+    const int rows_per_sample = HW * p.a_imgs_per_sample;
+    // Per register set: the raw rows of one phase, plus what depends on the TILE only (source row of every item; flat tiles, which
+    // run across samples: the item's offset into the GroupNorm coefficient table) -- recomputed when the set moves to another tile,
+    // not per chunk (an integer division per item and chunk was a third of these waves' instructions).
+    f32x4 preg[2][PW_MAXP];
+    unsigned roff[2][PW_MAXP];   // byte offset of the item's 16 bytes from (source 1 + first channel of the chunk): row * lda1 * 4 + k4 * 16
+    unsigned valid[2] = {0, 0};  // bit ps: the item is a real row (else zero padding / beyond the patch)
+    unsigned second[2] = {0, 0}; // flat tiles: bit ps: the item belongs to the SECOND sample the tile touches (a patch spans at most two)
+    int smp0[2] = {0, 0};        // flat tiles: first sample of the patch
+    int tile_of[2] = {-1, -1};
+    // GroupNorm * FiLM coefficients of this thread's four channels: [0..1] of the (first) sample, [2..3] flat tiles: of the second one
+    f32x4 cf[2][4];
+    Geo gq[2];
+    int cq[2];
+    auto set_tile = [&](auto set, int i) {
+      constexpr int S = decltype(set)::value;
+      if (tile_of[S] == i) return;
+      tile_of[S] = i;
+      const Geo g = geo_of(i);
+      gq[S] = g;
+      unsigned vmask = 0, smask = 0;
+      if (!MODE) smp0[S] = max(g.g0 - a.halo, 0) / rows_per_sample;
+      const int row_s1 = MODE ? 0 : (smp0[S] + 1) * rows_per_sample;  // first row of the second sample
+#pragma unroll
+      for (int ps = 0; ps < PW_MAXP; ++ps) {
+        const int r = (pt >> 2) + ps * 48;
+        int sr = -1;
+        if (r < a.PR) {
+          if (MODE) {
+            const int py = r / 18, px = r - py * 18;
+            const int h = g.ty0 - 1 + py, w = g.tx0 - 1 + px;
+            if (h >= 0 && h < H && w >= 0 && w < W) sr = g.img * HW + h * W + w;
+          } else {
+            const int gg = g.g0 - a.halo + r;
+            if (gg >= 0 && gg < a.total_rows) sr = gg;
+          }
+        }
+        if (sr >= 0) vmask |= 1u << ps;
+        if (!MODE && sr >= row_s1) smask |= 1u << ps;
+        roff[S][ps] = ((unsigned)max(sr, 0) * (unsigned)p.lda1 + k4 * 4) * 4u;
+      }
+      valid[S] = vmask;
+      second[S] = smask;
+    };
+    // Every global load of these waves is an inline-asm statement, every wait is placed by hand, and the code is straight-line (padded
+    // items load row 0 and are zeroed by a select; rows beyond the patch land in the buffer's slack).  The rows of phase q + 2 must
+    // stay in flight across the LDS stores of phase q + 1 AND across the barrier; hipcc's own bookkeeping cannot express that here:
+    // with a branch per item it waited vmcnt(0) before every LDS store, with straight-line loads it folded the two register sets into
+    // one body joined by register copies (which wait for the rows just requested), and once the bodies were kept apart it still
+    // drained the queue before re-using the address temporaries (the .s of each attempt; cdna_hip_programming.md 5.7, form (ii)).
+#define PW_GLOAD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define PW_GLOAD_S(dst, off, base) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
+    auto load_patch = [&](auto set, int cc) {  // raw loads only; the operand transform runs at store time, one phase later
+      constexpr int S = decltype(set)::value;
+      cq[S] = cc;
+      const int c0 = cc * CK2;
+      const bool src1 = c0 < p.C1;
+      // (always the same number of loads -- PW_LOADS -- whatever the layer: the waits below count on it)
+      const bool xf = p.a_mode == 1 && src1;
+      const int smp = MODE ? gq[S].img / p.a_imgs_per_sample : smp0[S];
+      const float* cfp = xf ? p.a_coef + ((long long)smp * p.C1 + c0 + k4 * 4) * 2 : p.a1;
+      f32x4 &c0r = cf[S][0], &c1r = cf[S][1];
+      const float* cfp4 = cfp + 4;
+      PW_GLOAD(c0r, cfp);
+      PW_GLOAD(c1r, cfp4);
+      if (!MODE) {  // the second sample a flat tile may run into (clamped to the last sample: never selected then)
+        const int nsmp = a.total_rows / rows_per_sample;
+        const float* cfq = xf ? p.a_coef + ((long long)min(smp + 1, nsmp - 1) * p.C1 + c0 + k4 * 4) * 2 : p.a1;
+        f32x4 &c2r = cf[S][2], &c3r = cf[S][3];
+        const float* cfq4 = cfq + 4;
+        PW_GLOAD(c2r, cfq);
+        PW_GLOAD(c3r, cfq4);
+      }
+      if (src1) {  // scalar base + the tile's per-item byte offsets: one instruction per item
+        const float* base = p.a1 + c0;
+#pragma unroll
+        for (int k = 0; k < PW_MAXP; ++k) {
+          const int ps = S ? PW_MAXP - 1 - k : k;  // (set 1 walks its items backwards: the two instantiations must not be isomorphic, see phase())
+          f32x4& dst = preg[S][ps];
+          const unsigned off = roff[S][ps];
+          PW_GLOAD_S(dst, off, base);
+        }
+      } else {     // second (concatenated) source: its own row pitch
+        const float* base = p.a2 + (c0 - p.C1);
+#pragma unroll
+        for (int k = 0; k < PW_MAXP; ++k) {
+          const int ps = S ? PW_MAXP - 1 - k : k;
+          f32x4& dst = preg[S][ps];
+          const unsigned off = roff[S][ps];  // (plan_pw: both sources share one row pitch)
+          PW_GLOAD_S(dst, off, base);
+        }
+      }
+    };
+    constexpr int PW_LOADS = PW_MAXP + (MODE ? 2 : 4);  // vector-memory operations of one load_patch
+    // the rows (and coefficients) of set S have landed once at most `younger` later vector-memory operations are outstanding; naming
+    // every destination "+v" keeps the compiler from touching them above this statement
+    auto wait_set = [&](auto set, auto younger) {
+      constexpr int S = decltype(set)::value;
+      constexpr int N = decltype(younger)::value;
+      static_assert(PW_MAXP == 7, "operand list below");
+      // (references first: clang does not capture a variable that only appears in an asm operand list of a generic lambda)
+      f32x4 &r0 = preg[S][0], &r1 = preg[S][1], &r2 = preg[S][2], &r3 = preg[S][3], &r4 = preg[S][4], &r5 = preg[S][5], &r6 = preg[S][6];
+      f32x4 &c0r = cf[S][0], &c1r = cf[S][1], &c2r = cf[S][2], &c3r = cf[S][3];
+      asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(N) : "memory");
+      __builtin_amdgcn_sched_barrier(0);  // nothing -- in particular no register copy of a destination -- moves above the wait
+      asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(c0r), "+v"(c1r));
+      if (!MODE) asm volatile("" : "+v"(c2r), "+v"(c3r));
+    };
+    auto store_patch = [&](auto set, unsigned char* dst) {
+      constexpr int S = decltype(set)::value;
+      unsigned short* Ph = reinterpret_cast<unsigned short*>(dst);
+      const int c0 = cq[S] * CK2;
+      const bool xform = c0 < p.C1 && p.a_mode == 1;
+#pragma unroll
+      for (int k = 0; k < PW_MAXP; ++k) {
+        const int ps = S ? PW_MAXP - 1 - k : k;
+        const int r = (pt >> 2) + ps * 48;
+        f32x4 v = preg[S][ps];
+        if (xform) {  // (wave-uniform)
+          f32x4 ca = cf[S][0], cb4 = cf[S][1];
+          if (!MODE && ((second[S] >> ps) & 1u)) { ca = cf[S][2]; cb4 = cf[S][3]; }
+          v.x = igemm::silu_fast(v.x * ca.x + ca.y);
+          v.y = igemm::silu_fast(v.y * ca.z + ca.w);
+          v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
+          v.w = igemm::silu_fast(v.w * cb4.z + cb4.w);
+        }
+        if (!((valid[S] >> ps) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding is applied AFTER the activation (vddp.py:268-285)
+        if constexpr (F32) {  // 16 floats per row (the same 64 + 16 bytes as 16 bf16 hi | 16 lo)
+          *reinterpret_cast<f32x4*>(&Ph[r * CROW2 + k4 * 8]) = v;
+        } else {
+          unsigned h0, l0, h1, l1;
+          split2c(v.x, v.y, h0, l0);
+          split2c(v.z, v.w, h1, l1);
+          *reinterpret_cast<uint2*>(&Ph[r * CROW2 + k4 * 4]) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(&Ph[r * CROW2 + CK2 + k4 * 4]) = make_uint2(l0, l1);
+        }
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    unsigned long long tsum[4] = {0, 0, 0, 0};  // tracing: cycles in (drain of half 1, requests, wait for the rows, transform + LDS stores)
+    // phase q = (tile q / nchunks, chunk q % nchunks).  Register set q & 1 holds the raw rows of phase q: requested during phase q - 2,
+    // stored (to patch buffer q & 1) during phase q - 1 -- a full phase in flight.
+    int li = 0, lc = 0;      // (tile, chunk) of the most recently REQUESTED phase
+    int ti = 0, tc = 0;
+    Geo g_cur = geo_of(0), g_prev = g_cur;
+    using N0 = std::integral_constant<int, 0>;
+    using NL = std::integral_constant<int, PW_LOADS>;
+    set_tile(S0{}, 0);
+    load_patch(S0{}, 0);
+    wait_set(S0{}, N0{});
+    store_patch(S0{}, smem_b);
+    if (P > 1) {
+      if (++lc == nchunks) { lc = 0; ++li; }
+    }
+    set_tile(S1{}, li);
+    load_patch(S1{}, lc);
+    PW_BARRIER_LDS();
+    auto phase = [&](auto cur, auto nxt, int q) {
+      // during phase q: request phase q + 2 into the set phase q just vacated (first: in flight while the other set is transformed),
+      // then store phase q + 1
+      // (the two instantiations differ only in which register set plays which part: without a distinguishing marker the compiler folds
+      // them into one body and swaps the sets with register copies -- copies that wait for the rows requested a moment ago)
+      asm volatile("; patch phase, rows in flight -> set %0" ::"n"(decltype(cur)::value));
+      // One shape for every phase: past the end the last chunk is simply requested again, so that the store below always finds exactly
+      // PW_LOADS younger operations in the queue (a second variant of the wait made the compiler copy the destinations ABOVE it).
+      // The two instantiations (register sets swapped) walk their items in opposite order: isomorphic bodies get folded into one that
+      // swaps the sets with register copies.
+      // (ti, tc) = (tile, chunk) being multiplied during this phase, g_cur / g_prev: geometry of that tile and of the one before
+      const bool first = tc == 0 && ti > 0, last = tc + 1 == nchunks;
+      const unsigned long long ts0 = tracing ? __builtin_readcyclecounter() : 0;
+      if (first) {  // second half of the previous tile (written between its Y and R barriers)
+        drain_read(sd1);
+        drain_store(sd1, 1, g_prev);
+      }
+      const unsigned long long ts1 = tracing ? __builtin_readcyclecounter() : 0;
+      if (!(a.dbg & 2)) {
+        if (q + 2 < P) {
+          if (++lc == nchunks) { lc = 0; ++li; }
+          set_tile(cur, li);
+        }
+        load_patch(cur, lc);
+        const unsigned long long ts2 = tracing ? __builtin_readcyclecounter() : 0;
+        if (tracing) { tsum[0] += ts1 - ts0; tsum[1] += ts2 - ts1; }
+        // At most PW_LOADS operations outstanding <=> the rows of set nxt have landed: loads retire in order among themselves, and if one
+        // of them were still out, so would be all PW_LOADS requests issued after it.  (Stores retire independently of loads on gfx9, so
+        // a larger count that "allows for" the drains' stores would not be a guarantee; this one makes the first phase of a tile wait
+        // for most of the sixteen stores issued since.)
+        const unsigned long long ts3 = tracing ? __builtin_readcyclecounter() : 0;
+        wait_set(nxt, NL{});
+        const unsigned long long ts4 = tracing ? __builtin_readcyclecounter() : 0;
+        store_patch(nxt, smem_b + ((q + 1) & 1) * a.patch_bytes);
+        if (tracing) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[2] += ts4 - ts3; tsum[3] += __builtin_readcyclecounter() - ts4; }
+      }
+      if (last) {
+        PW_BARRIER_LDS();      // X: half 0 of this tile is staged
+        drain_read(sd0);
+        PW_BARRIER_LDS();      // Y: ... and has been read
+        drain_store(sd0, 0, g_cur);
+      }
+      PW_BARRIER_LDS();
+      if (++tc == nchunks) {
+        tc = 0;
+        ++ti;
+        g_prev = g_cur;
+        if (ti < cnt) g_cur = geo_of(ti);
+      }
+    };
+    for (int q = 0; q < P; q += 2) {
+      phase(S0{}, S1{}, q);
+      if (q + 1 < P) phase(S1{}, S0{}, q + 1);
+    }
+    drain_read(sd1);
+    drain_store(sd1, 1, g_prev);
+    if (tracing) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int k = 0; k < 4; ++k) a.trace[128 * 16 + (wave - 4) * 4 + k] = tsum[k];
+    }
+#undef PW_GLOAD
+#undef PW_GLOAD_S
+    return;
+  }
+
+  // ============================================================================================================ matrix waves
+  if (a.dbg & 128) __builtin_amdgcn_s_setprio(2);
+  const int wm = wave;
+  const int lrow = lane & 31, lk = lane >> 5;
+  // 2-D tiles: lane -> pixel of the wave's 4 x 16 pixel strip.  Lanes 16-31 of an MFMA tile take the second pixel row ROTATED by two
+  // columns: with the 80-byte patch pitch the sixteen lanes of every ds_read_b128 service group then sit on sixteen different patch
+  // rows modulo 16, i.e. on disjoint bank quads (identity mapping: two-way conflicts on every A-operand read).
+  const int tr_l = lrow >> 4, pc_l = lrow < 16 ? lrow : ((lrow - 2) & 15);
+  Geo g = geo_of(0);
+  unsigned tapmask[2] = {0x1FFu, 0x1FFu};
+  auto set_masks = [&](const Geo& gg) {
+    if (MODE) return;  // out-of-image patch rows hold zeros
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = wm * 64 + i * 32 + lrow;
+      unsigned msk = 0;
+      const int gr = gg.g0 + m;
+      if (gr < a.total_rows) {
+        const int pix = gr % HW;
+        const int h = pix / W, w = pix - h * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+          if (hh >= 0 && hh < H && ww >= 0 && ww < W) msk |= 1u << t;
+        }
+      }
+      tapmask[i] = msk;
+    }
+  };
+  set_masks(g);
+
+  // The column tile of a workgroup never changes (grid 256: J = 32 is a multiple of the number of column tiles; smaller grids run one
+  // tile per workgroup): its bias lives in registers for the whole launch and is what the accumulators are initialised with.
+  f32x16 bias_r[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int gq2 = 0; gq2 < 4; ++gq2) {
+      const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + g.n0 + j * 32 + 8 * gq2 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias_r[j][4 * gq2] = b4.x; bias_r[j][4 * gq2 + 1] = b4.y; bias_r[j][4 * gq2 + 2] = b4.z; bias_r[j][4 * gq2 + 3] = b4.w;
+    }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = bias_r[j];
+
+  const int pitch = MODE ? 18 : a.pitch;
+  int abase0[2][3];  // byte offsets into patch buffer 0; the kernel column and the hi | lo plane are immediate offsets
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wm * 64 + i * 32 + lrow;
+    const int prow = MODE ? (wm * 4 + i * 2 + tr_l + 1) * 18 + pc_l + 1 : m + a.halo;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) abase0[i][kh] = ((prow + (kh - 1) * pitch - 1) * CROW2 + lk * (F32 ? 16 : 8)) * 2;
+  }
+  int abase[2][3];
+  const int woff0 = 2 * a.patch_bytes + lane * 16;  // byte offset of this lane's 16 bytes in plane 0 of weight stage 0
+  int woff = woff0;
+  auto load_ab = [&](uint4 (&av)[4], uint4 (&bv)[4], int tap) {
+    const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned char* q = smem_b + abase[i][kh] + kw * (CROW2 * 2);
+      uint4 vh = *reinterpret_cast<const uint4*>(q);
+      uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 16 : CK2 * 2));
+      if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+      av[2 * i] = vh;
+      av[2 * i + 1] = vl;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) bv[pl] = *reinterpret_cast<const uint4*>(smem_b + woff + (tap * 4 + pl) * 1024);
+  };
+  auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
+    if constexpr (F32) {
+      const float pa[2][8] = {{__uint_as_float(av[0].x), __uint_as_float(av[0].y), __uint_as_float(av[0].z), __uint_as_float(av[0].w),
+                               __uint_as_float(av[1].x), __uint_as_float(av[1].y), __uint_as_float(av[1].z), __uint_as_float(av[1].w)},
+                              {__uint_as_float(av[2].x), __uint_as_float(av[2].y), __uint_as_float(av[2].z), __uint_as_float(av[2].w),
+                               __uint_as_float(av[3].x), __uint_as_float(av[3].y), __uint_as_float(av[3].z), __uint_as_float(av[3].w)}};
+      const float wb[2][8] = {{__uint_as_float(b[0].x), __uint_as_float(b[0].y), __uint_as_float(b[0].z), __uint_as_float(b[0].w),
+                               __uint_as_float(b[1].x), __uint_as_float(b[1].y), __uint_as_float(b[1].z), __uint_as_float(b[1].w)},
+                              {__uint_as_float(b[2].x), __uint_as_float(b[2].y), __uint_as_float(b[2].z), __uint_as_float(b[2].w),
+                               __uint_as_float(b[3].x), __uint_as_float(b[3].y), __uint_as_float(b[3].z), __uint_as_float(b[3].w)}};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j][e], pa[i][e], acc[i][j], 0, 0, 0);
+      return;
+    }
+    const bf16x8 ah0 = __builtin_bit_cast(bf16x8, av[0]), al0 = __builtin_bit_cast(bf16x8, av[1]);
+    const bf16x8 ah1 = __builtin_bit_cast(bf16x8, av[2]), al1 = __builtin_bit_cast(bf16x8, av[3]);
+    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
+    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
+    // weights are the MFMA "A" (rows = output channels), pixels the "B" (columns): a lane holds 4 x 4 consecutive output channels of
+    // one pixel -> 16-byte epilogue stores.  Pass-major order: consecutive MFMAs never share an accumulator.
+    auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0); };
+    acc[0][0] = mm(al0, bh0, acc[0][0]);
+    acc[0][1] = mm(al0, bh1, acc[0][1]);
+    acc[1][0] = mm(al1, bh0, acc[1][0]);
+    acc[1][1] = mm(al1, bh1, acc[1][1]);
+    acc[0][0] = mm(ah0, bl0, acc[0][0]);
+    acc[0][1] = mm(ah0, bl1, acc[0][1]);
+    acc[1][0] = mm(ah1, bl0, acc[1][0]);
+    acc[1][1] = mm(ah1, bl1, acc[1][1]);
+    acc[0][0] = mm(ah0, bh0, acc[0][0]);
+    acc[0][1] = mm(ah0, bh1, acc[0][1]);
+    acc[1][0] = mm(ah1, bh0, acc[1][0]);
+    acc[1][1] = mm(ah1, bh1, acc[1][1]);
+  };
+
+  const int ep_off = ep_base + wm * EP_WAVE;
+  auto stage_half = [&](int i) {
+    // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave
+    // (the bias is already in the accumulators: they start from it)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq2 = 0; gq2 < 4; ++gq2) {
+        const f32x4 v = {acc[i][j][4 * gq2], acc[i][j][4 * gq2 + 1], acc[i][j][4 * gq2 + 2], acc[i][j][4 * gq2 + 3]};
+        *reinterpret_cast<f32x4*>(smem_b + ep_off + lrow * EP_PITCH + (j * 32 + 8 * gq2 + 4 * lk) * 4) = v;
+      }
+  };
+  auto gn_sums = [&](const Geo& gg) {
+    if (MODE && p.gn_part && !(a.dbg & 64)) {
+      // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels the
+      // sum and the sum of squares over this wave's 64 pixels -- reduce-scatter butterfly (8 + 4 + 2 + 1 shuffles, then two plain steps) --
+      // written as this WAVE's own slot of the (sample, group)'s contribution list: no LDS, no barrier, no atomics
+      float gv[16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int gq2 = 0; gq2 < 4; ++gq2) {
+          float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float v0 = acc[i][j][4 * gq2], v1 = acc[i][j][4 * gq2 + 1], v2 = acc[i][j][4 * gq2 + 2], v3 = acc[i][j][4 * gq2 + 3];
+            s1 += (v0 + v1) + (v2 + v3);
+            s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          }
+          gv[(j * 4 + gq2) * 2] = s1;
+          gv[(j * 4 + gq2) * 2 + 1] = s2;
+        }
+      }
+#pragma unroll
+      for (int bit = 5, n = 8; bit >= 2; --bit, n >>= 1) {
+        const bool hi = (lane >> bit) & 1;
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+          const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
+          gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+        }
+      }
+      gv[0] += __shfl_xor(gv[0], 2, 64);
+      gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
+      if ((lane & 3) == 0) {
+        const int slot = lane >> 2, run = slot >> 1;
+        const int cout0 = gg.n0 + (run >> 2) * 32 + (run & 3) * 8;
+        const int cpg = p.Cout / p.gn_groups, rpg = cpg >> 3;
+        const int grp = cout0 / cpg, rig = (cout0 - grp * cpg) >> 3;
+        const int smp = gg.img / p.a_imgs_per_sample, fr = gg.img - smp * p.a_imgs_per_sample;
+        const int n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * 4 * rpg;
+        const int k = ((fr * a.tiles_per_frame + (gg.mtile - gg.img * a.tiles_per_frame)) * 4 + wm) * rpg + rig;
+        p.gn_part[(((long long)smp * p.gn_groups + grp) * n_contrib + k) * 2 + (slot & 1)] = gv[0];
+      }
+    }
+  };
+
+  // nine k16 steps (taps) per chunk; the operands of step t + 1 are requested before the MFMAs of step t
+  uint4 aa[2][4], bb[2][4];
+  PW_BARRIER_LDS();  // phase 0 is staged
+  int ph = 0;
+  for (int i = 0; i < cnt; ++i) {
+    for (int cc = 0; cc < nchunks; ++cc, ++ph) {
+      const int poff = (ph & 1) * a.patch_bytes;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          abase[ii][kh] = abase0[ii][kh] + poff;
+          asm volatile("" : "+v"(abase[ii][kh]));  // keep the six bases opaque: the per-step addresses stay base + immediate
+        }
+      woff = woff0 + (ph & 1) * PW_STAGE;
+      asm volatile("" : "+v"(woff));
+      load_ab(aa[0], bb[0], 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) load_ab(aa[(t + 1) & 1], bb[(t + 1) & 1], t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(aa[t & 1], bb[t & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (cc + 1 == nchunks) {
+        stage_half(0);
+        PW_BARRIER_LDS();  // X: the producer waves read half 0 ...
+        gn_sums(g);        // (... while the GroupNorm sums are formed)
+        PW_BARRIER_LDS();  // Y
+        stage_half(1);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ii][j] = bias_r[j];
+      }
+      PW_BARRIER_LDS();  // phase ph + 1 is staged in the other buffers; this phase's buffers may be overwritten
+    }
+    if (i + 1 < cnt) {
+      g = geo_of(i + 1);
+      set_masks(g);
+    }
+  }
+#undef PW_BARRIER_LDS
+#undef PW_BARRIER_DMA
+}
+
+template <int MODE, bool F32>
+int launch_pw(const PWArgs& a, hipStream_t s) {
+  const size_t shm = (size_t)2 * a.patch_bytes + 2 * PW_STAGE + 4 * 32 * 272;  // patches, weight stages, epilogue staging = 160 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pw_kernel<MODE, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  // one workgroup per CU (256 CUs, 8 XCDs); fewer tiles than CUs: one tile each, rounded up to whole XCD groups
+  const int grid = a.n_units >= 256 ? 256 : ((a.n_units + 7) / 8) * 8;
+  static const int trace_launch = [] { const char* e = getenv("VMM_PW_TRACE"); return e ? atoi(e) : -1; }();
+  static int launch_no = 0;
+  static unsigned long long* trace_buf = nullptr;
+  PWArgs aa = a;
+  const bool tracing = trace_launch >= 0 && launch_no++ == trace_launch;
+  if (tracing) {
+    if (!trace_buf) (void)hipMalloc(&trace_buf, (128 * 16 + 16) * sizeof(unsigned long long));
+    (void)hipMemset(trace_buf, 0, (128 * 16 + 16) * sizeof(unsigned long long));
+    aa.trace = trace_buf;
+  }
+  hipLaunchKernelGGL((conv3x3_pw_kernel<MODE, F32>), dim3((unsigned)grid), dim3(512), shm, s, aa);
+  VMM_LAUNCH_CHECK();
+  if (tracing) {  // measurement aid only: synchronises the device and prints workgroup 0's barrier time line
+    (void)hipDeviceSynchronize();
+    static unsigned long long h[128 * 16 + 16];
+    (void)hipMemcpy(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[pw trace] Cin %d Cout %d HxW %dx%d mode %d units %d grid %d a_mode %d\n", a.p.C1 + a.p.C2, a.p.Cout, a.p.Hin, a.p.Win, a.mode, a.n_units, grid, a.p.a_mode);
+    for (int w = 0; w < 3; ++w)
+      fprintf(stderr, "  patch wave %d: drain-1 %lld, requests %lld, wait for rows %lld, transform + LDS stores %lld cycles in total\n", w, (long long)h[128 * 16 + w * 4],
+              (long long)h[128 * 16 + w * 4 + 1], (long long)h[128 * 16 + w * 4 + 2], (long long)h[128 * 16 + w * 4 + 3]);
+    const unsigned long long t0 = h[0];
+    for (int q = 0; q < 128 && h[(q * 8) * 2 + 1]; ++q) {
+      fprintf(stderr, "  barrier %3d:", q);
+      for (int w = 0; w < 8; ++w) fprintf(stderr, " w%d %7lld+%-6lld", w, (long long)(h[(q * 8 + w) * 2] - t0), (long long)(h[(q * 8 + w) * 2 + 1] - h[(q * 8 + w) * 2]));
+      fprintf(stderr, "\n");
+    }
+  }
+  return 0;
+}
+
+// geometry of the persistent variant: 256-pixel x 64-column tiles for every layer; false when the shape is outside its envelope
+bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
+  const long long M = (long long)d.nimg * d.Hin * d.Win;
+  a.p = d;
+  a.n_tiles = d.Cout / 64;
+  a.total_rows = (int)M;
+  a.KS = 9 * (d.C1 + d.C2) / 16;
+  int mtiles;
+  if (d.Win >= 32 && d.Win % 16 == 0 && d.Hin % 16 == 0) {
+    a.mode = 1;
+    a.tiles_x = d.Win / 16;
+    a.tiles_per_frame = a.tiles_x * (d.Hin / 16);
+    a.pitch = 18;
+    a.halo = 0;
+    a.PR = 18 * 18;
+    mtiles = d.nimg * a.tiles_per_frame;
+  } else {
+    a.mode = 0;
+    a.tiles_x = a.tiles_per_frame = 1;
+    a.pitch = d.Win;
+    a.halo = d.Win + 1;
+    a.PR = 256 + 2 * a.halo;
+    mtiles = (int)cdiv(M, 256);
+  }
+  if (a.PR > PW_MAXP * 48 || d.Cout % 64) return false;
+  if (d.C2 > 0 && d.lda2 != d.lda1) return false;  // the patch waves keep ONE byte offset per row
+  // flat tiles with the fused transform: a patch may touch two samples, not three
+  if (a.mode == 0 && d.a_mode == 1 && (long long)d.Hin * d.Win * d.a_imgs_per_sample < a.PR) return false;
+  a.patch_bytes = (PW_MAXP * 48 * CROW2 * 2 + 1023) / 1024 * 1024;  // room for every item of every patch thread: stores need no row check
+  a.n_units = mtiles * a.n_tiles;
+  static const int dbg = [] { const char* e = getenv("VMM_PW_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
+  a.trace = nullptr;
+  static const int stagger_env = [] { const char* e = getenv("VMM_PW_STAGGER"); return e ? atoi(e) : -1; }();
+  const int nchunks = (d.C1 + d.C2) / CK2;
+  // a quarter of a tile's time (about 4.5k cycles per 16-channel chunk); only worth it when a workgroup runs several short tiles
+  a.stagger = stagger_env >= 0 ? stagger_env * nchunks : ((a.n_units >= 4 * 256 && nchunks <= 8) ? 1100 * nchunks : 0);
+  return true;
+}
+
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
@@ -546,8 +1271,39 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
 
 }  // namespace
 
+// unsplit layers run the persistent wave-specialised kernel (VMM_C3_LEGACY=1 in the environment keeps the one-tile-per-workgroup
+// kernel for A/B measurements; read once)
+// 0: never, 1: where it measured faster (2-D tiles of 64-column layers), 2: every shape inside its envelope
+static int c3_persistent() {
+  static const int mode = [] {
+    const char* l = getenv("VMM_C3_LEGACY");
+    if (l && l[0] == '1') return 0;
+    const char* e = getenv("VMM_C3_PERSISTENT");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+static bool c3_use_pw(const vmm_conv_desc& d, int ksplit, PWArgs& pa) {
+  const int mode = c3_persistent();
+  if (mode == 0 || ksplit != 1 || !plan_pw(d, pa)) return false;
+  return mode >= 2 || (pa.mode == 1 && d.Cout == 64);
+}
+// measurement aid: VMM_PW_ONLY=k keeps the persistent kernel for the k-th eligible launch of the process only (layer bisection)
+static bool c3_pw_this_launch() {
+  static const int only = [] { const char* e = getenv("VMM_PW_ONLY"); return e ? atoi(e) : -1; }();
+  static int n = 0;
+  return only < 0 || n++ == only;
+}
+
 template <bool F32>
 int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t s) {
+  PWArgs pa;
+  if (c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
+    pa.p.gn_part = a.p.gn_part;  // (cleared by plan_c3 when the statistics are not fused)
+    if (getenv("VMM_PW_LOG")) fprintf(stderr, "[pw] Cin %d+%d Cout %d %dx%d nimg %d mode %d units %d a_mode %d gn %p res %p lda %d %d ldo %d\n", a.p.C1, a.p.C2, a.p.Cout, a.p.Hin,
+                                      a.p.Win, a.p.nimg, pa.mode, pa.n_units, a.p.a_mode, (void*)pa.p.gn_part, (void*)a.p.res, a.p.lda1, a.p.lda2, a.p.ldo);
+    return pa.mode ? launch_pw<1, F32>(pa, s) : launch_pw<0, F32>(pa, s);
+  }
   if (ksplit > 1) {
     if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32>(a, mtiles, ksplit, s);
     return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32>(a, mtiles, ksplit, s);
@@ -559,10 +1315,14 @@ int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t 
 // Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
 // vmm_groupnorm_stats and hands them to vmm_groupnorm_coef), 0 when it will not.  Pure host logic.
 extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
+  if (getenv("VMM_NO_GN_FUSE")) return 0;  // measurement aid
   C3Args a;
   int mtiles, ksplit;
   bool gn = false;
   if (plan_c3(*dp, a, mtiles, ksplit, gn) != 0 || !gn) return 0;
+  PWArgs pa;
+  if (c3_use_pw(*dp, ksplit, pa))  // the persistent kernel leaves one slot per 64-pixel wave tile of its 256-pixel tiles
+    return dp->a_imgs_per_sample * pa.tiles_per_frame * 4 * ((dp->Cout / dp->gn_groups) >> 3);
   return dp->a_imgs_per_sample * a.tiles_per_frame * ((dp->Cout / dp->gn_groups) >> 3);
 }
 

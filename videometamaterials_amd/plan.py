@@ -578,9 +578,11 @@ class _Builder:
         h2 = self.act(Cout, H, W)
         d2 = self.conv(a1=h1, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
                        a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2)
+        # (h1 and its coefficients are conv2's INPUT: they are released only after the GroupNorm partial sums of conv2's output have
+        # their buffer -- conv2 writes those while it is still reading h1, so the two must never share memory)
+        c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0, conv_desc=d2 if halo2 else None)
         self.free_act(h1)
         self.free(c1_off, c1_n)
-        c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0, conv_desc=d2 if halo2 else None)
         has_res = (name + ".res_conv.weight") in self.shapes
         out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
         dr, gwr = None, 0
