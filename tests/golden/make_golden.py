@@ -39,8 +39,10 @@ def build(cfg_name):
     return model.eval()
 
 
-def unet_goldens():
+def unet_goldens(only=None):
     for cfg_name in helpers.CONFIGS:
+        if only and cfg_name not in only:
+            continue
         model = build(cfg_name)
         x, t, cond = helpers.synth_inputs(cfg_name)
         out = {}
@@ -160,6 +162,9 @@ def table_goldens(nograd):
 
 
 if __name__ == "__main__":
-    unet_goldens()
-    ng = diffusion_goldens()
-    table_goldens(ng)
+    if len(sys.argv) > 1:  # python make_golden.py <config> [...]: only the Unet3D goldens of the named configs (adding one leaves the rest untouched)
+        unet_goldens(only=sys.argv[1:])
+    else:
+        unet_goldens()
+        ng = diffusion_goldens()
+        table_goldens(ng)

@@ -29,6 +29,10 @@ CONFIGS = {
     # cfg4 wiring reduced: per_frame_cond=False, self-stacked with 16 CNN tokens, temporal cond
     "hires16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16,
                      use_temporal_attention_cond=True, per_frame_cond=False), (2, 6, 16, 16), 51),
+    # BASELINE configs[3] wiring at the real widths with its 22 frames (more than the fused temporal kernels' 16 slots: the
+    # two-frame-tile temporal attention path at every level), small frames
+    "hires64t22": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16,
+                        use_temporal_attention_cond=True, per_frame_cond=False), (2, 22, 32, 32), 51),  # (B = 1 crashes the reference: torch.squeeze in SignalEmbedding, vddp.py:571)
 }
 
 

@@ -84,7 +84,8 @@ def test_backward_matches_reference_golden_gradients(gpu):
     assert {k for k, p in named.items() if p.grad is None} == nograd
 
 
-@pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False)])
+@pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
+                                               ("hires64t22", False)])
 def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_val):
     kw, sd, model, diff = _setup(cfg_name, gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)

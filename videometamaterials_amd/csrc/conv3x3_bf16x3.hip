@@ -758,7 +758,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
         PW_GLOAD(c2r, cfq);
         PW_GLOAD(c3r, cfq4);
       }
-      if (src1) {  // scalar base + the tile's per-item byte offsets: one instruction per item
+      if (a.dbg & 512) {
+      } else if (src1) {  // scalar base + the tile's per-item byte offsets: one instruction per item
         const float* base = p.a1 + c0;
 #pragma unroll
         for (int k = 0; k < PW_MAXP; ++k) {
