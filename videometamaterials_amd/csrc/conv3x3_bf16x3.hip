@@ -427,56 +427,94 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
           *reinterpret_cast<f32x4*>(orp + j * 32 + 8 * g) = v;
         }
     }
-    if (MODE && p.gn_part) {
+    if (p.gn_part) {
       // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels
-      // the sum and the sum of squares over this wave's 64 pixels, combined over the workgroup's waves in LDS, then one fp64
-      // atomic per (run, moment) into sums[sample][group] -- the separate statistics pass over the output disappears.
+      // the sum and the sum of squares over this wave's 64 pixels, combined over the workgroup's waves in LDS and written as this
+      // tile's own slot of the (sample, group)'s contribution list (every slot exactly once: no zero-fill, no atomics; summed in a
+      // fixed order by vmm_groupnorm_coef) -- the separate statistics pass over the output disappears.
+      // 2-D tiles lie inside one frame, hence one sample.  Flat row tiles run across frames and samples: a tile (at most as long as a
+      // sample, plan_c3) touches at most two samples, A = that of its first row and B = the next one, and keeps two sets of sums.
+      const int R = HW * p.a_imgs_per_sample;                      // rows per sample
+      const int smpA = MODE ? img / p.a_imgs_per_sample : g0 / R;
+      const int bnd = MODE ? 0x7fffffff : (smpA + 1) * R;           // first row of sample B
+      const bool straddle = !MODE && g0 + BM > bnd && bnd < a.total_rows;
       // 16 values per lane: (sum, sum of squares) x 8 runs; wave totals by a reduce-scatter butterfly -- every exchange halves the
       // values a lane still carries (8 + 4 + 2 + 1 shuffles), two plain steps finish: 17 shuffles instead of 96
-      float gv[16];
+      auto wave_sums = [&](bool setB) -> float {
+        float gv[16];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
+          for (int g = 0; g < 4; ++g) {
+            float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-            s1 += (v0 + v1) + (v2 + v3);
-            s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            for (int i = 0; i < 2; ++i) {
+              bool mine = true;
+              if (!MODE) {
+                const int row = g0 + wm * 64 + i * 32 + lrow;
+                mine = row < a.total_rows && ((row >= bnd) == setB);
+              }
+              if (mine) {
+                const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                s1 += (v0 + v1) + (v2 + v3);
+                s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+              }
+            }
+            gv[(j * 4 + g) * 2] = s1;
+            gv[(j * 4 + g) * 2 + 1] = s2;
           }
-          gv[(j * 4 + g) * 2] = s1;
-          gv[(j * 4 + g) * 2 + 1] = s2;
         }
-      }
 #pragma unroll
-      for (int bit = 5, n = 8; bit >= 2; --bit, n >>= 1) {
-        const bool hi = (lane >> bit) & 1;
+        for (int bit = 5, n = 8; bit >= 2; --bit, n >>= 1) {
+          const bool hi = (lane >> bit) & 1;
 #pragma unroll
-        for (int k = 0; k < n; ++k) {
-          const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
-          gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+          for (int k = 0; k < n; ++k) {
+            const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
+            gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+          }
         }
-      }
-      gv[0] += __shfl_xor(gv[0], 2, 64);
-      gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
+        gv[0] += __shfl_xor(gv[0], 2, 64);
+        gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
+        return gv[0];
+      };
+      const float totA = wave_sums(false);
+      const float totB = straddle ? wave_sums(true) : 0.f;
       __syncthreads();  // every wave is done with the patch: reuse its LDS
       float* sc = reinterpret_cast<float*>(smem);
-      if ((lane & 3) == 0) sc[wave * 16 + (lane >> 2)] = gv[0];
+      if ((lane & 3) == 0) {
+        sc[wave * 16 + (lane >> 2)] = totA;
+        sc[64 + wave * 16 + (lane >> 2)] = totB;
+      }
       __syncthreads();
       if (tid < WN * 16) {
         const int wn2 = tid >> 4, slot = tid & 15, run = slot >> 1;
-        float v = 0.f;
+        float vA = 0.f, vB = 0.f;
 #pragma unroll
-        for (int w2 = 0; w2 < WM; ++w2) v += sc[(w2 * WN + wn2) * 16 + slot];
-        // slot of this (frame, tile, 8-channel run) among the contributions to its (sample, group): written exactly once, no atomics
+        for (int w2 = 0; w2 < WM; ++w2) {
+          vA += sc[(w2 * WN + wn2) * 16 + slot];
+          vB += sc[64 + (w2 * WN + wn2) * 16 + slot];
+        }
         const int cout0 = n0 + wn2 * 64 + (run >> 2) * 32 + (run & 3) * 8;
         const int cpg = p.Cout / p.gn_groups, rpg = cpg >> 3;
         const int grp = cout0 / cpg, rig = (cout0 - grp * cpg) >> 3;
-        const int smp = img / p.a_imgs_per_sample, fr = img - smp * p.a_imgs_per_sample;
-        const int n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * rpg;
-        const int k = (fr * a.tiles_per_frame + (mtile - img * a.tiles_per_frame)) * rpg + rig;
-        p.gn_part[(((long long)smp * p.gn_groups + grp) * n_contrib + k) * 2 + (slot & 1)] = v;
+        if (MODE) {
+          const int fr = img - smpA * p.a_imgs_per_sample;
+          const int n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * rpg;
+          const int k = (fr * a.tiles_per_frame + (mtile - img * a.tiles_per_frame)) * rpg + rig;
+          p.gn_part[(((long long)smpA * p.gn_groups + grp) * n_contrib + k) * 2 + (slot & 1)] = vA;
+        } else {
+          // sample s owns the tiles floor(s R / BM) .. floor(((s + 1) R - 1) / BM): ceil(R / BM) or one more of them.  Its slot list has
+          // room for the larger count; the sample's last tile zeroes the spare slot when the count is the smaller one.
+          const int n_max = (R + BM - 1) / BM + 1, n_contrib = n_max * rpg;
+          auto put = [&](int smp, float v) {
+            const int first_t = (int)(((long long)smp * R) / BM), last_t = (int)((((long long)smp + 1) * R - 1) / BM);
+            float* base = p.gn_part + (((long long)smp * p.gn_groups + grp) * n_contrib) * 2 + (slot & 1);
+            base[((mtile - first_t) * rpg + rig) * 2] = v;
+            if (mtile == last_t && last_t - first_t + 1 < n_max) base[((n_max - 1) * rpg + rig) * 2] = 0.f;
+          };
+          put(smpA, vA);
+          if (straddle) put(smpA + 1, vB);
+        }
       }
     }
   }
@@ -1264,8 +1302,10 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   ksplit = (int)cdiv(nch, a.chunks_per_split);
   // GroupNorm statistics of the output in the epilogue: unsplit 2-D tiles (one frame, hence one sample, per workgroup), groups of whole
   // 8-channel runs, no residual in the output
-  gn = d.gn_part && d.gn_groups > 0 && a.mode == 1 && ksplit == 1 && !d.res && d.a_imgs_per_sample > 0 && d.Cout % d.gn_groups == 0 &&
-       (d.Cout / d.gn_groups) % 8 == 0 && d.nimg % d.a_imgs_per_sample == 0;
+  // (flat row tiles: a tile may touch two samples, not three)
+  gn = d.gn_part && d.gn_groups > 0 && ksplit == 1 && !d.res && d.a_imgs_per_sample > 0 && d.Cout % d.gn_groups == 0 &&
+       (d.Cout / d.gn_groups) % 8 == 0 && d.nimg % d.a_imgs_per_sample == 0 &&
+       (a.mode == 1 || (long long)d.Hin * d.Win * d.a_imgs_per_sample >= BM);
   if (!gn) a.p.gn_part = nullptr;
   return 0;
 }
@@ -1300,7 +1340,7 @@ template <bool F32>
 int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t s) {
   PWArgs pa;
   if (c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
-    pa.p.gn_part = a.p.gn_part;  // (cleared by plan_c3 when the statistics are not fused)
+    pa.p.gn_part = pa.mode == 1 ? a.p.gn_part : nullptr;  // (cleared by plan_c3 when the statistics are not fused; the persistent kernel fuses them for 2-D tiles only)
     if (getenv("VMM_PW_LOG")) fprintf(stderr, "[pw] Cin %d+%d Cout %d %dx%d nimg %d mode %d units %d a_mode %d gn %p res %p lda %d %d ldo %d\n", a.p.C1, a.p.C2, a.p.Cout, a.p.Hin,
                                       a.p.Win, a.p.nimg, pa.mode, pa.n_units, a.p.a_mode, (void*)pa.p.gn_part, (void*)a.p.res, a.p.lda1, a.p.lda2, a.p.ldo);
     return pa.mode ? launch_pw<1, F32>(pa, s) : launch_pw<0, F32>(pa, s);
@@ -1321,10 +1361,14 @@ extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
   int mtiles, ksplit;
   bool gn = false;
   if (plan_c3(*dp, a, mtiles, ksplit, gn) != 0 || !gn) return 0;
+  const int rpg = (dp->Cout / dp->gn_groups) >> 3;
   PWArgs pa;
-  if (c3_use_pw(*dp, ksplit, pa))  // the persistent kernel leaves one slot per 64-pixel wave tile of its 256-pixel tiles
-    return dp->a_imgs_per_sample * pa.tiles_per_frame * 4 * ((dp->Cout / dp->gn_groups) >> 3);
-  return dp->a_imgs_per_sample * a.tiles_per_frame * ((dp->Cout / dp->gn_groups) >> 3);
+  if (c3_use_pw(*dp, ksplit, pa))  // the persistent kernel (2-D tiles only) leaves one slot per 64-pixel wave tile of its 256-pixel tiles
+    return pa.mode == 1 ? dp->a_imgs_per_sample * pa.tiles_per_frame * 4 * rpg : 0;
+  if (a.mode == 1) return dp->a_imgs_per_sample * a.tiles_per_frame * rpg;
+  const int BM = dp->Cout >= 128 ? 128 : 256;
+  const long long R = (long long)dp->Hin * dp->Win * dp->a_imgs_per_sample;
+  return (int)((R + BM - 1) / BM + 1) * rpg;  // flat row tiles: the most tiles a sample can touch
 }
 
 // Weights: vmm_pack_weights fmt 2 (MFMA fragment order).  Returns 1 (nothing launched) when the descriptor is outside this

@@ -1009,8 +1009,15 @@ class _Builder:
         self.ekv_info: Dict[str, tuple] = {}
         rot_sites: List[int] = []
 
+        # rotated token keys of all temporal sites live in ONE block: a single rotary launch covers them (they were nine 3-microsecond launches)
+        n_rot = (2 * len(m.in_out) + 1) if (tokens is not None and m.use_temporal_attention_cond and m.per_frame_cond) else 0
+        rot_block = self.alloc(n_rot * B * ntok * hid) if n_rot else 0
+
         def add_ekv(site: str, pfx: str, rotate: bool):
-            eo, vo = self.alloc(B * ntok * hid), self.alloc(B * ntok * hid)
+            if rotate:
+                eo, vo = rot_block + len(rot_sites) * B * ntok * hid, self.alloc(B * ntok * hid)
+            else:
+                eo, vo = self.alloc(B * ntok * hid), self.alloc(B * ntok * hid)
             lvl3.append(dict(x=self.ptr(tokens), w=self.wraw(pfx + ".to_k.weight"), y=self.ptr(eo), rows=B * ntok, K=D, N=hid))
             lvl3.append(dict(x=self.ptr(tokens), w=self.wraw(pfx + ".to_v.weight"), y=self.ptr(vo), rows=B * ntok, K=D, N=hid))
             geo, gvo = (self.scratch(B * ntok * hid), self.scratch(B * ntok * hid)) if tr else (0, 0)
@@ -1034,8 +1041,8 @@ class _Builder:
         if rot_sites:
             if ntok > T:
                 raise ValueError("rotating token keys needs tokens <= frames")
-            for p_ in rot_sites:
-                self.step(lib.vmm_rotary_rows, (p_, self.rot_ptr, B, ntok, heads, 32), "rotate token keys")
+            assert len(rot_sites) == n_rot
+            self.step(lib.vmm_rotary_rows, (self.ptr(rot_block), self.rot_ptr, B * n_rot, ntok, heads, 32), "rotate token keys (all sites)")
 
         def embed_bwd():
             self.dense_bwd_level(self.bwd_lvl3, "embed level 3 bwd")
