@@ -2,6 +2,7 @@
 of the same op, on seeded inputs.  Tolerances are fp32-roundoff class (the kernels compute in fp32)."""
 import ctypes as C
 import math
+import os
 
 import pytest
 import torch
@@ -193,7 +194,9 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
         assert relerr(out.cpu(), ref - res) < tol
         assert relerr(part.cpu().double().sum(1).reshape(B, G, 2), want) < 2e-5  # every slot written exactly once (no NaN left)
     else:  # only flat row tiles longer than a sample (a tile would touch three samples) go without the fused sums
-        assert not (W >= 32 and W % 16 == 0 and H % 16 == 0) and T * H * W < (128 if Cout >= 128 else 256)
+        assert not (W >= 32 and W % 16 == 0 and H % 16 == 0)
+        if os.environ.get("VMM_C3_PERSISTENT") != "2":  # (2 = the persistent kernel for every shape: it fuses the sums for 2-D tiles only)
+            assert T * H * W < (128 if Cout >= 128 else 256)
 
 
 def test_conv_concat_residual_and_fused_gn(gpu):

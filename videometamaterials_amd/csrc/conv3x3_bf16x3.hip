@@ -608,58 +608,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
 #define PW_BARRIER_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(0); asm volatile("s_barrier" ::: "memory"); stamp(1); } while (0)
 #define PW_BARRIER_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); asm volatile("s_barrier" ::: "memory"); stamp(1); } while (0)
 
-  // Epilogue: the matrix waves never store to global memory.  vmcnt counts stores, and a register a store has not read yet cannot be
-  // re-used: with every CU finishing a tile at the same moment (16.8 MB of output queued chip-wide) the matrix waves sat ~8k cycles
-  // behind their own stores at the start of every tile.  They transpose a 32-pixel half of their tile through LDS instead
-  // (4 waves x 32 rows x (256 + 16 pad) bytes behind the weight stages -- that is all the LDS left, hence the two halves and the two
-  // extra barriers per tile) and the four producer waves write it out: a store instruction covers four whole 256-byte rows (an
-  // accumulator lane holds 4 x 4 channels of ONE pixel: stored directly, 64 requests of 16 bytes per instruction), from registers that
-  // nothing touches again before the next tile ends, so the write burst drains in the background of the next tile's MFMAs.
+  // Epilogue staging: 4 waves x 32 pixel rows x (256 + 16 pad) bytes behind the weight stages, private to each matrix wave (see there).
   constexpr int EP_PITCH = 272, EP_WAVE = 32 * EP_PITCH;
   const int ep_base = 2 * a.patch_bytes + 2 * PW_STAGE;
-  const int dt = tid - 256;  // producer waves: 0 .. 255
-  f32x4 sd0[8], sd1[8];      // store data of half 0 / half 1 (kept alive until that half's next turn)
-  auto drain_read = [&](f32x4 (&sd)[8]) {
-    if (PW_KEEP_SD && MODE) {  // naming the registers here keeps the compiler from re-using them since the previous drain of this half
-      asm volatile("" ::"v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]), "v"(sd[4]), "v"(sd[5]), "v"(sd[6]), "v"(sd[7]));
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int px = (dt >> 4) + 16 * k;  // pixel slot 0 .. 127 of the half: matrix wave px >> 5, MFMA column px & 31
-      sd[k] = *reinterpret_cast<const f32x4*>(smem_b + ep_base + (px >> 5) * EP_WAVE + (px & 31) * EP_PITCH + (dt & 15) * 16);
-    }
-  };
-  // Output addressing of the drains: a per-thread byte offset per piece that does not depend on the tile (computed once) on top of a
-  // per-tile scalar base -- one store instruction per piece, no vector address arithmetic (a producer wave issues roughly one
-  // instruction per four cycles at best: its instruction count per phase, not any unit's bandwidth, is what it is short of).
-  unsigned doff[8];
-  if (wave >= 4) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int px = (dt >> 4) + 16 * k, wmm = px >> 5, r = px & 31;
-      const int rel = MODE ? (wmm * 4 + (r >> 4)) * W + (r < 16 ? r : ((r - 2) & 15)) : wmm * 64 + r;  // pixel row relative to the tile's first
-      doff[k] = ((unsigned)rel * (unsigned)p.ldo + (dt & 15) * 4) * 4u;
-    }
-  }
-  auto drain_store = [&](f32x4 (&sd)[8], int h, const Geo& gg) {
-    // first output row of half h of the tile (2-D: the half's pixel rows start 2 h image rows down; flat: 32 h rows)
-    const long long row0 = MODE ? (long long)gg.img * HW + (gg.ty0 + 2 * h) * W + gg.tx0 : (long long)gg.g0 + 32 * h;
-    char* obase = reinterpret_cast<char*>(p.out + row0 * p.ldo + gg.n0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int px = (dt >> 4) + 16 * k;
-      bool ok = true;
-      if (!MODE) ok = gg.g0 + (px >> 5) * 64 + h * 32 + (px & 31) < a.total_rows;
-      if (ok) {
-        f32x4 v = sd[k];
-        if (p.res) {  // (gradient accumulation of the training path; same row layout)
-          const long long rel = doff[k] / 4u / (unsigned)p.ldo;
-          v += *reinterpret_cast<const f32x4*>(p.res + (row0 + rel) * p.ldres + gg.n0 + (dt & 15) * 4);
-        }
-        if (!(a.dbg & 32)) *reinterpret_cast<f32x4*>(obase + doff[k]) = v;
-      }
-    }
-  };
+  const int bias_off = PW_MAXP * 48 * CROW2 * 2;  // 64 floats in the slack at the end of patch buffer 0: the bias of this workgroup's column tile
 
   if (wave >= 4 && (a.dbg & 256)) __builtin_amdgcn_s_setprio(2);
   if (wave == 7) {
@@ -674,48 +626,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + idx * 1024), 16, 0, 0);
       }
     };
-    // (the stage must have landed before the barrier; loads and stores retire independently of each other, so "everything" is the only
-    // count that guarantees it once this wave also has drain stores in flight)
-#define PW_BARRIER_DMA_N(n) PW_BARRIER_DMA()
     Geo g = geo_of(0);   // tile being STAGED (one phase ahead)
     int si = 0, sc = 0;
+    // the column tile of a workgroup never changes (grid 256: J = 32 is a multiple of the number of column tiles; smaller grids run one
+    // tile per workgroup): its bias is parked in LDS once
+    reinterpret_cast<float*>(smem_b + bias_off)[lane] = p.bias ? p.bias[g.n0 + lane] : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stage(g, 0, wstage);
-    if (a.stagger > 0) {
-      // Workgroups start a quarter of a tile apart (everybody else waits at the first barrier): left alone, all 256 CUs finish their
-      // tiles at the same moment and the output of a whole round (16.8 MB) hits the memory system as one burst -- the producer waves
-      // then sat thousands of cycles in the issue of their stores and of the next patch requests.
-      const unsigned long long t0 = __builtin_readcyclecounter();
-      const unsigned long long d = (unsigned long long)(j_in & 3) * a.stagger;
-      while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(8);
-    }
     PW_BARRIER_DMA();
-    int ph = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const Geo gt = geo_of(i);  // tile being MULTIPLIED
-      for (int cc = 0; cc < nchunks; ++cc, ++ph) {
-        if (ph + 1 < P) {
-          if (++sc == nchunks) { sc = 0; ++si; g = geo_of(si); }
-          if (!(a.dbg & 4)) stage(g, sc, wstage + ((ph + 1) & 1) * PW_STAGE);
-        }
-        bool drained = false;
-        if (cc == 0 && i > 0) {  // second half of the previous tile (written between its Y and R barriers)
-          const Geo gp = geo_of(i - 1);
-          drain_read(sd1);
-          drain_store(sd1, 1, gp);
-          drained = true;
-        }
-        if (cc + 1 == nchunks) {
-          PW_BARRIER_LDS();      // X: half 0 of this tile is staged
-          drain_read(sd0);
-          PW_BARRIER_LDS();      // Y: ... and has been read
-          drain_store(sd0, 0, gt);
-          drained = true;
-        }
-        PW_BARRIER_DMA_N(drained);
+    for (int ph = 0; ph < P; ++ph) {
+      if (ph + 1 < P) {
+        if (++sc == nchunks) { sc = 0; ++si; g = geo_of(si); }
+        if (!(a.dbg & 4)) stage(g, sc, wstage + ((ph + 1) & 1) * PW_STAGE);
       }
+      PW_BARRIER_DMA();  // (this wave's only vector-memory operations are the stage's loads)
     }
-    drain_read(sd1);
-    drain_store(sd1, 1, geo_of(cnt - 1));
     return;
   }
 
@@ -868,8 +793,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     // phase q = (tile q / nchunks, chunk q % nchunks).  Register set q & 1 holds the raw rows of phase q: requested during phase q - 2,
     // stored (to patch buffer q & 1) during phase q - 1 -- a full phase in flight.
     int li = 0, lc = 0;      // (tile, chunk) of the most recently REQUESTED phase
-    int ti = 0, tc = 0;
-    Geo g_cur = geo_of(0), g_prev = g_cur;
     using N0 = std::integral_constant<int, 0>;
     using NL = std::integral_constant<int, PW_LOADS>;
     set_tile(S0{}, 0);
@@ -892,14 +815,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
       // PW_LOADS younger operations in the queue (a second variant of the wait made the compiler copy the destinations ABOVE it).
       // The two instantiations (register sets swapped) walk their items in opposite order: isomorphic bodies get folded into one that
       // swaps the sets with register copies.
-      // (ti, tc) = (tile, chunk) being multiplied during this phase, g_cur / g_prev: geometry of that tile and of the one before
-      const bool first = tc == 0 && ti > 0, last = tc + 1 == nchunks;
       const unsigned long long ts0 = tracing ? __builtin_readcyclecounter() : 0;
-      if (first) {  // second half of the previous tile (written between its Y and R barriers)
-        drain_read(sd1);
-        drain_store(sd1, 1, g_prev);
-      }
-      const unsigned long long ts1 = tracing ? __builtin_readcyclecounter() : 0;
+      const unsigned long long ts1 = ts0;
       if (!(a.dbg & 2)) {
         if (q + 2 < P) {
           if (++lc == nchunks) { lc = 0; ++li; }
@@ -908,36 +825,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
         load_patch(cur, lc);
         const unsigned long long ts2 = tracing ? __builtin_readcyclecounter() : 0;
         if (tracing) { tsum[0] += ts1 - ts0; tsum[1] += ts2 - ts1; }
-        // At most PW_LOADS operations outstanding <=> the rows of set nxt have landed: loads retire in order among themselves, and if one
-        // of them were still out, so would be all PW_LOADS requests issued after it.  (Stores retire independently of loads on gfx9, so
-        // a larger count that "allows for" the drains' stores would not be a guarantee; this one makes the first phase of a tile wait
-        // for most of the sixteen stores issued since.)
+        // At most PW_LOADS operations outstanding <=> the rows of set nxt have landed: these waves issue loads only, loads retire in
+        // order, and PW_LOADS of them were requested after the ones waited for.
         const unsigned long long ts3 = tracing ? __builtin_readcyclecounter() : 0;
         wait_set(nxt, NL{});
         const unsigned long long ts4 = tracing ? __builtin_readcyclecounter() : 0;
         store_patch(nxt, smem_b + ((q + 1) & 1) * a.patch_bytes);
         if (tracing) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[2] += ts4 - ts3; tsum[3] += __builtin_readcyclecounter() - ts4; }
       }
-      if (last) {
-        PW_BARRIER_LDS();      // X: half 0 of this tile is staged
-        drain_read(sd0);
-        PW_BARRIER_LDS();      // Y: ... and has been read
-        drain_store(sd0, 0, g_cur);
-      }
       PW_BARRIER_LDS();
-      if (++tc == nchunks) {
-        tc = 0;
-        ++ti;
-        g_prev = g_cur;
-        if (ti < cnt) g_cur = geo_of(ti);
-      }
     };
     for (int q = 0; q < P; q += 2) {
       phase(S0{}, S1{}, q);
       if (q + 1 < P) phase(S1{}, S0{}, q + 1);
     }
-    drain_read(sd1);
-    drain_store(sd1, 1, g_prev);
     if (tracing) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int k = 0; k < 4; ++k) a.trace[128 * 16 + (wave - 4) * 4 + k] = tsum[k];
@@ -978,22 +879,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
   };
   set_masks(g);
 
-  // The column tile of a workgroup never changes (grid 256: J = 32 is a multiple of the number of column tiles; smaller grids run one
-  // tile per workgroup): its bias lives in registers for the whole launch and is what the accumulators are initialised with.
-  f32x16 bias_r[2];
+  // `acc` collects the tile being multiplied.  A finished tile (bias added) is written out one small step per k16 step of the NEXT tile,
+  // through this wave's private 32-pixel LDS staging area, so that a store instruction covers four whole 256-byte rows (an accumulator
+  // lane holds 4 x 4 channels of ONE pixel: stored directly that is 64 write requests of 16 bytes per instruction): its first half
+  // (pixels i = 0) goes to the staging area at the tile's end, its second half waits in `prev1` until the first has left.  Nothing is
+  // ever waited for (vmcnt counts stores; these waves never wait on vmcnt), and a CU's 64 KB of output leave spread over 24 of the
+  // next tile's 36+ steps instead of as one burst at every tile end.
+  f32x16 acc[2][2], prev1[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int gq2 = 0; gq2 < 4; ++gq2) {
-      const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + g.n0 + j * 32 + 8 * gq2 + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      bias_r[j][4 * gq2] = b4.x; bias_r[j][4 * gq2 + 1] = b4.y; bias_r[j][4 * gq2 + 2] = b4.z; bias_r[j][4 * gq2 + 3] = b4.w;
-    }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = bias_r[j];
+    for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; acc[1][j][r] = 0.f; prev1[j][r] = 0.f; }
 
   const int pitch = MODE ? 18 : a.pitch;
   int abase0[2][3];  // byte offsets into patch buffer 0; the kernel column and the hi | lo plane are immediate offsets
@@ -1044,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
     const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
     // weights are the MFMA "A" (rows = output channels), pixels the "B" (columns): a lane holds 4 x 4 consecutive output channels of
-    // one pixel -> 16-byte epilogue stores.  Pass-major order: consecutive MFMAs never share an accumulator.
+    // one pixel.  Pass-major order: consecutive MFMAs never share an accumulator.
     auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0); };
     acc[0][0] = mm(al0, bh0, acc[0][0]);
     acc[0][1] = mm(al0, bh1, acc[0][1]);
@@ -1060,39 +956,71 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     acc[1][1] = mm(ah1, bh1, acc[1][1]);
   };
 
+  // ---- writing a finished tile out, 17 units: 0-7 read row 4 k + er of the staged first half back (16 lanes per 256-byte row) and
+  // store it, 8 stages the second half (eight 16-byte pieces per lane), 9-16 read / store its rows.  ONE copy of the code, unit index
+  // at run time: specialised copies of the step loop made the accumulators change registers between copies (hundreds of spills).
   const int ep_off = ep_base + wm * EP_WAVE;
-  auto stage_half = [&](int i) {
-    // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave
-    // (the bias is already in the accumulators: they start from it)
+  const int er = lane >> 4, ec = lane & 15;
+  const unsigned half_step = (MODE ? 2u * (unsigned)W : 32u) * (unsigned)p.ldo * 4u;  // half 1 starts 2 image rows (flat: 32 rows) further
+  Geo gp = g;          // geometry of the tile being written out
+  int uidx = 17;       // next unit (17 = nothing pending)
+  char* obase = nullptr;
+  // A unit is split around the step's MFMAs: its staging read is requested BEFORE the step's operand reads (LDS answers in order, so
+  // it is back long before them), its store is issued AFTER the step's MFMAs have been issued -- placed between the operand reads and
+  // the MFMAs, the store's wait for its data held up the MFMAs by an LDS round trip at every unit (+500 cycles per step, measured).
+  f32x4 ustage = {0.f, 0.f, 0.f, 0.f};
+  auto unit_read = [&]() {
+    if (uidx >= 17 || uidx == 8) return;  // (wave-uniform)
+    const int k = uidx > 8 ? uidx - 9 : uidx;
+    ustage = *reinterpret_cast<const f32x4*>(smem_b + ep_off + (4 * k + er) * EP_PITCH + ec * 16);
+  };
+  auto unit_write = [&]() {
+    if (uidx >= 17) return;
+    if (uidx == 8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq2 = 0; gq2 < 4; ++gq2) {
+          const f32x4 v = {prev1[j][4 * gq2], prev1[j][4 * gq2 + 1], prev1[j][4 * gq2 + 2], prev1[j][4 * gq2 + 3]};
+          *reinterpret_cast<f32x4*>(smem_b + ep_off + lrow * EP_PITCH + (j * 32 + 8 * gq2 + 4 * lk) * 4) = v;
+        }
+    } else {
+      const int h = uidx > 8, k = h ? uidx - 9 : uidx;
+      const int r = 4 * k + er;  // MFMA column (pixel) r of the half
+      const int rel = MODE ? (wm * 4 + (r >> 4)) * W + (r < 16 ? r : ((r - 2) & 15)) : wm * 64 + r;
+      bool ok = true;
+      if (!MODE) ok = gp.g0 + wm * 64 + h * 32 + r < a.total_rows;
+      if (ok && !(a.dbg & 32)) *reinterpret_cast<f32x4*>(obase + ((unsigned)rel * (unsigned)p.ldo + ec * 4) * 4u + (h ? half_step : 0u)) = ustage;
+    }
+    ++uidx;
+  };
+
+  // Tile end: bias (from LDS) added, first half staged, second half parked in prev1, accumulators cleared; and the GroupNorm statistics
+  // of the tile (vddp.py:274-279) while it is in registers: per run of 8 consecutive output channels the sum and the sum of squares over
+  // this wave's 64 pixels -- reduce-scatter butterfly (8 + 4 + 2 + 1 shuffles, then two plain steps) -- written as this WAVE's own slot
+  // of the (sample, group)'s contribution list: no barrier, no atomics.  The previous tile's 24 units are all done by now (plan_pw: at
+  // least four chunks, i.e. 36 steps, per tile).
+  auto finish_tile = [&](const Geo& gg) {
+    float gv[16];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq2 = 0; gq2 < 4; ++gq2) {
-        const f32x4 v = {acc[i][j][4 * gq2], acc[i][j][4 * gq2 + 1], acc[i][j][4 * gq2 + 2], acc[i][j][4 * gq2 + 3]};
-        *reinterpret_cast<f32x4*>(smem_b + ep_off + lrow * EP_PITCH + (j * 32 + 8 * gq2 + 4 * lk) * 4) = v;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem_b + bias_off + (j * 32 + 8 * gq2 + 4 * lk) * 4);
+        const f32x4 v0 = {acc[0][j][4 * gq2] + b4.x, acc[0][j][4 * gq2 + 1] + b4.y, acc[0][j][4 * gq2 + 2] + b4.z, acc[0][j][4 * gq2 + 3] + b4.w};
+        const f32x4 v1 = {acc[1][j][4 * gq2] + b4.x, acc[1][j][4 * gq2 + 1] + b4.y, acc[1][j][4 * gq2 + 2] + b4.z, acc[1][j][4 * gq2 + 3] + b4.w};
+        *reinterpret_cast<f32x4*>(smem_b + ep_off + lrow * EP_PITCH + (j * 32 + 8 * gq2 + 4 * lk) * 4) = v0;
+        prev1[j][4 * gq2] = v1.x; prev1[j][4 * gq2 + 1] = v1.y; prev1[j][4 * gq2 + 2] = v1.z; prev1[j][4 * gq2 + 3] = v1.w;
+        gv[(j * 4 + gq2) * 2] = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+        gv[(j * 4 + gq2) * 2 + 1] = ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) + ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[i][j][4 * gq2] = 0.f; acc[i][j][4 * gq2 + 1] = 0.f; acc[i][j][4 * gq2 + 2] = 0.f; acc[i][j][4 * gq2 + 3] = 0.f; }
       }
-  };
-  auto gn_sums = [&](const Geo& gg) {
+    gp = gg;
+    uidx = 0;
+    const long long row0 = MODE ? (long long)gg.img * HW + (long long)gg.ty0 * W + gg.tx0 : (long long)gg.g0;
+    obase = reinterpret_cast<char*>(p.out + row0 * p.ldo + gg.n0);
     if (MODE && p.gn_part && !(a.dbg & 64)) {
-      // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels the
-      // sum and the sum of squares over this wave's 64 pixels -- reduce-scatter butterfly (8 + 4 + 2 + 1 shuffles, then two plain steps) --
-      // written as this WAVE's own slot of the (sample, group)'s contribution list: no LDS, no barrier, no atomics
-      float gv[16];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int gq2 = 0; gq2 < 4; ++gq2) {
-          float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float v0 = acc[i][j][4 * gq2], v1 = acc[i][j][4 * gq2 + 1], v2 = acc[i][j][4 * gq2 + 2], v3 = acc[i][j][4 * gq2 + 3];
-            s1 += (v0 + v1) + (v2 + v3);
-            s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-          }
-          gv[(j * 4 + gq2) * 2] = s1;
-          gv[(j * 4 + gq2) * 2 + 1] = s2;
-        }
-      }
 #pragma unroll
       for (int bit = 5, n = 8; bit >= 2; --bit, n >>= 1) {
         const bool hi = (lane >> bit) & 1;
@@ -1117,9 +1045,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     }
   };
 
-  // nine k16 steps (taps) per chunk; the operands of step t + 1 are requested before the MFMAs of step t
+  // nine k16 steps (taps) per chunk; the operands of step t + 1 are requested before the MFMAs of step t; one unit of the previous
+  // tile's write-out rides along with each of the first 17 steps of a tile
   uint4 aa[2][4], bb[2][4];
-  PW_BARRIER_LDS();  // phase 0 is staged
+  auto chunk_steps = [&]() {
+    load_ab(aa[0], bb[0], 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      unit_read();
+      if (t + 1 < 9) load_ab(aa[(t + 1) & 1], bb[(t + 1) & 1], t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(aa[t & 1], bb[t & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      unit_write();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  PW_BARRIER_LDS();  // phase 0 is staged (and the bias is parked)
   int ph = 0;
   for (int i = 0; i < cnt; ++i) {
     for (int cc = 0; cc < nchunks; ++cc, ++ph) {
@@ -1133,25 +1075,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
         }
       woff = woff0 + (ph & 1) * PW_STAGE;
       asm volatile("" : "+v"(woff));
-      load_ab(aa[0], bb[0], 0);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) load_ab(aa[(t + 1) & 1], bb[(t + 1) & 1], t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_step(aa[t & 1], bb[t & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (cc + 1 == nchunks) {
-        stage_half(0);
-        PW_BARRIER_LDS();  // X: the producer waves read half 0 ...
-        gn_sums(g);        // (... while the GroupNorm sums are formed)
-        PW_BARRIER_LDS();  // Y
-        stage_half(1);
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[ii][j] = bias_r[j];
-      }
+      chunk_steps();
+      if (cc + 1 == nchunks) finish_tile(g);
       PW_BARRIER_LDS();  // phase ph + 1 is staged in the other buffers; this phase's buffers may be overwritten
     }
     if (i + 1 < cnt) {
@@ -1159,6 +1084,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
       set_masks(g);
     }
   }
+  // the last tile's write-out
+  while (uidx < 17) { unit_read(); unit_write(); }
 #undef PW_BARRIER_LDS
 #undef PW_BARRIER_DMA
 }
@@ -1228,6 +1155,8 @@ bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
     mtiles = (int)cdiv(M, 256);
   }
   if (a.PR > PW_MAXP * 48 || d.Cout % 64) return false;
+  if ((d.C1 + d.C2) / CK2 < 2) return false;  // a tile's 17 write-out units ride on the next tile's steps: at least 18 of them
+  if (d.res) return false;                     // (gradient accumulation into an existing tensor stays on the one-tile-per-workgroup kernel)
   if (d.C2 > 0 && d.lda2 != d.lda1) return false;  // the patch waves keep ONE byte offset per row
   // flat tiles with the fused transform: a patch may touch two samples, not three
   if (a.mode == 0 && d.a_mode == 1 && (long long)d.Hin * d.Win * d.a_imgs_per_sample < a.PR) return false;
@@ -1238,8 +1167,8 @@ bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
   a.trace = nullptr;
   static const int stagger_env = [] { const char* e = getenv("VMM_PW_STAGGER"); return e ? atoi(e) : -1; }();
   const int nchunks = (d.C1 + d.C2) / CK2;
-  // a quarter of a tile's time (about 4.5k cycles per 16-channel chunk); only worth it when a workgroup runs several short tiles
-  a.stagger = stagger_env >= 0 ? stagger_env * nchunks : ((a.n_units >= 4 * 256 && nchunks <= 8) ? 1100 * nchunks : 0);
+  // VMM_PW_STAGGER = cycles per 16-channel chunk between the starts of consecutive workgroup quarters (measurement aid)
+  a.stagger = stagger_env > 0 ? stagger_env * nchunks : 0;  // (measured without effect on the 96 x 96 layers: off unless asked for)
   return true;
 }
 
