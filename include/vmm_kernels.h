@@ -177,7 +177,9 @@ int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, co
 /* Fused temporal-attention BLOCK for the full-resolution level (vddp.py:615,630,680: x + to_out(attn(rotary(to_qkv(LayerNorm(x)))))):
  * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections, scores and value mix all run on the
  * split-bf16 matrix cores (wqkv_packed = vmm_pack_weights fmt 2 of to_qkv (768,64), wout_packed = fmt 3 of to_out (64,256)).
- * Envelope: C == 64, heads == 8, dim_head == 32, T <= 16, ntok <= 16, HW even; returns 1 (nothing launched) otherwise. */
+ * Envelope: C == 64, heads == 8, dim_head == 32, ntok <= 16, and T <= 16 with HW even (two pixels per 32-row tile) or T <= 32 (one pixel
+ * per tile); returns 1 (nothing launched) otherwise.  vmm_temporal_block_supported: 0 = outside, 1 / 2 = which kernel would run. */
+int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads);
 int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
                               const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                               const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,

@@ -399,6 +399,61 @@ def test_temporal_core_with_to_out(gpu, Cc, T, HW, ntok, bias_on_cond):
     assert relerr(out.cpu() - x, branch) < 5e-5  # on the attention branch alone (the residual would mask errors)
 
 
+@pytest.mark.parametrize("version", [1, 2])
+@pytest.mark.parametrize("B,T,HW,ntok,bias_on_cond", [(2, 11, 36, 11, 1), (1, 16, 10, 0, 0), (3, 5, 130, 7, 0), (1, 11, 2304, 16, 0), (2, 1, 4, 3, 0),
+                                                      (2, 22, 37, 16, 0), (1, 32, 5, 0, 0), (1, 17, 64, 2, 0)])
+def test_fused_temporal_block(gpu, monkeypatch, version, B, T, HW, ntok, bias_on_cond):
+    """vmm_temporal_block_bf16x3 = x + to_out(attention over frames(rotary(to_qkv(LayerNorm(x))))) (vddp.py:615,630,680) in one kernel, against the
+    same block in fp32 torch: both kernels (lock-step heads / two tiles in flight with the head groups half a tile apart), two pixels or one pixel
+    per tile (T <= 16 / T <= 32), several tiles per workgroup, odd tile counts, padded frame slots, tokens with and without the bias."""
+    from videometamaterials_amd import hostmath
+    N, lib = _lib()
+    monkeypatch.setenv("VMM_TB_VERSION", str(version))
+    Cc, heads, hid = 64, 8, 256
+    kind = lib.vmm_temporal_block_supported(T, ntok, HW, Cc, heads)
+    if T > 16 and version == 1:
+        assert kind == 0
+        return
+    assert kind == version
+    g = torch.Generator().manual_seed(23 + T)
+    x = torch.randn(B, T, HW, Cc, generator=g)
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    wqkv = torch.randn(3 * hid, Cc, generator=g) / 8
+    wout = torch.randn(Cc, hid, generator=g) / 16
+    bias = torch.randn(heads, T, T, generator=g)
+    rot = hostmath.rotary_table(T, 32)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    y = (x - mean) / (var + 1e-5).sqrt() * gamma
+    qkv = (y @ wqkv.t()).reshape(B, T, HW, 3, heads, 32)
+    cos, sin = rot[:, :, 0].repeat_interleave(2, -1)[None, :, None, None], rot[:, :, 1].repeat_interleave(2, -1)[None, :, None, None]
+
+    def rotate(t):
+        pr = t.reshape(*t.shape[:-1], 16, 2)
+        return t * cos + torch.stack((-pr[..., 1], pr[..., 0]), -1).reshape(t.shape) * sin
+
+    q, k, v = rotate(qkv[:, :, :, 0] * 32 ** -0.5), rotate(qkv[:, :, :, 1]), qkv[:, :, :, 2]
+    q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))  # b hw h t d
+    bfull = bias[None, None]
+    ek = ev = None
+    if ntok:
+        ek, ev = torch.randn(B, ntok, heads, 32, generator=g), torch.randn(B, ntok, heads, 32, generator=g)
+        k = torch.cat([ek.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), k], dim=-2)
+        v = torch.cat([ev.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), v], dim=-2)
+        bfull = torch.cat([bias if bias_on_cond else torch.zeros(heads, T, ntok), bias], dim=-1)[None, None]
+    o = _attn_ref(q, k, v, bfull).permute(0, 3, 1, 2, 4).reshape(B * T * HW, hid)
+    branch = o @ wout.t()
+    wq, wo = _pack_frag(N, lib, gpu, wqkv, 2), _pack_frag(N, lib, gpu, wout, 3)
+    xg, gg, bg, rg = x.reshape(B * T * HW, Cc).to(gpu), gamma.to(gpu), bias.to(gpu), rot.to(gpu)
+    ekg = ek.reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.reshape(B, ntok, hid).to(gpu) if ntok else None
+    out = torch.full_like(xg, 7.0)
+    N.check(lib.vmm_temporal_block_bf16x3(xg.data_ptr(), Cc, gg.data_ptr(), wq.data_ptr(), wo.data_ptr(), ekg.data_ptr() if ntok else None,
+                                          evg.data_ptr() if ntok else None, ntok, bg.data_ptr(), bias_on_cond, rg.data_ptr(), out.data_ptr(), Cc,
+                                          B, T, HW, Cc, heads, C.c_float(32 ** -0.5), C.c_float(1e-5), _s()), "temporal block")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu() - x.reshape(B * T * HW, Cc), branch) < 5e-5  # on the attention branch alone (the residual would mask errors)
+
+
 @pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0)])
 def test_spatial_attention_core(gpu, HW, ntok, per_frame):
     N, lib = _lib()

@@ -22,6 +22,8 @@
 // 75 MFMA 32x32x16 per tile and head (3 split-bf16 passes each); padded frame slots and the off-diagonal score blocks are the price
 // for needing no data movement between the products.
 #include "igemm_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +35,7 @@ constexpr int TC = 64;    // channels
 constexpr int HEADS = 8;  // = waves per workgroup
 constexpr int DHd = 32;
 constexpr int HID = HEADS * DHd;
+constexpr int TB_TRACE_N = 40;  // intervals recorded by VMM_TB_TRACE
 
 struct TBArgs {
   const float* x; int ldx;
@@ -45,6 +48,8 @@ struct TBArgs {
   float* out; int ldo;
   int T, HW, nsplit, tps;  // tps: pixel pairs per split
   float q_scale, eps;
+  int group_mode;  // second version: which heads form the late group (0: heads 4-7, 1: odd heads)
+  unsigned long long* trace;  // VMM_TB_TRACE: s_memtime stamps of workgroup 0, [interval][wave][4]
 };
 
 __device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) {
@@ -338,16 +343,401 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second version: the same products, two tiles in flight, the two waves of a SIMD half a tile apart.
+//
+// The kernel above runs its eight head-waves in lock step (two workgroup barriers per tile): ~69 MFMAs (2.2k matrix-pipe cycles per
+// wave) and ~550 vector instructions (2.2k VALU cycles per wave) alternate, both waves of a SIMD are in the same phase at the same time,
+// and the matrix pipes idle whenever the rotary / split / softmax arithmetic runs: measured 0.33 matrix-pipe utilisation, padding included.
+// Here every tile's work is cut in two halves of similar length,
+//   F: LayerNorm rows -> q^T, k^T, v (36 MFMAs), rotary, q / k split into bf16 hi | lo, frame and token scores (12), logits
+//   S: softmax, value mix, to_out share, partial sums to LDS (21 MFMAs), and the workgroup-level roles below
+// and the heads of group B (the second wave of every SIMD) run one interval behind group A: while an A wave streams its projections a
+// B wave does its softmax and vice versa.  One workgroup barrier per interval; what crosses it through LDS is double-buffered where the
+// two groups' life times overlap:
+//   interval n = 2j     LayerNorm(tile j) -> ytile[j & 1]           (group B's threads, next to their S half)
+//              2j + 2   A: F(j)     2j + 3  A: S(j) -> redA[j & 1]   B: F(j)
+//              2j + 4   B: S(j) -> redB                              2j + 5  head sum(j) + residual -> out    (group A's threads, next to S)
+// Frame slots: SLOTS = 16 (two pixels per 32-row tile, T <= 16) or 32 (one pixel, T <= 32: the 22-frame configuration).
+template <int SLOTS, int PARK>
+__global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a) {
+  constexpr int NP = 32 / SLOTS;  // pixels per tile
+  constexpr int NK = SLOTS / 2;   // frame keys per lane
+  constexpr int YPITCH = 2 * TC + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int T = a.T, HW = a.HW;
+  const int ntok = a.ek ? a.ntok : 0;
+  const int Tp = (T + 3) & ~3;                                           // frame slots kept in the partial sums: whole groups of 4 accumulator rows
+  const int rows = NP * Tp;
+  float* red = reinterpret_cast<float*>(smem_raw);                       // [2 x 4 group-A heads | 4 group-B heads][rows][64]
+  uint4* ekf = reinterpret_cast<uint4*>(red + 12 * rows * TC);           // [8 heads][2 steps][hi|lo][16 token rows x 2 halves]   (ntok > 0)
+  uint4* evf = ekf + (ntok ? HEADS * 4 * 32 : 0);                        // [8 heads][hi|lo][64 lanes]
+  float* biasf = reinterpret_cast<float*>(evf + (ntok ? HEADS * 2 * 64 : 0));  // [8 heads][2 halves][T frames][NK]
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(biasf + HEADS * 2 * T * NK);  // [2][32 rows][hi 64 | lo 64 | pad 8]
+  float* rotf = reinterpret_cast<float*>(ytile + 2 * 32 * YPITCH);       // [2 halves][T frames][8 pairs][cos, sin]
+  float* gamf = rotf + 2 * T * 8 * 2;                                    // [64]
+  uint4* wvp = reinterpret_cast<uint4*>(gamf + TC);                      // [PARK][8 heads][64 lanes]: the weight fragments that do not fit in registers
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = a.group_mode ? (h & 1) : (h >> 2), hidx = a.group_mode ? (h >> 1) : (h & 3);
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int pa = SLOTS == 16 ? (lrow >> 4) : 0, ft = lrow & (SLOTS - 1);
+  const int ftc = min(ft, T - 1);
+  const int b = blockIdx.x / a.nsplit, split = blockIdx.x - b * a.nsplit;
+  const int units = HW / NP;
+  const int p_begin = split * a.tps, p_end = min(units, p_begin + a.tps);
+  const int nt = p_end - p_begin;
+
+  if (ntok) {
+    uint4* eks = ekf + h * 4 * 32;
+    uint4* evs = evf + h * 2 * 64;
+    if (lrow < 16) {  // token rows 16 .. 31 of the A operand only feed score rows 16 .. 31, which nobody reads: those lanes re-read rows 0 .. 15
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = lrow < ntok ? a.ek[((long long)b * ntok + lrow) * HID + h * DHd + slot(s, lk, j)] : 0.f;
+        uint4 hi, lo;
+        split8v(v, hi, lo);
+        eks[(s * 2 + 0) * 32 + lk * 16 + lrow] = hi;
+        eks[(s * 2 + 1) * 32 + lk * 16 + lrow] = lo;
+      }
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      v[j] = tk < ntok ? a.ev[((long long)b * ntok + tk) * HID + h * DHd + lrow] : 0.f;
+    }
+    uint4 hi, lo;
+    split8v(v, hi, lo);
+    evs[lane] = hi;
+    evs[64 + lane] = lo;
+  }
+  for (int i = tid; i < HEADS * 2 * T * NK; i += 512) {
+    const int jj = i % NK, r1 = i / NK, t = r1 % T, r2 = r1 / T, l2 = r2 & 1, hh = r2 >> 1;
+    const int tk = slot(jj >> 3, l2, jj & 7);
+    biasf[i] = tk < T ? a.bias[(hh * T + t) * T + tk] * LOG2E : -INFINITY;  // logits in base 2; a key frame that does not exist: -inf
+  }
+  for (int i = tid; i < 2 * T * 8; i += 512) {
+    const int pr = i & 7, r1 = i >> 3, t = r1 % T, l2 = r1 / T;
+    const int d = slot(pr >> 2, l2, (2 * pr) & 7);
+    const float2 cs = *reinterpret_cast<const float2*>(a.rot + (t * 16 + (d >> 1)) * 2);
+    rotf[i * 2] = cs.x;
+    rotf[i * 2 + 1] = cs.y;
+  }
+
+  // q / k / v weight fragments of this head: 24 - PARK stay in registers, PARK (1 or, LDS permitting, 3) are re-read from LDS every tile.
+  // With all 24 in registers the compiler spills to scratch, and a scratch reload is a vmcnt(0) wait in the middle of the projections
+  // -- behind the next tile's rows that were requested just before.
+  constexpr int NREG = 4 - PARK;
+  uint4 wqh[4], wql[4], wkh[4], wkl[4], wvh[4], wvl[NREG];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4* q = a.wqkv + (((long long)h * 4 + s) * 2) * 64 + lane;
+    const uint4* k = a.wqkv + (((long long)(HEADS + h) * 4 + s) * 2) * 64 + lane;
+    const uint4* v = a.wqkv + (((long long)(2 * HEADS + h) * 4 + s) * 2) * 64 + lane;
+    wqh[s] = q[0]; wql[s] = q[64];
+    wkh[s] = k[0]; wkl[s] = k[64];
+    wvh[s] = v[0];
+    if (s < NREG) wvl[s < NREG ? s : 0] = v[64];
+    else wvp[(s - NREG) * 512 + tid] = v[64];
+  }
+  const uint4* wo_l = a.wout + ((long long)2 * h * 2) * 64 + lane;
+  const uint4* eks_l = ekf + h * 4 * 32 + lk * 16 + (lrow & 15);
+  const float* rot_l = rotf + ((lk * T + ftc) * 8) * 2;
+  const float* bias_l = biasf + ((h * 2 + lk) * T + ftc) * NK;
+  float* red_mine = red + ((grp ? 8 : 0) + hidx) * rows * TC;   // group A: + (j & 1) * 4 * rows * TC
+
+  // Roles besides the head's matrix work.  They belong to the group that is in its (shorter) S half: group B's 256 threads normalise
+  // the next tile's rows in the even intervals, group A's 256 threads sum the heads' shares of a finished tile in the odd ones.
+  // Thread gt of its group: rows rm0 = gt >> 4 and rm0 + 16 of the tile, channels rcol .. rcol + 3.
+  const int gt = hidx * 64 + lane;
+  const int rm0 = gt >> 4, rcol = (gt & 15) * 4;
+  if (tid < TC) gamf[tid] = a.gamma[tid];
+  // (SLOTS == 16: the two rows are frame slot rm0 of the tile's two pixels; SLOTS == 32: frame slots rm0 and rm0 + 16 of its one pixel)
+  const int rft[2] = {rm0, SLOTS == 16 ? rm0 : rm0 + 16};
+  const int rpx[2] = {0, SLOTS == 16 ? 1 : 0};
+  auto x_row = [&](int j, int i) { return (((long long)b * T + rft[i]) * HW + (long long)(p_begin + j) * NP + rpx[i]); };
+  // Always two loads, no branch around them (frame slots / tiles that do not exist re-read one that does; the LayerNorm zeroes them):
+  // with a lane-dependent branch around a load the compiler stops counting and waits for vmcnt(0) at the first use of ANY loaded
+  // value, i.e. for a full HBM round trip of whatever was requested last.
+  const int rfc[2] = {min(rft[0], T - 1), min(rft[1], T - 1)};
+  auto load_x = [&](int j, f32x4 (&v)[2]) {
+    const int jc = min(max(j, 0), nt - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      v[i] = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * T + rfc[i]) * HW + (long long)(p_begin + jc) * NP + rpx[i]) * a.ldx + rcol);
+  };
+  // sum over the 16 lanes of a row, every lane gets it: four rotate-and-add steps inside the DPP row (no LDS permutes, no waits)
+  auto row_sum16 = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+  };
+
+  // the value lane ^ 32 holds (v_permlane32_swap: no LDS permute, no wait)
+  auto other_half = [](float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+  };
+
+  // state a head carries from its F half to its S half: the logits of its query against its frame keys and the tokens, v
+  f32x16 vt = zero16();
+  float f[NK], g[8];
+#pragma unroll
+  for (int jj = 0; jj < NK; ++jj) f[jj] = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) g[jj] = 0.f;
+  f32x4 xv[2];
+  load_x(grp ? 0 : -1, xv);
+  __syncthreads();
+
+  const bool tracing = a.trace && blockIdx.x == 0;
+  auto stamp = [&](int n, int k) {
+    if (tracing && n < TB_TRACE_N && lane == 0) a.trace[(n * 8 + h) * 4 + k] = __builtin_amdgcn_s_memtime();
+  };
+  for (int n = 0; n < 2 * nt + 4; ++n) {
+    stamp(n, 0);
+    if (!(n & 1)) {
+      const int j = n >> 1;
+      if (grp) {
+        if (j < nt) {  // LayerNorm of tile j: 16 lanes per row, rows to LDS as bf16 hi | lo (zero rows for the empty frame slots)
+          const f32x4 gam = *reinterpret_cast<const f32x4*>(gamf + rcol);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 x = rft[i] < T ? xv[i] : z4;
+            const float mean = row_sum16((x.x + x.y) + (x.z + x.w)) * (1.0f / TC);
+            const f32x4 c = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
+            const float rstd = __builtin_amdgcn_rsqf(row_sum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / TC) + a.eps);  // 1 ulp
+            unsigned l0, l1;
+            const unsigned h0 = pack_split(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
+            const unsigned h1 = pack_split(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
+            unsigned short* yt = ytile + (j & 1) * 32 * YPITCH + (rm0 + 16 * i) * YPITCH;
+            *reinterpret_cast<uint2*>(yt + rcol) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(yt + TC + rcol) = make_uint2(l0, l1);
+          }
+        }
+      }
+    } else if (!grp) {
+      const int j = (n - 5) >> 1;
+      if (n >= 5 && j < nt) {  // head sum of tile j, heads in order 0 .. 7 (group_mode 0), + residual
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (rft[i] < T) {
+            const int rs = rpx[i] * Tp + rft[i];
+            const float* ra = red + (((j & 1) * 4) * rows + rs) * TC + rcol;
+            const float* rb = red + (8 * rows + rs) * TC + rcol;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(ra + w * rows * TC);
+              acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(rb + w * rows * TC);
+              acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            acc.x += xv[i].x; acc.y += xv[i].y; acc.z += xv[i].z; acc.w += xv[i].w;
+            *reinterpret_cast<f32x4*>(a.out + x_row(j, i) * a.ldo + rcol) = acc;
+          }
+        }
+      }
+    }
+    stamp(n, 1);
+
+    // ---- the head's half tile
+    const int m = n - 2 - grp;
+    const int j = m >> 1;
+    if (m >= 0 && j < nt) {
+      if (!(m & 1)) {
+        // F: projections, rotary, frame scores (keys x queries)
+        const unsigned short* yt = ytile + (j & 1) * 32 * YPITCH + lrow * YPITCH + lk * 8;
+        f32x16 qt = zero16(), kt = zero16();
+        vt = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
+          qt = mfma3(wqh[s], wql[s], yh, yl, qt);  // [d][m]
+          kt = mfma3(wkh[s], wkl[s], yh, yl, kt);  // [d][m]
+          vt = mfma3(yh, yl, wvh[s], s < NREG ? wvl[s < NREG ? s : 0] : wvp[(s < NREG ? 0 : s - NREG) * 512 + tid], vt);  // [m][d]
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(rot_l + i4 * 4);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int i = 2 * i4 + k;
+            const float c = k ? cs.z : cs.x, sn = k ? cs.w : cs.y;
+            float e = qt[2 * i], o = qt[2 * i + 1];
+            qt[2 * i] = e * c - o * sn;
+            qt[2 * i + 1] = o * c + e * sn;
+            e = kt[2 * i]; o = kt[2 * i + 1];
+            kt[2 * i] = e * c - o * sn;
+            kt[2 * i + 1] = o * c + e * sn;
+          }
+        }
+        uint4 qh[2], ql[2];
+        split8(qt, 0, qh[0], ql[0]);
+        split8(qt, 8, qh[1], ql[1]);
+        f32x16 st = zero16(), sk = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          uint4 kh, kl;
+          split8(kt, s * 8, kh, kl);
+          st = mfma3(kh, kl, qh[s], ql[s], st);
+          if (ntok) sk = mfma3(eks_l[(s * 2) * 32], eks_l[(s * 2 + 1) * 32], qh[s], ql[s], sk);
+        }
+        // logits of this lane's query: 8 (16) frame keys and 8 tokens per lane half, relative-position bias from LDS
+        float bz[NK];
+#pragma unroll
+        for (int i = 0; i < NK / 4; ++i) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(bias_l + i * 4);
+          bz[4 * i] = v.x; bz[4 * i + 1] = v.y; bz[4 * i + 2] = v.z; bz[4 * i + 3] = v.w;
+        }
+        const unsigned pmask = pa ? 0xffffffffu : 0u;
+        const float qs2 = a.q_scale * LOG2E;
+#pragma unroll
+        for (int jj = 0; jj < NK; ++jj) {
+          // (bit blend, not a select between st[8 + jj] and st[jj]: see the first kernel)
+          const float sv = SLOTS == 16 ? __uint_as_float((__float_as_uint(st[(8 + jj) & 15]) & pmask) | (__float_as_uint(st[jj]) & ~pmask)) : st[jj];
+          f[jj] = sv * qs2 + bz[jj];  // (scores of the empty frame slots are finite -- their k rows are zero -- and their table entry is -inf)
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int tk = slot(0, lk, jj);
+          g[jj] = tk < ntok ? sk[jj] * qs2 + (a.bias_on_cond ? bz[jj] : 0.f) : -INFINITY;
+        }
+      } else {
+        // S: softmax, value mix, this head's share of to_out
+        // to_out fragments of this head (8 KB, L2-resident): requested a softmax / value phase before their use
+        uint4 woh[2][2], wol[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const uint4* q = wo_l + ((ct * 16 + s) * 2) * 64;
+            woh[ct][s] = q[0];
+            wol[ct][s] = q[64];
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < NK; ++jj) mx = fmaxf(mx, f[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) mx = fmaxf(mx, g[jj]);
+        mx = fmaxf(mx, other_half(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NK; ++jj) {
+          f[jj] = __builtin_amdgcn_exp2f(f[jj] - mx);
+          sum += f[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          g[jj] = __builtin_amdgcn_exp2f(g[jj] - mx);
+          sum += g[jj];
+        }
+        sum += other_half(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const float inv0 = (SLOTS == 16 && pa) ? 0.f : inv, inv1 = (SLOTS == 16 && !pa) ? 0.f : inv;
+        f32x16 ot = zero16();
+        {
+          uint4 vh, vl, ph, pl;
+          float p0[8], p1[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            p0[jj] = f[jj] * inv0;                    // SLOTS == 16: keys of pixel 0 <-> k16 step 0, zero for the queries of pixel 1
+            p1[jj] = f[(8 + jj) & (NK - 1)] * inv1;  //              keys of pixel 1 <-> k16 step 1, zero for the queries of pixel 0
+            g[jj] *= inv;
+          }
+          split8(vt, 0, vh, vl);
+          split8v(p0, ph, pl);
+          ot = mfma3(vh, vl, ph, pl, ot);
+          split8(vt, 8, vh, vl);
+          split8v(p1, ph, pl);
+          ot = mfma3(vh, vl, ph, pl, ot);
+          if (ntok) {
+            const uint4* evs = evf + h * 2 * 64 + lane;
+            split8v(g, ph, pl);
+            ot = mfma3(evs[0], evs[64], ph, pl, ot);
+          }
+        }
+        f32x16 pc[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          uint4 oh, ol;
+          split8(ot, s * 8, oh, ol);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+        }
+        // accumulator rows r of a lane half: frame slots 8 (r >> 2) + 4 lk + (r & 3) -- whole groups of four exist or do not (Tp)
+        float* rb0 = red_mine + (grp ? 0 : (j & 1) * 4 * rows * TC) + (4 * lk) * TC + lrow;
+        float* rb1 = rb0 + Tp * TC;  // second pixel of the tile (SLOTS == 16)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int fbase = SLOTS == 16 ? 8 * (g4 & 1) : 8 * g4;
+          float* q = (SLOTS == 16 && g4 >= 2) ? rb1 : rb0;
+          if (fbase + 4 * lk < Tp) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              q[(fbase + r4) * TC] = pc[0][g4 * 4 + r4];
+              q[(fbase + r4) * TC + 32] = pc[1][g4 * 4 + r4];
+            }
+          }
+        }
+      }
+    }
+    // The role's next input, requested at the END of the interval: the group's next interval is an F half (no global memory waits in
+    // it), so the rows have a whole interval to arrive and are not live across this interval's S half.
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == ((n & 1) ^ 1)) load_x(grp ? (n >> 1) + 1 : ((n - 5) >> 1) + 1, xv);  // B: LayerNorm(n / 2 + 1) at n + 2; A: head sum at n + 2
+    stamp(n, 2);
+    __syncthreads();
+    stamp(n, 3);
+  }
+}
+
+size_t tb2_lds_bytes(int slots, int T, int ntok, int park) {
+  const int np = 32 / slots, nk = slots / 2, rows = np * ((T + 3) & ~3);
+  return sizeof(float) * 12 * rows * TC + (ntok ? sizeof(uint4) * (HEADS * 4 * 32 + HEADS * 2 * 64) : 0) + sizeof(float) * HEADS * 2 * T * nk +
+         sizeof(unsigned short) * 2 * 32 * (2 * TC + 8) + sizeof(float) * (2 * T * 8 * 2 + TC) + sizeof(uint4) * 512 * park;
+}
+
+int tb_version() {  // read at every call (a host-side getenv per plan build / launch): the tests switch kernels inside one process
+  const char* e = getenv("VMM_TB_VERSION");
+  return e ? atoi(e) : 2;
+}
+
 }  // namespace
 
 // Weights: wqkv_frag = vmm_pack_weights fmt 2 of to_qkv (768, 64), wout_frag = fmt 3 of to_out (64, 256).
-// Returns 1 (nothing launched) when the shape is outside the kernel's envelope: C == 64, heads == 8, dim_head == 32, T <= 16,
-// ntok <= 16, HW even.
+// Returns 1 (nothing launched) when the shape is outside the envelope: C == 64, heads == 8, dim_head == 32, ntok <= 16, and T <= 16 with an
+// even HW (two pixels per tile) or T <= 32 (one pixel per tile, second kernel only, LDS permitting -- vmm_temporal_block_supported).
+// 0: outside the envelope of both kernels; 1: first kernel only (T <= 16); 2: two-tiles-in-flight kernel (LDS permitting, T <= 32)
+extern "C" int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads) {
+  if (C != TC || heads != HEADS || T < 1 || T > 32 || ntok < 0 || ntok > 16) return 0;
+  const int slots = T <= 16 ? 16 : 32;
+  if (slots == 16 && (HW & 1)) return 0;
+  if (tb_version() >= 2 && tb2_lds_bytes(slots, T, ntok, 1) <= 160 * 1024) return 2;
+  return T <= 16 ? 1 : 0;
+}
+
 extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
                                          const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                                          const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
                                          int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
-  if (C != TC || heads != HEADS || T > 16 || T < 1 || (HW & 1) || (ldx & 3) || (ldo & 3) || (ek && ntok > 16)) return 1;
+  if ((ldx & 3) || (ldo & 3)) return 1;
+  const int kind = vmm_temporal_block_supported(T, ek ? ntok : 0, HW, C, heads);
+  if (kind == 0) return 1;
   if (bias_on_cond && ek && ntok != T) return -2;
   if (B <= 0) return 0;
   TBArgs a;
@@ -357,18 +747,58 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
   a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0;
   a.bias = bias; a.bias_on_cond = bias_on_cond; a.rot = rot_tab;
   a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.q_scale = q_scale; a.eps = eps;
-  const int pairs = HW / 2;
-  int ns = max(1, min(pairs, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
-  a.tps = (pairs + ns - 1) / ns;
-  a.nsplit = (pairs + a.tps - 1) / a.tps;
-  const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
-                     sizeof(unsigned short) * 32 * (2 * TC + 8) + sizeof(float) * 2 * 16 * 8 * 2;
+  a.group_mode = getenv("VMM_TB_GROUP") ? atoi(getenv("VMM_TB_GROUP")) : 1;  // odd heads late: measured 2-4 % ahead of "heads 4-7 late"
+  a.trace = nullptr;
+  const bool want_trace = getenv("VMM_TB_TRACE") && kind == 2;
+  if (want_trace) {
+    hipMalloc(reinterpret_cast<void**>(&a.trace), sizeof(unsigned long long) * TB_TRACE_N * 8 * 4);
+    hipMemset(a.trace, 0, sizeof(unsigned long long) * TB_TRACE_N * 8 * 4);
+  }
+  const int slots = (kind == 2 && T > 16) ? 32 : 16;
+  const int units = HW / (32 / slots);
+  int ns = max(1, min(units, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
+  a.tps = (units + ns - 1) / ns;
+  a.nsplit = (units + a.tps - 1) / a.tps;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(temporal_block_kernel, dim3((unsigned)(B * a.nsplit)), dim3(512), shm, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(B * a.nsplit));
+  if (kind == 2) {
+    const int park = tb2_lds_bytes(slots, T, a.ntok, 3) <= 160 * 1024 ? 3 : 1;
+    const size_t shm = tb2_lds_bytes(slots, T, a.ntok, park);
+    if (slots == 16 && park == 3) hipLaunchKernelGGL((temporal_block2_kernel<16, 3>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (slots == 16) hipLaunchKernelGGL((temporal_block2_kernel<16, 1>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (park == 3) hipLaunchKernelGGL((temporal_block2_kernel<32, 3>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((temporal_block2_kernel<32, 1>), grid, dim3(512), shm, (hipStream_t)stream, a);
+  } else {
+    const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
+                       sizeof(unsigned short) * 32 * (2 * TC + 8) + sizeof(float) * 2 * 16 * 8 * 2;
+    hipLaunchKernelGGL(temporal_block_kernel, grid, dim3(512), shm, (hipStream_t)stream, a);
+  }
   VMM_LAUNCH_CHECK();
+  if (want_trace) {  // debugging aid: time line of workgroup 0 (ticks of s_memtime relative to the first stamp)
+    static unsigned long long hbuf[TB_TRACE_N * 8 * 4];
+    hipStreamSynchronize((hipStream_t)stream);
+    hipMemcpy(hbuf, a.trace, sizeof(hbuf), hipMemcpyDeviceToHost);
+    hipFree(a.trace);
+    unsigned long long t0 = ~0ull;
+    for (unsigned long long v : hbuf) if (v && v < t0) t0 = v;
+    fprintf(stderr, "temporal_block2 trace (T=%d HW=%d ntok=%d): per interval and wave: start | role | half | barrier wait (ticks)\n", T, HW, a.ntok);
+    for (int n = 0; n < TB_TRACE_N; ++n) {
+      if (!hbuf[(n * 8) * 4]) break;
+      fprintf(stderr, "n=%2d @%7llu:", n, hbuf[(n * 8) * 4] - t0);
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long* q = hbuf + (n * 8 + w) * 4;
+        fprintf(stderr, "  w%d %4llu/%5llu/%5llu", w, q[1] - q[0], q[2] - q[1], q[3] - q[2]);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
   return 0;
 }

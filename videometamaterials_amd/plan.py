@@ -748,8 +748,8 @@ class _Builder:
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
-        if (temporal and self.x3 and not self.training and x.C == 64 and heads == 8 and T <= 16 and HW % 2 == 0 and (not site or self.ntok <= 16)
-                and getattr(self.m, "use_fused_temporal", True)):
+        if (temporal and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
+                and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
             # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
             wq, _ = self.pack_linear(p + ".to_qkv.weight", frag=2)
             wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
