@@ -111,9 +111,24 @@ typedef struct vmm_pack_job {
                 *    lane l = column (l & 31), k = step*16 + (l >> 5)*8 .. +7 (N and K padded to 32 with zeros);
                 * 3: as 2 with k permuted inside every 32-block to the accumulator-register order (linattn_block.hip);
                 * 4: fp32 in the fragment order of 2 for vmm_conv3x3_f32 / vmm_proj_f32: [N/32][Kpad/16][e 0..3 | e 4..7][64 lanes][4].
-                *    1-4: direction 0 only. */
+                * 5 / 6: the (1,4,4) stride-2 resampling kernels for vmm_conv_s2_bf16x3 in the fragment order of 2, as 3 x 3 convolutions
+                *    (TH = TW = 4; strides of the torch tensor as usual; h0 / hs / w0 / ws / Cp unused):
+                *    5 = Conv3d (N, C, 1, 4, 4) over 2 x 2 input cells: K = 9 taps x 4 C cell channels, [N/32][9*4C/16][hi|lo][64][8];
+                *    6 = ConvTranspose3d (C, N, 1, 4, 4) with the four output phases as 4 N columns: [4N/32][9*C/16][hi|lo][64][8];
+                *    1-6: direction 0 only. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
+
+/* ---- K3b: the resampling layers (vddp.py:155 Upsample = ConvTranspose3d (1,4,4) stride (1,2,2) pad (0,1,1); vddp.py:158 Downsample = Conv3d
+ * of the same geometry) as tap-subset 3 x 3 convolutions with an LDS halo patch (conv3x3_bf16x3.hip): every input element is staged once
+ * per channel chunk instead of gathered once per tap.  x rows [nimg][Hin][Win] x Cin (ldx), out rows [nimg][Hout][Wout] x Cout (ldo),
+ * Hout = Hin / 2 (up == 0) or 2 Hin (up == 1); weights = vmm_pack_weights fmt 5 (up == 0) / fmt 6 (up == 1); bias [Cout] or NULL.
+ * Returns 1 (nothing launched) outside the envelope -- Cin a power of two >= 32, Cout == 64 or Cout % 128 == 0, even Hin / Win for
+ * up == 0, tile space (input pixels / 2 x 2 input cells) at most 31 wide or a multiple of 16 wide and of 8 (16 when Cout == 64 and
+ * up == 0) high -- the caller then uses vmm_conv_igemm_bf16x3 (four phase launches for the transposed convolution). */
+int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up); /* 1: inside the envelope */
+int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_packed, const float* bias, float* out, int32_t ldo, int32_t nimg,
+                       int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream);
 
 /* ---- K6: GroupNorm(groups, C) statistics + fused affine/FiLM/SiLU (vddp.py:274-285) ---- */
 /* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */

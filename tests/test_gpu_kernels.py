@@ -240,6 +240,52 @@ def test_conv_transpose_as_four_phases(gpu):
     assert relerr(out.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("up,nimg,H,W,Cin,Cout", [
+    (1, 3, 48, 48, 64, 64),     # 2-D tiles, four phases = 256 columns (ups.2.4)
+    (1, 5, 24, 24, 128, 128),   # flat row tiles across frames, partial last tile
+    (1, 2, 12, 12, 256, 256),   # 12 x 12 level
+    (1, 1, 8, 32, 32, 64),      # non-square 2-D tiles, one channel chunk
+    (0, 3, 96, 96, 64, 64),     # cells 48 x 48: 2-D tiles of 256 cells x 64 columns (downs.0.4)
+    (0, 5, 48, 48, 128, 128),   # cells 24 x 24: flat tiles
+    (0, 2, 24, 24, 256, 256),   # cells 12 x 12
+    (0, 1, 64, 32, 32, 128),    # cells 32 x 16: flat (16 wide), one chunk per sub-pixel
+])
+def test_stride2_resampling_as_tap_subset_convolutions(gpu, up, nimg, H, W, Cin, Cout):
+    """vmm_conv_s2_bf16x3: Downsample = Conv3d (1,4,4)/2 pad 1 (vddp.py:158) and Upsample = ConvTranspose3d (1,4,4)/2 pad 1 (vddp.py:155) as 3 x 3
+    neighbourhood convolutions whose units use a 2 x 2 corner of the taps (pack formats 5 / 6), against torch's convolutions."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(31 + H + Cin + up)
+    x = torch.randn(nimg, Cin, H, W, generator=g)
+    b = torch.randn(Cout, generator=g)
+    if up:
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) / math.sqrt(Cin * 4)
+        ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+        sn, sc = 16, Cout * 16
+    else:
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) / math.sqrt(Cin * 16)
+        ref = F.conv2d(x, w, b, stride=2, padding=1)
+        sn, sc = Cin * 16, 16
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    wg = w.contiguous().to(gpu)
+    n_el = 9 * (Cin if up else 4 * Cin) * (4 * Cout if up else Cout)
+    packed = torch.zeros(n_el, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 4, 4, Cin, Cin, Cout
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = sn, sc, 4, 1, 0, 1, 0, 1, 0, 6 if up else 5
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, n_el, 0, _s()), "pack")
+    xg = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(gpu)
+    out = torch.full((nimg * Ho * Wo, Cout), 7.0, device=gpu)
+    bg = b.to(gpu)
+    rc = lib.vmm_conv_s2_bf16x3(xg.data_ptr(), Cin, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout, nimg, H, W, Cin, Cout, up, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 2e-5
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -44,6 +44,7 @@ struct C3Args {
   int KS;                        // k16 steps per 32-column tile in the packed weights
   int chunks_per_split;
   int total_rows;                // nimg * H * W
+  int cps_shift;                 // TS == 2: log2(channel chunks per sub-pixel)
 };
 
 __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -53,9 +54,19 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
+// TS ("tap subsets"): the stride-2 resampling layers as 3 x 3 neighbourhood convolutions of which every unit uses a 2 x 2 corner:
+//   TS == 1  ConvTranspose (1,4,4) stride 2 pad 1 (Upsample, vddp.py:155): output pixel (2y + py, 2x + px) is a 2 x 2 convolution over the
+//            input neighbourhood rows {y - 1 + py, y + py}, i.e. the four output phases are 4 x Cout output columns of ONE 3 x 3
+//            convolution over the input tile, each phase with its own corner of the nine taps (weights: vmm_pack_weights fmt 6);
+//   TS == 2  Conv (1,4,4) stride 2 pad 1 (Downsample, vddp.py:158) over 2 x 2 input cells: a 3 x 3 convolution over the cell grid with
+//            4 x Cin cell channels; the channels of sub-pixel (sy, sx) meet the taps of the corner (1 - sy, 1 - sx) only (fmt 5).  The
+//            tile space (p.Hin x p.Win, patch rows) is the CELL grid, the source image is twice as large.
+// Eight k16 steps per chunk instead of eighteen; every input element is still staged once (the generic kernel gathers it four times).
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS>
+__device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   constexpr int BM = WM * 64;
+  constexpr int NQ = TS ? 8 : 18;  // k16 steps per chunk
+  static_assert(!TS || (!SPLIT && !F32), "tap-subset layers: unsplit split-bf16 only");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ph = smem;
   const vmm_conv_desc& p = a.p;
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   const int mtile = blockIdx.x / a.n_tiles;
   const int n0 = (blockIdx.x % a.n_tiles) * (WN * 64);
   const int Cin = p.C1 + p.C2;
-  const int nchunks = Cin / CK;
+  const int nchunks = (TS == 2 ? 4 : 1) * Cin / CK;
   const int c_begin = blockIdx.y * a.chunks_per_split;
   const int c_end = min(nchunks, c_begin + a.chunks_per_split);
   if (c_begin >= c_end) return;
@@ -111,14 +122,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
 
   // patch staging: item (row r, 4 channels k4); source row of every item is chunk-invariant
   const int k4 = tid & 7;
-  auto src_row = [&](int ps) -> int {  // recomputed per chunk rather than kept in MAXP registers
+  // TS == 2, flat tiles: source pixel of the (0, 0) sub-pixel of every patch cell, kept (decoding a cell index costs two divisions)
+  int cpix[(TS == 2 && !MODE) ? MAXP : 1];
+  if (TS == 2 && !MODE) {
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps) {
+      const int g = g0 - a.halo + (tid >> 3) + ps * 32;
+      int s = -1;
+      if ((tid >> 3) + ps * 32 < a.PR && g >= 0 && g < a.total_rows) {
+        const int im = g / HW, rem = g - im * HW, h = rem / W, w = rem - h * W;
+        s = im * 4 * HW + 4 * h * W + 2 * w;
+      }
+      cpix[(TS == 2 && !MODE) ? ps : 0] = s;
+    }
+  }
+  auto src_row = [&](int ps, int sub) -> int {  // recomputed per chunk rather than kept in MAXP registers; sub = 2 sy + sx (TS == 2)
     const int r = (tid >> 3) + ps * 32;
     int s = -1;
+    if (TS == 2 && !MODE) {
+      s = cpix[(TS == 2 && !MODE) ? ps : 0];
+      if (s >= 0) s += (sub >> 1) * 2 * W + (sub & 1);
+      return s;
+    }
     if (r < a.PR) {
       if (MODE) {
         const int py = r / 18, px = r - py * 18;
         const int h = ty0 - 1 + py, w = tx0 - 1 + px;
-        if (h >= 0 && h < H && w >= 0 && w < W) s = img * HW + h * W + w;
+        if (h >= 0 && h < H && w >= 0 && w < W) s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : img * HW + h * W + w;
       } else {
         const int g = g0 - a.halo + r;
         if (g >= 0 && g < a.total_rows) s = g;
@@ -126,13 +156,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
     }
     return s;
   };
+  // channel chunk -> (sub-pixel, first channel): TS == 2 walks the four sub-pixels of the cell, Cin channels each
+  auto sub_of = [&](int cc) { return TS == 2 ? cc >> a.cps_shift : 0; };
+  auto chan_of = [&](int cc) { return (TS == 2 ? cc & ((1 << a.cps_shift) - 1) : cc) * CK; };
   f32x4 preg[MAXP];
   // GroupNorm * FiLM coefficients of this thread's four channels for the chunk in flight (2-D tiles: one sample per tile).  Requested with
   // the chunk's patch loads, not when the patch is stored: a dependent L2 round trip would otherwise sit on the critical path.
   f32x4 cfa = {1.f, 0.f, 1.f, 0.f}, cfb = cfa;
   auto load_coef = [&](int cc) {
     const int c0 = cc * CK;
-    if (MODE && p.a_mode == 1 && c0 < p.C1) {
+    if (!TS && MODE && p.a_mode == 1 && c0 < p.C1) {
       const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + c0 + k4 * 4) * 2;
       cfa = *reinterpret_cast<const f32x4*>(cf);
       cfb = *reinterpret_cast<const f32x4*>(cf + 4);
@@ -140,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   };
   auto load_patch = [&](int cc) {  // raw loads only, so that they stay in flight under the MFMAs; the operand transform runs at store time
     load_coef(cc);
-    const int c0 = cc * CK;
+    const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
     const int ld = src1 ? p.lda1 : p.lda2;
@@ -148,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int sr = src_row(ps);
+      const int sr = src_row(ps, sub_of(cc));
       if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
       preg[ps] = v;
     }
@@ -157,19 +190,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   // until it lands: the prefetch is issued one item per k16 step, AFTER that step's weight loads, which leaves it PFB + 1 steps to
   // arrive before anything waits on it (all MAXP items at the chunk top parked the waves for ~40 % of their cycles).
   auto load_patch_item = [&](int cc, int ps) {
-    const int c0 = cc * CK;
+    const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
     const int ld = src1 ? p.lda1 : p.lda2;
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int sr = src_row(ps);
+    const int sr = src_row(ps, sub_of(cc));
     if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
     preg[ps] = v;
   };
   auto store_patch = [&](int cc) {
-    const int c0 = cc * CK;
-    const bool xform = c0 < p.C1 && p.a_mode == 1;
+    const int c0 = chan_of(cc);
+    const bool xform = !TS && c0 < p.C1 && p.a_mode == 1;
     const int rows_per_sample = HW * p.a_imgs_per_sample;
     // GroupNorm * FiLM coefficients of this thread's four channels: one sample per 2-D tile -> fetched once per chunk, not per item
     f32x4 ca = cfa, cb4 = cfb;
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       const int r = (tid >> 3) + ps * 32;
       if (r < a.PR) {
         f32x4 v = preg[ps];
-        const int sr = xform ? src_row(ps) : -1;
+        const int sr = xform ? src_row(ps, 0) : -1;
         if (sr >= 0) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
           if (!MODE) {  // flat row tiles run across samples
             const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
@@ -208,7 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   const uint4* bbase[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) bbase[j] = wf + (long long)((n0 + wn * 64) / 32 + j) * a.KS * 128 + lane;
-  const int cin16 = Cin / 16;
+  const int cin16 = (TS == 2 ? 4 : 1) * Cin / 16;
+  // TS: the unit's corner of the 3 x 3 taps -- rows tr0, tr0 + 1 and columns tc0, tc0 + 1.  TS == 1: the output phase of this wave's 64
+  // columns (phase-major columns); TS == 2: the sub-pixel of the channel chunk.
+  const int phase = TS == 1 ? (n0 + wn * 64) / p.Cout : 0;
+  auto corner = [&](int cc, int& tr0, int& tc0) {
+    if (TS == 1) { tr0 = phase >> 1; tc0 = phase & 1; }
+    else { const int sub = sub_of(cc); tr0 = 1 - (sub >> 1); tc0 = 1 - (sub & 1); }
+  };
   auto load_b = [&](uint4 (&d)[4], int ks) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -240,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // bf16x3: 8 hi then 8 lo values of channels s*16 + lk*8 .. +7;  fp32: those eight channels as two float4
-      const unsigned short* q = Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
+      // (TS: the tap is a run-time, wave-uniform value: the kernel-row base is selected, the rest is a scalar offset)
+      const unsigned short* q = TS ? Ph + (kh == 0 ? abase[i][0] : kh == 1 ? abase[i][1] : abase[i][2]) + (kw * CROW + s * 16)
+                                   : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       uint4 vh = *reinterpret_cast<const uint4*>(q);
       uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
       if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
@@ -301,14 +343,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
   // of step q + 1 are requested before the MFMAs of step q (PFB = 2 covers an L2 hit even when the sibling wave does not leave the
   // line in L1).  sched_barrier pins that order (the scheduler otherwise sinks the loads next to their uses to save registers).
   constexpr int NB = PFB + 1;
+  static_assert(NQ % NB == 0, "the weight-fragment ring must close at a chunk boundary");
   uint4 bb[NB][4], aa[2][4];
-  auto ks_of = [&](int cc, int q) { return (q >> 1) * cin16 + cc * 2 + (q & 1); };
+  // step q of a chunk: tap (q >> 1) and channel half (q & 1); TS: the (q >> 1)-th tap of the unit's corner
+  auto tap_of = [&](int cc, int q) {
+    if (!TS) return q >> 1;
+    int tr0, tc0;
+    corner(cc, tr0, tc0);
+    return (tr0 + (q >> 2)) * 3 + tc0 + ((q >> 1) & 1);
+  };
+  auto ks_of = [&](int cc, int q) { return tap_of(cc, q) * cin16 + cc * 2 + (q & 1); };
   load_patch(c_begin);
 #pragma unroll
   for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
   store_patch(c_begin);
   __syncthreads();
-  load_a(aa[0], 0, 0);
+  load_a(aa[0], tap_of(c_begin, 0), 0);
   for (int cc = c_begin; cc < c_end; ++cc) {
     const bool more = cc + 1 < c_end;
     // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
@@ -318,12 +368,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
 #pragma unroll
-    for (int q = 0; q < 18; ++q) {
-      if (q + PFB < 18) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
-      else if (more) load_b(bb[(q + PFB) % NB], ks_of(cc + 1, q + PFB - 18));
+    for (int q = 0; q < NQ; ++q) {
+      if (q + PFB < NQ) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
+      else if (more) load_b(bb[(q + PFB) % NB], ks_of(cc + 1, q + PFB - NQ));
       if (q == 0 && more) load_coef(cc + 1);
-      if (q < MAXP && more) load_patch_item(cc + 1, q);
-      if (q + 1 < 18) load_a(aa[(q + 1) & 1], (q + 1) >> 1, (q + 1) & 1);
+      if (TS) {  // eight steps for up to eleven patch items: two per step
+        if (2 * q < MAXP && more) load_patch_item(cc + 1, 2 * q);
+        if (2 * q + 1 < MAXP && more) load_patch_item(cc + 1, 2 * q + 1);
+      } else if (q < MAXP && more) {
+        load_patch_item(cc + 1, q);
+      }
+      if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[q & 1], bb[q % NB]);
       __builtin_amdgcn_sched_barrier(0);
@@ -332,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       __syncthreads();  // every wave is done reading the patch of chunk cc
       store_patch(cc + 1);
       __syncthreads();
-      load_a(aa[0], 0, 0);
+      load_a(aa[0], tap_of(cc + 1, 0), 0);
     }
   }
 
@@ -390,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          bv[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bv[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + j * 32 + 8 * g + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -406,11 +461,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       long long orow;
       if (MODE) {
         orow = (long long)img * HW + (ty0 + (m >> 4)) * W + tx0 + (m & 15);
+        // TS == 1: input pixel (y, x), phase (py, px) -> output pixel (2y + py, 2x + px) of the 2H x 2W frame
+        if (TS == 1) orow = (long long)img * 4 * HW + (2 * (ty0 + (m >> 4)) + (phase >> 1)) * 2 * W + 2 * (tx0 + (m & 15)) + (phase & 1);
       } else {
         if (g0 + m >= a.total_rows) continue;
         orow = g0 + m;
+        if (TS == 1) {
+          const int g = g0 + m, im = g / HW, rem = g - im * HW, y = rem / W, x = rem - y * W;
+          orow = (long long)im * 4 * HW + (2 * y + (phase >> 1)) * 2 * W + 2 * x + (phase & 1);
+        }
       }
-      const int c0 = n0 + wn * 64 + 4 * lk;
+      const int c0 = n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + 4 * lk;
       f32x4 rv[2][4];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -518,6 +579,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
       }
     }
   }
+}
+
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
+  conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0>(a);
+}
+
+// the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
+template <int WM, int WN, int MAXP, int MODE, int TS>
+__global__ __launch_bounds__(256, 2) void conv_s2_kernel(const C3Args a) {
+  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, false, false, TS>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1185,6 +1257,19 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
+template <int WM, int WN, int MAXP, int MODE, int TS>
+int launch_s2(const C3Args& a, int mtiles, hipStream_t s) {
+  const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS>), dim3((unsigned)(mtiles * a.n_tiles)), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 // shape planning shared by the launcher and the query below; returns 0 and fills a / mtiles / ksplit / gn, or the launcher's status
 int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& gn) {
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 &&
@@ -1314,6 +1399,72 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   const bool wide = d.Cout >= 128;
   hipStream_t s = (hipStream_t)stream;
   return dispatch_c3<false>(a, mtiles, ksplit, wide, s);
+}
+
+// The resampling layers on the tap-subset variants of the kernel (TS, see there):
+//   up == 0: Conv3d (1,4,4) stride (1,2,2) pad (0,1,1) (Downsample, vddp.py:158): x [nimg][Hin][Win][Cin] -> out [nimg][Hin/2][Win/2][Cout],
+//            weights = vmm_pack_weights fmt 5 of the (Cout, Cin, 1, 4, 4) tensor;
+//   up == 1: ConvTranspose3d (1,4,4) stride (1,2,2) pad (0,1,1) (Upsample, vddp.py:155): -> out [nimg][2 Hin][2 Win][Cout], fmt 6 of (Cin, Cout, 1, 4, 4).
+// Returns 1 (nothing launched) outside the envelope: Cin a power of two >= 32, Cout == 64 or Cout % 128 == 0, even Hin / Win for up == 0, and the
+// tile space (input pixels for up == 1, 2 x 2 input cells for up == 0) 2-D-tileable (W >= 32, W % 16 == 0, H % 8 (16 for 64 output columns) == 0)
+// or at most 31 wide.
+static int s2_plan(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg, int32_t Hin,
+                   int32_t Win, int32_t Cin, int32_t Cout, int32_t up, C3Args& a, int& mtiles, bool& wide) {
+  if (Cin < 32 || (Cin & (Cin - 1)) || !(Cout == 64 || Cout % 128 == 0) || (ldx & 3) || (ldo & 3) || Hin <= 0 || Win <= 0 || nimg <= 0) return 1;
+  if (!up && ((Hin | Win) & 1)) return 1;
+  const int Ht = up ? Hin : Hin / 2, Wt = up ? Win : Win / 2;
+  const long long M = (long long)nimg * Ht * Wt;
+  if (M * 4 >= (1LL << 31)) return 1;
+  const int ncols = up ? 4 * Cout : Cout;
+  wide = ncols >= 128;
+  const int BM = wide ? 128 : 256, TH = BM / 16;
+  a = C3Args{};
+  a.p.a1 = x; a.p.C1 = Cin; a.p.lda1 = ldx; a.p.w = w_frag; a.p.bias = bias; a.p.out = out; a.p.ldo = ldo;
+  a.p.nimg = nimg; a.p.Hin = Ht; a.p.Win = Wt; a.p.Cout = Cout; a.p.a_imgs_per_sample = 1;
+  a.n_tiles = ncols / (wide ? 128 : 64);
+  a.total_rows = (int)M;
+  a.KS = 9 * (up ? 1 : 4) * Cin / 16;
+  a.chunks_per_split = (up ? 1 : 4) * Cin / CK;
+  a.cps_shift = 0;
+  while ((CK << a.cps_shift) < Cin) ++a.cps_shift;
+  if (Wt >= 32 && Wt % 16 == 0 && Ht % TH == 0) {
+    a.mode = 1;
+    a.tiles_x = Wt / 16;
+    a.tiles_per_frame = a.tiles_x * (Ht / TH);
+    a.pitch = 18;
+    a.PR = (TH + 2) * 18;
+    mtiles = nimg * a.tiles_per_frame;
+  } else {
+    a.mode = 0;
+    a.tiles_x = a.tiles_per_frame = 1;
+    a.pitch = Wt;
+    a.halo = Wt + 1;
+    a.PR = BM + 2 * a.halo;
+    mtiles = (int)cdiv(M, BM);
+  }
+  if (a.PR > (wide ? 6 : 11) * 32) return 1;
+  return 0;
+}
+
+// 1 when vmm_conv_s2_bf16x3 takes the shape, 0 when it would return 1 (pure host logic)
+extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up) {
+  C3Args a;
+  int mtiles;
+  bool wide;
+  return s2_plan(nullptr, 0, nullptr, nullptr, nullptr, 0, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide) == 0 ? 1 : 0;
+}
+
+extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
+                                  int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
+  C3Args a;
+  int mtiles;
+  bool wide;
+  const int rc = s2_plan(x, ldx, w_frag, bias, out, ldo, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1>(a, mtiles, s);
+  if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2>(a, mtiles, s);
+  return a.mode ? launch_s2<4, 1, 11, 1, 2>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2>(a, mtiles, s);
 }
 
 // The same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32, 1e-6 parity): weights = vmm_pack_weights fmt 4

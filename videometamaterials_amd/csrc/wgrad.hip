@@ -277,6 +277,44 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
+  if (jb.fmt == 5 || jb.fmt == 6) {
+    // The (1,4,4) stride-2 resampling kernels as fmt-2 fragment planes of a 3 x 3 convolution (conv3x3_bf16x3.hip, TS variants); TH = TW = 4.
+    //   5 (Downsample, torch (N, C, 1, 4, 4)): K = 9 taps x 4 C cell channels, cell channel = (2 sy + sx) C + c of sub-pixel (sy, sx);
+    //     tap (th, tw) of sub-pixel (sy, sx) is kernel element (2 th + sy - 1, 2 tw + sx - 1), zero outside the kernel;
+    //   6 (Upsample, torch (C, N, 1, 4, 4)): 4 N columns, column = (2 py + px) N + n of output phase (py, px), K = 9 taps x C;
+    //     tap (th, tw) of phase (py, px) is kernel element ((py ? 4 : 3) - 2 th, (px ? 4 : 3) - 2 tw), zero outside the kernel.
+    if (direction != 0) return;
+    const int Cc = jb.fmt == 5 ? 4 * jb.C : jb.C, Nc = jb.fmt == 6 ? 4 * jb.N : jb.N;
+    const int KS = 9 * Cc / 16, NT = Nc / 32;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(jb.packed);
+    const long long tot = (long long)NT * KS * 512;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int e = (int)(i & 7), l = (int)(i >> 3) & 63;
+      const long long pl = i >> 9;
+      const int ks = (int)(pl % KS), nt = (int)(pl / KS);
+      const int ncol = nt * 32 + (l & 31);
+      const int k = ks * 16 + (l >> 5) * 8 + e;
+      const int tap = k / Cc, cc = k - tap * Cc, th = tap / 3, tw = tap - th * 3;
+      int n, c, kh, kw;
+      if (jb.fmt == 5) {
+        const int sub = cc / jb.C;
+        n = ncol; c = cc - sub * jb.C;
+        kh = 2 * th + (sub >> 1) - 1; kw = 2 * tw + (sub & 1) - 1;
+      } else {
+        const int ph = ncol / jb.N;
+        n = ncol - ph * jb.N; c = cc;
+        kh = ((ph >> 1) ? 4 : 3) - 2 * th; kw = ((ph & 1) ? 4 : 3) - 2 * tw;
+      }
+      float v = 0.f;
+      if (kh >= 0 && kh < 4 && kw >= 0 && kw < 4) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)kh * jb.sh + (long long)kw * jb.sw];
+      const __bf16 h = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)h);
+      const long long o = pl * 1024 + l * 8 + e;
+      dst[o] = __builtin_bit_cast(unsigned short, h);
+      dst[o + 512] = __builtin_bit_cast(unsigned short, lo);
+    }
+    return;
+  }
   if (jb.fmt == 2 || jb.fmt == 3 || jb.fmt == 4) {
     // split-bf16 operand in MFMA fragment order for conv3x3_bf16x3.hip / proj_bf16x3.hip: plane (column tile nt of 32, k16 step ks, hi|lo)
     // = 64 lanes x 8 bf16; lane l holds column nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +7.  K = (th, tw, c) padded to 32, N to 32.

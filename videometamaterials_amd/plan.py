@@ -320,7 +320,9 @@ class _Builder:
         self._touch(name)
         frag = desc.pop("frag", False)
         n_fp32, fp32_desc = n_elems, desc
-        if (want_grad if gemm is None else gemm) and self.f32frag and frag:  # fp32 fragment order (vmm_conv3x3_f32 / vmm_proj_f32)
+        if "fmt" in desc:  # an explicit operand format (5 / 6: the resampling layers' fragment planes); n_elems is the packed size
+            assert not want_grad
+        elif (want_grad if gemm is None else gemm) and self.f32frag and frag:  # fp32 fragment order (vmm_conv3x3_f32 / vmm_proj_f32)
             assert frag != 3
             kpad = (desc["TH"] * desc["TW"] * desc["Cp"] + 31) // 32 * 32
             n_elems = (desc["N"] + 31) // 32 * 32 * kpad
@@ -1106,10 +1108,18 @@ class _Builder:
                 pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
                 xs = x
                 nm = f"downs.{i}.4"
-                wd, gwd = self.pack_conv(nm + ".weight")
                 d = self.act(x.C, x.H // 2, x.W // 2)
-                dd = self.conv(a1=xs, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C, Hv=xs.H // 2,
-                               Wv=xs.W // 2, what=nm)
+                co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
+                if self.x3 and not tr and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
+                    # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
+                    wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
+                    self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0), nm,
+                              flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
+                    dd = gwd = None
+                else:
+                    wd, gwd = self.pack_conv(nm + ".weight")
+                    dd = self.conv(a1=xs, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C,
+                                   Hv=xs.H // 2, Wv=xs.W // 2, what=nm)
 
                 def down_bwd(nm=nm, xs=xs, d=d, dd=dd, gwd=gwd):
                     gd, _ = self.grad_of(d)
@@ -1144,7 +1154,13 @@ class _Builder:
                 u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
                 one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
-                for ph in range(2):
+                s2 = self.x3 and not tr and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
+                if s2:
+                    # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
+                    wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
+                    self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wu, self.wraw(nm + ".bias"), u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1), nm,
+                              flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
+                for ph in range(2 if not s2 else 0):
                     for pw in range(2):
                         # ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'
                         wp, gwp = self.pack(nm + ".weight", 4 * ci_ * co_, TH=2, TW=2, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, h0=1 - ph, hs=2,
@@ -1153,7 +1169,7 @@ class _Builder:
                                    Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw))
                         du = self.conv_desc(**kw_) if one_launch else self.conv(what=nm + f" phase {ph}{pw}", **kw_)
                         phases.append((du, gwp))
-                if one_launch:
+                if one_launch and not s2:
                     arr = (N.ConvDesc * 4)(*[du for du, _ in phases])
                     self.plan.keepalive.append(arr)
                     rows_in = B * T * xs.H * xs.W
