@@ -115,9 +115,17 @@ typedef struct vmm_pack_job {
                 *    (TH = TW = 4; strides of the torch tensor as usual; h0 / hs / w0 / ws / Cp unused):
                 *    5 = Conv3d (N, C, 1, 4, 4) over 2 x 2 input cells: K = 9 taps x 4 C cell channels, [N/32][9*4C/16][hi|lo][64][8];
                 *    6 = ConvTranspose3d (C, N, 1, 4, 4) with the four output phases as 4 N columns: [4N/32][9*C/16][hi|lo][64][8];
-                *    1-6: direction 0 only. */
+                * 7: the stem convolution (N, C <= 4, 1, k, k), k <= 8, for vmm_stem_conv_bf16x3: fragment order of 2 with
+                *    K = (kernel row, tap 0..7, channel 0..3), zero beyond tap k - 1 and channel C - 1: [N/32][2k][hi|lo][64][8] (TH = TW = k);
+                *    1-7: direction 0 only. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
+
+/* ---- K3a: the stem, Conv3d(C <= 4, 64, (1,k,k)) pad k/2 (vddp.py:600 init_conv, k = 7): x rows [nimg*H*W][4] (vmm_ncthw_to_rows with
+ * ldo = 4), weights = vmm_pack_weights fmt 7, out rows x 64 (ldo).  A 16 x 16 pixel tile's neighbourhood is staged once in LDS and a k16
+ * step = four neighbouring taps = two 32-byte LDS reads.  Returns 1 (nothing launched) unless Cout == 64 and k is odd and <= 8. */
+int vmm_stem_conv_bf16x3(const float* x, const float* w_packed, const float* bias, float* out, int32_t ldo, int32_t nimg, int32_t H, int32_t W,
+                         int32_t Cout, int32_t k, vmm_stream_t stream);
 
 /* ---- K3b: the resampling layers (vddp.py:155 Upsample = ConvTranspose3d (1,4,4) stride (1,2,2) pad (0,1,1); vddp.py:158 Downsample = Conv3d
  * of the same geometry) as tap-subset 3 x 3 convolutions with an LDS halo patch (conv3x3_bf16x3.hip): every input element is staged once

@@ -286,6 +286,35 @@ def test_stride2_resampling_as_tap_subset_convolutions(gpu, up, nimg, H, W, Cin,
     assert relerr(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("nimg,H,W,Cc,k", [(3, 96, 96, 3, 7), (2, 20, 37, 4, 5), (1, 8, 8, 1, 3), (5, 16, 48, 2, 7)])
+def test_stem_convolution(gpu, nimg, H, W, Cc, k):
+    """vmm_stem_conv_bf16x3 (init_conv, vddp.py:600: Conv3d(channels, 64, (1,k,k)) pad k/2) against torch; whole and partial 16 x 16 tiles,
+    fewer than four channels, kernel sizes below 7 (zero-weight taps)."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(40 + k + Cc)
+    x = torch.randn(nimg, Cc, H, W, generator=g)
+    w = torch.randn(64, Cc, k, k, generator=g) / math.sqrt(Cc * k * k)
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x, w, b, padding=k // 2).permute(0, 2, 3, 1).reshape(-1, 64)
+    xr = torch.zeros(nimg * H * W, 4)
+    xr[:, :Cc] = x.permute(0, 2, 3, 1).reshape(-1, Cc)
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros(2048 * k, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = k, k, Cc, Cc, 64
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cc * k * k, k * k, k, 1, 0, 1, 0, 1, 0, 7
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, 2048 * k, 0, _s()), "pack")
+    xg, bg = xr.to(gpu), b.to(gpu)
+    out = torch.full((nimg * H * W, 64), 7.0, device=gpu)
+    rc = lib.vmm_stem_conv_bf16x3(xg.data_ptr(), packed.data_ptr(), bg.data_ptr(), out.data_ptr(), 64, nimg, H, W, 64, k, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 2e-5
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

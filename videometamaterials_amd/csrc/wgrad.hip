@@ -277,6 +277,29 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
+  if (jb.fmt == 7) {
+    // stem convolution (stem_conv.hip): fmt-2 fragment planes with K = (kernel row, tap 0..7, channel 0..3); taps >= TW and channels >= C are zero
+    if (direction != 0) return;
+    const int KS = 2 * jb.TH, NT = jb.N / 32;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(jb.packed);
+    const long long tot = (long long)NT * KS * 512;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int e = (int)(i & 7), l = (int)(i >> 3) & 63;
+      const long long pl = i >> 9;
+      const int ks = (int)(pl % KS), nt = (int)(pl / KS);
+      const int n = nt * 32 + (l & 31);
+      const int k = ks * 16 + (l >> 5) * 8 + e;
+      const int th = k >> 5, tw = (k >> 2) & 7, c = k & 3;
+      float v = 0.f;
+      if (tw < jb.TW && c < jb.C) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)th * jb.sh + (long long)tw * jb.sw];
+      const __bf16 h = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)h);
+      const long long o = pl * 1024 + l * 8 + e;
+      dst[o] = __builtin_bit_cast(unsigned short, h);
+      dst[o + 512] = __builtin_bit_cast(unsigned short, lo);
+    }
+    return;
+  }
   if (jb.fmt == 5 || jb.fmt == 6) {
     // The (1,4,4) stride-2 resampling kernels as fmt-2 fragment planes of a 3 x 3 convolution (conv3x3_bf16x3.hip, TS variants); TH = TW = 4.
     //   5 (Downsample, torch (N, C, 1, 4, 4)): K = 9 taps x 4 C cell channels, cell channel = (2 sy + sx) C + c of sub-pixel (sy, sx);

@@ -1064,10 +1064,17 @@ class _Builder:
         k = m.init_kernel_size
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
-        wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
         x = self.act(m.init_dim, H, W)
-        dinit = self.conv(a1=xin, w=wi, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr, ldo=m.init_dim,
-                          Hv=H, Wv=W, what="init_conv")
+        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8:
+            # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
+            wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
+            self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
+                      flops=2.0 * rows0 * k * k * Cx * 64, nbytes=4.0 * rows0 * (4 + 64))
+            dinit = gwi = None
+        else:
+            wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
+            dinit = self.conv(a1=xin, w=wi, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr,
+                              ldo=m.init_dim, Hv=H, Wv=W, what="init_conv")
         self.free_act(xin)
         x0 = x
 
