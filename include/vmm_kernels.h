@@ -160,6 +160,12 @@ int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, c
 int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y, int32_t ldy,
                     int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream);
 
+/* the last ResnetBlock's output pass and final_conv.1 (vddp.py:311,729) in one kernel: out (B, Cout, T, HW) = bias + w (Cout, 64) .
+ * (silu(x*a + b') + res) per row; the block's output is never stored.  Returns 1 (nothing launched) unless C == 64 and Cout <= 4. */
+int vmm_affine_silu_pointwise_to_ncthw(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, int32_t C,
+                                       const float* w, const float* bias, int32_t B, int32_t Cout, int32_t T, int32_t HW, float* out,
+                                       vmm_stream_t stream);
+
 /* ---- K7: channel LayerNorm, gamma only, eps inside sqrt (vddp.py:245-254) ---- */
 int vmm_channel_layernorm(const float* x, int32_t ldx, const float* gamma, float* y, int32_t ldy, int64_t rows, int32_t C,
                           float eps, vmm_stream_t stream);

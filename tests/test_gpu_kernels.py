@@ -315,6 +315,31 @@ def test_stem_convolution(gpu, nimg, H, W, Cc, k):
     assert relerr(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,HW,Cout,with_res", [(2, 3, 100, 3, True), (1, 1, 37, 1, False), (3, 2, 2304, 4, True)])
+def test_output_pass_with_final_pointwise_conv(gpu, B, T, HW, Cout, with_res):
+    """vmm_affine_silu_pointwise_to_ncthw: silu(x * a + b') + res (the last ResnetBlock's output pass, vddp.py:311) and final_conv.1
+    (1x1 convolution to (B, Cout, T, HW), vddp.py:729) in one kernel; partial 64-row groups."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(50 + Cout)
+    rows = B * T * HW
+    x = torch.randn(rows, 64, generator=g)
+    coef = torch.randn(B, 64, 2, generator=g)
+    res = torch.randn(rows, 64, generator=g) if with_res else None
+    w = torch.randn(Cout, 64, generator=g) / 8
+    b = torch.randn(Cout, generator=g)
+    a_, b_ = coef[:, :, 0].repeat_interleave(T * HW, 0), coef[:, :, 1].repeat_interleave(T * HW, 0)
+    y = F.silu(x * a_ + b_) + (res if with_res else 0)
+    ref = (y @ w.t() + b).reshape(B, T, HW, Cout).permute(0, 3, 1, 2).contiguous()
+    out = torch.full((B, Cout, T, HW), 7.0, device=gpu)
+    xg, cg, wg, bg = x.to(gpu), coef.to(gpu), w.to(gpu), b.to(gpu)
+    rg = res.to(gpu) if with_res else None
+    rc = lib.vmm_affine_silu_pointwise_to_ncthw(xg.data_ptr(), 64, cg.data_ptr(), rg.data_ptr() if with_res else None, 64, 64, wg.data_ptr(), bg.data_ptr(),
+                                                B, Cout, T, HW, out.data_ptr(), _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 3e-6
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -112,6 +112,7 @@ SIGNATURES = {
     "vmm_groupnorm_stats_partials": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_affine_silu_pointwise_to_ncthw": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],
     "vmm_temporal_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_temporal_attention_staged": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],

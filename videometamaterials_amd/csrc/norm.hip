@@ -148,6 +148,65 @@ __global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- last block's output pass + final 1x1 convolution
+// out[b][co][t][hw] = bias[co] + sum_c w[co][c] * (silu(x[r][c] * a + b') + res[r][c]),  C == 64, Cout <= 4 (vddp.py:311 then final_conv.1,
+// vddp.py:729): the block's output never goes to memory.  16 lanes per row (one float4 each, 256-byte row reads), a wave walks 64
+// consecutive rows, the per-row dot products are reduced inside the DPP row and leave through LDS so that lane r writes row r (256-byte
+// runs of every output plane).
+__global__ __launch_bounds__(256) void affine_silu_pointwise_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coef,
+                                                                    const float* __restrict__ res, int ldres, int rows_per_sample,
+                                                                    const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                                    int T, int HW, float* __restrict__ out, long long nrows) {
+  __shared__ float sm[4][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
+  const int c = sub * 4;
+  f32x4 wv[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) wv[co] = co < Cout ? *reinterpret_cast<const f32x4*>(w + co * 64 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (r0 >= nrows) return;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const long long r = r0 + it * 4 + grp;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < nrows) {
+      const int b = (int)(r / rows_per_sample);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+      const float* cf = coef + ((long long)b * 64 + c) * 2;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf), c1 = *reinterpret_cast<const f32x4*>(cf + 4);
+      f32x4 o = {silu_f(v.x * c0.x + c0.y), silu_f(v.y * c0.z + c0.w), silu_f(v.z * c1.x + c1.y), silu_f(v.w * c1.z + c1.w)};
+      if (res) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(res + r * ldres + c);
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      }
+#pragma unroll
+      for (int co = 0; co < 4; ++co) d[co] = (o.x * wv[co].x + o.y * wv[co].y) + (o.z * wv[co].z + o.w * wv[co].w);
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      float v = d[co];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+      d[co] = v;
+    }
+    if (sub == 0) *reinterpret_cast<f32x4*>(&sm[wave][it * 4 + grp][0]) = f32x4{d[0], d[1], d[2], d[3]};
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS writes (the rows of a wave are private to it)
+  __builtin_amdgcn_wave_barrier();
+  const long long r = r0 + lane;
+  if (r < nrows) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&sm[wave][lane][0]);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const int hw = (int)(r % HW);
+    const int t = (int)((r / HW) % T);
+    const long long b = r / ((long long)HW * T);
+    for (int co = 0; co < Cout; ++co) out[((b * Cout + co) * T + t) * HW + hw] = vv[co] + (bias ? bias[co] : 0.f);
+  }
+}
+
 // ---------------------------------------------------------------- channel LayerNorm
 // GS lanes cooperate on one row (GS = power of two <= 64); each lane strides float4s over C.
 template <int GS>
@@ -256,6 +315,20 @@ extern "C" int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, c
   const int blocks = (int)min((long long)cdiv(total, 256), 8192LL);
   hipLaunchKernelGGL(affine_silu_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, coef, res, ldres, y, ldy, (long long)rows,
                      rows_per_sample, C);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// x = the block's pre-norm convolution output (rows x 64), coef = vmm_groupnorm_coef's [B][64][2], res = the block's residual rows or NULL,
+// w = (Cout, 64) torch weight of the 1x1 convolution, out = (B, Cout, T, HW).  Returns 1 (nothing launched) unless C == 64 and Cout <= 4.
+extern "C" int vmm_affine_silu_pointwise_to_ncthw(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, int32_t C,
+                                                  const float* w, const float* bias, int32_t B, int32_t Cout, int32_t T, int32_t HW, float* out,
+                                                  vmm_stream_t stream) {
+  if (C != 64 || Cout < 1 || Cout > 4 || (ldx & 3) || (res && (ldres & 3))) return 1;
+  const long long nrows = (long long)B * T * HW;
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(affine_silu_pointwise_kernel, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, coef, res, ldres,
+                     T * HW, w, bias, Cout, T, HW, out, nrows);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -562,8 +562,10 @@ class _Builder:
                    B, self.T * h.H * h.W, C_, G, self.ptr(sc), dh_ptr, C_, 0, gnw, gnb, dfilm_ptr or None), prefix + ".norm bwd", nbytes=20.0 * h.n)
         self.tmp_free((sc, n_sc))
 
-    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film: Optional[Tuple[int, int]]) -> Act:
-        """ResnetBlock (vddp.py:287-311): conv-GN-FiLM-SiLU, conv-GN-SiLU, + res_conv(x).  film = (ptr, grad ptr)."""
+    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film: Optional[Tuple[int, int]], tail: Optional[Callable] = None) -> Optional[Act]:
+        """ResnetBlock (vddp.py:287-311): conv-GN-FiLM-SiLU, conv-GN-SiLU, + res_conv(x).  film = (ptr, grad ptr).
+        tail (inference only): emits the consumer of the block's output fused with the output pass -- called with (h2, coef ptr, residual ptr,
+        residual ld) instead of vmm_affine_silu; the block then returns None (its output is never materialised)."""
         pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         Cout = self.shapes[name + ".block1.proj.weight"][0]
         H, W = x1.H, x1.W
@@ -598,6 +600,14 @@ class _Builder:
         else:
             assert x2 is None and x1.C == Cout
             r, res_ptr, ldres = None, x1.ptr, x1.ld
+        if tail is not None:
+            assert not self.training
+            tail(h2, c2_ptr, res_ptr, ldres)
+            if r is not None:
+                self.free_act(r)
+            self.free(c2_off, c2_n)
+            self.free_act(h2)
+            return None
         self.step(self.lib.vmm_affine_silu, (h2.ptr, Cout, c2_ptr, res_ptr, ldres, out.ptr, Cout, rows, self.T * H * W, Cout), name + " out", nbytes=12.0 * h2.n)
         if r is not None:
             self.free_act(r)
@@ -1195,6 +1205,19 @@ class _Builder:
                 self.on_backward(up_bwd, pg_start, uj_start)
                 self.free_act(xs)
                 x = u
+        fc0 = self.shapes["final_conv.0.block1.proj.weight"][0]
+        if not tr and fc0 == 64 and m.out_dim <= 4:
+            # the last block's output pass and the final 1x1 convolution in one kernel: the block's output is never stored
+            def fused_tail(h2, c2_ptr, res_ptr, ldres):
+                self.step(lib.vmm_affine_silu_pointwise_to_ncthw, (h2.ptr, h2.ld, c2_ptr, res_ptr, ldres, 64, self.wraw("final_conv.1.weight"),
+                                                                   self.wraw("final_conv.1.bias"), B, m.out_dim, T, H * W, self.ptr(out_off)),
+                          "final_conv.0 out + final_conv.1", nbytes=4.0 * (2 * h2.n + B * m.out_dim * T * H * W))
+            self.resnet_block("final_conv.0", x, r, None, tail=fused_tail)
+            self.free_act(x)
+            self.free_act(r)
+            self._touch("final_conv.1.weight")
+            self._touch("final_conv.1.bias")
+            return self.plan
         f = self.resnet_block("final_conv.0", x, r, None)
         self.free_act(x)
         self.free_act(r)
