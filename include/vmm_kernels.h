@@ -81,6 +81,9 @@ int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
  * separate vmm_channel_layernorm pass.  Envelope: KH = KW = 1, stride 1, identity row mapping, K = C1 + C2 padded to 32 in
  * {32, 64, 128, 256}; returns 1 (nothing launched) otherwise. */
 int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
+/* ResnetBlock tail (vddp.py:311) in one launch: out = silu(res * a + b') + proj(x); res = d->res = the pre-norm output of block2's
+ * convolution (may alias d->out), (a, b') = res_coef [B][Cout][2] from vmm_groupnorm_coef, proj = res_conv.  Envelope of vmm_proj_bf16x3. */
+int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* d, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream);
 /* exact-fp32 variant (d->w = fmt-4 output of vmm_pack_weights) */
 int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
 

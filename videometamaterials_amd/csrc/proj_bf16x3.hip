@@ -27,6 +27,8 @@ struct PJArgs {
   int M;               // rows
   int n_chunks;        // column chunks of WN*64
   int chunks_per_y;    // column chunks per blockIdx.y
+  const float* res_coef;  // non-NULL: the residual enters as silu(res * a + b'), (a, b') = res_coef[sample][column][2] (vmm_proj_bf16x3_res_silu)
+  int res_rps;            // rows per sample
 };
 
 __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) {
@@ -247,6 +249,17 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
           if (resrow) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const f32x4*>(resrow + c0 + 8 * g);
+            if (a.res_coef) {  // the ResnetBlock's main branch arrives pre-norm: GroupNorm * SiLU on the way in (vddp.py:311)
+              const float* cf = a.res_coef + ((long long)(m / a.res_rps) * p.Cout + c0) * 2;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(cf + 16 * g), k1 = *reinterpret_cast<const f32x4*>(cf + 16 * g + 4);
+                rv[g].x = igemm::silu_fast(rv[g].x * k0.x + k0.y);
+                rv[g].y = igemm::silu_fast(rv[g].y * k0.z + k0.w);
+                rv[g].z = igemm::silu_fast(rv[g].z * k1.x + k1.y);
+                rv[g].w = igemm::silu_fast(rv[g].w * k1.z + k1.w);
+              }
+            }
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -356,7 +369,7 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
 // channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
 // identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 32; returns 1 (nothing launched) otherwise.
 template <bool F32>
-static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
+static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream, const float* res_coef = nullptr, int res_rps = 1) {
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
                         d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
   const int K = d.C1 + d.C2;
@@ -373,6 +386,8 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   a.p.a_mode = ln_gamma ? 2 : 0;
   a.gamma = ln_gamma;
   a.eps = ln_eps;
+  a.res_coef = res_coef;
+  a.res_rps = res_rps;
   a.M = (int)M;
   const int KP = (K + 31) / 32 * 32;
   // workgroup shape: as many rows as fit 80 KB of LDS; column chunk = 256 / rows * 64
@@ -395,6 +410,14 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
 
 extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
   return run_proj<false>(*dp, ln_gamma, ln_eps, stream);
+}
+
+// ResnetBlock tail (vddp.py:311): out = silu(res * a + b') + proj(x) in one launch -- res = the pre-norm output of block2's convolution
+// (d->res, may be d->out: in place), (a, b') = vmm_groupnorm_coef's [B][Cout][2], proj = res_conv.  Replaces the res_conv launch, its
+// output buffer and the vmm_affine_silu pass.  Same envelope as vmm_proj_bf16x3; d->res must be set.
+extern "C" int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* dp, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream) {
+  if (!dp->res || !res_coef || rows_per_sample <= 0) return -1;
+  return run_proj<false>(*dp, nullptr, 0.f, stream, res_coef, rows_per_sample);
 }
 
 // The same kernel on the exact-fp32 matrix-core instruction (d->w = vmm_pack_weights fmt 4); the "fp32" arithmetic mode's projections.

@@ -102,6 +102,11 @@ class _Arena:
         self.free_list = merged
 
 
+def _enabled(feature: str) -> bool:
+    """Measurement aid: VMM_DISABLE=stem,s2,res_tail,final_tail in the environment builds plans without those fusions (A/B runs on one box)."""
+    return feature not in os.environ.get("VMM_DISABLE", "").split(",")
+
+
 def _pack_table(jobs: List[dict], base_of: Callable[[dict], int]):
     arr = (N.PackJob * len(jobs))()
     max_elems = 0
@@ -590,6 +595,19 @@ class _Builder:
         has_res = (name + ".res_conv.weight") in self.shapes
         out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
         dr, gwr = None, 0
+        if (has_res and tail is None and not self.training and self.x3 and _enabled("res_tail")
+                and self.proj_ok(x1.C + (x2.C if x2 is not None else 0), Cout)):
+            # out = silu(GN(h2)) + res_conv(x) in ONE launch: the projection kernel takes h2 as its residual and normalises it on the way in
+            # (in place: out = h2); no res_conv output buffer, no separate output pass
+            wr, _ = self.pack_linear(name + ".res_conv.weight", frag=2)
+            dr = self.conv_desc(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
+                                res_ptr=h2.ptr, ldres=Cout)
+            kin = x1.C + (x2.C if x2 is not None else 0)
+            self.step(self.lib.vmm_proj_bf16x3_res_silu, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
+                      flops=2.0 * rows * kin * Cout, nbytes=4.0 * rows * (kin + 2 * Cout))
+            self.free(c2_off, c2_n)
+            self.plan.named[name] = h2
+            return h2
         if has_res:
             pjr = self.proj_ok(x1.C + (x2.C if x2 is not None else 0), Cout)
             wr, gwr = self.pack_linear(name + ".res_conv.weight", frag=2 if pjr else False)
@@ -1075,7 +1093,7 @@ class _Builder:
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
         x = self.act(m.init_dim, H, W)
-        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8:
+        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and _enabled("stem"):
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
             self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
@@ -1127,7 +1145,7 @@ class _Builder:
                 nm = f"downs.{i}.4"
                 d = self.act(x.C, x.H // 2, x.W // 2)
                 co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
-                if self.x3 and not tr and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
+                if self.x3 and not tr and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
                     self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0), nm,
@@ -1171,7 +1189,7 @@ class _Builder:
                 u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
                 one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
-                s2 = self.x3 and not tr and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
+                s2 = self.x3 and not tr and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
                     wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
@@ -1206,7 +1224,7 @@ class _Builder:
                 self.free_act(xs)
                 x = u
         fc0 = self.shapes["final_conv.0.block1.proj.weight"][0]
-        if not tr and fc0 == 64 and m.out_dim <= 4:
+        if not tr and fc0 == 64 and m.out_dim <= 4 and _enabled("final_tail"):
             # the last block's output pass and the final 1x1 convolution in one kernel: the block's output is never stored
             def fused_tail(h2, c2_ptr, res_ptr, ldres):
                 self.step(lib.vmm_affine_silu_pointwise_to_ncthw, (h2.ptr, h2.ld, c2_ptr, res_ptr, ldres, 64, self.wraw("final_conv.1.weight"),
