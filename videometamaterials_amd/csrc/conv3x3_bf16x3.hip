@@ -531,11 +531,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 #pragma unroll
           for (int k = 0; k < n; ++k) {
             const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
-            gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+            gv[k] = keep + lane_xor(send, bit);
           }
         }
-        gv[0] += __shfl_xor(gv[0], 2, 64);
-        gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
+        gv[0] += lane_xor(gv[0], 1);
+        gv[0] += lane_xor(gv[0], 0);  // lane L now holds the wave total of value (L >> 2) & 15
         return gv[0];
       };
       const float totA = wave_sums(false);
@@ -1046,6 +1046,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     const int k = uidx > 8 ? uidx - 9 : uidx;
     ustage = *reinterpret_cast<const f32x4*>(smem_b + ep_off + (4 * k + er) * EP_PITCH + ec * 16);
   };
+  // one bookkeeping region per step, behind the step's MFMAs: finish unit uidx (store the row its read fetched / stage half 1), then
+  // request the next unit's row -- one scalar test and one branch per step when nothing is pending
   auto unit_write = [&]() {
     if (uidx >= 17) return;
     if (uidx == 8) {
@@ -1065,6 +1067,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
       if (ok && !(a.dbg & 32)) *reinterpret_cast<f32x4*>(obase + ((unsigned)rel * (unsigned)p.ldo + ec * 4) * 4u + (h ? half_step : 0u)) = ustage;
     }
     ++uidx;
+    unit_read();
   };
 
   // Tile end: bias (from LDS) added, first half staged, second half parked in prev1, accumulators cleared; and the GroupNorm statistics
@@ -1090,6 +1093,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
       }
     gp = gg;
     uidx = 0;
+    unit_read();  // (after the staging stores above: a wave's LDS operations execute in order)
     const long long row0 = MODE ? (long long)gg.img * HW + (long long)gg.ty0 * W + gg.tx0 : (long long)gg.g0;
     obase = reinterpret_cast<char*>(p.out + row0 * p.ldo + gg.n0);
     if (MODE && p.gn_part && !(a.dbg & 64)) {
@@ -1099,11 +1103,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
 #pragma unroll
         for (int k = 0; k < n; ++k) {
           const float send = hi ? gv[k] : gv[k + n], keep = hi ? gv[k + n] : gv[k];
-          gv[k] = keep + __shfl_xor(send, 1 << bit, 64);
+          gv[k] = keep + lane_xor(send, bit);
         }
       }
-      gv[0] += __shfl_xor(gv[0], 2, 64);
-      gv[0] += __shfl_xor(gv[0], 1, 64);  // lane L now holds the wave total of value (L >> 2) & 15
+      gv[0] += lane_xor(gv[0], 1);
+      gv[0] += lane_xor(gv[0], 0);  // lane L now holds the wave total of value (L >> 2) & 15
       if ((lane & 3) == 0) {
         const int slot = lane >> 2, run = slot >> 1;
         const int cout0 = gg.n0 + (run >> 2) * 32 + (run & 3) * 8;
@@ -1124,10 +1128,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     load_ab(aa[0], bb[0], 0);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      unit_read();
       if (t + 1 < 9) load_ab(aa[(t + 1) & 1], bb[(t + 1) & 1], t + 1);
-      __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[t & 1], bb[t & 1]);
+      // The matrix pipe takes a new MFMA every 32 cycles and nothing queues behind the one in flight: whatever else this wave issues between
+      // two MFMA groups is a bubble.  The next step's eight operand reads therefore go BETWEEN this step's MFMAs, one per MFMA (all of them
+      // in front of the group cost ~50 cycles per step).
+      if (t + 1 < 9) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       unit_write();
       __builtin_amdgcn_sched_barrier(0);
@@ -1157,7 +1170,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     }
   }
   // the last tile's write-out
-  while (uidx < 17) { unit_read(); unit_write(); }
+  while (uidx < 17) unit_write();
 #undef PW_BARRIER_LDS
 #undef PW_BARRIER_DMA
 }
