@@ -915,3 +915,17 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
     if ntok:
         assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 2e-5
         assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_persistent_conv3x3_variants(gpu, mode):
+    """The persistent wave-specialised 3 x 3 kernel is opt-in (VMM_C3_PERSISTENT, read once per process; default 0):
+    the 3 x 3 kernel tests and the denoiser goldens again in a process that uses it for the 64-column 2-D layers (1) / every shape (2)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VMM_C3_PERSISTENT=mode)
+    env.pop("VMM_C3_LEGACY", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k",
+                        "conv3x3_halo or fused_gn or forward_matches_reference_golden"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -173,7 +173,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension must be built (python -m videometamaterials_amd.build); "
                 "there is no CPU/PyTorch fallback for the hot path"
             )
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(os.environ.get("VMM_LIB_PATH", LIB_PATH))  # (VMM_LIB_PATH: A/B measurements of two builds on one box)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes

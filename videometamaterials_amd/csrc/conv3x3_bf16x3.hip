@@ -30,6 +30,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef VMM_C3_INTERLEAVE
+#define VMM_C3_INTERLEAVE 1
+#endif
+constexpr bool C3_INTERLEAVE = VMM_C3_INTERLEAVE;  // memory requests of step q + 1 between the MFMAs of step q (-DVMM_C3_INTERLEAVE=0: A/B builds)
 constexpr int CK = 32;    // channels per chunk
 constexpr int CROW = 72;  // LDS patch row pitch in bf16: 32 hi | 32 lo | 8 pad = 144 bytes (9 x 16 B: ds_read_b128 over consecutive rows is conflict-free)
 
@@ -379,8 +383,25 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         load_patch_item(cc + 1, q);
       }
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (F32 || !C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[q & 1], bb[q % NB]);
+      if constexpr (!F32 && C3_INTERLEAVE) {
+        // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
+        // longest way), not in front of them as one block during which the matrix pipe runs dry
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one vector-memory read
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the patch prefetch item(s) of this step, if any
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {
@@ -1341,13 +1362,18 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
 
 // unsplit layers run the persistent wave-specialised kernel (VMM_C3_LEGACY=1 in the environment keeps the one-tile-per-workgroup
 // kernel for A/B measurements; read once)
-// 0: never, 1: where it measured faster (2-D tiles of 64-column layers), 2: every shape inside its envelope
+// 0: never (default), 1: 2-D tiles of 64-column layers, 2: every shape inside its envelope.
+// Default 0 although the persistent kernel is the faster KERNEL on those layers (185 against 205 us, launches timed one by one): inside the
+// captured sampling step the chip's clock governor answers its denser matrix-pipe activity with a lower sustained clock for the whole step
+// (rocm-smi during bench.py on one box: 2.16-2.17 GHz at 1.11 kW with it, 2.27-2.30 GHz at 1.20-1.24 kW without; staggering the
+// workgroups' starts changes nothing), and the step as a whole came out 0.15-0.4 ms SLOWER on three of four boxes (0.3 ms faster on
+// the fourth).  DESIGN.md section 7.
 static int c3_persistent() {
   static const int mode = [] {
     const char* l = getenv("VMM_C3_LEGACY");
     if (l && l[0] == '1') return 0;
     const char* e = getenv("VMM_C3_PERSISTENT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
   }();
   return mode;
 }
