@@ -1,0 +1,26 @@
+"""Measurement aid: a second library with extra -D flags on selected sources, for A/B runs of two builds on ONE box (box-to-box
+variance of the captured step is ~3 %):   python tools/build_ab.py conv3x3_bf16x3 -DVMM_C3_XCD_ORDER=0
+writes videometamaterials_amd/libvmm_hip_ab.so (git-ignored; select it with VMM_LIB_PATH=$PWD/videometamaterials_amd/libvmm_hip_ab.so)."""
+import glob
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videometamaterials_amd import build as b  # noqa: E402
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if not a.startswith("-")]
+    flags = [a for a in sys.argv[1:] if a.startswith("-")]
+    b.build(verbose=False)
+    objs = []
+    for s in sorted(glob.glob(os.path.join(b.CSRC, "*.hip"))):
+        stem = os.path.basename(s)[:-4]
+        o = os.path.join(b.OBJDIR, stem + ".o")
+        if stem in names:
+            o = os.path.join("/tmp", stem + "_ab.o")
+            subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-c", s, "-o", o], check=True)
+        objs.append(o)
+    out = os.path.join(os.path.dirname(b.OUT), "libvmm_hip_ab.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
+    print(out)

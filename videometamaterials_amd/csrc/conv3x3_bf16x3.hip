@@ -34,6 +34,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define VMM_C3_INTERLEAVE 1
 #endif
 constexpr bool C3_INTERLEAVE = VMM_C3_INTERLEAVE;  // memory requests of step q + 1 between the MFMAs of step q (-DVMM_C3_INTERLEAVE=0: A/B builds)
+#ifndef VMM_C3_XCD_ORDER
+#define VMM_C3_XCD_ORDER 1
+#endif
+constexpr bool C3_XCD_ORDER = VMM_C3_XCD_ORDER;  // XCD-contiguous tile numbering (-DVMM_C3_XCD_ORDER=0: A/B builds)
 constexpr int CK = 32;    // channels per chunk
 constexpr int CROW = 72;  // LDS patch row pitch in bf16: 32 hi | 32 lo | 8 pad = 144 bytes (9 x 16 B: ds_read_b128 over consecutive rows is conflict-free)
 
@@ -79,8 +83,13 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane & 31, lk = lane >> 5;
   const int W = p.Win, H = p.Hin, HW = H * W;
-  const int mtile = blockIdx.x / a.n_tiles;
-  const int n0 = (blockIdx.x % a.n_tiles) * (WN * 64);
+  // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
+  // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in
+  // one L2 instead of being fetched once per XCD.
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int tile_id = C3_XCD_ORDER ? xcd * (G >> 3) + min(xcd, G & 7) + jx : (int)blockIdx.x;
+  const int mtile = tile_id / a.n_tiles;
+  const int n0 = (tile_id % a.n_tiles) * (WN * 64);
   const int Cin = p.C1 + p.C2;
   const int nchunks = (TS == 2 ? 4 : 1) * Cin / CK;
   const int c_begin = blockIdx.y * a.chunks_per_split;
