@@ -78,15 +78,11 @@ __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const 
 constexpr int YPITCH = 2 * LC + 8;  // bf16 per LDS row: hi 64 | lo 64 | pad (272 bytes = 17 x 16: conflict-free ds_read_b128)
 
 __device__ __forceinline__ void stage_norm_row(const LAArgs& a, const f32x4& x, const f32x4& gam, unsigned short* ytile, int tid) {
-  float s = (x.x + x.y) + (x.z + x.w);
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-  const float mean = s * (1.0f / LC);
+  // (row sums inside the DPP row, v_rsq_f32: the eight ds_bpermute round trips and the IEEE sqrt / divide were ~1k cycles of every tile,
+  // in front of the barrier all eight head-waves wait at)
+  const float mean = row_sum16((x.x + x.y) + (x.z + x.w)) * (1.0f / LC);
   const f32x4 c = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
-  float q = (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / LC) + a.eps);
+  const float rstd = __builtin_amdgcn_rsqf(row_sum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / LC) + a.eps);
   unsigned l0, l1;
   const unsigned h0 = pack_split(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
   const unsigned h1 = pack_split(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
@@ -154,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void linattn_ctx_kernel(const LAArgs a) {
     float tm = kt[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, kt[r]);
-    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    tm = fmaxf(tm, lane_xor(tm, 5));
     const float mn = fmaxf(m, tm);
     const float f = __expf(m - mn);
     float ps = 0.f;
@@ -174,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void linattn_ctx_kernel(const LAArgs a) {
       ctx = mfma3(vh, vl, ph, pl, ctx);  // ctx^T[e][d] += sum_pixels v[pixel][e] p[pixel][d]
     }
   }
-  ssum += __shfl_xor(ssum, 32, 64);
+  ssum += lane_xor(ssum, 5);
   float* pp = a.part + (((long long)frame * a.nsplit + split) * LH + h) * PART;
   if (lk == 0) { pp[lrow] = m; pp[32 + lrow] = ssum; }
 #pragma unroll
@@ -280,12 +276,12 @@ __global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
     float mx = qt[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, lane_xor(mx, 5));
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { qt[r] = __expf(qt[r] - mx); sum += qt[r]; }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    sum += lane_xor(sum, 5);
+    const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int r = 0; r < 16; ++r) qt[r] *= inv;
     f32x16 ot = zero16();  // rows e, column pixel

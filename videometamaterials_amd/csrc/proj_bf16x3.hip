@@ -82,8 +82,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < IPL; ++i) s += (v[ps][i].x + v[ps][i].y) + (v[ps][i].z + v[ps][i].w);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        s = row_sum16(s);  // (the row's 16 lanes are one DPP row)
         const float mean = s / (float)K;
         float q = 0.f;
 #pragma unroll
@@ -94,9 +93,8 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
             q += (v[ps][i].x * v[ps][i].x + v[ps][i].y * v[ps][i].y) + (v[ps][i].z * v[ps][i].z + v[ps][i].w * v[ps][i].w);
           }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
-        const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+        q = row_sum16(q);
+        const float rstd = __builtin_amdgcn_rsqf(q / (float)K + a.eps);
 #pragma unroll
         for (int i = 0; i < IPL; ++i) {
           const int c = (l16 + 16 * i) * 4;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
       g[j] = tk < ntok ? sk[j] + (a.bias_on_cond ? bz[j] : 0.f) : -INFINITY;
       mx = fmaxf(mx, fmaxf(f[j], g[j]));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, lane_xor(mx, 5));
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
       g[j] = __expf(g[j] - mx);
       sum += f[j] + g[j];
     }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    sum += lane_xor(sum, 5);
+    const float inv = __builtin_amdgcn_rcpf(sum);
     float p0[8], p1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -64,6 +64,15 @@ __device__ __forceinline__ float lane_xor(float v, int bit) {
   }
 }
 
+// sum over the 16 lanes of a DPP row, every lane gets it: four rotate-and-add steps (v_add_f32_dpp row_ror), no LDS permutes
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Zero-fill on a stream as a KERNEL.  The library never uses hipMemsetAsync: captured into a hipGraph its memset node was observed
