@@ -169,6 +169,13 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     }
     return s;
   };
+  // which of this thread's patch items are real rows (chunk-invariant).  The loads below are UNCONDITIONAL (padding / beyond-the-patch items
+  // re-read row 0 and are zeroed when the patch is stored): a lane-dependent branch around a load splits the step's basic block, and
+  // then neither the compiler's waits are counted nor can the requests be interleaved with the MFMAs.
+  unsigned vmask = 0;
+#pragma unroll
+  for (int ps = 0; ps < MAXP; ++ps)
+    if (src_row(ps, 0) >= 0) vmask |= 1u << ps;
   // channel chunk -> (sub-pixel, first channel): TS == 2 walks the four sub-pixels of the cell, Cin channels each
   auto sub_of = [&](int cc) { return TS == 2 ? cc >> a.cps_shift : 0; };
   auto chan_of = [&](int cc) { return (TS == 2 ? cc & ((1 << a.cps_shift) - 1) : cc) * CK; };
@@ -193,10 +200,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int sr = src_row(ps, sub_of(cc));
-      if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
-      preg[ps] = v;
+      const int sr = max(src_row(ps, sub_of(cc)), 0);
+      preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
     }
   };
   // One item of the next chunk's patch.  vmcnt retires in order, so an HBM-latency load blocks every younger weight-fragment wait
@@ -208,10 +213,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     const float* src = src1 ? p.a1 : p.a2;
     const int ld = src1 ? p.lda1 : p.lda2;
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int sr = src_row(ps, sub_of(cc));
-    if (sr >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
-    preg[ps] = v;
+    const int sr = max(src_row(ps, sub_of(cc)), 0);
+    preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
   };
   auto store_patch = [&](int cc) {
     const int c0 = chan_of(cc);
@@ -224,9 +227,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       const int r = (tid >> 3) + ps * 32;
       if (r < a.PR) {
         f32x4 v = preg[ps];
-        const int sr = xform ? src_row(ps, 0) : -1;
-        if (sr >= 0) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
+        const bool real = (vmask >> ps) & 1u;
+        if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xform && real) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
           if (!MODE) {  // flat row tiles run across samples
+            const int sr = src_row(ps, 0);
             const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
             ca = *reinterpret_cast<const f32x4*>(cf);
             cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
