@@ -379,6 +379,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   load_a(aa[0], tap_of(c_begin, 0), 0);
   for (int cc = c_begin; cc < c_end; ++cc) {
     const bool more = cc + 1 < c_end;
+    const int nxt = more ? cc + 1 : cc;
     // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
     // instead of being hoisted out of the loop into 36 address registers
 #pragma unroll
@@ -387,14 +388,16 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      // (the prefetches are issued for the last chunk too -- they re-read it: a wave-uniform branch around them is still a basic-block
+      // boundary in the middle of the step, i.e. requests in one lump between the MFMA groups)
       if (q + PFB < NQ) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
-      else if (more) load_b(bb[(q + PFB) % NB], ks_of(cc + 1, q + PFB - NQ));
-      if (q == 0 && more) load_coef(cc + 1);
+      else load_b(bb[(q + PFB) % NB], ks_of(nxt, q + PFB - NQ));
+      if (q == 0) load_coef(nxt);
       if (TS) {  // eight steps for up to eleven patch items: two per step
-        if (2 * q < MAXP && more) load_patch_item(cc + 1, 2 * q);
-        if (2 * q + 1 < MAXP && more) load_patch_item(cc + 1, 2 * q + 1);
-      } else if (q < MAXP && more) {
-        load_patch_item(cc + 1, q);
+        if (2 * q < MAXP) load_patch_item(nxt, 2 * q);
+        if (2 * q + 1 < MAXP) load_patch_item(nxt, 2 * q + 1);
+      } else if (q < MAXP) {
+        load_patch_item(nxt, q);
       }
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
       if constexpr (F32 || !C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
@@ -1417,7 +1420,10 @@ int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t 
     return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32>(a, mtiles, ksplit, s);
   }
   if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32>(a, mtiles, 1, s);
-  return a.mode ? launch_c3<4, 1, 11, 1, 1, false, F32>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, 1, false, F32>(a, mtiles, 1, s);
+  // (weight fragments two steps ahead where the registers allow it: with the requests interleaved into the MFMA stream one step is less
+  // than an L2 round trip)
+  constexpr int PF = F32 ? 1 : 2;
+  return a.mode ? launch_c3<4, 1, 11, 1, PF, false, F32>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, PF, false, F32>(a, mtiles, 1, s);
 }
 
 // Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
