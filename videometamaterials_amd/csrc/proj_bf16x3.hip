@@ -133,15 +133,12 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   auto load_b = [&](uint4 (&d)[4], int nc, int s) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int nt = (nc * BN + wn * 64) / 32 + j;
-      if (nt * 32 < p.Cout) {  // (wave-uniform) column tiles past Cout are not in the packed operand
-        const uint4* q = wf + ((long long)nt * KS + s) * 128 + lane;
-        d[2 * j] = q[0];
-        d[2 * j + 1] = q[64];
-      } else {
-        d[2 * j] = make_uint4(0u, 0u, 0u, 0u);
-        d[2 * j + 1] = make_uint4(0u, 0u, 0u, 0u);
-      }
+      // column tiles past Cout are not in the packed operand: they re-read the last one that is (their accumulators are never stored);
+      // no branch -- the step stays one basic block and its requests interleave with the MFMAs
+      const int nt = min((nc * BN + wn * 64) / 32 + j, p.Cout / 32 - 1);
+      const uint4* q = wf + ((long long)nt * KS + s) * 128 + lane;
+      d[2 * j] = q[0];
+      d[2 * j + 1] = q[64];
     }
   };
   int abase[2];
@@ -333,12 +330,25 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       if (s + 1 < KS) {
         load_b(bb[(s + 1) & 1], nc, s + 1);
         load_a(aa[(s + 1) & 1], s + 1);
-      } else if (more) {
-        load_b(bb[0], nc + 1, 0);
+      } else {
+        load_b(bb[0], more ? nc + 1 : nc, 0);
         load_a(aa[0], 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (F32) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[s & 1], bb[s & 1]);
+      if constexpr (!F32) {  // the next step's requests between this step's MFMAs (conv3x3_bf16x3.hip, same reasoning)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     store_chunk(nc);
