@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("a_mode", c_i32), ("a_coef", c_ptr), ("a_imgs_per_sample", c_i32),
         ("split_tickets", c_ptr), ("n_tickets", c_i32),
         ("gn_part", c_ptr), ("gn_groups", c_i32),
+        ("gn_gamma", c_ptr), ("gn_beta", c_ptr), ("gn_film", c_ptr), ("gn_ldfilm", c_i32), ("gn_eps", c_f32), ("gn_coef", c_ptr),
     ]
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "vmm_conv_igemm_bf16x3_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_finalises_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],

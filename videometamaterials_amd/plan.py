@@ -543,7 +543,16 @@ class _Builder:
         if n_part:
             part_off = self.alloc(B * G * n_part * 2)
             conv_desc.gn_part = self.ptr(part_off)
-            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
+            if not self.training and os.environ.get("VMM_GN_FINAL") == "1" and int(self.lib.vmm_conv3x3_finalises_gn(C.byref(conv_desc))):
+                # Opt-in: one trailing workgroup per sample of the convolution itself totals the partial sums and writes the coefficients --
+                # no coefficient launch: 162 -> 124 launches per guided step, and the step 0.15-0.2 ms SLOWER in every same-box A/B (a
+                # dependent ~5 us tail inside each of 38 kernels against ~3 us for a 64-workgroup launch inside the hipGraph): the launch
+                # count is not what bounds the step
+                conv_desc.gn_gamma, conv_desc.gn_beta = self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias")
+                conv_desc.gn_film, conv_desc.gn_ldfilm, conv_desc.gn_eps = film_ptr or None, ldfilm, 1e-5
+                conv_desc.gn_coef = self.ptr(coef_off)
+            else:
+                self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
             self.free(part_off, B * G * n_part * 2)
         elif rows_ps * (C_ // G) <= GN_DIRECT_MAX and (C_ // G) % 4 == 0:
             # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
