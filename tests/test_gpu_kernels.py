@@ -933,6 +933,17 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
         assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
 
 
+def test_in_kernel_groupnorm_finalisation_variant(gpu):
+    """VMM_GN_FINAL=1 (opt-in): the plans drop the 38 coefficient launches, the convolutions' trailing workgroups write the
+    coefficients; the denoiser goldens and a guided sampling step again in a process built that way."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_unet.py", "-k",
+                        "forward_matches_reference_golden or graphed_sampler or sampling_loops"], cwd=root, env=dict(os.environ, VMM_GN_FINAL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_persistent_conv3x3_variants(gpu, mode):
     """The persistent wave-specialised 3 x 3 kernel is opt-in (VMM_C3_PERSISTENT, read once per process; default 0):
