@@ -60,6 +60,16 @@ class Act:
         return self.C
 
 
+@dataclass
+class ActView:
+    """A column slice of a feature map (same rows, `C` of its `ld` columns)."""
+    ptr: int
+    C: int
+    ld: int
+    H: int
+    W: int
+
+
 class _Arena:
     """First-fit allocator over float offsets; used identically in the sizing pass and the real pass."""
 
@@ -499,6 +509,19 @@ class _Builder:
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
+    def split_k_ok(self, k: int, cout: int) -> bool:
+        """K = 512 projections (inference): two K = 256 launches of the A-stationary projection kernel, the second adding onto the first
+        (its epilogue's scale / rotary are linear), instead of one generic implicit GEMM at ~95 TFLOP/s."""
+        return bool(self.x3 and not self.training and k == 512 and cout >= 128 and self.proj_ok(256, cout) and _enabled("split_k"))
+
+    def proj_split_k(self, y: Act, wname: str, Cout: int, out_ptr: int, what: str, **epi) -> None:
+        half = y.C // 2
+        for i in range(2):
+            w = self.pack(wname, Cout * half, want_grad=False, gemm=True, TH=1, TW=1, C=half, Cp=half, N=Cout, sn=y.C, sc=1, src_off=i * half, frag=2)[0]
+            a = ActView(y.ptr + 4 * i * half, half, y.C, y.H, y.W)
+            self.conv(a1=a, w=w, Cout=Cout, out_ptr=out_ptr, ldo=Cout, Hv=y.H, Wv=y.W, what=f"{what} (K half {i})", proj=True,
+                      res_ptr=out_ptr if i else 0, ldres=Cout, **epi)
+
     def wgrad(self, d: "N.ConvDesc", dy_ptr: int, lddy: int, gw_ptr: int, what: str, gb_ptr: int = 0) -> None:
         """Weight gradient of the layer with forward descriptor d; gb_ptr: its bias gradient (column sums of dY) from the same launch."""
         if not gw_ptr:
@@ -728,10 +751,14 @@ class _Builder:
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
-        wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
-        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv", proj=pj,
-                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+        if not pj and self.split_k_ok(x.C, 3 * hid):
+            self.proj_split_k(y, name + ".fn.fn.to_qkv.weight", 3 * hid, qkv.ptr, name + " to_qkv")
+            dq = gwq = None
+        else:
+            wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2 if pj else False)
+            dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv", proj=pj,
+                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
         if not fuse_ln:
             self.free_act(y)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
@@ -804,12 +831,17 @@ class _Builder:
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
-        wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
         qkv = self.act(3 * hid, x.H, x.W)
         q_scale = 32 ** -0.5
-        dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
-                       rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
-                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+        if not pj and self.split_k_ok(x.C, 3 * hid):
+            self.proj_split_k(y, p + ".to_qkv.weight", 3 * hid, qkv.ptr, name + " to_qkv", rot_tab=self.rot_ptr if temporal else 0,
+                              rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid)
+            dq = gwq = None
+        else:
+            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
+            dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
+                           rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
+                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
         if not fuse_ln:
             self.free_act(y)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
