@@ -40,7 +40,10 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) {
 }
 
 // KS = k16 steps (K padded to 32 -> KS = Kpad / 16 in {2, 4, 8, 16})
-template <int WM, int WN, int KS, bool F32>
+// KSPLIT4: the four waves split the k16 steps of ONE column slice (Cout <= 64 under the 1 x 4 arrangement).  A template parameter, not a
+// run-time branch: with both step loops in one kernel the accumulators live in different registers in the two copies and the K = 256
+// instance spilled 102-109 registers to scratch (every launch of it, whichever path it took).
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int KP = KS * 16;         // padded K
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   const uint4* wf = reinterpret_cast<const uint4*>(p.w);
   // Cout <= 64 under the 1 x 4 wave arrangement (K = 256: a 64-row tile is all the LDS holds) leaves one column slice: the four waves then
   // split the k16 steps of that slice instead of three of them idling, and wave 0 sums the partial accumulators through LDS.
-  const bool ksplit4 = WN == 4 && p.Cout <= 64;
+  constexpr bool ksplit4 = KSPLIT4;
   const int wn = ksplit4 ? 0 : wn_id;
   auto load_b = [&](uint4 (&d)[4], int nc, int s) {
 #pragma unroll
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   // software pipeline over the flattened (column chunk, k16 step) sequence: weights and tile fragments of the next step are
   // requested before the MFMAs of the current one; KS is even, so the two register buffers alternate cleanly across chunks
   uint4 bb[2][4], aa[2][4];
-  if (ksplit4) {
+  if constexpr (ksplit4) {
     if constexpr (WN == 4 && KS % 4 == 0) {
       const int s_begin = wave * (KS / 4);
       zero_acc();
@@ -355,18 +358,18 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   }
 }
 
-template <int WM, int WN, int KS, bool F32>
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
 int launch_pj(const PJArgs& a, hipStream_t s) {
   constexpr int BM = WM * 64;
   const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int mt = (int)cdiv(a.M, BM);
   const int ny = (int)cdiv(a.n_chunks, a.chunks_per_y);
-  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -412,7 +415,7 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
     if (KP == 96) return 1;
     return launch_pj<2, 2, 8, F32>(a, s);
   }
-  if (KP == 256) return launch_pj<1, 4, 16, F32>(a, s);
+  if (KP == 256) return d.Cout <= 64 ? launch_pj<1, 4, 16, F32, true>(a, s) : launch_pj<1, 4, 16, F32, false>(a, s);
   return 1;
 }
 
