@@ -17,14 +17,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
 
+// The value lane ^ (1 << bit) holds, without an LDS permute (ds_bpermute: an LDS round trip and an lgkmcnt wait per exchange):
+// bits 5 / 4: v_permlane32_swap / v_permlane16_swap (gfx950); bit 3: DPP row_ror:8; bit 2: ds_swizzle SWAP,4 (crossbar only);
+// bits 1 / 0: DPP quad_perm.  `bit` must fold to a constant.
+__device__ __forceinline__ float lane_xor(float v, int bit) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const int i = __builtin_bit_cast(int, v);
+  switch (bit) {
+    case 5: { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]); }
+    case 4: { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]); }
+    case 3: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, false));
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101f));
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false));
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false));
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int bit = 5; bit >= 0; --bit) v += lane_xor(v, bit);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int bit = 5; bit >= 0; --bit) v = fmaxf(v, lane_xor(v, bit));
   return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -47,22 +63,6 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 __device__ __forceinline__ float silu_rcp(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// The value lane ^ (1 << bit) holds, without an LDS permute (ds_bpermute: an LDS round trip and an lgkmcnt wait per exchange):
-// bits 5 / 4: v_permlane32_swap / v_permlane16_swap (gfx950); bit 3: DPP row_ror:8; bit 2: ds_swizzle SWAP,4 (crossbar only);
-// bits 1 / 0: DPP quad_perm.  `bit` must fold to a constant.
-__device__ __forceinline__ float lane_xor(float v, int bit) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const int i = __builtin_bit_cast(int, v);
-  switch (bit) {
-    case 5: { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]); }
-    case 4: { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]); }
-    case 3: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, false));
-    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(i, 0x101f));
-    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, false));
-    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, false));
-  }
-}
 
 // sum over the 16 lanes of a DPP row, every lane gets it: four rotate-and-add steps (v_add_f32_dpp row_ror), no LDS permutes
 __device__ __forceinline__ float row_sum16(float v) {
