@@ -499,9 +499,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         load_patch_item(nxt, q);
       }
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
-      if constexpr (F32 || !C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[q & 1], bb[q % NB]);
-      if constexpr (!F32 && C3_INTERLEAVE) {
+      if constexpr (C3_INTERLEAVE) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
         // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
         // longest way), not in front of them as one block during which the matrix pipe runs dry
 #pragma unroll

@@ -337,9 +337,8 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         load_b(bb[0], more ? nc + 1 : nc, 0);
         load_a(aa[0], 0);
       }
-      if constexpr (F32) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[s & 1], bb[s & 1]);
-      if constexpr (!F32) {  // the next step's requests between this step's MFMAs (conv3x3_bf16x3.hip, same reasoning)
+      {  // the next step's requests between this step's MFMAs (conv3x3_bf16x3.hip, same reasoning)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
