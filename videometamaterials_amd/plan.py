@@ -1134,7 +1134,7 @@ class _Builder:
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
         x = self.act(m.init_dim, H, W)
-        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and _enabled("stem"):
+        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and _enabled("stem"):
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
             self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
