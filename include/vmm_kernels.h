@@ -107,6 +107,11 @@ int vmm_conv_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, fl
 int vmm_conv_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
                           float* bias_scratch, vmm_stream_t stream);
 /* out[c] += sum_{k < n} part[k * ld + c], fixed order: second stage of the reductions that leave one partial row per workgroup */
+/* the 3 x 3 / stride 1 / pad 1 case of vmm_conv_wgrad_f32 with all nine taps of a (64 input channels) x (64 output channels) block in one
+ * workgroup (one LDS patch of x and dY per row segment; wgrad3x3.hip).  vmm_conv_wgrad_f32 forwards to it; returns 1 (nothing launched)
+ * outside its envelope: no fused operand transform, C1 / C2 / Cout multiples of 64, W a multiple of 24 or W = 12 with an even H. */
+int vmm_conv3x3_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
+                          float* bias_scratch, vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);

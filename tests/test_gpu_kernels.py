@@ -356,6 +356,41 @@ def test_output_pass_with_final_pointwise_conv(gpu, B, T, HW, Cout, with_res):
     assert relerr(out.cpu(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("nimg,H,W,C1,C2,Cout,nsplit", [(2, 48, 48, 64, 0, 64, 37), (1, 12, 12, 128, 64, 128, 3), (3, 24, 24, 64, 0, 128, 500), (1, 5, 96, 64, 64, 64, 4), (2, 6, 12, 64, 0, 64, 2)])
+def test_conv3x3_weight_gradient_nine_taps(gpu, nimg, H, W, C1, C2, Cout, nsplit):
+    """vmm_conv3x3_wgrad_f32 (all nine taps of a 64 x 64 channel block from one LDS patch, exact fp32 MFMA) against torch autograd's weight and
+    bias gradients of the same 3 x 3 'same' convolution: image borders, two concatenated sources, several rows per segment (W = 12, 24),
+    two segments per row (W = 96), more slices than segments."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(60 + W)
+    Cin = C1 + C2
+    x = torch.randn(nimg, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    dy = torch.randn(nimg, Cout, H, W, generator=g)
+    F.conv2d(x, w, b, padding=1).backward(dy)
+    want_w = w.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout)
+    xr = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    x1g = xr[:, :C1].contiguous().to(gpu)
+    x2g = xr[:, C1:].contiguous().to(gpu) if C2 else None
+    dyg = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = x1g.data_ptr(), C1, C1
+    if C2:
+        d.a2, d.C2, d.lda2 = x2g.data_ptr(), C2, C2
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout = H, W, 1, Cout
+    dw = torch.zeros(9 * Cin, Cout, device=gpu)
+    db = torch.zeros(Cout, device=gpu)
+    scratch = torch.full((nsplit, Cout), float("nan"), device=gpu)
+    rc = lib.vmm_conv3x3_wgrad_f32(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), nsplit, db.data_ptr(), scratch.data_ptr(), _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), want_w) < 3e-6
+    assert relerr(db.cpu(), b.grad) < 3e-6
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vmm_conv3x3_finalises_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],

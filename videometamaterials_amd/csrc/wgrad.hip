@@ -8,6 +8,7 @@
 //
 // pack:   one batched launch converts every torch-layout weight into the k-major operand layouts the forward /
 // data-gradient GEMMs read, and (direction = 1) scatters packed weight gradients back into torch layout.
+#include <stdlib.h>
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
@@ -404,6 +405,13 @@ extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int3
                                   float* bias_scratch, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || (lddy & 3) || nsplit < 1 || (dbias && !bias_scratch)) return -1;
+  {  // the 3 x 3 "same" convolutions: all nine taps from one LDS patch (wgrad3x3.hip); VMM_WGRAD3X3=0 keeps the generic kernel (A/B runs)
+    static const bool use3 = [] { const char* e = getenv("VMM_WGRAD3X3"); return !e || e[0] != '0'; }();
+    if (use3) {
+      const int rc = vmm_conv3x3_wgrad_f32(dp, dy, lddy, dw_packed, nsplit, dbias, bias_scratch, stream);
+      if (rc != 1) return rc;
+    }
+  }
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   const int Ktot = d.KH * d.KW * (d.C1 + d.C2);
   const long long rps = (cdiv(M, nsplit) + WK - 1) / WK * WK;
