@@ -56,12 +56,7 @@ struct C3Args {
   int n_final;                   // trailing workgroups that finalise the GroupNorm coefficients, one per sample (p.gn_coef), else 0
 };
 
-__device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-}
+__device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
 
 // GroupNorm * FiLM coefficients of sample `smp` from the partial sums every tile of the sample has left in p.gn_part -- run by the last
 // workgroup to arrive for that sample (all 256 threads).  The same arithmetic as gn_coef_kernel (norm.hip): fp64 totals in a fixed

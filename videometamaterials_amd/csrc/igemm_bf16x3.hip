@@ -24,12 +24,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int XK = 32;      // K elements per chunk
 constexpr int XROW = 40;    // LDS row pitch in bf16 (80 bytes)
 
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
 
 struct DescBatch { vmm_conv_desc d[4]; };  // same-shaped problems launched together (blockIdx.y): the 4 output phases of a transposed conv
 

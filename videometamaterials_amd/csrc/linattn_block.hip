@@ -47,13 +47,7 @@ struct LAArgs {
   float q_scale;
 };
 
-__device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) {
-  const f32x2 v = {a, b};
-  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-  return hi;
-}
+__device__ __forceinline__ unsigned pack_split(float a, float b, unsigned& lo) { return split_bf16_pair(a, b, lo); }
 
 // 8 consecutive accumulator registers -> one k16 operand fragment (hi, lo)
 __device__ __forceinline__ void split8(const f32x16& c, int r0, uint4& hi, uint4& lo) {

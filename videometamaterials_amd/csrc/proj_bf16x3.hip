@@ -31,13 +31,7 @@ struct PJArgs {
   int res_rps;            // rows per sample
 };
 
-__device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) {
-  const f32x2 v = {a, b};
-  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-  return hi;
-}
+__device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { return split_bf16_pair(a, b, lo); }
 
 // KS = k16 steps (K padded to 32 -> KS = Kpad / 16 in {2, 4, 8, 16})
 // KSPLIT4: the four waves split the k16 steps of ONE column slice (Cout <= 64 under the 1 x 4 arrangement).  A template parameter, not a

@@ -27,12 +27,7 @@ struct StemArgs {
   int nimg, H, W, k, tiles_x, tiles_y, ntiles;
 };
 
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const f32x2 v = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
 
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -64,6 +64,19 @@ __device__ __forceinline__ float silu_rcp(float x) { return x * __builtin_amdgcn
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Split two fp32 values into packed bf16 hi | lo parts (x = hi + lo up to 2^-17 relative; both round-to-nearest-even): the operand form of
+// every split-bf16 kernel.  Five instructions per pair (v_cvt_pk_bf16_f32, shift, mask, v_pk_add_f32, v_cvt_pk_bf16_f32); gfx950 has no
+// v_fma_mix_f32_bf16 that could subtract hi straight from its packed half (the assembler rejects it: "not supported on this GPU").
+__device__ __forceinline__ unsigned split_bf16_pair(float x0, float x1, unsigned& lo) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {x0, x1};
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+  return hi;
+}
+
 // sum over the 16 lanes of a DPP row, every lane gets it: four rotate-and-add steps (v_add_f32_dpp row_ror), no LDS permutes
 __device__ __forceinline__ float row_sum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
