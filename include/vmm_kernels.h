@@ -61,6 +61,10 @@ typedef struct vmm_conv_desc {
    * (scale | shift) or NULL, eps): the separate vmm_groupnorm_coef launch disappears.  Uses split_tickets[0 .. B) as arrival counters
    * (left zero again). */
   const float* gn_gamma; const float* gn_beta; const float* gn_film; int32_t gn_ldfilm; float gn_eps; float* gn_coef;
+  /* periodic ("circular") padding instead of zero padding along h / w (vddp.py:163-243: padding_mode 'circular' = both, 'circular_1d' =
+   * w only): taps that leave the frame read the opposite border.  Honoured by the implicit-GEMM kernels, vmm_conv_wgrad_f32 and the 2-D-tiled
+   * instances of the 3 x 3 halo kernels (flat row tiles, the persistent kernel, vmm_conv_s2 / vmm_stem_conv return 1 / are not used). */
+  int32_t wrap_h, wrap_w;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;

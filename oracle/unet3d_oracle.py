@@ -117,18 +117,49 @@ def rotary_rotate(t: Tensor, freqs: Optional[Tensor] = None) -> Tensor:
     return t * ang.cos() + rot * ang.sin()
 
 
-def frame_conv(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int = 1, pad: int = 0) -> Tensor:
-    """Conv3d with a (1,k,k) kernel == per-frame 2-D conv (vddp.py:241,271,297,626)."""
+def _pad_frames(x2: Tensor, pad: int, mode: str) -> Tensor:
+    """The explicit padding of the periodic variants (vddp.py:163-237): 'circular' wraps both image axes (nn.Conv3d padding_mode='circular'
+    / CircularUpsample), 'circular_1d' wraps the horizontal axis and zero-pads the vertical one (Circular_1d_Conv3d / Circular_1d_Upsample)."""
+    if pad == 0:
+        return x2
+    if mode == "circular":
+        return F.pad(x2, (pad, pad, pad, pad), mode="circular")
+    x2 = F.pad(x2, (pad, pad, 0, 0), mode="circular")
+    return F.pad(x2, (0, 0, pad, pad), mode="constant")
+
+
+def frame_conv(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int = 1, pad: int = 0, mode: str = "zeros") -> Tensor:
+    """Conv3d with a (1,k,k) kernel == per-frame 2-D conv (vddp.py:241,271,297,626); mode: the layer's padding_mode."""
     B, C, T, H, W = x.shape
-    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W), w[:, :, 0], b, stride=stride, padding=pad)
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    if mode == "zeros":
+        y = F.conv2d(x2, w[:, :, 0], b, stride=stride, padding=pad)
+    else:
+        y = F.conv2d(_pad_frames(x2, pad, mode), w[:, :, 0], b, stride=stride, padding=0)
     return y.reshape(B, T, *y.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
-def frame_conv_transpose(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
-    """ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) (vddp.py:155)."""
+def frame_conv_transpose(x: Tensor, w: Tensor, b: Tensor, mode: str = "zeros") -> Tensor:
+    """ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1) (vddp.py:155); periodic variants (vddp.py:163-213): the input is padded by
+    true_padding = k - 1 - p = 2 explicitly and the transposed convolution crops removed_padding = (k - 1) + s + p - 1 = 5."""
     B, C, T, H, W = x.shape
-    y = F.conv_transpose2d(x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W), w[:, :, 0], b, stride=2, padding=1)
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    if mode == "zeros":
+        y = F.conv_transpose2d(x2, w[:, :, 0], b, stride=2, padding=1)
+    else:
+        y = F.conv_transpose2d(_pad_frames(x2, 2, mode), w[:, :, 0], b, stride=2, padding=5)
     return y.reshape(B, T, *y.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def ref_key(mode: str, k: str) -> str:
+    """state_dict name of a convolution parameter under the layer's padding_mode: the periodic variants wrap their convolutions in
+    helper modules (Circular_1d_Conv3d.conv, Circular*Upsample.conv_transpose; vddp.py:153-243, 268-273, 625-629)."""
+    import re
+    if mode in ("circular", "circular_1d"):
+        k = re.sub(r"^(ups\.\d+\.4)\.(weight|bias)$", r"\1.conv_transpose.\2", k)
+    if mode == "circular_1d":
+        k = re.sub(r"^(.*\.block[12]\.proj|init_conv|downs\.\d+\.4)\.(weight|bias)$", r"\1.conv.\2", k)
+    return k
 
 
 def channel_layernorm(x: Tensor, gamma: Tensor, eps: float = 1e-5) -> Tensor:
@@ -138,9 +169,9 @@ def channel_layernorm(x: Tensor, gamma: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mean) / torch.sqrt(var + eps) * gamma
 
 
-def conv_gn_act(sd, p: str, x: Tensor, groups: int, scale_shift=None) -> Tensor:
+def conv_gn_act(sd, p: str, x: Tensor, groups: int, scale_shift=None, mode: str = "zeros") -> Tensor:
     """Block (vddp.py:267-285): conv3x3 -> GroupNorm -> optional FiLM -> SiLU."""
-    y = frame_conv(x, sd[p + ".proj.weight"], sd[p + ".proj.bias"], pad=1)
+    y = frame_conv(x, sd[ref_key(mode, p + ".proj.weight")], sd[ref_key(mode, p + ".proj.bias")], pad=1, mode=mode)
     y = F.group_norm(y, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-5)
     if scale_shift is not None:
         s, sh = scale_shift
@@ -148,15 +179,15 @@ def conv_gn_act(sd, p: str, x: Tensor, groups: int, scale_shift=None) -> Tensor:
     return F.silu(y)
 
 
-def resnet_block(sd, p: str, x: Tensor, temb: Optional[Tensor], groups: int) -> Tensor:
+def resnet_block(sd, p: str, x: Tensor, temb: Optional[Tensor], groups: int, mode: str = "zeros") -> Tensor:
     """ResnetBlock (vddp.py:287-311); only block1 receives scale/shift."""
     ss = None
     if (p + ".mlp.1.weight") in sd:
         e = F.linear(F.silu(temb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])
         e = e[:, :, None, None, None]
         ss = e.chunk(2, dim=1)
-    h = conv_gn_act(sd, p + ".block1", x, groups, ss)
-    h = conv_gn_act(sd, p + ".block2", h, groups)
+    h = conv_gn_act(sd, p + ".block1", x, groups, ss, mode)
+    h = conv_gn_act(sd, p + ".block2", h, groups, None, mode)
     if (p + ".res_conv.weight") in sd:
         x = frame_conv(x, sd[p + ".res_conv.weight"], sd[p + ".res_conv.bias"])
     return h + x
@@ -316,12 +347,13 @@ def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor,
             taps[name] = v.detach().clone()
         return v
 
-    if cfg.padding_mode != "zeros":
-        raise ValueError("oracle covers padding_mode='zeros' only (SURVEY a14)")
+    pm = cfg.padding_mode
+    if pm not in ("zeros", "circular", "circular_1d"):
+        raise ValueError(f"padding_mode {pm!r}")
     g = cfg.resnet_groups
     T = x.shape[2]
     bias = rel_pos_bias(sd, T)
-    x = frame_conv(x, sd["init_conv.weight"], sd["init_conv.bias"], pad=cfg.init_kernel_size // 2)
+    x = frame_conv(x, sd[ref_key(pm, "init_conv.weight")], sd[ref_key(pm, "init_conv.bias")], pad=cfg.init_kernel_size // 2, mode=pm)
     x = tap("init_temporal_attn", temporal_attention_block(sd, "init_temporal_attn", x, cfg, bias, None))
     r = x.clone()
     t = sinusoidal_embedding(time, cfg.dim)
@@ -334,27 +366,27 @@ def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor,
     skips = []
     n_lvl = len(cfg.level_io)
     for i in range(n_lvl):
-        x = tap(f"downs.{i}.0", resnet_block(sd, f"downs.{i}.0", x, t, g))
-        x = tap(f"downs.{i}.1", resnet_block(sd, f"downs.{i}.1", x, t, g))
+        x = tap(f"downs.{i}.0", resnet_block(sd, f"downs.{i}.0", x, t, g, pm))
+        x = tap(f"downs.{i}.1", resnet_block(sd, f"downs.{i}.1", x, t, g, pm))
         x = tap(f"downs.{i}.2", linear_attention_block(sd, f"downs.{i}.2", x, cfg, tokens))
         x = tap(f"downs.{i}.3", temporal_attention_block(sd, f"downs.{i}.3", x, cfg, bias, tokens_t))
         skips.append(x)
         if i < n_lvl - 1:
-            x = frame_conv(x, sd[f"downs.{i}.4.weight"], sd[f"downs.{i}.4.bias"], stride=2, pad=1)
-    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g))
+            x = frame_conv(x, sd[ref_key(pm, f"downs.{i}.4.weight")], sd[ref_key(pm, f"downs.{i}.4.bias")], stride=2, pad=1, mode=pm)
+    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g, pm))
     x = tap("mid_spatial_attn", mid_spatial_attention_block(sd, "mid_spatial_attn", x, cfg, tokens))
     x = tap("mid_temporal_attn", temporal_attention_block(sd, "mid_temporal_attn", x, cfg, bias, tokens_t))
-    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g))
+    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g, pm))
     for i in range(n_lvl):
         x = torch.cat((x, skips.pop()), dim=1)
-        x = tap(f"ups.{i}.0", resnet_block(sd, f"ups.{i}.0", x, t, g))
-        x = tap(f"ups.{i}.1", resnet_block(sd, f"ups.{i}.1", x, t, g))
+        x = tap(f"ups.{i}.0", resnet_block(sd, f"ups.{i}.0", x, t, g, pm))
+        x = tap(f"ups.{i}.1", resnet_block(sd, f"ups.{i}.1", x, t, g, pm))
         x = tap(f"ups.{i}.2", linear_attention_block(sd, f"ups.{i}.2", x, cfg, tokens))
         x = tap(f"ups.{i}.3", temporal_attention_block(sd, f"ups.{i}.3", x, cfg, bias, tokens_t))
         if i < n_lvl - 1:
-            x = frame_conv_transpose(x, sd[f"ups.{i}.4.weight"], sd[f"ups.{i}.4.bias"])
+            x = frame_conv_transpose(x, sd[ref_key(pm, f"ups.{i}.4.weight")], sd[ref_key(pm, f"ups.{i}.4.bias")], mode=pm)
     x = torch.cat((x, r), dim=1)
-    x = tap("final_conv.0", resnet_block(sd, "final_conv.0", x, None, g))
+    x = tap("final_conv.0", resnet_block(sd, "final_conv.0", x, None, g, pm))
     return frame_conv(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
 
 

@@ -33,6 +33,12 @@ CONFIGS = {
     # two-frame-tile temporal attention path at every level), small frames
     "hires64t22": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16,
                         use_temporal_attention_cond=True, per_frame_cond=False), (2, 22, 32, 32), 51),  # (B = 1 crashes the reference: torch.squeeze in SignalEmbedding, vddp.py:571)
+    # periodic padding variants (vddp.py:153-243): 'circular' at the real widths (2-D-tiled halo kernels at 32 x 32, wrapped implicit GEMMs
+    # below; Upsample = CircularUpsample), 'circular_1d' at dim 16 (horizontal axis periodic; every convolution wrapped in a helper module)
+    "circ64": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                    per_frame_cond=True, cond_bias=True, padding_mode="circular"), (1, 11, 32, 32), 11),
+    "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                      per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
 }
 
 

@@ -86,7 +86,8 @@ def test_state_dict_is_a_drop_in(cfg_name):
     m.load_state_dict(no_freqs, strict=True)
     m2 = copy.deepcopy(m)
     m3 = pickle.loads(pickle.dumps(m))
-    assert torch.equal(m2.state_dict()["init_conv.weight"], m3.state_dict()["init_conv.weight"])
+    stem = next(k for k in shapes if k.startswith("init_conv.") and k.endswith("weight"))  # ('init_conv.conv.weight' under circular_1d)
+    assert torch.equal(m2.state_dict()[stem], m3.state_dict()[stem]) and torch.equal(m2.state_dict()[stem], ref_sd[stem])
 
 
 def test_constructor_rejections():

@@ -254,7 +254,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     if (r < a.PR) {
       if (MODE) {
         const int py = r / 18, px = r - py * 18;
-        const int h = ty0 - 1 + py, w = tx0 - 1 + px;
+        int h = ty0 - 1 + py, w = tx0 - 1 + px;
+        // periodic padding (vddp.py:163-243; 2-D tiles only, plan_c3): the halo rows / columns that leave the frame come from the opposite border
+        if (p.wrap_h) h = h < 0 ? h + H : (h >= H ? h - H : h);
+        if (p.wrap_w) w = w < 0 ? w + W : (w >= W ? w - W : w);
         if (h >= 0 && h < H && w >= 0 && w < W) s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : img * HW + h * W + w;
       } else {
         const int g = g0 - a.halo + r;
@@ -1365,6 +1368,7 @@ int launch_pw(const PWArgs& a, hipStream_t s) {
 
 // geometry of the persistent variant: 256-pixel x 64-column tiles for every layer; false when the shape is outside its envelope
 bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
+  if (d.wrap_h || d.wrap_w) return false;  // (periodic padding: the one-tile kernel's 2-D instances)
   const long long M = (long long)d.nimg * d.Hin * d.Win;
   a.p = d;
   a.n_tiles = d.Cout / 64;
@@ -1467,6 +1471,7 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
     mtiles = (int)cdiv(M, BM);
   }
   if (a.PR > (wide ? 6 : 11) * 32) return 1;
+  if ((d.wrap_h || d.wrap_w) && a.mode == 0) return 1;  // periodic padding: the flat row tiles' neighbourhood is a contiguous row range
   // few-row layers (12 x 12 level): split the channel chunks so that both workgroup slots of every CU are filled a few times over;
   // the partial sums are added in a fixed order (tickets, see the kernel epilogue)
   const int nch = (d.C1 + d.C2) / CK;

@@ -53,7 +53,10 @@ struct KPos {
 // one float4 of A for row `ri` at K position `kp` (all-zero when padded / out of range)
 __device__ __forceinline__ f32x4 load_a4(const vmm_conv_desc& p, const RowInfo& ri, const KPos& kp, int Ktot) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  const int ih = ri.ih0 + p.off_h + p.sgn_h * kp.kh, iw = ri.iw0 + p.off_w + p.sgn_w * kp.kw;
+  int ih = ri.ih0 + p.off_h + p.sgn_h * kp.kh, iw = ri.iw0 + p.off_w + p.sgn_w * kp.kw;
+  // periodic padding (vddp.py:163-243): a tap that leaves the frame reads the opposite border (kernels reach at most one frame beyond)
+  if (p.wrap_h) ih = ih < 0 ? ih + p.Hin : (ih >= p.Hin ? ih - p.Hin : ih);
+  if (p.wrap_w) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
   if (kp.k < Ktot && ri.img >= 0 && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
     const long long pix = (long long)((ri.img * p.Hin + ih) * p.Win + iw);
     if (kp.ci < p.C1) {

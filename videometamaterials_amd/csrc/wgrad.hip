@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const vmm_conv_desc p, c
 #pragma unroll
       for (int u = 0; u < AI; ++u) {
         if (!ivalid[u]) continue;
-        const int ih = a * p.stride + dh[u], iw = b * p.stride + dwo[u];
+        int ih = a * p.stride + dh[u], iw = b * p.stride + dwo[u];
+        if (p.wrap_h) ih = ih < 0 ? ih + p.Hin : (ih >= p.Hin ? ih - p.Hin : ih);  // periodic padding (vddp.py:163-243)
+        if (p.wrap_w) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
         if (ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win) {
           const long long pix = ((long long)img * p.Hin + ih) * p.Win + iw;
           if (ci[u] < p.C1) {

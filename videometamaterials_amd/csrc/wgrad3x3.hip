@@ -155,7 +155,7 @@ extern "C" int vmm_conv3x3_wgrad_f32(const vmm_conv_desc* dp, const float* dy, i
                                      float* bias_scratch, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 && d.Hv == d.Hin &&
-                        d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
+                        d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0 && !d.wrap_h && !d.wrap_w;
   const bool chan_ok = d.C1 > 0 && d.C1 % 64 == 0 && d.C2 % 64 == 0 && d.Cout % 64 == 0 && (d.lda1 & 3) == 0 && (!d.C2 || (d.lda2 & 3) == 0) && (lddy & 3) == 0;
   if (!shape_ok || !chan_ok || nsplit < 1 || (dbias && !bias_scratch)) return 1;
   W3Args a;

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const vmm_conv_desc p, co
       f32x4 x = {0.f, 0.f, 0.f, 0.f};
       if (m < m_end && cvalid) {
         if (a_role) {
-          const int ih = a * p.stride + dh, iw = b * p.stride + dwo;
+          int ih = a * p.stride + dh, iw = b * p.stride + dwo;
+          if (p.wrap_h) ih = ih < 0 ? ih + p.Hin : (ih >= p.Hin ? ih - p.Hin : ih);  // periodic padding (vddp.py:163-243)
+          if (p.wrap_w) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
           if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) {
             x = *reinterpret_cast<const f32x4*>(acol + (((long long)img * p.Hin + ih) * p.Win + iw) * lda);
             vmask |= 1u << r;

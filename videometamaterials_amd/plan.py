@@ -263,6 +263,8 @@ class _Builder:
         self.shapes = {k: tuple(v.shape) for k, v in model._params_flat().items()}
         self.trainable = {k for k, p in model.named_parameters() if p.requires_grad}
         self.G = model.resnet_groups
+        pm = getattr(model, "padding_mode", "zeros")  # 'circular': both image axes periodic; 'circular_1d': the horizontal one (vddp.py:163-243)
+        self.wrap_h, self.wrap_w = int(pm == "circular"), int(pm in ("circular", "circular_1d"))
         self.heads = model.attn_heads
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
@@ -382,6 +384,8 @@ class _Builder:
         bm = 128 if cout >= 128 else 256
         if W >= 32 and W % 16 == 0 and H % (bm // 16) == 0:
             return True
+        if self.wrap_h or self.wrap_w:  # periodic padding: the 2-D-tiled instances only (flat row tiles assume a contiguous neighbourhood)
+            return False
         return bm + 2 * (W + 1) <= (6 if cout >= 128 else 11) * 32
 
     def pack_conv_dgrad(self, name: str, ci0: int, nci: int, flip: bool = False, frag=False, gemm: bool = False) -> int:
@@ -478,6 +482,8 @@ class _Builder:
             self.tickets_ptr = self.wslot(N_TICKETS)
         d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
         d.gn_part, d.gn_groups = None, self.G
+        if KH > 1 or KW > 1:  # padding_mode 'circular' / 'circular_1d' (vddp.py:163-243): every spatial kernel wraps instead of zero-padding
+            d.wrap_h, d.wrap_w = self.wrap_h, self.wrap_w
         self.plan.keepalive.append(d)
         return d
 
@@ -958,6 +964,7 @@ class _Builder:
         Cx = m.channels
         hid = 32 * heads
         tr = self.training
+        wrap = bool(self.wrap_h or self.wrap_w)
         rows0 = B * T * H * W
         # static inputs / outputs
         x_in_off = self.alloc(B * Cx * T * H * W)
@@ -1134,7 +1141,7 @@ class _Builder:
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
         x = self.act(m.init_dim, H, W)
-        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and _enabled("stem"):
+        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem"):
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
             self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
@@ -1186,7 +1193,7 @@ class _Builder:
                 nm = f"downs.{i}.4"
                 d = self.act(x.C, x.H // 2, x.W // 2)
                 co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
-                if self.x3 and not tr and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
+                if self.x3 and not tr and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
                     self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0), nm,
@@ -1230,7 +1237,7 @@ class _Builder:
                 u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
                 one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
-                s2 = self.x3 and not tr and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
+                s2 = self.x3 and not tr and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
                     wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]

@@ -70,8 +70,8 @@ class Unet3D(nn.Module):
         assert init_kernel_size % 2 == 1  # vddp.py:621
         if cond_att_GRU:
             raise NotImplementedError("cond_att_GRU (ablation-only GRU embedding, vddp.py:546-549) is not built")
-        if padding_mode != "zeros":
-            raise NotImplementedError("circular padding variants (vddp.py:163-237) are not built; model.yaml uses 'zeros'")
+        if padding_mode not in ("zeros", "circular", "circular_1d"):
+            raise ValueError(f"padding_mode {padding_mode!r}: 'zeros', 'circular' or 'circular_1d' (vddp.py:153-243)")
         if cond_to_time != "add":
             raise NotImplementedError("cond_to_time='concat' is not built; model.yaml uses 'add'")
         if attn_dim_head != 32:
@@ -107,6 +107,7 @@ class Unet3D(nn.Module):
         self._plans: Dict[tuple, "_plan.Plan"] = {}
         self._generation = 0
         self.register_load_state_dict_pre_hook(Unet3D._ckpt_pre_hook)
+        self._register_state_dict_hook(Unet3D._ref_names_hook)
         self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
         # matrix-core arithmetic of the contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative, 5x the MFMA
         # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
@@ -206,6 +207,36 @@ class Unet3D(nn.Module):
         _attach(self, "null_text_token", torch.randn(1, self.cond_attention_tokens, cd))
         _attach(self, "null_text_hidden", torch.randn(1, td))
 
+    # The periodic-padding variants wrap their convolutions in helper modules (vddp.py:153-243: Circular_1d_Conv3d.conv, CircularUpsample /
+    # Circular_1d_Upsample.conv_transpose), which moves the parameters one level down in the reference's state_dict.  The parameter tree
+    # here keeps ONE set of names (the 'zeros' ones, which the launch plans use); state_dict() / load_state_dict() translate.
+    def _ref_key(self, k: str) -> str:
+        import re
+        if self.padding_mode in ("circular", "circular_1d"):
+            k = re.sub(r"^(ups\.\d+\.4)\.(weight|bias)$", r"\1.conv_transpose.\2", k)
+        if self.padding_mode == "circular_1d":
+            k = re.sub(r"^(.*\.block[12]\.proj|init_conv|downs\.\d+\.4)\.(weight|bias)$", r"\1.conv.\2", k)
+        return k
+
+    def _own_key(self, k: str) -> str:
+        import re
+        if self.padding_mode in ("circular", "circular_1d"):
+            k = re.sub(r"^(ups\.\d+\.4)\.conv_transpose\.(weight|bias)$", r"\1.\2", k)
+        if self.padding_mode == "circular_1d":
+            k = re.sub(r"^(.*\.block[12]\.proj|init_conv|downs\.\d+\.4)\.conv\.(weight|bias)$", r"\1.\2", k)
+        return k
+
+    @staticmethod
+    def _ref_names_hook(module, state_dict, prefix, local_metadata):
+        if module.padding_mode == "zeros":
+            return
+        items = list(state_dict.items())
+        state_dict.clear()
+        for k, v in items:
+            if k.startswith(prefix):
+                k = prefix + module._ref_key(k[len(prefix):])
+            state_dict[k] = v
+
     @staticmethod
     def _ckpt_pre_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         """Checkpoint tolerances, applied wherever this module sits in the tree being loaded -- the reference loads at the
@@ -218,6 +249,11 @@ class Unet3D(nn.Module):
         wrapped = prefix + "module."
         for k in [k for k in state_dict if k.startswith(wrapped)]:
             state_dict[prefix + k[len(wrapped):]] = state_dict.pop(k)
+        if module.padding_mode != "zeros":  # the reference's names of the wrapped convolutions -> this tree's
+            for k in [k for k in state_dict if k.startswith(prefix)]:
+                own_k = prefix + module._own_key(k[len(prefix):])
+                if own_k != k:
+                    state_dict[own_k] = state_dict.pop(k)
         own = {prefix + k: v for k, v in module.state_dict().items() if ".rotary_emb." in k}
         for k in [k for k in state_dict if k.startswith(prefix) and ".rotary_emb." in k and k not in own]:
             del state_dict[k]
