@@ -356,6 +356,121 @@ def test_output_pass_with_final_pointwise_conv(gpu, B, T, HW, Cout, with_res):
     assert relerr(out.cpu(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("wrap", [(1, 1), (0, 1)])
+@pytest.mark.parametrize("nimg,H,W,Cin,Cout,k,stride", [(2, 32, 32, 64, 64, 3, 1), (1, 96, 96, 64, 128, 3, 1), (2, 16, 48, 32, 64, 3, 1), (3, 12, 12, 128, 128, 3, 1),
+                                                     (2, 16, 16, 32, 32, 4, 2), (1, 24, 24, 4, 64, 7, 1), (2, 10, 6, 20, 24, 3, 1)])
+def test_periodic_padding_convolutions(gpu, wrap, nimg, H, W, Cin, Cout, k, stride):
+    """wrap_h / wrap_w of the descriptor (padding_mode 'circular' = both axes, 'circular_1d' = w only, vddp.py:163-243): taps that leave the frame
+    read the opposite border.  Every kernel that accepts the flags against torch on a circularly padded input: exact-fp32 and split-bf16
+    implicit GEMM, both 3 x 3 halo kernels where the shape gets 2-D tiles (they must refuse, not mis-compute, elsewhere), the data gradient
+    (reversed taps) and the weight gradient."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(70 + H + k)
+    x = torch.randn(nimg, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    pad = {3: 1, 7: 3, 4: 1}[k]
+    xl = x.clone().requires_grad_(True)
+    xp = F.pad(xl, (pad, pad, 0, 0), mode="circular")                       # w always wraps
+    xp = F.pad(xp, (0, 0, pad, pad), mode="circular") if wrap[0] else F.pad(xp, (0, 0, pad, pad))
+    ref4 = F.conv2d(xp, w, b, stride=stride)
+    Ho, Wo = ref4.shape[-2:]
+    dy = torch.randn(ref4.shape, generator=g)
+    ref4.backward(dy)
+    ref = ref4.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+    xr = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(gpu)
+    bg = b.detach().to(gpu)
+    wg = w.detach().contiguous().to(gpu)
+    K = k * k * Cin
+    Kpad = (K + 31) // 32 * 32
+
+    def packed(fmt, flip=False, transpose=False):
+        """fmt 0-like plain [tap][c][n] built on the host, or a vmm_pack_weights format; flip / transpose: the data-gradient operand."""
+        src = wg
+        ci, co = Cin, Cout
+        if transpose:
+            src = wg.permute(1, 0, 2, 3).contiguous()
+            ci, co = Cout, Cin
+        if flip:
+            src = src.flip(2, 3).contiguous()
+        if fmt == 0:
+            return src.permute(2, 3, 1, 0).reshape(k * k * ci, co).contiguous(), ci, co
+        kp = (k * k * ci + 31) // 32 * 32
+        buf = torch.zeros((co + 31) // 32 * 32 * kp, device=gpu)
+        job = (N.PackJob * 1)()
+        j = job[0]
+        j.torch_w, j.packed = src.data_ptr(), buf.data_ptr()
+        j.TH, j.TW, j.C, j.Cp, j.N = k, k, ci, ci, co
+        j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = ci * k * k, k * k, k, 1, 0, 1, 0, 1, 0, fmt
+        tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+        N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, co * kp, 0, _s()), "pack")
+        buf._keep = (src, tab)
+        return buf, ci, co
+
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+
+    def desc(a, wbuf, ci, co, out, hin, win, hv, wv, bias=None, st=1):
+        d = N.ConvDesc()
+        d.a1, d.C1, d.lda1, d.w, d.out, d.ldo = a.data_ptr(), ci, ci, wbuf.data_ptr(), out.data_ptr(), co
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, hin, win, hv, wv, st
+        d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = k, k, -pad, -pad, 1, 1
+        d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = hv, wv, 1, co, 32, 1.0
+        d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
+        d.wrap_h, d.wrap_w = wrap
+        return d
+
+    # forward: the two implicit GEMMs, and the halo kernels where they take the shape
+    ran = set()
+    for name, fn, fmt, tol in (("igemm_f32", lib.vmm_conv_igemm_f32, 0, 3e-6), ("igemm_x3", lib.vmm_conv_igemm_bf16x3, 1, 5e-5),
+                               ("halo_x3", lib.vmm_conv3x3_bf16x3, 2, 5e-5), ("halo_f32", lib.vmm_conv3x3_f32, 4, 3e-6)):
+        if name.startswith("halo") and (k != 3 or stride != 1 or Cin % 32 or Cout % 32):
+            continue
+        wbuf, ci, co = packed(fmt)
+        out = torch.full((nimg * Ho * Wo, Cout), 7.0, device=gpu)
+        rc = fn(C.byref(desc(xr, wbuf, ci, co, out, H, W, Ho, Wo, bias=bg, st=stride)), _s())
+        torch.cuda.synchronize()
+        if name.startswith("halo") and rc == 1:  # flat row tiles: no periodic neighbourhood, nothing launched
+            assert torch.all(out == 7.0)
+            continue
+        assert rc == 0, (name, rc)
+        assert relerr(out.cpu(), ref) < tol, name
+        ran.add(name)
+    assert {"igemm_f32", "igemm_x3"} <= ran
+    if k == 3 and W >= 32 and W % 16 == 0 and H % 16 == 0 and Cin % 32 == 0:
+        assert {"halo_x3", "halo_f32"} <= ran  # the 2-D-tiled instances do wrap
+    if k == 3:
+        # data gradient = the periodic convolution of dY with the reversed, transposed taps
+        dyr = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(gpu)
+        want_dx = xl.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+        for name, fn, fmt, tol in (("igemm_f32", lib.vmm_conv_igemm_f32, 0, 3e-6), ("halo_x3", lib.vmm_conv3x3_bf16x3, 2, 5e-5)):
+            if name == "halo_x3" and (Cin % 32 or Cout % 32):
+                continue
+            wbuf, ci, co = packed(fmt, flip=True, transpose=True)
+            dx = torch.full((nimg * H * W, Cin), 7.0, device=gpu)
+            rc = fn(C.byref(desc(dyr, wbuf, ci, co, dx, H, W, H, W)), _s())
+            torch.cuda.synchronize()
+            if rc == 1 and name == "halo_x3":
+                continue
+            assert rc == 0, (name, rc)
+            assert relerr(dx.cpu(), want_dx) < tol, name
+    # weight and bias gradient (generic kernel: the nine-tap kernel declines periodic layers)
+    if Cin % 4 == 0 and Cout % 4 == 0:
+        dyr = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(gpu)
+        nsplit = 5
+        dw = torch.zeros(K, Cout, device=gpu)
+        db = torch.zeros(Cout, device=gpu)
+        scratch = torch.zeros(nsplit, Cout, device=gpu)
+        dummy = torch.zeros(1, device=gpu)
+        d = desc(xr, dummy, Cin, Cout, dummy, H, W, Ho, Wo, st=stride)
+        assert lib.vmm_conv3x3_wgrad_f32(C.byref(d), dyr.data_ptr(), Cout, dw.data_ptr(), nsplit, db.data_ptr(), scratch.data_ptr(), _s()) == 1
+        rc = lib.vmm_conv_wgrad_f32(C.byref(d), dyr.data_ptr(), Cout, dw.data_ptr(), nsplit, db.data_ptr(), scratch.data_ptr(), _s())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert relerr(dw.cpu(), w.grad.permute(2, 3, 1, 0).reshape(K, Cout)) < 3e-6
+        assert relerr(db.cpu(), b.grad) < 3e-6
+
+
 @pytest.mark.parametrize("nimg,H,W,C1,C2,Cout,nsplit", [(2, 48, 48, 64, 0, 64, 37), (1, 12, 12, 128, 64, 128, 3), (3, 24, 24, 64, 0, 128, 500), (1, 5, 96, 64, 64, 64, 4), (2, 6, 12, 64, 0, 64, 2)])
 def test_conv3x3_weight_gradient_nine_taps(gpu, nimg, H, W, C1, C2, Cout, nsplit):
     """vmm_conv3x3_wgrad_f32 (all nine taps of a 64 x 64 channel block from one LDS patch, exact fp32 MFMA) against torch autograd's weight and

@@ -85,7 +85,7 @@ def test_backward_matches_reference_golden_gradients(gpu):
 
 
 @pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
-                                               ("hires64t22", False)])
+                                               ("hires64t22", False), ("circ64", False), ("circ1d16", False)])
 def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_val):
     kw, sd, model, diff = _setup(cfg_name, gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)
@@ -95,13 +95,13 @@ def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_va
     want_loss, want = _oracle_grads(cfg_name, kw, sd, x0, t, cond, noise, mask_val)
     loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=1.0 if mask_val else 0.0)
     loss.backward()
-    assert abs(float(loss) - want_loss) < 1e-4 * abs(want_loss)
-    got = {k: p.grad for k, p in model.named_parameters()}
+    assert abs(float(loss.detach()) - want_loss) < 1e-4 * abs(want_loss)
+    got = {model._ref_key(k): p.grad for k, p in model.named_parameters()}  # (the periodic variants' state_dict names differ from the parameter tree's)
     bad = _report(got, want)
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
 
 
-@pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", False), ("lagr64", False), ("lagr64", True)])
+@pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", False), ("lagr64", False), ("lagr64", True), ("circ64", False), ("circ64", True)])
 def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     """train_precision = "bf16x3": forward and data gradients on the split-bf16 matrix cores (3x3 data gradients through the halo kernel
     with reversed taps, 1x1 ones through the projection kernel), weight gradients exact fp32.  Checked with the smooth l2 loss: with l1 the
@@ -130,7 +130,7 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
     loss.backward()
     assert abs(float(loss) - float(want_loss)) < 1e-4 * abs(float(want_loss))
-    bad = _report({k: p.grad for k, p in model.named_parameters()}, want)
+    bad = _report({model._ref_key(k): p.grad for k, p in model.named_parameters()}, want)
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
     plan = model.get_plan(B, T, H, W, cond.shape[1], gpu, training=True)
     used = {fn.__name__ for fn, _, _ in plan.bwd_steps}
