@@ -399,6 +399,15 @@ int vmm_ema_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, fl
 int vmm_extract_geometry(const float* videos, int32_t N, int32_t C, int32_t T, int32_t P, int32_t lagrangian, float zero_u_2,
                          int32_t* out, vmm_stream_t stream);
 
+/* ---- training-sample assembly: Dataset.__getitem__ of the reference (vddp.py:1304-1397) for a minibatch gathered by
+ * index from a dataset resident in HBM as decoded bytes.  frames [N][n_fields][f][HW] u8, field 0 = the topology; index [B] = dataset
+ * rows; chan_src [nch]: source field of output channel c (| 0x100: pass the bytes / 255 through, i.e. the topology channel itself);
+ * coef [N][nch][4] = (un_range, un_lo, g_lo, g_range) as fp32:  v = u8 / 255;  v = v * un_range + un_lo;  v = 0 where topology == 0;
+ * out = (v - g_lo) / g_range, each operation rounded to fp32 in that order (bit-exact against the reference's torch expressions).
+ * out [B][nch][T_out][HW] fp32; frames t >= f are zero (cast_num_frames pads, vddp.py:1115), t >= T_out dropped. */
+int vmm_fields_to_samples(const uint8_t* frames, int32_t n_fields, int32_t f, int64_t HW, const int32_t* index, int32_t B,
+                          const int32_t* chan_src, const float* coef, int32_t nch, int32_t T_out, float* out, vmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,3 +132,41 @@ def synth_geometry_videos(seed: int, N: int, T: int, P: int, zero_u_2: float) ->
     v[:, 1] = zero_u_2 + dev + mask[:, None].float() * onehot * bump[:, None]   # material: one frame leaves the band
     v[:, 0, 0] = torch.where(mask, 0.55 + 0.4 * torch.rand(N, P, P, generator=g), 0.45 * torch.rand(N, P, P, generator=g))
     return v
+
+
+# ---------------------------------------------------------------- training-sample assembly
+DATASET_CASES = {  # name -> (seed, reference_frame, N samples, frames in the GIFs, H = W, num_frames, selected_channels, per_frame_cond)
+    "lagr": (21, "lagrangian", 5, 11, 24, 11, [0, 1, 3], True),
+    "lagr_pad": (22, "lagrangian", 3, 7, 16, 11, [0, 1, 2, 3], False),     # fewer frames than asked: zero-padded
+    "lagr_crop": (23, "lagrangian", 3, 11, 20, 6, [1, 3], True),           # more frames than asked: cropped
+    "euler": (24, "eulerian", 4, 11, 24, 11, [0, 1, 2, 3], True),
+    "single": (25, "lagrangian", 4, 1, 32, 1, [0, 1, 2, 3], False),        # one-frame ablation: topology + sigma_22 whatever was selected
+}
+
+
+def synth_dataset(seed: int, frame: str, N: int, f: int, P: int):
+    """Synthetic stand-in for a dataset folder: decoded GIF frames (N, n_fields, f, P, P) uint8 in oracle.dataset_oracle.FIELDS order
+    (topology binary 0 / 255 with some grey pixels, fields using the whole byte range and exact zeros), frame_range_data.csv (N, 8)
+    float64 with mixed signs, stress_strain_data.csv (N, 52) float64.  Deterministic in its arguments."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    nf = 5 if frame == "lagrangian" else 4
+    frames = rng.integers(0, 256, size=(N, nf, f, P, P), dtype=np.uint8)
+    topo = (rng.random((N, 1, P, P)) > 0.4).astype(np.uint8) * 255
+    topo[rng.random((N, 1, P, P)) > 0.97] = 128
+    frames[:, 0] = np.broadcast_to(topo, (N, f, P, P))
+    frames[:, 1:][rng.random((N, nf - 1, f, P, P)) > 0.9] = 0
+    fr = np.zeros((N, 8))
+    if frame == "lagrangian":  # min_u_1, max_u_1, min_u_2, max_u_2, max_s_mises, min_s_22, max_s_22, max_strain_energy
+        fr[:, 0], fr[:, 1] = -rng.random(N) * 0.3, rng.random(N) * 0.25
+        fr[:, 2], fr[:, 3] = -rng.random(N) * 0.21, rng.random(N) * 0.013
+        fr[:, 4] = rng.random(N) * 311.7 + 5
+        fr[:, 5], fr[:, 6] = -rng.random(N) * 123.4 - 1, rng.random(N) * 88.8 + 1
+        fr[:, 7] = rng.random(N) * 3.3
+    else:                      # max_s_mises, min_s_22, max_s_22, max_strain_energy
+        fr[:, 0] = rng.random(N) * 311.7 + 5
+        fr[:, 1], fr[:, 2] = -rng.random(N) * 123.4 - 1, rng.random(N) * 88.8 + 1
+        fr[:, 3] = rng.random(N) * 3.3
+    curves = np.cumsum(rng.random((N, 52)) * 0.7 - 0.2, axis=1)
+    curves[:, 0] = 0.0
+    return frames, fr, curves

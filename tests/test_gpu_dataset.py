@@ -1,0 +1,66 @@
+"""Training-sample assembly on the GPU (videometamaterials_amd.Dataset, vmm_fields_to_samples) against fixtures produced by the
+reference's own Dataset (tests/golden/make_golden_dataset.py) and against the oracle: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from test_dataset_oracle import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(helpers.DATASET_CASES))
+def test_minibatch_assembly_matches_reference_dataset(gpu, name):
+    import videometamaterials_amd as vm
+    frame, N, num_frames, sel, per_frame, frames, fr, curves, gold = load_case(name)
+    ds = vm.Dataset(frames, fr, curves, selected_channels=sel, num_frames=num_frames, per_frame_cond=per_frame, reference_frame=frame, device=gpu)
+    assert len(ds) == N
+    assert np.array_equal(ds.labels.numpy(), gold["labels"])
+    if frame == "lagrangian":
+        assert np.array_equal(ds.zero_u_2.numpy(), gold["zero_u_2"])
+    for k in gold.files:
+        if k.startswith("g_"):
+            assert float(getattr(ds, k[2:])) == float(gold[k])
+    x, lab = ds.batch(list(range(N)))
+    want = np.stack([gold[f"sample{i}"] for i in range(N)])
+    assert x.shape == want.shape and x.dtype == torch.float32
+    assert np.array_equal(x.cpu().numpy(), want)
+    assert np.array_equal(lab.cpu().numpy(), gold["labels"])
+    # any order, repeats, one at a time
+    idx = [N - 1, 0, 0, N // 2]
+    x2, lab2 = ds.batch(torch.tensor(idx))
+    assert np.array_equal(x2.cpu().numpy(), want[idx]) and np.array_equal(lab2.cpu().numpy(), gold["labels"][idx])
+    xi, li = ds[1]
+    assert np.array_equal(xi.cpu().numpy(), want[1]) and np.array_equal(li.cpu().numpy(), gold["labels"][1])
+    with pytest.raises(IndexError):
+        ds.batch([N])
+
+
+@pytest.mark.parametrize("P,frame", [(15, "lagrangian"), (96, "lagrangian"), (7, "eulerian")])
+def test_minibatch_assembly_matches_oracle(gpu, P, frame):
+    """Sizes without fixtures: a pixel count that is not a multiple of four (scalar path), and the full 96 x 96 frames."""
+    import videometamaterials_amd as vm
+    from oracle import dataset_oracle as do
+    N, f = 6, 11
+    frames, fr, curves = helpers.synth_dataset(90 + P, frame, N, f, P)
+    frames, fr = torch.from_numpy(frames), torch.tensor(fr)
+    sel = [0, 1, 3]
+    ds = vm.Dataset(frames, fr, curves, selected_channels=sel, num_frames=11, per_frame_cond=True, reference_frame=frame, device=gpu)
+    g = do.global_ranges(fr, frame)
+    want = torch.stack([do.fields_to_sample(frames[i], fr[i], g, frame, sel, 11) for i in range(N)])
+    x, _ = ds.batch(range(N))
+    assert torch.equal(x.cpu(), want)
+
+
+def test_dataset_rejections(gpu):
+    import videometamaterials_amd as vm
+    frames, fr, curves = helpers.synth_dataset(1, "lagrangian", 2, 3, 8)
+    with pytest.raises(NotImplementedError):
+        vm.Dataset(torch.from_numpy(frames), fr, curves, horizontal_flip=True, reference_frame="lagrangian", device=gpu)
+    with pytest.raises(ValueError):
+        vm.Dataset(torch.from_numpy(frames), fr, curves, reference_frame="eulerian", device=gpu)  # five fields given, four expected
+    with pytest.raises(ValueError):
+        vm.Dataset(torch.from_numpy(frames).float(), fr, curves, reference_frame="lagrangian", device=gpu)

@@ -188,7 +188,7 @@ def test_full_size_training_gradients_match_oracle_autograd(setup, gpu, prec):
     try:
         loss = diff.p_losses(x0.to(gpu), tt.to(gpu), cond=cc.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
         loss.backward()
-        assert abs(float(loss) - float(want_loss)) < 1e-4 * float(want_loss)
+        assert abs(float(loss.detach()) - float(want_loss)) < 1e-4 * float(want_loss)
         live = dict(m.named_parameters())
         bad = []
         for k in names:

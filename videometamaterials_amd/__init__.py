@@ -8,5 +8,6 @@ from .unet3d import Unet3D  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from . import hostmath  # noqa: F401
 from .geometry import extract_geometries  # noqa: F401
+from .dataset import Dataset  # noqa: F401
 
-__all__ = ["Unet3D", "GaussianDiffusion", "hostmath", "extract_geometries"]
+__all__ = ["Unet3D", "GaussianDiffusion", "hostmath", "extract_geometries", "Dataset"]
