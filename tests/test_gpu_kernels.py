@@ -119,7 +119,9 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
 
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 12, 12, 64, 0, 64, False), (2, 1, 24, 24, 32, 32, 128, False), (1, 2, 96, 96, 64, 0, 64, True),
                                                       (1, 1, 12, 12, 512, 512, 256, False), (2, 3, 10, 20, 64, 64, 128, True), (2, 1, 32, 32, 64, 0, 64, True),
-                                                      (2, 1, 48, 48, 32, 32, 128, True), (1, 11, 12, 12, 256, 0, 512, False)])
+                                                      (2, 1, 48, 48, 32, 32, 128, True), (1, 11, 12, 12, 256, 0, 512, False),
+                                                      # more tiles than resident workgroups: the multi-tile kernels (a workgroup walks several tiles)
+                                                      (2, 9, 96, 96, 64, 0, 64, True), (3, 11, 48, 48, 64, 0, 128, True), (1, 17, 96, 96, 32, 32, 64, False)])
 @pytest.mark.parametrize("exact", [False, True])
 def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
     """LDS halo-patch 3x3 kernel (weights in fragment order, fmt 2; exact: its fp32-MFMA variant vmm_conv3x3_f32, fmt 4): image borders, flat row tiles running across frames and samples with a

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 #include "igemm_common.h"
 
 namespace {
@@ -53,7 +54,10 @@ struct C3Args {
   int chunks_per_split;
   int total_rows;                // nimg * H * W
   int cps_shift;                 // TS == 2: log2(channel chunks per sub-pixel)
+  unsigned tpf_magic, tx_magic;  // floor(2^32 / d) + 1 for d = tiles_per_frame, tiles_x: n / d = mulhi(n, magic) for n d < 2^32 -- a run-time
+                                 // division is expanded on the VECTOR unit (v_rcp_iflag) and leaves the wave-uniform tile coordinates in VGPRs
   int n_final;                   // trailing workgroups that finalise the GroupNorm coefficients, one per sample (p.gn_coef), else 0
+  unsigned long long* trace = nullptr;  // VMM_C3_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (16 slots per workgroup)
 };
 
 __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
@@ -150,6 +154,14 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane & 31, lk = lane >> 5;
   const int W = p.Win, H = p.Hin, HW = H * W;
+  auto stamp = [&](int k) {  // measurement aid (outside the step loop only)
+    if (a.trace && tid == 0 && k < 14) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = __builtin_readcyclecounter();
+  };
+  if (a.trace && tid == 0) {
+    a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
+    a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
+  }
+  stamp(0);
   // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
   // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in
   // one L2 instead of being fetched once per XCD.
@@ -192,9 +204,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 
   int img = 0, ty0 = 0, tx0 = 0, g0 = 0;
   if (MODE) {
-    img = mtile / a.tiles_per_frame;
+    img = (int)__umulhi((unsigned)mtile, a.tpf_magic);
     const int t = mtile - img * a.tiles_per_frame;
-    const int tyi = t / a.tiles_x;
+    const int tyi = (int)__umulhi((unsigned)t, a.tx_magic);
     ty0 = tyi * (BM / 16);
     tx0 = (t - tyi * a.tiles_x) * 16;
   } else {
@@ -243,28 +255,31 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       cpix[(TS == 2 && !MODE) ? ps : 0] = s;
     }
   }
+  const int PRc = MODE ? 18 * (BM / 16 + 2) : a.PR;  // 2-D tiles: the patch geometry is a compile-time constant
+  // Straight-line selects, no branches: this runs MAXP times before the first request of a workgroup can leave (measured: with nested ifs --
+  // 110 exec-mask branches in the prologue -- 10k cycles passed between entry and the first patch load, a fifth of the workgroup's life).
   auto src_row = [&](int ps, int sub) -> int {  // recomputed per chunk rather than kept in MAXP registers; sub = 2 sy + sx (TS == 2)
     const int r = (tid >> 3) + ps * 32;
-    int s = -1;
     if (TS == 2 && !MODE) {
-      s = cpix[(TS == 2 && !MODE) ? ps : 0];
-      if (s >= 0) s += (sub >> 1) * 2 * W + (sub & 1);
-      return s;
+      const int s = cpix[(TS == 2 && !MODE) ? ps : 0];
+      return s >= 0 ? s + (sub >> 1) * 2 * W + (sub & 1) : s;
     }
-    if (r < a.PR) {
-      if (MODE) {
-        const int py = r / 18, px = r - py * 18;
-        int h = ty0 - 1 + py, w = tx0 - 1 + px;
-        // periodic padding (vddp.py:163-243; 2-D tiles only, plan_c3): the halo rows / columns that leave the frame come from the opposite border
-        if (p.wrap_h) h = h < 0 ? h + H : (h >= H ? h - H : h);
-        if (p.wrap_w) w = w < 0 ? w + W : (w >= W ? w - W : w);
-        if (h >= 0 && h < H && w >= 0 && w < W) s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : img * HW + h * W + w;
-      } else {
-        const int g = g0 - a.halo + r;
-        if (g >= 0 && g < a.total_rows) s = g;
-      }
+    bool ok = r < PRc;
+    int s;
+    if (MODE) {
+      const int py = r / 18, px = r - py * 18;
+      int h = ty0 - 1 + py, w = tx0 - 1 + px;
+      // periodic padding (vddp.py:163-243; 2-D tiles only, plan_c3): the halo rows / columns that leave the frame come from the opposite border
+      const int hwrap = h + (h < 0 ? H : 0) - (h >= H ? H : 0), wwrap = w + (w < 0 ? W : 0) - (w >= W ? W : 0);
+      h = p.wrap_h ? hwrap : h;
+      w = p.wrap_w ? wwrap : w;
+      ok = ok & ((unsigned)h < (unsigned)H) & ((unsigned)w < (unsigned)W);
+      s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : img * HW + h * W + w;
+    } else {
+      s = g0 - a.halo + r;
+      ok = ok & (s >= 0) & (s < a.total_rows);
     }
-    return s;
+    return ok ? s : -1;
   };
   // which of this thread's patch items are real rows (chunk-invariant).  The loads below are UNCONDITIONAL (padding / beyond-the-patch items
   // re-read row 0 and are zeroed when the patch is stored): a lane-dependent branch around a load splits the step's basic block, and
@@ -313,6 +328,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     const int sr = max(src_row(ps, sub_of(cc)), 0);
     preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
   };
+  // (2-D tiles: the patch geometry is a compile-time constant, so only the last item keeps a row test; everything up to the LDS store is
+  // selects -- the nested ifs this replaces compiled to three exec-mask branches per item, between the arrival of the patch and the barrier)
   auto store_patch = [&](int cc) {
     const int c0 = chan_of(cc);
     const bool xform = !TS && c0 < p.C1 && p.a_mode == 1;
@@ -322,22 +339,23 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       const int r = (tid >> 3) + ps * 32;
-      if (r < a.PR) {
-        f32x4 v = preg[ps];
-        const bool real = (vmask >> ps) & 1u;
-        if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (xform && real) {  // zero padding is applied AFTER the activation (vddp.py:268-285), so padded items stay 0
-          if (!MODE) {  // flat row tiles run across samples
-            const int sr = src_row(ps, 0);
-            const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
-            ca = *reinterpret_cast<const f32x4*>(cf);
-            cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
-          }
-          v.x = igemm::silu_fast(v.x * ca.x + ca.y);
-          v.y = igemm::silu_fast(v.y * ca.z + ca.w);
-          v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
-          v.w = igemm::silu_fast(v.w * cb4.z + cb4.w);
-        }
+      f32x4 v = preg[ps];
+      const bool real = (vmask >> ps) & 1u;
+      if (!MODE && xform) {  // flat row tiles run across samples (wave-uniform condition; padding items read sample 0's coefficients, unused)
+        const int sr = max(src_row(ps, 0), 0);
+        const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
+        ca = *reinterpret_cast<const f32x4*>(cf);
+        cb4 = *reinterpret_cast<const f32x4*>(cf + 4);
+      }
+      if (xform) {  // wave-uniform
+        v.x = igemm::silu_fast(v.x * ca.x + ca.y);
+        v.y = igemm::silu_fast(v.y * ca.z + ca.w);
+        v.z = igemm::silu_fast(v.z * cb4.x + cb4.y);
+        v.w = igemm::silu_fast(v.w * cb4.z + cb4.w);
+      }
+      // zero padding is applied AFTER the activation (vddp.py:268-285): padded items are 0 whatever the transform made of the stand-in row
+      v.x = real ? v.x : 0.f; v.y = real ? v.y : 0.f; v.z = real ? v.z : 0.f; v.w = real ? v.w : 0.f;
+      if ((ps + 1) * 32 <= PRc || r < PRc) {
         if constexpr (F32) {  // exact-fp32 variant: the patch row is 32 floats (the same 128 + 16 bytes as bf16 hi | lo)
           *reinterpret_cast<f32x4*>(&Ph[r * CROW + k4 * 8]) = v;
         } else {
@@ -471,8 +489,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   load_patch(c_begin);
 #pragma unroll
   for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
+  stamp(1);
   store_patch(c_begin);
+  stamp(2);
   __syncthreads();
+  stamp(3);
   load_a(aa[0], tap_of(c_begin, 0), 0);
   for (int cc = c_begin; cc < c_end; ++cc) {
     const bool more = cc + 1 < c_end;
@@ -518,10 +539,12 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(4 + 2 * (cc - c_begin));
     if (more) {
       __syncthreads();  // every wave is done reading the patch of chunk cc
       store_patch(cc + 1);
       __syncthreads();
+      stamp(5 + 2 * (cc - c_begin));
       load_a(aa[0], tap_of(cc + 1, 0), 0);
     }
   }
@@ -623,6 +646,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
           *reinterpret_cast<f32x4*>(orp + j * 32 + 8 * g) = v;
         }
     }
+    stamp(12);
     if (p.gn_part) {
       // GroupNorm statistics of the output (vddp.py:274-279) while it is still in registers: per run of 8 consecutive output channels
       // the sum and the sum of squares over this wave's 64 pixels, combined over the workgroup's waves in LDS and written as this
@@ -729,6 +753,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         }
       }
     }
+    stamp(13);
   }
 }
 
@@ -1409,6 +1434,8 @@ bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
   return true;
 }
 
+inline int* c3_launch_counter() { static int n = 0; return &n; }  // one count over all instances
+
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
@@ -1417,7 +1444,33 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3((unsigned)(mtiles * a.n_tiles + (SPLIT ? 0 : a.n_final)), ksplit), dim3(256), shm, s, a);
+  // VMM_C3_TRACE=<k>: the k-th launch of this process dumps its workgroups' phase stamps to VMM_C3_TRACE_FILE (tools/trace_c3.py reads them)
+  static const int trace_launch = [] { const char* e = getenv("VMM_C3_TRACE"); return e ? atoi(e) : -1; }();
+  static int* launch_no = c3_launch_counter();
+  const unsigned nwg = (unsigned)(mtiles * a.n_tiles + (SPLIT ? 0 : a.n_final));
+  if (trace_launch >= 0 && (*launch_no)++ == trace_launch) {
+    C3Args at = a;
+    const size_t n = (size_t)nwg * ksplit * 16;
+    (void)hipMalloc(&at.trace, n * sizeof(unsigned long long));
+    (void)hipMemsetAsync(at.trace, 0, n * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3(nwg, ksplit), dim3(256), shm, s, at);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), at.trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(at.trace);
+    const char* fn = getenv("VMM_C3_TRACE_FILE");
+    FILE* f = fopen(fn ? fn : "c3_trace.txt", "w");
+    if (f) {
+      fprintf(f, "# Cin %d Cout %d HxW %dx%d mode %d WM %d WN %d nwg %u ksplit %d a_mode %d\n", a.p.C1 + a.p.C2, a.p.Cout, a.p.Hin, a.p.Win, MODE, WM, WN, nwg, ksplit, a.p.a_mode);
+      for (size_t w = 0; w < (size_t)nwg * ksplit; ++w) {
+        for (int k = 0; k < 16; ++k) fprintf(f, "%llu ", h[w * 16 + k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3(nwg, ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -1458,6 +1511,8 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
     a.mode = 1;
     a.tiles_x = d.Win / 16;
     a.tiles_per_frame = a.tiles_x * (d.Hin / TH);
+    a.tpf_magic = (unsigned)(0x100000000ull / (unsigned)a.tiles_per_frame) + 1u;
+    a.tx_magic = (unsigned)(0x100000000ull / (unsigned)a.tiles_x) + 1u;
     a.pitch = 18;
     a.halo = 0;
     a.PR = (TH + 2) * 18;
@@ -1465,6 +1520,7 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   } else {
     a.mode = 0;
     a.tiles_x = a.tiles_per_frame = 1;
+    a.tpf_magic = a.tx_magic = 0;
     a.pitch = d.Win;
     a.halo = d.Win + 1;
     a.PR = BM + 2 * a.halo;
@@ -1626,12 +1682,15 @@ static int s2_plan(const float* x, int32_t ldx, const float* w_frag, const float
     a.mode = 1;
     a.tiles_x = Wt / 16;
     a.tiles_per_frame = a.tiles_x * (Ht / TH);
+    a.tpf_magic = (unsigned)(0x100000000ull / (unsigned)a.tiles_per_frame) + 1u;
+    a.tx_magic = (unsigned)(0x100000000ull / (unsigned)a.tiles_x) + 1u;
     a.pitch = 18;
     a.PR = (TH + 2) * 18;
     mtiles = nimg * a.tiles_per_frame;
   } else {
     a.mode = 0;
     a.tiles_x = a.tiles_per_frame = 1;
+    a.tpf_magic = a.tx_magic = 0;
     a.pitch = Wt;
     a.halo = Wt + 1;
     a.PR = BM + 2 * a.halo;
