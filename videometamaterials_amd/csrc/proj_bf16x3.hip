@@ -58,19 +58,29 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   // ---- stage the row tile: 16 lanes per row, lane l16 owns channels (l16 + 16 i) * 4 .. +3
   {
     const int l16 = tid & 15, r0 = tid >> 4;
+    // Straight-line: every item is loaded (rows past M re-read the last row, channels past K re-read channel 0) and zeroed by a select
+    // afterwards.  With `if (m < M && c < K)` around the loads and a branch per source the staging was ~50 exec-mask branches before the
+    // first barrier (conv3x3_bf16x3.hip, same finding: tools/trace_c3.py).
     f32x4 v[PASSES][IPL];
+    const bool two = p.C2 > 0;  // wave-uniform
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int m = m0 + ps * 16 + r0;
+      const long long mc = min(m, a.M - 1);
 #pragma unroll
       for (int i = 0; i < IPL; ++i) {
         const int c = (l16 + 16 * i) * 4;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (m < a.M && c < K) {
-          t = c < p.C1 ? *reinterpret_cast<const f32x4*>(p.a1 + (long long)m * p.lda1 + c)
-                       : *reinterpret_cast<const f32x4*>(p.a2 + (long long)m * p.lda2 + (c - p.C1));
+        const bool okc = c < K;
+        const int cc = okc ? c : 0;
+        const float* q1 = p.a1 + mc * p.lda1 + min(cc, p.C1 - 4);
+        const float* src = q1;
+        if (two) {  // (uniform branch; the select inside is per lane)
+          const float* q2 = p.a2 + mc * p.lda2 + max(cc - p.C1, 0);
+          src = cc < p.C1 ? q1 : q2;
         }
-        v[ps][i] = t;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        const bool ok = okc & (m < a.M);
+        v[ps][i] = f32x4{ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f};
       }
     }
 #pragma unroll
@@ -85,20 +95,17 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
 #pragma unroll
         for (int i = 0; i < IPL; ++i) {
           const int c = (l16 + 16 * i) * 4;
-          if (c < K) {
-            v[ps][i].x -= mean; v[ps][i].y -= mean; v[ps][i].z -= mean; v[ps][i].w -= mean;
-            q += (v[ps][i].x * v[ps][i].x + v[ps][i].y * v[ps][i].y) + (v[ps][i].z * v[ps][i].z + v[ps][i].w * v[ps][i].w);
-          }
+          const float mk = c < K ? mean : 0.f;  // (padding channels hold 0 and stay 0)
+          v[ps][i].x -= mk; v[ps][i].y -= mk; v[ps][i].z -= mk; v[ps][i].w -= mk;
+          q += (v[ps][i].x * v[ps][i].x + v[ps][i].y * v[ps][i].y) + (v[ps][i].z * v[ps][i].z + v[ps][i].w * v[ps][i].w);
         }
         q = row_sum16(q);
         const float rstd = __builtin_amdgcn_rsqf(q / (float)K + a.eps);
 #pragma unroll
         for (int i = 0; i < IPL; ++i) {
           const int c = (l16 + 16 * i) * 4;
-          if (c < K) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c);
-            v[ps][i].x *= rstd * g.x; v[ps][i].y *= rstd * g.y; v[ps][i].z *= rstd * g.z; v[ps][i].w *= rstd * g.w;
-          }
+          const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + (c < K ? c : 0));  // (padding channels: 0 * whatever)
+          v[ps][i].x *= rstd * g.x; v[ps][i].y *= rstd * g.y; v[ps][i].z *= rstd * g.z; v[ps][i].w *= rstd * g.w;
         }
       }
       unsigned short* row = At + (ps * 16 + r0) * PITCH;
