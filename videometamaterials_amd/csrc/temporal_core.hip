@@ -115,28 +115,29 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
   const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
 
   // this wave's slice of the qkv rows of one tile, in operand layout
+  // Straight-line: every request is issued whatever the lane's frame slot or the tile index (padding slots re-read frame 0, the look-ahead
+  // past the last tile re-reads it) and padding is zeroed by selects.  With a lane-dependent `if` around each of the 20 loads the tile's
+  // requests left one basic block at a time, each behind a wait for the previous one.
   auto load_tile = [&](int pp, QKV& d) {
-    const bool ok = pp < p_end && ft < T;
-    const float* row = a.qkv + (((long long)b * T + (ok ? ft : 0)) * HW + (ok ? pp * 2 + pa : 0)) * a.ldqkv + h * DHd + 4 * lk;
+    const int ppc = min(pp, p_end - 1);
+    const bool ok = ft < T;
+    const float* row = a.qkv + (((long long)b * T + (ok ? ft : 0)) * HW + ppc * 2 + pa) * a.ldqkv + h * DHd + 4 * lk;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {  // elements j = 4g .. 4g+3 of step s: features 16 s + 8 g + 4 lk + 0..3
-        f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4;
-        if (ok) {
-          q4 = *reinterpret_cast<const f32x4*>(row + 16 * s + 8 * g);
-          k4 = *reinterpret_cast<const f32x4*>(row + HID + 16 * s + 8 * g);
-        }
-        d.q[s * 8 + g * 4 + 0] = q4.x; d.q[s * 8 + g * 4 + 1] = q4.y; d.q[s * 8 + g * 4 + 2] = q4.z; d.q[s * 8 + g * 4 + 3] = q4.w;
-        d.k[s * 8 + g * 4 + 0] = k4.x; d.k[s * 8 + g * 4 + 1] = k4.y; d.k[s * 8 + g * 4 + 2] = k4.z; d.k[s * 8 + g * 4 + 3] = k4.w;
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + 16 * s + 8 * g);
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(row + HID + 16 * s + 8 * g);
+        d.q[s * 8 + g * 4 + 0] = ok ? q4.x : 0.f; d.q[s * 8 + g * 4 + 1] = ok ? q4.y : 0.f; d.q[s * 8 + g * 4 + 2] = ok ? q4.z : 0.f; d.q[s * 8 + g * 4 + 3] = ok ? q4.w : 0.f;
+        d.k[s * 8 + g * 4 + 0] = ok ? k4.x : 0.f; d.k[s * 8 + g * 4 + 1] = ok ? k4.y : 0.f; d.k[s * 8 + g * 4 + 2] = ok ? k4.z : 0.f; d.k[s * 8 + g * 4 + 3] = ok ? k4.w : 0.f;
       }
     // v^T: lane = feature lrow, element (s, j) = key row slot(s, lk, j) = (pixel, frame) of the tile
+    const float* vbase = a.qkv + ((long long)b * T * HW + ppc * 2) * a.ldqkv + 2 * HID + h * DHd + lrow;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = slot(e >> 3, lk, e & 7), va = m >> 4, vt = m & 15;
-      float v = 0.f;
-      if (pp < p_end && vt < T) v = a.qkv[(((long long)b * T + vt) * HW + pp * 2 + va) * a.ldqkv + 2 * HID + h * DHd + lrow];
-      d.v[e] = v;
+      const float v = vbase[((long long)min(vt, T - 1) * HW + va) * a.ldqkv];
+      d.v[e] = vt < T ? v : 0.f;
     }
   };
 
