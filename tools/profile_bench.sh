@@ -15,7 +15,7 @@ CMD="python $ROOT/bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-extras"
 if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
   cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $KEEP/${TAG}_kernel_stats.csv 2>/dev/null
-  tail -1 $OUT/stats.log > $KEEP/${TAG}_bench.json
+  grep -m1 "^{\"metric\"" $OUT/stats.log > $KEEP/${TAG}_bench.json
 fi
 # counter passes on the sampling leg only (eager launches), so that the per-kernel figures are those of the launches the roofline object describes;
 # a kernel-trace pass of exactly that command gives the un-profiled duration of the same launch mix (the full command above also runs
