@@ -326,6 +326,11 @@ int vmm_cfg_combine(const float* eps_cond, const float* eps_null, float w, float
 int vmm_lincomb(const float* x, const float* y, const float* z, float a, float b, float c, float d, float* out, int64_t n,
                 vmm_stream_t stream);
 
+/* out_a[i] = out_b[i] = x[i] (n a multiple of 4, pointers 16-byte aligned): classifier-free guidance runs both branches as ONE batch whose
+ * halves carry the same x; everything the network computes before the conditioning enters (the stem and init_temporal_attn, vddp.py:739-742)
+ * is computed once for one half and handed to both */
+int vmm_copy2(const float* x, float* out_a, float* out_b, int64_t n, vmm_stream_t stream);
+
 /* ================================ training path (autograd of the calls above) ================================ */
 /* GroupNorm(+FiLM)+SiLU backward: dz = grad of z = silu(a*h + b'); writes dh (= or +=), accumulates dgamma/dbeta [C],
  * writes dfilm [B][ldfilm] (scale | shift) when given.  stats = (mean, rstd) from vmm_groupnorm_coef. */

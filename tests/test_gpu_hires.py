@@ -28,7 +28,7 @@ def test_hires_22x192x192_paths_agree(gpu):
     rel = float((outs["bf16x3"] - outs["fp32"]).norm() / outs["fp32"].norm())
     assert rel < 2e-4, rel
     m.precision = "bf16x3"
-    plan = m.get_plan(2 * B, T, H, H, 51, gpu)  # guidance runs the conditional and the null branch as one batch
+    plan = m.get_plan(2 * B, T, H, H, 51, gpu, mirrored=True)  # guidance runs the conditional and the null branch as one batch
     used = {fn.__name__ for fn, _, _ in plan.steps}
     assert "vmm_conv3x3_bf16x3" in used and "vmm_linattn_block_bf16x3" in used and "vmm_temporal_attention" in used
 

@@ -82,6 +82,15 @@ __global__ void lincomb_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// one read, two writes (16 bytes per lane): the shared prefix of the two guidance branches handed to both halves of the batch
+__global__ __launch_bounds__(256) void copy2_kernel(const float4* __restrict__ x, float4* __restrict__ a, float4* __restrict__ b, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    a[i] = v;
+    b[i] = v;
+  }
+}
+
 // classifier-free guidance, same association as the reference: null + (cond - null) * w (vddp.py:728)
 __global__ void cfg_combine_kernel(const float* __restrict__ ec, const float* __restrict__ en, float w, float* __restrict__ out,
                                    long long n) {
@@ -232,6 +241,16 @@ extern "C" int vmm_lincomb(const float* x, const float* y, const float* z, float
                            vmm_stream_t stream) {
   const int blocks = (int)min((long long)cdiv(n, 256), 4096LL);
   hipLaunchKernelGGL(lincomb_kernel, dim3(max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, y, z, a, b, c, d, out, (long long)n);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_copy2(const float* x, float* out_a, float* out_b, int64_t n, vmm_stream_t stream) {
+  if (!x || !out_a || !out_b || n < 0 || (n & 3) || (((uintptr_t)x | (uintptr_t)out_a | (uintptr_t)out_b) & 15)) return -1;
+  if (n == 0) return 0;
+  const int blocks = (int)min((long long)cdiv(n / 4, 256), 8192LL);
+  hipLaunchKernelGGL(copy2_kernel, dim3(max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                     reinterpret_cast<float4*>(out_a), reinterpret_cast<float4*>(out_b), (long long)(n / 4));
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -279,7 +279,7 @@ class _GraphedStep:
         n = self.img.numel() // B
         self.k_lo, self.frac = hostmath.quantile_rank(n, diff.dynamic_thres_percentile)
         _, C_, T, H, W = shape
-        self.plan = diff.denoise_fn.get_plan(2 * B, T, H, W, cond_len, dev)
+        self.plan = diff.denoise_fn.get_plan(2 * B, T, H, W, cond_len, dev, mirrored=True)
         self.graph = None
         self.captured = False
 
@@ -287,7 +287,7 @@ class _GraphedStep:
         """Re-pack the plan's operand layouts if the parameters changed since they were packed (the packed buffers have static
         addresses, so a captured graph stays valid)."""
         _, _, T, H, W = self.shape
-        self.plan = self.diff.denoise_fn.get_plan(2 * self.B, T, H, W, self.cond2.shape[1], self.img.device)
+        self.plan = self.diff.denoise_fn.get_plan(2 * self.B, T, H, W, self.cond2.shape[1], self.img.device, mirrored=True)
 
     def set_cond(self, cond):
         self.cond2[: self.B].copy_(cond)
@@ -302,7 +302,8 @@ class _GraphedStep:
         # memset node of this graph was observed to run unordered with its neighbouring kernels -- the captured
         # step consists of kernel nodes only
         torch.add(self.img, 0, out=pl.x_in[:B])
-        torch.add(self.img, 0, out=pl.x_in[B:])
+        if not pl.mirrored:  # (a mirrored plan reads the first half only: both guidance branches see the same x)
+            torch.add(self.img, 0, out=pl.x_in[B:])
         torch.add(self.t, 0, out=pl.time_in[:B])
         torch.add(self.t, 0, out=pl.time_in[B:])
         pl.launch()

@@ -150,6 +150,7 @@ class Plan:
         self.named: Dict[str, Act] = {}  # debug taps (name -> feature map)
         self.shape = None
         self.training = False
+        self.mirrored = False  # built for x[B/2:] == x[:B/2] (guidance): only the first half of x_in is read
         self.arena_floats = 0
 
     # ------------------------------------------------------------------ weights
@@ -249,8 +250,12 @@ def cfg_combine(eps_c: torch.Tensor, eps_n: torch.Tensor, w: float) -> torch.Ten
 
 # ====================================================================================== builder
 class _Builder:
-    def __init__(self, model, B, T, H, W, cond_len, device, bases: Tuple[int, int, int, int], training: bool):
+    def __init__(self, model, B, T, H, W, cond_len, device, bases: Tuple[int, int, int, int], training: bool, mirrored: bool = False):
         self.m = model
+        # mirrored: the caller guarantees x[B/2:] == x[:B/2] (the two branches of classifier-free guidance as one batch, vddp.py:715-728):
+        # what the network computes from x alone -- the stem and init_temporal_attn, before time / conditioning enter -- is computed for
+        # one half and duplicated
+        self.mirrored = bool(mirrored and not training and B % 2 == 0 and _enabled("mirror"))
         self.B, self.T, self.H, self.W, self.cond_len = B, T, H, W, cond_len
         self.device = device
         self.base, self.wbase, self.pgbase, self.gsbase = bases
@@ -1134,6 +1139,9 @@ class _Builder:
 
         # ---- stem
         pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
+        if self.mirrored:  # (the builder's batch is what every emitter sizes its launches and buffers by)
+            self.B = B = B // 2
+            rows0 = B * T * H * W
         xin = Act(self.alloc(rows0 * 4), 4, H, W, rows0 * 4)
         xin.ptr = self.ptr(xin.off)
         self.step(lib.vmm_ncthw_to_rows, (self.ptr(x_in_off), B, Cx, T, H * W, xin.ptr, 4), "ncthw -> rows")
@@ -1161,6 +1169,13 @@ class _Builder:
         x_new = self.softmax_attn_block("init_temporal_attn", x, None, temporal=True)
         self.free_act(x)
         x = x_new
+        if self.mirrored:
+            self.B = B = 2 * B
+            rows0 = B * T * H * W
+            both = self.act(x.C, H, W)
+            self.step(lib.vmm_copy2, (x.ptr, both.ptr, both.ptr + 4 * x.n, x.n), "shared prefix -> both guidance branches", nbytes=12.0 * x.n)
+            self.free_act(x)
+            x = both
         r = x  # kept until the final block (vddp.py:744; no clone needed, every op is out of place)
 
         def stage(side: str, i: int, x1: Act, x2: Optional[Act]) -> Act:
@@ -1318,27 +1333,28 @@ class _Builder:
         return self.plan
 
 
-def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> Plan:
+def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False) -> Plan:
     # plan buffers outlive the caller's autograd mode: never create them as inference tensors
     with torch.inference_mode(False), torch.no_grad():
-        return _build_plan(model, B, T, H, W, cond_len, device, training)
+        return _build_plan(model, B, T, H, W, cond_len, device, training, mirrored)
 
 
-def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool) -> Plan:
+def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool, mirrored: bool = False) -> Plan:
     # pass 1: sizes only (addresses relative to 0); pass 2: identical allocation order over real buffers
     # (fake but non-zero bases, so "pointer or None" decisions are identical in both passes)
-    sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training)
+    sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training, mirrored)
     sizing.build()
     arena = torch.empty(sizing.arena.peak + ALIGN, dtype=torch.float32, device=device)
     wbuf = torch.zeros(sizing.wtop + ALIGN, dtype=torch.float32, device=device)
     pgrad = torch.zeros(sizing.pgtop + ALIGN, dtype=torch.float32, device=device) if training else None
     gscr = torch.zeros(sizing.gstop + ALIGN, dtype=torch.float32, device=device) if training else None
     bases = (arena.data_ptr(), wbuf.data_ptr(), pgrad.data_ptr() if training else 0, gscr.data_ptr() if training else 0)
-    b = _Builder(model, B, T, H, W, cond_len, device, bases, training)
+    b = _Builder(model, B, T, H, W, cond_len, device, bases, training, mirrored)
     plan = b.build()
     assert b.arena.peak == sizing.arena.peak and b.wtop == sizing.wtop and b.pgtop == sizing.pgtop and b.gstop == sizing.gstop
     plan.arena, plan.wbuf, plan.pgrad, plan.gscratch = arena, wbuf, pgrad, gscr
     plan.shape = (B, T, H, W, cond_len)
+    plan.mirrored = b.mirrored
     for off, host in b.job_uploads:
         wbuf[off:off + (host.numel() + 3) // 4].view(torch.uint8)[: host.numel()].copy_(host)
     for off, t in b.consts:

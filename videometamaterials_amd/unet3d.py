@@ -293,11 +293,12 @@ class Unet3D(nn.Module):
                 pl.refresh_weights(self._params_flat())
                 pl.weights_version = ver
 
-    def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False) -> "_plan.Plan":
-        key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision)
+    def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False) -> "_plan.Plan":
+        """mirrored: the caller feeds x[B/2:] == x[:B/2] (guidance: both branches in one batch) -- the conditioning-free prefix is shared."""
+        key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision, bool(mirrored))
         pl = self._plans.get(key)
         if pl is None:
-            pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training)
+            pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training, mirrored=mirrored)
             self._plans[key] = pl
             pl.weights_version = None
         if not (self.static_weights and pl.weights_version is not None):
@@ -355,7 +356,7 @@ class Unet3D(nn.Module):
     def guided_pair(self, x, time, cond):
         """(eps_cond, eps_null) views into the plan's static output (valid until the next call)."""
         B, _, T, H, W = x.shape
-        pl = self.get_plan(2 * B, T, H, W, cond.shape[-1], x.device)
+        pl = self.get_plan(2 * B, T, H, W, cond.shape[-1], x.device, mirrored=True)
         mask = torch.cat([torch.zeros(B, dtype=torch.uint8, device=x.device), torch.ones(B, dtype=torch.uint8, device=x.device)])
         out = pl.run(torch.cat([x, x]), torch.cat([time, time]), torch.cat([cond, cond]), mask)
         return out[:B], out[B:]
