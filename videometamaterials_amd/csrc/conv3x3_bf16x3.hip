@@ -319,14 +319,27 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   // One item of the next chunk's patch.  vmcnt retires in order, so an HBM-latency load blocks every younger weight-fragment wait
   // until it lands: the prefetch is issued one item per k16 step, AFTER that step's weight loads, which leaves it PFB + 1 steps to
   // arrive before anything waits on it (all MAXP items at the chunk top parked the waves for ~40 % of their cycles).
-  auto load_patch_item = [&](int cc, int ps) {
+  // `last` (wave-uniform; unsplit 3 x 3 layers): the tile's last chunk has nothing to prefetch, and the request cannot be skipped without a
+  // branch in the step -- it used to re-read its own patch (41 KB per workgroup for nothing).  It fetches the epilogue's bias pieces instead:
+  // item ps < 8 = the 16 bytes that bias piece (j, g) = (ps >> 2, ps & 3) of this lane needs, so the epilogue finds them in registers.
+  constexpr int NBIAS = (!SPLIT && !TS) ? (MAXP < 8 ? MAXP : 8) : 0;  // bias pieces that ride in the prefetch registers
+  auto load_patch_item = [&](int cc, int ps, bool last) {
     const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
     const int ld = src1 ? p.lda1 : p.lda2;
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
     const int sr = max(src_row(ps, sub_of(cc)), 0);
-    preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
+    const float* q = src + (long long)sr * ld + cb;
+    if (NBIAS) {
+      // (lane offset recomputed here, two instructions: as a loop-invariant 64-bit pointer it cost the 256 x 64 kernel a spill whose reload in
+      // the epilogue waited, vmcnt being in order, for every output store)
+      int lko = lane;
+      asm volatile("" : "+v"(lko));
+      const float* qb = p.bias ? p.bias + (n0 + wn * 64 + 4 * (lko >> 5) + (ps < NBIAS ? (ps >> 2) * 32 + 8 * (ps & 3) : 0)) : p.a1;
+      q = last ? qb : q;
+    }
+    preg[ps] = *reinterpret_cast<const f32x4*>(q);
   };
   // (2-D tiles: the patch geometry is a compile-time constant, so only the last item keeps a row test; everything up to the LDS store is
   // selects -- the nested ifs this replaces compiled to three exec-mask branches per item, between the arrival of the patch and the barrier)
@@ -512,10 +525,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       else load_b(bb[(q + PFB) % NB], ks_of(nxt, q + PFB - NQ));
       if (q == 0) load_coef(nxt);
       if (TS) {  // eight steps for up to eleven patch items: two per step
-        if (2 * q < MAXP) load_patch_item(nxt, 2 * q);
-        if (2 * q + 1 < MAXP) load_patch_item(nxt, 2 * q + 1);
+        if (2 * q < MAXP) load_patch_item(nxt, 2 * q, false);
+        if (2 * q + 1 < MAXP) load_patch_item(nxt, 2 * q + 1, false);
       } else if (q < MAXP) {
-        load_patch_item(nxt, q);
+        load_patch_item(nxt, q, !more);
       }
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
       if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
@@ -603,7 +616,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          bv[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + j * 32 + 8 * g + 4 * lk) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bv[j][g] = !p.bias                ? f32x4{0.f, 0.f, 0.f, 0.f}
+                     : (j * 4 + g < NBIAS) ? preg[(j * 4 + g < NBIAS) ? j * 4 + g : 0]  // (requested during the last chunk's steps)
+                                           : *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + j * 32 + 8 * g + 4 * lk);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
