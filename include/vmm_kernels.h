@@ -65,6 +65,10 @@ typedef struct vmm_conv_desc {
    * w only): taps that leave the frame read the opposite border.  Honoured by the implicit-GEMM kernels, vmm_conv_wgrad_f32 and the 2-D-tiled
    * instances of the 3 x 3 halo kernels (flat row tiles, the persistent kernel, vmm_conv_s2 / vmm_stem_conv return 1 / are not used). */
   int32_t wrap_h, wrap_w;
+  /* > 0: source frame i >= a_img_mod reads frame i - a_img_mod of a1 (the a_coef sample and the output row stay those of frame i): the two
+   * halves of a guidance batch sharing ONE pre-norm tensor that the first convolution computed for half the batch (plan.py, mirrored
+   * plans).  Honoured by the 2-D-tiled unsplit instances of the 3 x 3 halo kernels; every other kernel returns 1 / -1 for it. */
+  int32_t a_img_mod;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;

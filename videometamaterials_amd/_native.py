@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
         ("split_tickets", c_ptr), ("n_tickets", c_i32),
         ("gn_part", c_ptr), ("gn_groups", c_i32),
         ("gn_gamma", c_ptr), ("gn_beta", c_ptr), ("gn_film", c_ptr), ("gn_ldfilm", c_i32), ("gn_eps", c_f32), ("gn_coef", c_ptr),
-        ("wrap_h", c_i32), ("wrap_w", c_i32),
+        ("wrap_h", c_i32), ("wrap_w", c_i32), ("a_img_mod", c_i32),
     ]
 
 

@@ -213,6 +213,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     g0 = mtile * BM;
   }
 
+  // p.a_img_mod (2-D tiles): frames of the batch's second half read the first half's rows of a1 (one pre-norm tensor shared by both guidance
+  // branches); coefficients and output rows stay those of the tile's own frame
+  const int simg = (!TS && MODE && p.a_img_mod > 0 && img >= p.a_img_mod) ? img - p.a_img_mod : img;
   // this lane's two output pixels: patch row of the centre tap and the mask of taps that read inside the image
   int prow[2];
   unsigned tapmask[2];
@@ -274,7 +277,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       h = p.wrap_h ? hwrap : h;
       w = p.wrap_w ? wwrap : w;
       ok = ok & ((unsigned)h < (unsigned)H) & ((unsigned)w < (unsigned)W);
-      s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : img * HW + h * W + w;
+      s = TS == 2 ? img * 4 * HW + (2 * h + (sub >> 1)) * 2 * W + 2 * w + (sub & 1) : simg * HW + h * W + w;
     } else {
       s = g0 - a.halo + r;
       ok = ok & (s >= 0) & (s < a.total_rows);
@@ -1408,7 +1411,7 @@ int launch_pw(const PWArgs& a, hipStream_t s) {
 
 // geometry of the persistent variant: 256-pixel x 64-column tiles for every layer; false when the shape is outside its envelope
 bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
-  if (d.wrap_h || d.wrap_w) return false;  // (periodic padding: the one-tile kernel's 2-D instances)
+  if (d.wrap_h || d.wrap_w || d.a_img_mod) return false;  // (periodic padding, shared source frames: the one-tile kernel's 2-D instances)
   const long long M = (long long)d.nimg * d.Hin * d.Win;
   a.p = d;
   a.n_tiles = d.Cout / 64;
@@ -1553,6 +1556,7 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   if (blocks < 128 && d.split_tickets && d.n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
+  if (d.a_img_mod && (a.mode == 0 || ksplit > 1 || d.a_img_mod < 0 || d.a_img_mod >= d.nimg)) return 1;  // shared source frames: unsplit 2-D tiles only
   // GroupNorm statistics of the output in the epilogue: unsplit 2-D tiles (one frame, hence one sample, per workgroup), groups of whole
   // 8-channel runs, no residual in the output
   // (flat row tiles: a tile may touch two samples, not three)

@@ -559,10 +559,12 @@ class _Builder:
         if out_ptr:
             self.step(self.lib.vmm_colsum_accumulate, (x_ptr, ldx, rows, C_, out_ptr), what + " bias grad", nbytes=4.0 * rows * C_)
 
-    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int, conv_desc: Optional["N.ConvDesc"] = None):
+    def gn_coef(self, h: Act, prefix: str, film_ptr: int, ldfilm: int, conv_desc: Optional["N.ConvDesc"] = None, mirror: bool = False):
         """GroupNorm statistics of h and the fused (scale, shift) coefficients; returns (coef_off, n, ptr, stats_ptr).
         conv_desc: descriptor of the vmm_conv3x3_bf16x3 launch that produced h -- where that kernel can, it leaves per-workgroup
-        partial sums of its output behind (conv3x3 epilogue) and the statistics pass over h is skipped."""
+        partial sums of its output behind (conv3x3 epilogue) and the statistics pass over h is skipped.
+        mirror (self.B is HALF the batch, h was computed for that half and holds for both): coefficients for both halves -- the same
+        statistics under each half's own FiLM rows -- from two coefficient launches over the one set of partial sums."""
         B, G, C_ = self.B, self.G, h.C
         rows_ps = self.T * h.H * h.W
         n_part = 0
@@ -570,7 +572,7 @@ class _Builder:
             conv_desc.gn_part, conv_desc.gn_groups = 1, G  # placeholder pointer for the host-side query
             n_part = int(self.lib.vmm_conv3x3_fuses_gn(C.byref(conv_desc)))
             conv_desc.gn_part = None
-        coef_off = self.alloc(B * C_ * 2)
+        coef_off = self.alloc((2 if mirror else 1) * B * C_ * 2)
         stats_ptr = self.ptr(self.alloc(B * G * 2)) if self.training else 0
         coef_args = (rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"), film_ptr or None, ldfilm,
                      B, C_, G, self.ptr(coef_off), stats_ptr or None)
@@ -587,6 +589,10 @@ class _Builder:
                 conv_desc.gn_coef = self.ptr(coef_off)
             else:
                 self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
+                if mirror:
+                    args2 = (rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
+                             (film_ptr + 4 * B * ldfilm) if film_ptr else None, ldfilm, B, C_, G, self.ptr(coef_off + B * C_ * 2), None)
+                    self.step(self.lib.vmm_groupnorm_coef, (None, *args2, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef (second half)")
             self.free(part_off, B * G * n_part * 2)
         elif rows_ps * (C_ // G) <= GN_DIRECT_MAX and (C_ // G) % 4 == 0:
             # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
@@ -597,7 +603,8 @@ class _Builder:
             self.step(self.lib.vmm_groupnorm_stats_partials, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(part_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
             self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), nslots, None, 0), prefix + ".norm coef")
             self.free(part_off, B * G * nslots * 2)
-        return coef_off, B * C_ * 2, self.ptr(coef_off), stats_ptr
+        assert not mirror or (n_part and not (os.environ.get("VMM_GN_FINAL") == "1"))
+        return coef_off, (2 if mirror else 1) * B * C_ * 2, self.ptr(coef_off), stats_ptr
 
     def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
         B, G, C_ = self.B, self.G, h.C
@@ -610,7 +617,8 @@ class _Builder:
                    B, self.T * h.H * h.W, C_, G, self.ptr(sc), dh_ptr, C_, 0, gnw, gnb, dfilm_ptr or None), prefix + ".norm bwd", nbytes=20.0 * h.n)
         self.tmp_free((sc, n_sc))
 
-    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film: Optional[Tuple[int, int]], tail: Optional[Callable] = None) -> Optional[Act]:
+    def resnet_block(self, name: str, x1: Act, x2: Optional[Act], film: Optional[Tuple[int, int]], tail: Optional[Callable] = None,
+                     mirror_in: bool = False) -> Optional[Act]:
         """ResnetBlock (vddp.py:287-311): conv-GN-FiLM-SiLU, conv-GN-SiLU, + res_conv(x).  film = (ptr, grad ptr).
         tail (inference only): emits the consumer of the block's output fused with the output pass -- called with (h2, coef ptr, residual ptr,
         residual ld) instead of vmm_affine_silu; the block then returns None (its output is never materialised)."""
@@ -621,15 +629,27 @@ class _Builder:
         film_ptr, dfilm_ptr = film if film else (0, 0)
         halo1 = self.halo_ok(x1.C, x2.C if x2 is not None else 0, Cout, H, W)
         w1, gw1 = self.pack_conv(name + ".block1.proj.weight", frag=halo1)
+        halo2 = self.halo_ok(Cout, 0, Cout, H, W)
+        # mirror_in (mirrored plans, the first block): x1's two batch halves are identical, so block1's convolution and its GroupNorm statistics
+        # are too -- time and conditioning enter with the FiLM rows of the coefficients.  The convolution runs on one half; block2's loader
+        # reads that half for both (a_img_mod) under each sample's own coefficients.  Needs the 2-D-tiled unsplit 3 x 3 kernel on both.
+        half = self.B // 2
+        mirror_in = bool(mirror_in and halo1 and halo2 and x2 is None and W >= 32 and W % 16 == 0 and H % 16 == 0
+                         and half * self.T * H * W >= 128 * 256 and os.environ.get("VMM_GN_FINAL") != "1" and _enabled("mirror_conv"))
+        if mirror_in:
+            self.B = half
         h1 = self.act(Cout, H, W)
         d1 = self.conv(a1=x1, a2=x2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
                        Wv=W, what=name + ".block1.proj", halo=halo1)
-        c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout, conv_desc=d1 if halo1 else None)
-        halo2 = self.halo_ok(Cout, 0, Cout, H, W)
+        c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout, conv_desc=d1 if halo1 else None, mirror=mirror_in)
+        if mirror_in:
+            self.B = 2 * half
         w2, gw2 = self.pack_conv(name + ".block2.proj.weight", frag=halo2)
         h2 = self.act(Cout, H, W)
         d2 = self.conv(a1=h1, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
                        a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2)
+        if mirror_in:
+            d2.a_img_mod = half * self.T
         # (h1 and its coefficients are conv2's INPUT: they are released only after the GroupNorm partial sums of conv2's output have
         # their buffer -- conv2 writes those while it is still reading h1, so the two must never share memory)
         c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0, conv_desc=d2 if halo2 else None)
@@ -1179,7 +1199,7 @@ class _Builder:
         r = x  # kept until the final block (vddp.py:744; no clone needed, every op is out of place)
 
         def stage(side: str, i: int, x1: Act, x2: Optional[Act]) -> Act:
-            y1 = self.resnet_block(f"{side}.{i}.0", x1, x2, film[f"{side}.{i}.0"])
+            y1 = self.resnet_block(f"{side}.{i}.0", x1, x2, film[f"{side}.{i}.0"], mirror_in=self.mirrored and side == "downs" and i == 0)
             if x1 is not r:
                 self.free_act(x1)
             if x2 is not None:
