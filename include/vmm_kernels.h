@@ -265,8 +265,8 @@ typedef struct vmm_dense_job {
   int32_t rows, K, N, ldx, ldy, ldadd;
   int32_t act_in, act_out; /* 0 none, 1 SiLU, 2 GELU(erf) */
 } vmm_dense_job;
-/* max_units = max over jobs of N * ceil(rows/8) (one wave per output column and 8-row chunk) */
-int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_units, vmm_stream_t stream);
+/* max_n = max over jobs of N (one wave per job and output column; it reads its weight row once and walks the rows eight at a time) */
+int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_n, vmm_stream_t stream);
 
 /* sinusoidal timestep embedding (vddp.py:139-151): out[b] = [sin(t*f_i) | cos(t*f_i)], f_i = exp(-i*ln(1e4)/(half-1)) */
 int vmm_sinusoidal_embed(const int64_t* t, int32_t B, int32_t dim, float neg_step /* -ln(1e4)/(half-1) */, float* out,

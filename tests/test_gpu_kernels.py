@@ -914,7 +914,8 @@ def test_quantile_matches_torch(gpu):
 def test_dense_batched_and_embeddings(gpu):
     N, lib = _lib()
     g = torch.Generator().manual_seed(10)
-    jobs_spec = [(5, 64, 256, 0, 2, True), (44, 256, 256, 0, 0, False), (4, 256, 1024, 1, 0, True), (3, 1, 32, 0, 1, True)]
+    jobs_spec = [(5, 64, 256, 0, 2, True), (44, 256, 256, 0, 0, False), (4, 256, 1024, 1, 0, True), (3, 1, 32, 0, 1, True), (88, 256, 256, 0, 0, True),
+                 (9, 1024, 40, 2, 1, True), (8, 1100, 12, 0, 0, False), (17, 36, 70, 1, 0, True)]
     arr = (N.DenseJob * len(jobs_spec))()
     keep, refs, outs = [], [], []
     max_units = 0
@@ -928,7 +929,7 @@ def test_dense_batched_and_embeddings(gpu):
         a = arr[i]
         a.x, a.w, a.b, a.y = xg.data_ptr(), wg.data_ptr(), bg.data_ptr() if hasb else None, yg.data_ptr()
         a.rows, a.K, a.N, a.ldx, a.ldy, a.ldadd, a.act_in, a.act_out = rows, K, Nn, K, Nn, Nn, ai, ao
-        max_units = max(max_units, Nn * ((rows + 7) // 8))
+        max_units = max(max_units, Nn)
     tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(gpu)
     N.check(lib.vmm_dense_batched(tab.data_ptr(), len(jobs_spec), max_units, _s()), "dense")
     torch.cuda.synchronize()

@@ -12,37 +12,124 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// one wave per (job, output column o, chunk of 8 rows): W[o,:] is streamed once and reused for the 8 rows
+// One wave per (job, output column o): W[o, :] is read ONCE into registers (16 bytes per lane and 256-wide K chunk) and applied to all rows,
+// eight at a time: per row a lane's four products are summed, the eight row sums of the wave then come out of ONE reduce-scatter butterfly
+// (4 + 2 + 1 exchanges halving the values a lane carries, three plain steps) instead of eight full wave reductions.  The first version -- a
+// wave per (column, 8-row chunk) with dword loads and eight wave_sum calls -- streamed W once per row chunk and spent its time in the
+// reductions: 130 us for the 54 jobs of the FiLM / token-key level (20 MB of weights) against ~10 us now.
 constexpr int DR = 8;
+constexpr int DKC = 4;  // K chunks of 256 kept in registers (K <= 1024 on the vector path; K <= 256 with four columns per wave)
+
+// columns o0 .. o0 + NC - 1 of one job, all rows (see the kernel's comment)
+template <int NC>
+__device__ __forceinline__ void dense_columns(const vmm_dense_job& jb, int o0, int lane) {
+  if (o0 >= jb.N) return;
+  constexpr int KC = NC == 1 ? DKC : 1;
+  const int nkc = (jb.K + 255) >> 8;
+  f32x4 w4[NC][KC];
+  float bv[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) {
+    const int o = min(o0 + n, jb.N - 1);  // (columns past N re-read the last one, never stored)
+    bv[n] = jb.b ? jb.b[o] : 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = c * 256 + lane * 4;
+      w4[n][c] = (c < nkc && k < jb.K) ? *reinterpret_cast<const f32x4*>(jb.w + (long long)o * jb.K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int r0 = 0; r0 < jb.rows; r0 += DR) {
+    float p[NC][DR];
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      const float* xr = jb.x + (long long)min(r0 + r, jb.rows - 1) * jb.ldx;  // (rows past the end re-read the last one, never stored)
+      float acc[NC];
+#pragma unroll
+      for (int n = 0; n < NC; ++n) acc[n] = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int k = c * 256 + lane * 4;
+        if (c < nkc) {  // wave-uniform
+          f32x4 x4 = k < jb.K ? *reinterpret_cast<const f32x4*>(xr + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (jb.act_in) { x4.x = act_apply(x4.x, jb.act_in); x4.y = act_apply(x4.y, jb.act_in); x4.z = act_apply(x4.z, jb.act_in); x4.w = act_apply(x4.w, jb.act_in); }
+#pragma unroll
+          for (int n = 0; n < NC; ++n) {
+            acc[n] = fmaf(x4.x, w4[n][c].x, acc[n]);
+            acc[n] = fmaf(x4.y, w4[n][c].y, acc[n]);
+            acc[n] = fmaf(x4.z, w4[n][c].z, acc[n]);
+            acc[n] = fmaf(x4.w, w4[n][c].w, acc[n]);
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NC; ++n) p[n][r] = acc[n];
+    }
+    const int r = r0 + (((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1));
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      // reduce-scatter over lane bits 5, 4, 3: afterwards p[n][0] of lane L is the sum over the 8 lanes {L ^ (b << 3)} of row 4 L5 + 2 L4 + L3
+#pragma unroll
+      for (int bit = 5, m = 4; bit >= 3; --bit, m >>= 1) {
+        const bool hi = (lane >> bit) & 1;
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          const float send = hi ? p[n][k] : p[n][k + m], keep = hi ? p[n][k + m] : p[n][k];
+          p[n][k] = keep + lane_xor(send, bit);
+        }
+      }
+      p[n][0] += lane_xor(p[n][0], 2);
+      p[n][0] += lane_xor(p[n][0], 1);
+      p[n][0] += lane_xor(p[n][0], 0);
+      if ((lane & 7) == 0 && r < jb.rows && o0 + n < jb.N) {
+        float v = act_apply(p[n][0] + bv[n], jb.act_out);
+        if (jb.add) v += jb.add[(long long)r * jb.ldadd + o0 + n];
+        jb.y[(long long)r * jb.ldy + o0 + n] = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void dense_batched_kernel(const vmm_dense_job* __restrict__ jobs) {
   const vmm_dense_job jb = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int rchunks = (jb.rows + DR - 1) / DR;
-  if (unit >= jb.N * rchunks) return;
-  const int o = unit % jb.N;
-  const int r0 = (unit / jb.N) * DR;
-  float acc[DR];
-#pragma unroll
-  for (int r = 0; r < DR; ++r) acc[r] = 0.f;
-  const float* wrow = jb.w + (long long)o * jb.K;
-  for (int k = lane; k < jb.K; k += 64) {
-    const float wv = wrow[k];
-#pragma unroll
-    for (int r = 0; r < DR; ++r) {
-      if (r0 + r < jb.rows) acc[r] = fmaf(act_apply(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), wv, acc[r]);
-    }
+  const bool vec = (jb.K & 3) == 0 && (jb.ldx & 3) == 0 && jb.K <= 256 * DKC && ((((uintptr_t)jb.w) | ((uintptr_t)jb.x)) & 15) == 0;
+  // many rows (the token key / value layers: 88 rows against 256 x 256 weights, 36 of the 54 jobs of the last level): four columns per wave, so
+  // that the activations -- re-read by every wave of the job, 88 KB each -- cross the L2 -> L1 path a quarter as often (eight columns: fewer, longer waves -- measured slower) (that traffic, 0.77 GB
+  // per step with one column per wave, was what the level's time went to)
+  if (vec && jb.rows > 16 && jb.K <= 256) {
+    dense_columns<4>(jb, (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, lane);
+    return;
   }
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= jb.N) return;
+  if (vec) {
+    dense_columns<1>(jb, o, lane);
+    return;
+  }
+  const float* wrow = jb.w + (long long)o * jb.K;
+  const float bv = jb.b ? jb.b[o] : 0.f;
+  // any K / alignment: dword loads, one wave reduction per row
+  for (int r0 = 0; r0 < jb.rows; r0 += DR) {
+    float acc[DR];
 #pragma unroll
-  for (int r = 0; r < DR; ++r) acc[r] = wave_sum(acc[r]);
-  if (lane == 0) {
-    const float bv = jb.b ? jb.b[o] : 0.f;
+    for (int r = 0; r < DR; ++r) acc[r] = 0.f;
+    for (int k = lane; k < jb.K; k += 64) {
+      const float wv = wrow[k];
 #pragma unroll
-    for (int r = 0; r < DR; ++r) {
-      if (r0 + r < jb.rows) {
-        float v = act_apply(acc[r] + bv, jb.act_out);
-        if (jb.add) v += jb.add[(long long)(r0 + r) * jb.ldadd + o];
-        jb.y[(long long)(r0 + r) * jb.ldy + o] = v;
+      for (int r = 0; r < DR; ++r) {
+        if (r0 + r < jb.rows) acc[r] = fmaf(act_apply(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), wv, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < DR; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < DR; ++r) {
+        if (r0 + r < jb.rows) {
+          float v = act_apply(acc[r] + bv, jb.act_out);
+          if (jb.add) v += jb.add[(long long)(r0 + r) * jb.ldadd + o];
+          jb.y[(long long)(r0 + r) * jb.ldy + o] = v;
+        }
       }
     }
   }
@@ -196,9 +283,9 @@ __global__ void tokens_from_hidden_kernel(const float* __restrict__ hidden, cons
 
 }  // namespace
 
-extern "C" int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_units, vmm_stream_t stream) {
-  if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(dense_batched_kernel, dim3(cdiv(max_units, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+extern "C" int vmm_dense_batched(const vmm_dense_job* jobs_dev, int32_t njobs, int32_t max_n, vmm_stream_t stream) {
+  if (njobs <= 0 || max_n <= 0) return 0;
+  hipLaunchKernelGGL(dense_batched_kernel, dim3(cdiv(max_n, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   VMM_LAUNCH_CHECK();
   return 0;
 }

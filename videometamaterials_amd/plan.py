@@ -953,7 +953,7 @@ class _Builder:
             a.rows, a.K, a.N = j["rows"], j["K"], j["N"]
             a.ldx, a.ldy, a.ldadd = j.get("ldx", j["K"]), j.get("ldy", j["N"]), j.get("ldadd", j["N"])
             a.act_in, a.act_out = j.get("act_in", 0), j.get("act_out", 0)
-            max_units = max(max_units, j["N"] * ((j["rows"] + 7) // 8))
+            max_units = max(max_units, j["N"])
         self.step(self.lib.vmm_dense_batched, (self._upload_table(arr), len(jobs), max_units), what)
 
     def dense_bwd_level(self, jobs: List[dict], what: str) -> None:
