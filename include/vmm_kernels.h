@@ -244,6 +244,11 @@ int vmm_spatial_attention(const float* qkv, int32_t ldqkv, const float* ek, cons
                           int32_t tok_per_frame, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads,
                           int32_t dh, float* lse /* or NULL */, vmm_stream_t stream);
 
+/* the same on the split-bf16 matrix cores (flash-attention forward, one wave per 32 queries; inference: no lse); returns 1 (nothing
+ * launched) unless dh == 32 and ntok <= 32 */
+int vmm_spatial_attention_bf16x3(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t tok_per_frame,
+                                 float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+
 /* ---- K9: spatial linear attention core (vddp.py:367-376), per (b*T frame, head):
  * ctx[d,e] = sum_n softmax_n(k)[d,n] * v[e,n]/HW over n = [tokens | HW pixels];  out[n, e] = sum_d ctx[d,e]*softmax_d(q[n,:])*scale */
 int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T,

@@ -722,7 +722,7 @@ def test_fused_temporal_block(gpu, monkeypatch, version, B, T, HW, ntok, bias_on
     assert relerr(out.cpu() - x.reshape(B * T * HW, Cc), branch) < 5e-5  # on the attention branch alone (the residual would mask errors)
 
 
-@pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0)])
+@pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0), (144, 16, 0), (576, 11, 0), (33, 1, 0)])
 def test_spatial_attention_core(gpu, HW, ntok, per_frame):
     N, lib = _lib()
     g = torch.Generator().manual_seed(7)
@@ -748,6 +748,13 @@ def test_spatial_attention_core(gpu, HW, ntok, per_frame):
                                       out.data_ptr(), hid, B, T, HW, heads, 32, None, _s()), "spatial")
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 5e-6
+    # the matrix-core (split-bf16) flash-attention version used for inference: partial last query / key tiles, token chunk, per-frame token
+    out2 = torch.full((B * T * HW, hid), 7.0, device=gpu)
+    rc = lib.vmm_spatial_attention_bf16x3(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, per_frame,
+                                          out2.data_ptr(), hid, B, T, HW, heads, 32, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(out2.cpu(), ref) < 3e-5
 
 
 def _pack_frag(N, lib, gpu, w2d, fmt):

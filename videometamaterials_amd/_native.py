@@ -127,6 +127,7 @@ SIGNATURES = {
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_spatial_attention_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
     "vmm_proj_bf16x3_res_silu": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr],
     "vmm_proj_f32": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],

@@ -252,6 +252,117 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
   }
 }
 
+
+// ---- mid-level spatial softmax attention per frame (vddp.py:687-689, 491-534) on the split-bf16 matrix cores: a flash-attention forward
+// for dim_head = 32.  One wave per (frame, head, 32 queries); keys in chunks of 32 (the conditioning tokens first, as one more chunk):
+//   s^T = k . q^T          lane = query, accumulator rows = the chunk's keys (each lane half holds 16 of the 32, its partner lane ^ 32 the rest)
+//   online softmax         per lane over its 16 scores + one exchange with the partner; running max / sum, the output rescaled per lane
+//   o^T += v^T . p^T       the probabilities enter as the MFMA's second operand in the accumulator order they already have (slot())
+// The thread-per-query VALU kernel this replaces for inference (vmm_spatial_attention) spent 0.13 ms per step on 2 GFLOP.
+struct SAArgs {
+  const float* qkv; int ldqkv;
+  const float* ek; const float* ev; int ntok, tok_per_frame;
+  float* out; int ldo;
+  int T, HW, heads;
+};
+
+__global__ __launch_bounds__(64) void spatial_attn_mfma_kernel(const SAArgs a) {
+  const int lane = threadIdx.x & 63, lrow = lane & 31, lk = lane >> 5;
+  const int head = blockIdx.y % a.heads, bt = blockIdx.y / a.heads;
+  const int b = bt / a.T, t = bt - b * a.T;
+  const int hid = a.heads * DHd;
+  const long long row0 = (long long)bt * a.HW;
+  const int q0 = blockIdx.x * 32;
+  // this lane's query row (rows past HW re-read the last one; their columns are never stored)
+  const float* qrow = a.qkv + (row0 + min(q0 + lrow, a.HW - 1)) * a.ldqkv + head * DHd + 4 * lk;
+  uint4 qh[2], ql[2];
+  {
+    float q[16];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * g);
+        q[s * 8 + g * 4 + 0] = v.x; q[s * 8 + g * 4 + 1] = v.y; q[s * 8 + g * 4 + 2] = v.z; q[s * 8 + g * 4 + 3] = v.w;
+      }
+    split8v(q, qh[0], ql[0]);
+    split8v(q + 8, qh[1], ql[1]);
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x16 ot = zero16();  // o^T: lane = query, rows = features (r & 3) + 8 (r >> 2) + 4 lk
+  const int ntok = a.ek ? a.ntok : 0;
+  const int nchunks = (a.HW + 31) >> 5;
+  for (int c = ntok ? -1 : 0; c < nchunks; ++c) {  // (wave-uniform trip count; chunk -1 = the conditioning tokens)
+    const bool tok = c < 0;
+    const int nkeys = tok ? ntok : min(32, a.HW - c * 32);
+    // keys of the chunk as rows: lane = key row lrow (clamped), 16 features in operand order
+    const float* krow = tok ? a.ek + ((long long)b * ntok + min(lrow, ntok - 1)) * hid + head * DHd + 4 * lk
+                            : a.qkv + (row0 + min(c * 32 + lrow, a.HW - 1)) * a.ldqkv + hid + head * DHd + 4 * lk;
+    f32x16 st = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float k[8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(krow + 16 * s + 8 * g);
+        k[g * 4 + 0] = v.x; k[g * 4 + 1] = v.y; k[g * 4 + 2] = v.z; k[g * 4 + 3] = v.w;
+      }
+      uint4 kh, kl;
+      split8v(k, kh, kl);
+      st = mfma3(kh, kl, qh[s], ql[s], st);
+    }
+    // values transposed: lane = feature lrow, element e = key slot(e >> 3, lk, e & 7) of the chunk
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kk = min(slot(e >> 3, lk, e & 7), nkeys - 1);
+      v[e] = tok ? a.ev[((long long)b * ntok + kk) * hid + head * DHd + lrow] : a.qkv[(row0 + c * 32 + kk) * a.ldqkv + 2 * hid + head * DHd + lrow];
+    }
+    // scores of this lane's query against keys (r & 3) + 8 (r >> 2) + 4 lk: mask, running max / sum
+    float p[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const bool ok = kk < nkeys && (!tok || !a.tok_per_frame || kk == t);  // tok_per_frame: frame t sees token t only (vddp.py:459-462)
+      p[r] = ok ? st[r] : -INFINITY;
+      mx = fmaxf(mx, p[r]);
+    }
+    mx = fmaxf(mx, lane_xor(mx, 5));
+    const float mn = fmaxf(m, mx);
+    const float alpha = mn == -INFINITY ? 1.f : __expf(m - mn);  // (a chunk with no visible key for this query leaves everything as it is)
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = mn == -INFINITY ? 0.f : __expf(p[r] - mn);
+      sum += p[r];
+    }
+    sum += lane_xor(sum, 5);
+    l = l * alpha + sum;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 vh, vl, ph, pl;
+      // zero the value columns of masked keys: their probability is 0, but a stand-in value could be anything finite only by luck
+      float vs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vs[j] = slot(s, lk, j) < nkeys ? v[8 * s + j] : 0.f;
+      split8v(vs, vh, vl);
+      split8v(p + 8 * s, ph, pl);
+      ot = mfma3(vh, vl, ph, pl, ot);
+    }
+  }
+  if (q0 + lrow < a.HW) {
+    const float inv = __builtin_amdgcn_rcpf(l);
+    float* o = a.out + (row0 + q0 + lrow) * a.ldo + head * DHd + 4 * lk;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(o + 8 * g) = f32x4{ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
+  }
+}
+
 }  // namespace
 
 // qkv rows [(b,t,hw)][768] with q pre-scaled and q, k pre-rotated (the to_qkv projection's epilogue), ek / ev [B][ntok][256] (ek
@@ -281,6 +392,20 @@ extern "C" int vmm_temporal_core_bf16x3(const float* qkv, int32_t ldqkv, const f
     attr_set = true;
   }
   hipLaunchKernelGGL(temporal_core_kernel, dim3((unsigned)(B * a.nsplit)), dim3(512), shm, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// The matrix-core (split-bf16) version of vmm_spatial_attention for inference: same arguments without the log-sum-exp output.  Returns 1
+// (nothing launched) outside its envelope: dim_head 32, at most 32 conditioning tokens.
+extern "C" int vmm_spatial_attention_bf16x3(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t tok_per_frame,
+                                            float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
+  if (dh != DHd || (ldqkv & 3) || (ldo & 3) || HW < 1 || (ek && (ntok < 1 || ntok > 32)) || (ek && tok_per_frame && ntok < T)) return 1;
+  if (B <= 0 || T <= 0) return 0;
+  SAArgs a;
+  a.qkv = qkv; a.ldqkv = ldqkv; a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0; a.tok_per_frame = tok_per_frame;
+  a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.heads = heads;
+  hipLaunchKernelGGL(spatial_attn_mfma_kernel, dim3((unsigned)((HW + 31) / 32), (unsigned)(B * T * heads)), dim3(64), 0, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -894,6 +894,10 @@ class _Builder:
         if temporal:
             self.step(self.lib.vmm_temporal_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
                                                         lse_ptr or None), name + " core", nbytes=4.0 * rows * 4 * hid)
+        elif self.x3 and not self.training and ntok <= 32 and (not (ek and pfc) or ntok >= T) and _enabled("sa_mfma"):
+            # flash-attention forward on the split-bf16 matrix cores (temporal_core.hip)
+            self.step(self.lib.vmm_spatial_attention_bf16x3, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, pfc, o.ptr, hid, B, T, HW, heads, 32),
+                      name + " core", flops=4.0 * rows * heads * 32 * (HW + ntok), nbytes=4.0 * rows * 4 * hid)
         else:
             self.step(self.lib.vmm_spatial_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, pfc, o.ptr, hid, B, T, HW, heads, 32, lse_ptr or None),
                       name + " core", nbytes=4.0 * rows * 4 * hid)
