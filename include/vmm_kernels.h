@@ -255,6 +255,14 @@ int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float* ek, const 
                         int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part /* [B*T*heads*nsplit][dh*dh+2*dh] */,
                         float* ctx /* [B*T*heads][dh*dh] */, float* kstat /* [B*T*heads][2*dh] (max | 1/sum) or NULL */,
                         vmm_stream_t stream);
+/* vmm_linattn_context with pass 1 (the per-slice partial contexts) on the split-bf16 matrix cores: one wave per (frame, head, slice),
+ * operands loaded transposed, online softmax over the positions per key feature (inference); vmm_linattn_partial_bf16x3 is that pass alone
+ * (rows_per_split a multiple of 32, the record layout [dh*dh + 2*dh] of `part`) */
+int vmm_linattn_context_bf16x3(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T,
+                               int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part, float* ctx, float* kstat,
+                               vmm_stream_t stream);
+int vmm_linattn_partial_bf16x3(const float* qkv, int32_t ldqkv, int32_t frames, int32_t HW, int32_t heads, int32_t nsplit,
+                               int32_t rows_per_split, float* part, vmm_stream_t stream);
 int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                       int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* the path vmm_linattn_apply takes for heads % 4 == 0 (returns 1 and launches nothing otherwise): out rows = softmax_d(q) scale . ctx on

@@ -898,6 +898,13 @@ def test_linear_attention_core(gpu, HW, ntok, nsplit):
     torch.cuda.synchronize()
     assert relerr(ctxg.cpu().reshape(B * T, heads, 32, 32), ctx) < 5e-6
     assert relerr(out.cpu(), ref) < 5e-6
+    # pass 1 on the split-bf16 matrix cores (inference): the same context within the split-bf16 tolerance
+    part.fill_(float("nan"))
+    ctx2 = torch.full_like(ctxg, float("nan"))
+    N.check(lib.vmm_linattn_context_bf16x3(qg.data_ptr(), 3 * hid, ekg.data_ptr() if ntok else None, evg.data_ptr() if ntok else None, ntok, B, T, HW, heads,
+                                           32, nsplit, part.data_ptr(), ctx2.data_ptr(), None, _s()), "ctx mfma")
+    torch.cuda.synchronize()
+    assert relerr(ctx2.cpu().reshape(B * T, heads, 32, 32), ctx) < 3e-5
 
 
 def test_quantile_matches_torch(gpu):

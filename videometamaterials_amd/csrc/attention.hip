@@ -315,6 +315,19 @@ extern "C" int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float*
   return 0;
 }
 
+// the same with pass 1 on the split-bf16 matrix cores (temporal_core.hip); inference
+extern "C" int vmm_linattn_context_bf16x3(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B,
+                                          int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part, float* ctx,
+                                          float* kstat, vmm_stream_t stream) {
+  if (dh != DH || (ldqkv & 3) || nsplit < 1) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int rows_per_split = cdiv(cdiv(HW, nsplit), LA_TILE) * LA_TILE;
+  if (const int rc = vmm_linattn_partial_bf16x3(qkv, ldqkv, B * T, HW, heads, nsplit, rows_per_split, part, stream)) return rc;
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * T * heads), dim3(256), 0, s, part, nsplit, ek, ev, ntok, T, HW, heads, ctx, kstat);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                                  int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
   if (dh != DH || (ldqkv & 3) || (ldo & 3) || heads > 64 || 256 % heads) return -1;

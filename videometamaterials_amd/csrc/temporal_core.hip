@@ -363,6 +363,82 @@ __global__ __launch_bounds__(64) void spatial_attn_mfma_kernel(const SAArgs a) {
   }
 }
 
+
+// ---- spatial linear attention, pass 1 (vddp.py:367-373): per (frame, head, slice of positions) the partial context
+//   ctx[d][e] = sum_n exp(k[n][d] - max_n k[:, d]) v[n][e],  max[d],  sum[d]        (the record linattn_merge_kernel totals, attention.hip)
+// on the split-bf16 matrix cores.  One wave per (frame, head, slice); positions in chunks of 32, both operands loaded transposed (lane =
+// feature, elements = positions in accumulator order, 32 lanes reading one row's 128 bytes):  ctx^T[e][d] += v^T[e][n] . p[n][d], so that a
+// lane's accumulators all belong to ONE key feature d and the online-softmax rescale exp(max_old - max_new) is a per-lane factor.
+// The VALU version (a thread per (d, 4 e), 2 x 32 x 32 flops per position on the vector unit) was compute-bound at 3x its HBM time.
+struct LPArgs {
+  const float* qkv; int ldqkv;
+  float* part;
+  int HW, heads, nsplit, rows_per_split;
+};
+
+__global__ __launch_bounds__(64) void linattn_partial_mfma_kernel(const LPArgs a) {
+  const int lane = threadIdx.x & 63, lrow = lane & 31, lk = lane >> 5;
+  const int split = blockIdx.x, fh = blockIdx.y;
+  const int head = fh % a.heads;
+  const long long frame = fh / a.heads;
+  const int hid = a.heads * DHd;
+  const int n_begin = split * a.rows_per_split, n_end = min(n_begin + a.rows_per_split, a.HW);
+  const float* kcol = a.qkv + frame * a.HW * a.ldqkv + hid + head * DHd + lrow;  // k[n][lrow] = kcol[n * ld], v[n][lrow] = kcol[n * ld + hid]
+  float m = -INFINITY, ssum = 0.f;
+  f32x16 ct = zero16();
+  // the next chunk's 32 requests are in flight while this one is reduced (one wave per workgroup: nothing else hides the latency)
+  float kn[16], vn[16];
+  auto load_chunk = [&](int n0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + slot(e >> 3, lk, e & 7);
+      const float* q = kcol + (long long)min(n, n_end - 1) * a.ldqkv;
+      const float kv = q[0], vv = q[hid];
+      kn[e] = n < n_end ? kv : -INFINITY;
+      vn[e] = n < n_end ? vv : 0.f;
+    }
+  };
+  if (n_begin < n_end) load_chunk(n_begin);
+  for (int n0 = n_begin; n0 < n_end; n0 += 32) {
+    float kt[16], vt[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { kt[e] = kn[e]; vt[e] = vn[e]; }
+    load_chunk(min(n0 + 32, n_end - 1));  // (past the end: re-reads the last position, unused)
+    float tm = kt[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tm = fmaxf(tm, kt[e]);
+    tm = fmaxf(tm, lane_xor(tm, 5));
+    const float mn = fmaxf(m, tm);  // (finite: the chunk holds at least one position)
+    const float alpha = __expf(m - mn);
+    float p[16], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      p[e] = __expf(kt[e] - mn);
+      sum += p[e];
+    }
+    sum += lane_xor(sum, 5);
+    ssum = ssum * alpha + sum;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ct[r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 vh, vl, ph, pl;
+      split8v(vt + 8 * s, vh, vl);
+      split8v(p + 8 * s, ph, pl);
+      ct = mfma3(vh, vl, ph, pl, ct);
+    }
+  }
+  // ct[r] = ctx[d = lrow][e = (r & 3) + 8 (r >> 2) + 4 lk]
+  float* pp = a.part + ((long long)fh * a.nsplit + split) * (DHd * DHd + 2 * DHd);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(pp + lrow * DHd + 8 * g + 4 * lk) = f32x4{ct[4 * g], ct[4 * g + 1], ct[4 * g + 2], ct[4 * g + 3]};
+  if (lk == 0) {
+    pp[DHd * DHd + lrow] = m;
+    pp[DHd * DHd + DHd + lrow] = ssum;
+  }
+}
+
 }  // namespace
 
 // qkv rows [(b,t,hw)][768] with q pre-scaled and q, k pre-rotated (the to_qkv projection's epilogue), ek / ev [B][ntok][256] (ek
@@ -406,6 +482,19 @@ extern "C" int vmm_spatial_attention_bf16x3(const float* qkv, int32_t ldqkv, con
   a.qkv = qkv; a.ldqkv = ldqkv; a.ek = ek; a.ev = ev; a.ntok = ek ? ntok : 0; a.tok_per_frame = tok_per_frame;
   a.out = out; a.ldo = ldo; a.T = T; a.HW = HW; a.heads = heads;
   hipLaunchKernelGGL(spatial_attn_mfma_kernel, dim3((unsigned)((HW + 31) / 32), (unsigned)(B * T * heads)), dim3(64), 0, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// pass 1 of vmm_linattn_context on the matrix cores (see linattn_partial_mfma_kernel); rows_per_split a multiple of 32.  attention.hip's
+// vmm_linattn_context_bf16x3 follows it with the merge pass.
+extern "C" int vmm_linattn_partial_bf16x3(const float* qkv, int32_t ldqkv, int32_t frames, int32_t HW, int32_t heads, int32_t nsplit,
+                                          int32_t rows_per_split, float* part, vmm_stream_t stream) {
+  if (nsplit < 1 || rows_per_split < 32 || (rows_per_split & 31) || HW < 1) return -1;
+  if (frames <= 0) return 0;
+  LPArgs a;
+  a.qkv = qkv; a.ldqkv = ldqkv; a.part = part; a.HW = HW; a.heads = heads; a.nsplit = nsplit; a.rows_per_split = rows_per_split;
+  hipLaunchKernelGGL(linattn_partial_mfma_kernel, dim3((unsigned)nsplit, (unsigned)(frames * heads)), dim3(64), 0, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -792,13 +792,17 @@ class _Builder:
                            ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
         if not fuse_ln:
             self.free_act(y)
+        la_mfma = self.x3 and not self.training and _enabled("la_mfma")
+        # (position slices per (frame, head); swept for the matrix-core pass -- one wave per slice -- too: 2048 / 4096 / 8192 / 16384 slices
+        # gave 0.122 / 0.145 / 0.157 / 0.173 ms at the C = 128 level, the partial records and their merge grow with the slices)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
         part_n, ctx_n = B * T * heads * nsplit * LA_PART, B * T * heads * 1024
         part, ctx = self.alloc(part_n), self.alloc(ctx_n)
         kstat_ptr = self.ptr(self.alloc(B * T * heads * 64)) if self.training else 0
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
         ntok = self.ntok if site else 0
-        self.step(self.lib.vmm_linattn_context, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, B, T, HW, heads, 32, nsplit, self.ptr(part), self.ptr(ctx),
+        ctx_fn = self.lib.vmm_linattn_context_bf16x3 if la_mfma else self.lib.vmm_linattn_context
+        self.step(ctx_fn, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, B, T, HW, heads, 32, nsplit, self.ptr(part), self.ptr(ctx),
                                                  kstat_ptr or None), name + " context", nbytes=4.0 * rows * 2 * hid)
         o = self.act(hid, x.H, x.W)
         self.step(self.lib.vmm_linattn_apply, (qkv.ptr, 3 * hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply", nbytes=4.0 * rows * 2 * hid)
