@@ -48,9 +48,10 @@ KERNEL_OF = {"vmm_conv3x3_bf16x3": ("conv3x3_x3_kernel", "conv3x3_pw_kernel"), "
              "vmm_temporal_core_bf16x3": ("temporal_core_kernel",), "vmm_proj_bf16x3": ("proj_x3_kernel",), "vmm_conv_wgrad_f32": ("wgrad_f32_kernel",),
              "vmm_conv3x3_f32": ("conv3x3_x3_kernel", "conv3x3_pw_kernel"), "vmm_proj_f32": ("proj_x3_kernel",),
              "vmm_linattn_context": ("linattn_partial_kernel", "linattn_merge_kernel"), "vmm_linattn_apply": ("linattn_apply_mfma_kernel",),
-             "vmm_spatial_attention": ("spatial_attn_kernel",)}
-ATTENTION_FAMILIES = ("vmm_temporal_block_bf16x3", "vmm_temporal_core_bf16x3", "vmm_linattn_block_bf16x3", "vmm_spatial_attention", "vmm_linattn_context",
-                      "vmm_linattn_apply", "vmm_temporal_attention")
+             "vmm_spatial_attention": ("spatial_attn_kernel",), "vmm_spatial_attention_bf16x3": ("spatial_attn_mfma_kernel",),
+             "vmm_linattn_context_bf16x3": ("linattn_partial_mfma_kernel", "linattn_merge_kernel")}
+ATTENTION_FAMILIES = ("vmm_temporal_block_bf16x3", "vmm_temporal_core_bf16x3", "vmm_linattn_block_bf16x3", "vmm_spatial_attention", "vmm_spatial_attention_bf16x3",
+                      "vmm_linattn_context", "vmm_linattn_context_bf16x3", "vmm_linattn_apply", "vmm_temporal_attention")
 
 
 def _committed(name: str):
