@@ -146,11 +146,22 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
   const int rpa = rm >> 4, rft = rm & 15;
   const int passes = a.C / PC;
 
+  // the residual rows of the first 128-channel pass travel with the tile's q / k / v (requested one tile ahead): loaded where they are added,
+  // behind the head-sum barrier, they were a full HBM round trip on every tile's critical path
+  auto load_res = [&](int pp, f32x4 (&d)[2]) {
+    const long long row = ((long long)b * T + min(rft, T - 1)) * HW + min(pp, p_end - 1) * 2 + rpa;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) d[hf] = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + rcol + hf * 64);
+  };
   QKV nx;
+  f32x4 xn[2];
   load_tile(p_begin, nx);
+  load_res(p_begin, xn);
   for (int pp = p_begin; pp < p_end; ++pp) {
     QKV cu = nx;
+    f32x4 xc[2] = {xn[0], xn[1]};
     load_tile(pp + 1, nx);  // in flight under this tile's MFMAs
+    load_res(pp + 1, xn);
     uint4 qh[2], ql[2];
     split8v(cu.q, qh[0], ql[0]);
     split8v(cu.q + 8, qh[1], ql[1]);
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void temporal_core_kernel(const TCArgs a) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int c = rcol + hf * 64;
-          f32x4 acc = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + ps * PC + c);
+          f32x4 acc = ps == 0 ? xc[hf] : *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + ps * PC + c);
 #pragma unroll
           for (int w = 0; w < HEADS; ++w) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rm) * PC + c);
