@@ -217,6 +217,52 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
             assert T * H * W < (128 if Cout >= 128 else 256)
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_conv3x3_shared_source_frames(gpu, exact):
+    """a_img_mod of the descriptor (mirrored plans): the frames of the batch's second half read the first half's rows of a1 -- one
+    pre-norm tensor shared by both guidance branches -- under each sample's own GroupNorm * FiLM coefficients; against torch on the duplicated
+    tensor.  Kernels that do not honour the field must refuse the descriptor."""
+    N, lib = _lib()
+    kernel, tol = (lib.vmm_conv3x3_f32, 3e-6) if exact else (lib.vmm_conv3x3_bf16x3, 5e-5)
+    g = torch.Generator().manual_seed(21)
+    Bh, T, H, W, Cc = 2, 9, 96, 96, 64  # 2 x Bh samples; enough tiles for the unsplit 2-D instance
+    h1 = torch.randn(Bh, Cc, T, H, W, generator=g)
+    coef = torch.randn(2 * Bh, Cc, 2, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9)
+    b = torch.randn(Cc, generator=g)
+    both = torch.cat([h1, h1], 0)
+    xa = F.silu(both * coef[:, :, 0][:, :, None, None, None] + coef[:, :, 1][:, :, None, None, None])
+    ref = F.conv2d(xa.permute(0, 2, 1, 3, 4).reshape(2 * Bh * T, Cc, H, W), w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    K = 9 * Cc
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros(Cc * K, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cc, Cc, Cc
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cc * 9, 9, 3, 1, 0, 1, 0, 1, 0, 4 if exact else 2
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cc * K, 0, _s()), "pack")
+    hr, bg, cg = rows_of(h1).to(gpu), b.to(gpu), coef.to(gpu)
+    out = torch.full((2 * Bh * T * H * W, Cc), 7.0, device=gpu)
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = hr.data_ptr(), Cc, Cc, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cc
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = 2 * Bh * T, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, W, 1, Cc, 32, 1.0
+    d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
+    d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
+    d.a_img_mod = Bh * T
+    N.check(kernel(C.byref(d), _s()), "conv3x3 shared source")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < tol
+    assert lib.vmm_conv_igemm_f32(C.byref(d), _s()) < 0 and lib.vmm_conv_igemm_bf16x3(C.byref(d), _s()) < 0
+    d.Hin = d.Hv = d.Hout = 12  # (flat row tiles: no shared source frames)
+    d.Win = d.Wv = d.Wout = 12
+    assert kernel(C.byref(d), _s()) == 1
+
+
 def test_conv_concat_residual_and_fused_gn(gpu):
     """two-source input (torch.cat skip), residual epilogue, and the fused GroupNorm+FiLM+SiLU operand transform."""
     N, lib = _lib()
