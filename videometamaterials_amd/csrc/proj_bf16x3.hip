@@ -37,6 +37,9 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { r
 // KSPLIT4: the four waves split the k16 steps of ONE column slice (Cout <= 64 under the 1 x 4 arrangement).  A template parameter, not a
 // run-time branch: with both step loops in one kernel the accumulators live in different registers in the two copies and the K = 256
 // instance spilled 102-109 registers to scratch (every launch of it, whichever path it took).
+#ifndef VMM_PJ_DBG
+#define VMM_PJ_DBG 0
+#endif
 template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   constexpr int BM = WM * 64, BN = WN * 64;
@@ -188,6 +191,10 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
     const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
     // weights = MFMA "A" (rows = output channels), rows of the tile = MFMA "B" (columns); pass-major order
+#if VMM_PJ_DBG == 2   // measurement aid: operands loaded, no matrix work
+    asm volatile("" :: "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1), "v"(ah0), "v"(ah1), "v"(al0), "v"(al1));
+    return;
+#endif
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, al0, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al1, acc[1][0], 0, 0, 0);
@@ -270,7 +277,11 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
               v.z = u.z * cs.z - u.w * cs.w; v.w = u.w * cs.z + u.z * cs.w;
             }
             v.x += rv[g].x; v.y += rv[g].y; v.z += rv[g].z; v.w += rv[g].w;
+#if VMM_PJ_DBG == 1   // measurement aid (tools/build_ab.py proj_bf16x3 -DVMM_PJ_DBG=1): no output stores unless a value is NaN
+            if (v.x != v.x) *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
+#else
             *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
+#endif
           }
         }
       }
