@@ -12,6 +12,9 @@
 // Epilogue: bias, q-scale, rotary (temporal to_qkv, vddp.py:449,456), residual -- as in igemm_common.h.
 // Wave tile 64 rows x 64 columns; workgroup 4 waves as 4x1 / 2x2 / 1x4 so that the LDS tile (rows x (4 K + 16) bytes) stays under
 // 80 KB and two workgroups share a CU (one stages / stores while the other computes).
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 #include "igemm_common.h"
 
 namespace {
@@ -27,6 +30,7 @@ struct PJArgs {
   int M;               // rows
   int n_chunks;        // column chunks of WN*64
   int chunks_per_y;    // column chunks per blockIdx.y
+  unsigned long long* trace = nullptr;  // VMM_PJ_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (18 slots)
   const float* res_coef;  // non-NULL: the residual enters as silu(res * a + b'), (a, b') = res_coef[sample][column][2] (vmm_proj_bf16x3_res_silu)
   int res_rps;            // rows per sample
 };
@@ -57,6 +61,10 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   const int K = p.C1 + p.C2;
   const int nc_begin = blockIdx.y * a.chunks_per_y, nc_end = min(a.n_chunks, nc_begin + a.chunks_per_y);
   if (nc_begin >= nc_end) return;
+  auto stamp = [&](int k) {  // measurement aid (tools/trace_proj.py)
+    if (a.trace && tid == 0 && k < 18) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 18 + k] = __builtin_readcyclecounter();
+  };
+  stamp(0);
 
   // ---- stage the row tile: 16 lanes per row, lane l16 owns channels (l16 + 16 i) * 4 .. +3
   {
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         v[ps][i] = f32x4{ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f};
       }
     }
+    stamp(1);
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       if (p.a_mode == 2) {  // channel LayerNorm: (x - mean) / sqrt(var + eps) * gamma, biased variance
@@ -129,7 +138,9 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       }
     }
   }
+  stamp(2);
   __syncthreads();
+  stamp(3);
 
   // ---- sweep the output columns
   const uint4* wf = reinterpret_cast<const uint4*>(p.w);
@@ -365,9 +376,14 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(4 + 2 * (nc - nc_begin));
     store_chunk(nc);
+    stamp(5 + 2 * (nc - nc_begin));
   }
+  stamp(16);
 }
+
+inline int* pj_launch_counter() { static int n = 0; return &n; }
 
 template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
 int launch_pj(const PJArgs& a, hipStream_t s) {
@@ -380,6 +396,31 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
   }
   const int mt = (int)cdiv(a.M, BM);
   const int ny = (int)cdiv(a.n_chunks, a.chunks_per_y);
+  static const int trace_launch = [] { const char* e = getenv("VMM_PJ_TRACE"); return e ? atoi(e) : -1; }();
+  static int* launch_no = pj_launch_counter();
+  if (trace_launch >= 0 && (*launch_no)++ == trace_launch) {  // measurement aid: dump the workgroups' phase stamps (tools/trace_proj.py)
+    PJArgs at = a;
+    const size_t n = (size_t)mt * ny * 18;
+    (void)hipMalloc(&at.trace, n * sizeof(unsigned long long));
+    (void)hipMemsetAsync(at.trace, 0, n * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, at);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), at.trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(at.trace);
+    const char* fn = getenv("VMM_PJ_TRACE_FILE");
+    FILE* f = fopen(fn ? fn : "pj_trace.txt", "w");
+    if (f) {
+      fprintf(f, "# K %d Cout %d M %d WM %d WN %d KS %d chunks %d per_y %d a_mode %d res %d rot %d\n", a.p.C1 + a.p.C2, a.p.Cout, a.M, WM, WN, KS, a.n_chunks, a.chunks_per_y,
+              a.p.a_mode, a.p.res != nullptr, a.p.rot_ncols);
+      for (size_t w = 0; w < (size_t)mt * ny; ++w) {
+        for (int k = 0; k < 18; ++k) fprintf(f, "%llu ", h[w * 18 + k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    return 0;
+  }
   hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
