@@ -261,7 +261,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   const int PRc = MODE ? 18 * (BM / 16 + 2) : a.PR;  // 2-D tiles: the patch geometry is a compile-time constant
   // Straight-line selects, no branches: this runs MAXP times before the first request of a workgroup can leave (measured: with nested ifs --
   // 110 exec-mask branches in the prologue -- 10k cycles passed between entry and the first patch load, a fifth of the workgroup's life).
-  auto src_row = [&](int ps, int sub) -> int {  // recomputed per chunk rather than kept in MAXP registers; sub = 2 sy + sx (TS == 2)
+  auto src_row_of = [&](int ps, int sub) -> int {  // sub = 2 sy + sx (TS == 2)
     const int r = (tid >> 3) + ps * 32;
     if (TS == 2 && !MODE) {
       const int s = cpix[(TS == 2 && !MODE) ? ps : 0];
@@ -284,6 +284,18 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     }
     return ok ? s : -1;
   };
+  // 3 x 3 layers: the eight threads that stage the same patch rows (channel groups k4 = 0 .. 7 of rows (tid >> 3) + 32 ps) would each compute
+  // all MAXP source rows -- ~35 vector instructions apiece, at the half rate the set-up gets in the sibling's MFMA shadow.  Each computes
+  // two of them (ps = k4 and k4 + 8) and the group exchanges them (consecutive lanes of one wave: ds_bpermute).
+  int srow[TS ? 1 : MAXP];
+  if (!TS) {
+    const int mine0 = src_row_of(tid & 7, 0);
+    const int mine1 = MAXP > 8 ? src_row_of((tid & 7) + 8 < MAXP ? (tid & 7) + 8 : 0, 0) : 0;
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps)
+      srow[TS ? 0 : ps] = __builtin_amdgcn_ds_bpermute(((lane & ~7) | (ps & 7)) << 2, ps < 8 ? mine0 : mine1);
+  }
+  auto src_row = [&](int ps, int sub) -> int { return TS ? src_row_of(ps, sub) : srow[TS ? 0 : ps]; };
   // which of this thread's patch items are real rows (chunk-invariant).  The loads below are UNCONDITIONAL (padding / beyond-the-patch items
   // re-read row 0 and are zeroed when the patch is stored): a lane-dependent branch around a load splits the step's basic block, and
   // then neither the compiler's waits are counted nor can the requests be interleaved with the MFMAs.
