@@ -108,12 +108,21 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(full: bool = False):
+def _cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(quick: bool = False):
     """Oracle (oracle/unet3d_oracle.py + diffusion_oracle.py, the parity-pinned CPU restatement of the reference) on the host cores, fp32,
-    torch CPU with every usable core.  Default = a bounded sample (about a minute): one warm-up forward, then the median of 3 guided
-    p_sample steps and one optimisation step (forward + backward + Adam), all at batch 1 -- every op of the path is per sample, so
-    batch 4 costs 4x (3.9 s at B = 1, 17.9 s at B = 4 for the reference itself).  full = SURVEY 8(d)'s protocol: forward, guided step and
-    training step at batch 4, median of 3 after a warm-up (about 10 minutes)."""
+    torch CPU with every usable core, by BASELINE.md section 3.2's protocol: batch 4, one warm-up, then the median of 3 guided p_sample
+    steps (w = 5: two denoiser passes + x0 / quantile / posterior) and the median of 3 optimisation steps (forward + backward + Adam), about
+    five minutes.  quick = the same at batch 1 scaled x4 (every op of the path is per sample), about a minute: profiling passes only."""
     from oracle import diffusion_oracle as do
     from oracle import unet3d_oracle as uo
     import videometamaterials_amd as vm
@@ -123,7 +132,7 @@ def cpu_baseline(full: bool = False):
     cfg = uo.UnetCfg(**{k: v for k, v in LAGRANGIAN.items()})
     nthreads = usable_cores()
     torch.set_num_threads(nthreads)
-    b = B_PER_GPU if full else 1
+    b = 1 if quick else B_PER_GPU
     g = torch.Generator().manual_seed(1)
     x = torch.randn(b, 3, T, HW, HW, generator=g)
     t = torch.randint(0, TIMESTEPS, (b,), generator=g)
@@ -141,8 +150,7 @@ def cpu_baseline(full: bool = False):
         return out
 
     with torch.no_grad():
-        timed(lambda: uo.unet3d_forward(sd, cfg, x, t, cond, zeros), 1)  # warm-up (thread pool, allocator)
-        fwd = timed(lambda: uo.unet3d_forward(sd, cfg, x, t, cond, zeros), 3) if full else None
+        fwd = timed(lambda: uo.unet3d_forward(sd, cfg, x, t, cond, zeros), 1)  # warm-up (thread pool, allocator); also the forward time
         step = timed(lambda: do.p_sample_step(sch, lambda a, c: uo.unet3d_guided(sd, cfg, a, c, cond, W_GUIDE), x, t, noise), 3)
     sdg = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
     params = [v for v in sdg.values() if v.requires_grad]
@@ -154,19 +162,18 @@ def cpu_baseline(full: bool = False):
         loss.backward()
         opt.step()
 
-    train = timed(train_step, 3 if full else 1)
+    train = timed(train_step, 1 if quick else 4)[0 if quick else 1:]  # (first optimisation step = warm-up of the autograd graph / Adam state)
     step_s, train_s = statistics.median(step), statistics.median(train)
     scale = B_PER_GPU / b  # per-sample cost is batch independent
-    out = {"value": round(B_PER_GPU * T / (TIMESTEPS * step_s * scale), 6), "unit": "frames/s", "cores": nthreads, "kind": "port",
-           "sample": (f"oracle (torch CPU fp32, {nthreads} threads), Lagrangian widths, 11x96x96, batch {b}: 1 warm-up forward, median of {len(step)} guided "
-                      f"p_sample steps (w=5, two denoiser passes + x0 / quantile / posterior) = {step_s:.2f} s, {len(train)} optimisation step(s) "
-                      f"(forward + backward + Adam) = {train_s:.2f} s" + ("" if full else f"; scaled x{int(scale)} to batch {B_PER_GPU} (per-sample cost is batch "
-                      "independent), x256 steps for a full sample")),
-           "guided_step_s": round(step_s * scale, 3), "guided_step_s_samples": [round(v, 3) for v in step], "batch_measured": b,
-           "train_step_s": round(train_s * scale, 3), "train_denoising_steps_per_sec": round(B_PER_GPU / (train_s * scale), 5)}
-    if fwd:
-        out["forward_s"] = round(statistics.median(fwd), 3)
-    return out
+    return {"value": round(B_PER_GPU * T / (TIMESTEPS * step_s * scale), 6), "unit": "frames/s", "cores": nthreads, "cpu_model": _cpu_model_name(),
+            "kind": "port", "kind_detail": "oracle (parity-pinned CPU restatement of the reference; the reference itself cannot travel to the GPU box)",
+            "sample": (f"oracle (torch CPU fp32, {nthreads} threads), Lagrangian widths, 11x96x96, batch {b}: 1 warm-up forward ({fwd[0]:.1f} s), median of "
+                       f"{len(step)} guided p_sample steps (w=5, two denoiser passes + x0 / quantile / posterior) = {step_s:.2f} s, median of {len(train)} "
+                       f"optimisation step(s) (forward + backward + Adam) = {train_s:.2f} s" + (f"; scaled x{int(scale)} to batch {B_PER_GPU}" if quick else "")
+                       + "; x256 steps for a full sample"),
+            "guided_step_s": round(step_s * scale, 3), "guided_step_s_samples": [round(v, 3) for v in step], "batch_measured": b,
+            "train_step_s": round(train_s * scale, 3), "train_step_s_samples": [round(v, 3) for v in train],
+            "train_denoising_steps_per_sec": round(B_PER_GPU / (train_s * scale), 5), "forward_s": round(fwd[0], 3)}
 
 
 def _family_times(meta, ms_lists):
@@ -181,17 +188,19 @@ def _family_times(meta, ms_lists):
     return fam
 
 
-def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precision: str = "fp32", want_roofline: bool = False):
+def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precision: str = "bf16x3", want_roofline: bool = False):
     """One data-parallel optimisation step = q_sample -> denoiser forward -> L1 loss -> hand-written backward -> bucketed RCCL
     all-reduce overlapped with the backward -> multi-tensor Adam (+ EMA every 10 steps); per-GPU batch 4 (model.yaml:2).
-    precision "fp32": exact-fp32 MFMA everywhere (the parity mode, gradients within 1e-3 of the reference);
-    "bf16x3": forward + data gradients on the split-bf16 matrix cores, weight gradients fp32."""
+    precision "bf16x3" (the measured training arithmetic; the reference trains under fp16 autocast, main.py:34): forward, data gradients and
+    the 3 x 3 weight gradients on the split-bf16 matrix cores (fp32-class products, 1.5e-5), the remaining weight gradients exact fp32;
+    "fp32": exact-fp32 MFMA everywhere (the parity mode, gradients within 1e-3 of the reference)."""
     from videometamaterials_amd.dp import DataParallelTrainer
     model.static_weights = False
     model.train_precision = precision
     model.train()
     tr = DataParallelTrainer(diff, train_lr=1e-4)
     assert tr.world == world
+    selfcheck = tr.rccl_selfcheck() if world > 1 else None
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(B_PER_GPU, 3, T, HW, HW, generator=g).to(dev)
     cond = (torch.rand(B_PER_GPU, 11, generator=g) * 2 - 1).to(dev)
@@ -213,11 +222,25 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
         el = float(et.item())
     ms = el / steps * 1e3
     pl = tr._plan
+    comm = None
+    if world > 1:
+        # one more (untimed) step with events on the side stream: how long the buckets keep it busy and how much of that lies inside the
+        # backward window (bucket i starts when the backward marks its tail slice final)
+        tr._reducer.timing = True
+        tr.train_step(x, cond)
+        torch.cuda.synchronize()
+        comm = tr._reducer.last_step_timing()
+        tr._reducer.timing = False
     fl = sum(f for _, f, _ in pl.meta) + sum(f for _, f, _ in pl.bwd_meta)
     out = {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
-           "batch_per_gpu": B_PER_GPU, "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3 forward + data gradients, fp32 weight gradients",
+           "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
+           "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32",
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
            "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if world > 1 else 0}
+    if comm:
+        out.update(allreduce_ms=comm["allreduce_ms"], overlap_frac=comm["overlap_frac"], comm_detail=comm)
+    if selfcheck:
+        out["rccl_selfcheck"] = selfcheck
     if want_roofline and rank == 0:
         # per-launch HIP events over one forward + backward of the training plan (same stream as the launches)
         fwd_ms, bwd_ms = pl.launch_timed(), pl.backward_timed()
@@ -228,7 +251,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
                 a[i] += v[i]
         dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
         objs = {}
-        for k in {dom, "vmm_conv_wgrad_f32", "vmm_conv3x3_f32" if precision == "fp32" else "vmm_conv3x3_bf16x3"} & set(fam):
+        for k in {dom, "vmm_conv_wgrad_f32", "vmm_conv3x3_wgrad_bf16x3", "vmm_conv3x3_f32" if precision == "fp32" else "vmm_conv3x3_bf16x3"} & set(fam):
             t_ms, flops, nbytes, n = fam[k]
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if k.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
             ach = flops / (t_ms * 1e-3) / 1e12
@@ -238,6 +261,48 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
         out["roofline_training"] = {"dominant": dom, "kernels": objs, "event_ms_forward": round(sum(fwd_ms), 2), "event_ms_backward": round(sum(bwd_ms), 2),
                                     "ms_by_kernel_family": {k: round(v[0], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]},
                                     "peak_note": "fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32); split-bf16 kernels: 2500 / 3"}
+    return out
+
+
+HIRES = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+             per_frame_cond=False)
+
+
+def bench_config4(vm, dev, timed_region, world, B: int = 8, frames: int = 22, size: int = 192):
+    """BASELINE.json configs[3]: 22 frames of 192 x 192, batch 8 per GPU, Lagrangian widths with the CNN signal embedding (random init): the
+    denoiser forward and one guided DDPM step (denoiser at batch 16), in the parity arithmetic (fp32 activations, split-bf16 MFMA) and in
+    the bf16 throughput mode when the model has one.  Skipped (None) when less than 40 GB of HBM is free."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40e9:
+        return {"skipped": f"only {free / 1e9:.0f} GB of HBM free"}
+    torch.manual_seed(0)
+    m = vm.Unet3D(**HIRES).to(dev).eval()
+    diff = vm.GaussianDiffusion(m, image_size=size, num_frames=frames, channels=3, timesteps=TIMESTEPS, use_dynamic_thres=True, sampling_timesteps=TIMESTEPS).to(dev)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 3, frames, size, size, generator=g).to(dev)
+    t = torch.randint(0, TIMESTEPS, (B,), generator=g).to(dev)
+    cond = (torch.rand(B, 51, generator=g) * 2 - 1).to(dev)
+    out = {"workload": f"configs[3]: {frames}x{size}x{size}, batch {B} per GPU, dim 64 (random init), CNN signal embedding + 16 tokens", "batch_per_gpu": B}
+    modes = [("bf16x3", "fp32 activations in HBM, split-bf16 MFMA (parity mode, 2e-4 vs the oracle at this size)")]
+    if "bf16" in getattr(vm.Unet3D, "PRECISIONS", ()):
+        modes.append(("bf16", "bf16 throughput mode"))
+    with torch.no_grad():
+        for prec, note in modes:
+            m.precision = prec
+            m._plans.clear()
+            n_f, n_s = 4, 3
+            m(x, t, cond=cond, null_cond_prob=0.0)
+            diff.p_sample(x, t, cond=cond, guidance_scale=W_GUIDE)
+            fwd = timed_region(lambda: [m(x, t, cond=cond, null_cond_prob=0.0) for _ in range(n_f)]) / n_f
+            stp = timed_region(lambda: [diff.p_sample(x, t, cond=cond, guidance_scale=W_GUIDE) for _ in range(n_s)]) / n_s
+            plan = m.get_plan(B, frames, size, size, 51, dev)
+            fl = sum(f for _, f, _ in plan.meta)
+            out[prec] = {"arithmetic": note, "denoiser_forward_ms": round(fwd * 1e3, 2), "forward_TFLOPs": round(fl / fwd / 1e12, 1),
+                         "guided_step_ms": round(stp * 1e3, 2), "sampled_frames_per_sec": round(world * B * frames / (stp * TIMESTEPS), 3),
+                         "launches_per_forward": len(plan.meta), "plan_GB": round(plan.arena_floats * 4 / 1e9, 1)}
+    m._plans.clear()
+    del m, diff
+    torch.cuda.empty_cache()
     return out
 
 
@@ -259,7 +324,8 @@ def main():
     ap.add_argument("--steps", type=int, default=TIMESTEPS, help="guided p_sample steps in the timed region (256 = one full sample)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY 8(d) protocol on the CPU: batch 4, median of 3 (about 10 minutes)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="CPU baseline at batch 1 scaled x4 (a minute) instead of BASELINE.md 3.2's batch-4 protocol")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[3] leg (22 x 192 x 192, batch 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step (profiling passes)")
     ap.add_argument("--detail", action="store_true", help="per-launch timing table on stderr")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
@@ -373,9 +439,18 @@ def main():
     if not args.no_train:
         nst = max(2, min(args.steps, 6))
         train = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, want_roofline=True)
-        # same step with the forward and the data gradients on the split-bf16 matrix cores (extra information, not the parity mode)
-        train["split_bf16_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="bf16x3")
+        # the same step in exact-fp32 arithmetic (the parity mode: every gradient within 1e-3 of the reference's fp32 autograd)
+        train["fp32_parity_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="fp32")
+        model.train_precision = "bf16x3"
         model.eval()
+        for k in [k for k, v in model._plans.items() if v.training]:  # the training plans keep every intermediate (19 GB at batch 4):
+            del model._plans[k]                                       # released before the configs[3] leg
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs[3]: 22 frames x 192 x 192, batch 8 per GPU (the HBM stress configuration)
+    config4 = None
+    if not args.no_config4 and not args.no_extras:
+        config4 = bench_config4(vm, dev, timed_region, world)
 
     if rank == 0:
         # ---- per-kernel-family timing with HIP events on the launch stream (separate, un-timed pass)
@@ -416,7 +491,7 @@ def main():
         families = {k: round(v[0] / reps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(full=args.cpu_baseline_full)
+            cpu = cpu_baseline(quick=args.cpu_baseline_quick)
         out = {
             "metric": "sampled frames/sec (guided DDPM sampling, 11x96x96 video)", "value": round(frames_per_s, 4), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0), "steps": args.steps,
@@ -435,7 +510,8 @@ def main():
             "denoising_sample_steps_per_sec": round(world * B_PER_GPU / (ms_per_step * 1e-3), 3),
             "full_sample": full_sample, "fp32_exact": fp32_exact,
             "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
-            "training": train, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
+            "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
+            "training": train, "config4": config4, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

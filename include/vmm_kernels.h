@@ -120,6 +120,15 @@ int vmm_conv_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy,
  * outside its envelope: no fused operand transform, C1 / C2 / Cout multiples of 64, W a multiple of 24 or W = 12 with an even H. */
 int vmm_conv3x3_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, int32_t nsplit, float* dbias,
                           float* bias_scratch, vmm_stream_t stream);
+/* the 3 x 3 / stride 1 / pad 1 case of vmm_conv_wgrad_bf16x3: all nine taps of a (64 x 64)-channel block per workgroup, x staged once in an
+ * LDS ring of [channel][position] bf16 hi | lo fragments, the horizontal taps as register shifts of the dY fragment (wgrad3x3_bf16x3.hip).
+ * vmm_conv_wgrad_bf16x3 forwards to it (without a workspace); returns 1 (nothing launched) outside its envelope: zero padding, no fused
+ * operand transform, C1 / C2 / Cout multiples of 64.  workspace: vmm_conv3x3_wgrad_bf16x3_workspace(d, lddy) floats (0 = outside the
+ * envelope), contents irrelevant -- the row slices leave partial blocks there and a second launch totals them in a fixed order
+ * (bit-reproducible, and a third of the time fp32 atomics take); NULL: atomics straight into dw_packed / dbias. */
+int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* d, int32_t lddy);
+int vmm_conv3x3_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                             vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
@@ -334,6 +343,17 @@ int vmm_quantile_rows(const float* absx, int32_t B, int64_t n, int64_t k_lo, flo
 int vmm_posterior_step(const float* x0, const float* x, const float* noise, const float* s, const int64_t* t,
                        const float* coef1, const float* coef2, const float* logvar, int32_t clip_mode, float* out, int32_t B,
                        int64_t per_sample, vmm_stream_t stream);
+/* the same step with the noise generated in the kernel (torch.randn_like of vddp.py:960 without the 4.9 MB noise tensor):
+ * Philox4x32-10 keyed by rng_seed[0] (a 64-bit seed in device memory, drawn once per sample() call from torch's device generator), counter
+ * = (element group, t[b], b), Box-Muller normals.  per_sample % 4 == 0, 16-byte aligned pointers.  t_next != NULL: t_next[b] = t[b] - 1
+ * (the next replay of a captured step reads its timestep from there, vmm_step_inputs). */
+int vmm_posterior_step_rng(const float* x0, const float* x, const int64_t* rng_seed, const float* s, const int64_t* t, const float* coef1,
+                           const float* coef2, const float* logvar, int32_t clip_mode, float* out, int32_t B, int64_t per_sample,
+                           int64_t* t_next, vmm_stream_t stream);
+/* inputs of a captured guided step in one launch: t[b] = time_in[b] = time_in[B + b] = t_src[b]; x_in[0 .. n) = img (n floats, a multiple
+ * of 4), and x_in[n .. 2n) = img too when copy_second_half (plans that are not mirrored) */
+int vmm_step_inputs(const float* img, const int64_t* t_src, float* x_in, int32_t copy_second_half, int64_t* t, int64_t* time_in, int32_t B,
+                    int64_t n, vmm_stream_t stream);
 /* sum |a-b| or (a-b)^2 -> out[0] (fp64 accumulate, zeroed by the call); sign/diff for backward (vddp.py:1053-1056) */
 int vmm_loss_reduce(const float* a, const float* b, int64_t n, int32_t squared, double* acc, float* out_mean,
                     vmm_stream_t stream);

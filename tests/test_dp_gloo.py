@@ -59,3 +59,47 @@ def test_bucketed_allreduce_and_sharded_gather_world2():
         assert contiguous, f"rank {rank}: buckets do not tile the buffer"
         assert 2 <= nlaunch <= 7
         assert full == [float(i) for i in range(7)]
+
+
+def _bcast_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import helpers
+        import videometamaterials_amd as vm
+        from videometamaterials_amd.dp import DataParallelTrainer
+        kw, (B, T, H, W), _ = helpers.CONFIGS["lagr16"]
+        torch.manual_seed(10 + rank)  # every rank starts from DIFFERENT weights
+        model = vm.Unet3D(**kw)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.01 * (rank + 1))
+        diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=3, timesteps=16, sampling_timesteps=16, loss_type="l1")
+        before = float(sum(p.double().sum() for p in model.parameters()))
+        tr = DataParallelTrainer(diff)  # constructor broadcast: ONE flat collective per dtype
+        after = float(sum(p.double().sum() for p in tr.unet.parameters()))
+        ema = float(sum(p.double().sum() for p in tr.ema_model.denoise_fn.parameters()))
+        check = tr.rccl_selfcheck()
+        q.put((rank, before, after, ema, check))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_constructor_broadcast_makes_replicas_identical_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 300
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, e0, c0), (_, b1, a1, e1, c1) = res
+    assert b0 != b1                      # the replicas really differed
+    assert a0 == b0 and a1 == b0         # rank 0's weights everywhere, rank 0 unchanged
+    assert e0 == b0 and e1 == b0         # the EMA copies follow
+    assert c0["ok"] and c1["ok"] and c0["sum_of_rank_ids"] == 1.0

@@ -103,3 +103,98 @@ def test_two_rank_training_step_equals_one_process_on_the_concatenated_batch(gpu
     mean_loss = [(a + b) / 2 for a, b in zip(ranks[0]["losses"], ranks[1]["losses"])]
     for a, b in zip(mean_loss, one["losses"]):
         assert abs(a - b) < 1e-4 * abs(b)
+
+
+# ---------------------------------------------------------------------------------------------------------------- sharded sampling
+N_ROWS = 7
+
+
+def _sampler(dev):
+    import videometamaterials_amd as vm
+    from videometamaterials_amd.dp import DataParallelTrainer
+    kw, (B, T, H, W), _ = helpers.CONFIGS[CFG]
+    model = vm.Unet3D(**kw)
+    model.load_state_dict(helpers.synth_state_dict(helpers.load_shapes(CFG)))
+    diff = vm.GaussianDiffusion(model.to(dev).eval(), image_size=H, num_frames=T, channels=3, timesteps=6, loss_type="l1", use_dynamic_thres=True,
+                                sampling_timesteps=6).to(dev)
+    return DataParallelTrainer(diff)
+
+
+def _cond_rows():
+    cl = helpers.CONFIGS[CFG][2]
+    return torch.rand(N_ROWS, cl, generator=torch.Generator().manual_seed(77)) * 2 - 1
+
+
+def _sample_worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        tr = _sampler(dev)
+        # only rank 0 knows the conditioning matrix (the reference broadcasts it from the main process, vddp.py:1745-1749)
+        cond = _cond_rows() if rank == 0 else torch.zeros(N_ROWS, helpers.CONFIGS[CFG][2])
+        out = tr.sample_sharded(cond.to(dev), guidance_scale=3.0, batch=1, use_ema=True, seed=500)
+        assert (out is None) == (rank != 0)
+        if rank == 0:
+            torch.save(out.cpu(), os.path.join(outdir, "sharded.pt"))
+        check = tr.rccl_selfcheck()
+        assert check["ok"], check
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sampling_equals_one_process(gpu, tmp_path):
+    """DataParallelTrainer.sample_sharded itself on two ranks (7 rows: 3 on rank 0, 4 on rank 1 -- the reference's floor(N / P) + remainder
+    rule, vddp.py:1506-1532; pad to the longest shard, all_gather, strip, vddp.py:1848-1868): rank 0's result equals the one-process one."""
+    ctx = mp.get_context("spawn")
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    one = _sampler(gpu).sample_sharded(_cond_rows().to(gpu), guidance_scale=3.0, batch=1, use_ema=True, seed=500).cpu()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    two = torch.load(os.path.join(str(tmp_path), "sharded.pt"))
+    assert two.shape == one.shape == (N_ROWS, 3) + tuple(helpers.CONFIGS[CFG][1][1:])
+    assert torch.isfinite(two).all()
+    assert torch.equal(two, one)
+    assert float((two[0] - two[3]).abs().max()) > 1e-3  # rows differ (a gather that repeated one shard would not)
+
+
+def test_trainer_checkpoint_round_trip_in_the_reference_layout(gpu, tmp_path):
+    """Trainer.save / load (vddp.py:1536-1585): {model, optimizer, steps, ema} with `optimizer` in torch.optim.Adam's format.  Two steps, save,
+    a third step; a fresh trainer that loads the file and takes the same third step ends with the same weights, EMA and moments; and
+    torch.optim.Adam itself accepts the optimizer entry."""
+    tr = _trainer(gpu)
+    for step in range(2):
+        x, cond, t, noise, mask = (a[:2].to(gpu) for a in _inputs(step))
+        tr.train_step(x, cond, t=t, noise=noise, mask=mask)
+    path = os.path.join(str(tmp_path), "checkpoint.pt")
+    tr.save(path)
+    obj = torch.load(path, map_location="cpu")
+    assert set(obj) == {"model", "optimizer", "steps", "ema"} and obj["steps"] == 2
+    names = [n for n, _ in tr.unet.named_parameters()]
+    assert obj["optimizer"]["param_groups"][0]["params"] == list(range(len(names)))
+    some = next(iter(obj["optimizer"]["state"].values()))
+    assert set(some) == {"step", "exp_avg", "exp_avg_sq"} and float(some["step"]) == 2.0
+    # torch's own Adam takes it (what Trainer.load does with the entry)
+    probe = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for p in tr.unet.parameters()], lr=1e-3)
+    probe.load_state_dict(obj["optimizer"])
+    x, cond, t, noise, mask = (a[:2].to(gpu) for a in _inputs(2))
+    tr.train_step(x, cond, t=t, noise=noise, mask=mask)
+    tr2 = _trainer(gpu)
+    tr2.load(path)
+    assert tr2.step == 2
+    tr2.train_step(x, cond, t=t, noise=noise, mask=mask)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(tr.unet.state_dict().items(), tr2.unet.state_dict().items()):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(tr.ema_model.state_dict().items(), tr2.ema_model.state_dict().items()):
+        assert torch.equal(a, b), k
+    for k, (m, v) in tr._moments.items():
+        assert torch.equal(m, tr2._moments[k][0]) and torch.equal(v, tr2._moments[k][1]), k

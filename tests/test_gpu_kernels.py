@@ -554,6 +554,60 @@ def test_conv3x3_weight_gradient_nine_taps(gpu, nimg, H, W, C1, C2, Cout, nsplit
     assert relerr(db.cpu(), b.grad) < 3e-6
 
 
+@pytest.mark.parametrize("nimg,H,W,C1,C2,Cout", [(2, 48, 48, 64, 0, 64), (1, 12, 12, 128, 64, 128), (3, 24, 24, 64, 0, 128), (1, 5, 96, 64, 64, 64),
+                                                 (2, 6, 12, 64, 0, 64), (5, 96, 96, 64, 0, 64), (2, 7, 20, 64, 0, 64), (3, 3, 8, 64, 64, 64),
+                                                 (44, 12, 12, 128, 0, 64)])
+def test_conv3x3_weight_gradient_nine_taps_bf16x3(gpu, nimg, H, W, C1, C2, Cout):
+    """vmm_conv3x3_wgrad_bf16x3 (position-space ring of x fragments, the horizontal taps as register shifts of the dY fragment, split-bf16
+    MFMA) against torch autograd's weight and bias gradients of the same 3 x 3 'same' convolution: frame borders in both directions, widths
+    that are not a multiple of eight (zero columns in position space), frames shorter than the look-ahead, two concatenated sources, more
+    workgroups than chunks, many frames per workgroup."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(160 + W + nimg)
+    Cin = C1 + C2
+    x = torch.randn(nimg, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    dy = torch.randn(nimg, Cout, H, W, generator=g)
+    F.conv2d(x, w, b, padding=1).backward(dy)
+    want_w = w.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout)
+    xr = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    x1g = xr[:, :C1].contiguous().to(gpu)
+    x2g = xr[:, C1:].contiguous().to(gpu) if C2 else None
+    dyg = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = x1g.data_ptr(), C1, C1
+    if C2:
+        d.a2, d.C2, d.lda2 = x2g.data_ptr(), C2, C2
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout = H, W, 1, Cout
+    n_ws = int(lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), Cout))
+    assert n_ws > 0
+    results = []
+    for use_ws in (True, True, False):  # partial blocks + fixed-order reduction (twice: bit-reproducible), then the atomics path
+        dw = torch.zeros(9 * Cin, Cout, device=gpu)
+        db = torch.zeros(Cout, device=gpu)
+        ws = torch.full((n_ws,), float("nan"), device=gpu) if use_ws else None
+        rc = lib.vmm_conv3x3_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(), ws.data_ptr() if use_ws else None, _s())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert relerr(dw.cpu(), want_w) < 5e-5
+        assert relerr(db.cpu(), b.grad) < 3e-6
+        for t in range(9):  # every tap on its own (a wrong shift at a border hides in the norm of the whole tensor)
+            assert relerr(dw[t * Cin:(t + 1) * Cin].cpu(), want_w[t * Cin:(t + 1) * Cin]) < 1e-4, t
+        results.append((dw, db))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    # through the generic entry point too (forwards here), and a periodic layer is declined
+    dw2 = torch.zeros_like(dw)
+    assert lib.vmm_conv_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw2.data_ptr(), 4, None, None, _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(dw2.cpu(), want_w) < 5e-5
+    d.wrap_w = 1
+    assert lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0
+    assert lib.vmm_conv3x3_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), None, None, _s()) == 1
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -101,11 +101,14 @@ def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_va
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
 
 
-@pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", False), ("lagr64", False), ("lagr64", True), ("circ64", False), ("circ64", True)])
+@pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", "f32"), ("lagr64", "f32"), ("lagr64", "x3"), ("lagr64", "x3+generic"), ("circ64", "f32"),
+                                               ("circ64", "x3+generic")])
 def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     """train_precision = "bf16x3": forward and data gradients on the split-bf16 matrix cores (3x3 data gradients through the halo kernel
-    with reversed taps, 1x1 ones through the projection kernel), weight gradients exact fp32.  Checked with the smooth l2 loss: with l1 the
-    loss gradient is a sign, and a 1e-5 forward difference flips enough of them to dominate the comparison (hence fp32 stays the default)."""
+    with reversed taps, 1x1 ones through the projection kernel); weight gradients: "x3" (the default) = the 3 x 3 layers on the nine-tap
+    split-bf16 kernel, the others exact fp32; "f32" = all exact fp32; "x3+generic" = the generic split-bf16 kernel for the others (and
+    for the periodic 3 x 3 layers, which the nine-tap kernel declines).  Checked with the smooth l2 loss: with l1 the loss gradient is a
+    sign, and a 1e-5 forward difference flips enough of them to dominate the comparison."""
     import videometamaterials_amd as vm
     from oracle import diffusion_oracle as do
     from oracle import unet3d_oracle as uo
@@ -115,7 +118,8 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     model.load_state_dict(sd, strict=True)
     model = model.to(gpu)
     model.train_precision = "bf16x3"
-    model.use_x3_wgrad = x3_wgrad  # opt-in split-bf16 weight-gradient kernel (wgrad_bf16x3.hip); default: exact fp32 weight gradients
+    model.use_x3_wgrad = x3_wgrad != "f32"
+    model.use_x3_wgrad_generic = x3_wgrad == "x3+generic"
     diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=256, loss_type="l2", sampling_timesteps=256).to(gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)
     g = torch.Generator().manual_seed(5)
@@ -135,7 +139,8 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     plan = model.get_plan(B, T, H, W, cond.shape[1], gpu, training=True)
     used = {fn.__name__ for fn, _, _ in plan.bwd_steps}
     assert "vmm_proj_bf16x3" in used and ("vmm_conv3x3_bf16x3" in used or cfg_name == "lagr16")
-    assert ("vmm_conv_wgrad_bf16x3" in used) == x3_wgrad and ("vmm_conv_wgrad_f32" in used) != x3_wgrad
+    assert ("vmm_conv_wgrad_bf16x3" in used) == (x3_wgrad == "x3+generic") and ("vmm_conv_wgrad_f32" in used) == (x3_wgrad != "x3+generic")
+    assert ("vmm_conv3x3_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name == "lagr64")
 
 
 def test_trainer_step_matches_torch_adam(gpu):

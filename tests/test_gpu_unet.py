@@ -133,19 +133,70 @@ def test_sampling_loops_match_reference_golden(gpu):
 
 
 def test_graphed_sampler_equals_eager(gpu):
-    """The hipGraph-captured step must be the same arithmetic as the eager step (same device RNG stream)."""
-    model = make_model("lagr16", gpu)
+    """The hipGraph-captured step is the same arithmetic as its own launch list run eagerly: the step noise comes from the in-kernel Philox
+    generator keyed once per sample() call from torch's device generator (vmm_posterior_step_rng), so both runs see the same noise and the
+    results are bit-identical; the torch-RNG step (p_sample with randn_like, use_graph = False) draws other numbers: same statistics."""
     _, (B, T, H, W), _ = helpers.CONFIGS["lagr16"]
     _, _, cond = (v.to(gpu) for v in helpers.synth_inputs("lagr16"))
-    diff = _diffusion(model, T, H, 6, 6)
-    outs = []
-    for use_graph in (True, False):
-        diff.use_graph = use_graph
+    outs = {}
+    for mode in (True, "eager", False):
+        diff = _diffusion(make_model("lagr16", gpu), T, H, 6, 6)
+        diff.use_graph = mode
         torch.manual_seed(5)
-        torch.cuda.manual_seed(5)
-        outs.append(diff.sample(cond=cond, guidance_scale=5.0).cpu())
-    assert outs[0].shape == (B, 3, T, H, W) and torch.isfinite(outs[0]).all()
-    # the two runs consume the Philox stream differently (graph capture registers its own offset), so compare statistics
-    assert abs(float(outs[0].mean()) - float(outs[1].mean())) < 0.1
-    key = next(iter(diff._graph_cache.values()))
-    assert key.graph is not None, "graph capture fell back to eager launches"
+        outs[mode] = diff.sample(cond=cond, guidance_scale=5.0).cpu()
+        if mode is True:
+            st = next(iter(diff._graph_cache.values()))
+            assert st.graph is not None, "graph capture fell back to eager launches"
+            torch.manual_seed(5)
+            assert torch.equal(diff.sample(cond=cond, guidance_scale=5.0).cpu(), outs[True])  # replays only: the capture consumed no randomness
+            torch.manual_seed(6)
+            assert not torch.equal(diff.sample(cond=cond, guidance_scale=5.0).cpu(), outs[True])  # another seed, another sample
+    assert outs[True].shape == (B, 3, T, H, W) and torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs["eager"])
+    assert abs(float(outs[True].mean()) - float(outs[False].mean())) < 0.1
+    assert abs(float(outs[True].std()) - float(outs[False].std())) < 0.1
+
+
+def test_in_kernel_step_noise_is_standard_normal(gpu):
+    """vmm_posterior_step_rng with x0 = x = 0: out = sigma[t] * noise.  Philox4x32-10 + Box-Muller: moments of a standard normal, no
+    correlation between neighbouring elements, samples or timesteps, reproducible for a key, different for another; t = 0 adds no noise."""
+    import ctypes as C
+    from videometamaterials_amd import _native as N
+    from videometamaterials_amd import hostmath
+    lib = N.lib()
+    B, n = 3, 1 << 20
+    sch = {k: v.to(gpu) for k, v in hostmath.schedule_buffers(256).items()}
+    zeros = torch.zeros(B, n, device=gpu)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def draw(key, tt):
+        rng = torch.tensor([key, 0], dtype=torch.long, device=gpu)
+        t = torch.tensor(tt, dtype=torch.long, device=gpu)
+        out = torch.empty(B, n, device=gpu)
+        tn = torch.zeros(B, dtype=torch.long, device=gpu)
+        N.check(lib.vmm_posterior_step_rng(zeros.data_ptr(), zeros.data_ptr(), rng.data_ptr(), None, t.data_ptr(), sch["posterior_mean_coef1"].data_ptr(),
+                                           sch["posterior_mean_coef2"].data_ptr(), sch["posterior_log_variance_clipped"].data_ptr(), 1, out.data_ptr(), B, n,
+                                           tn.data_ptr(), s), "posterior")
+        torch.cuda.synchronize()
+        assert tn.tolist() == [v - 1 for v in tt]
+        sig = torch.exp(0.5 * sch["posterior_log_variance_clipped"][t])[:, None]
+        return (out / sig).double().cpu()
+
+    z = draw(1234, [200, 200, 7])
+    assert torch.isfinite(z).all()
+    for b in range(B):
+        v = z[b]
+        assert abs(float(v.mean())) < 5e-3 and abs(float(v.var()) - 1) < 1e-2
+        assert abs(float((v ** 3).mean())) < 2e-2 and abs(float((v ** 4).mean()) - 3) < 5e-2
+        for lag in (1, 2, 3, 4):
+            assert abs(float((v[:-lag] * v[lag:]).mean())) < 5e-3
+    assert abs(float((z[0] * z[1]).mean())) < 5e-3 and abs(float((z[0] * z[2]).mean())) < 5e-3  # other sample / other timestep
+    assert torch.equal(draw(1234, [200, 200, 7]), z)
+    assert abs(float((draw(1235, [200, 200, 7])[0] * z[0]).mean())) < 5e-3
+    rng = torch.tensor([9, 0], dtype=torch.long, device=gpu)
+    t0 = torch.zeros(B, dtype=torch.long, device=gpu)
+    out = torch.empty(B, n, device=gpu)
+    N.check(lib.vmm_posterior_step_rng(zeros.data_ptr(), zeros.data_ptr(), rng.data_ptr(), None, t0.data_ptr(), sch["posterior_mean_coef1"].data_ptr(),
+                                       sch["posterior_mean_coef2"].data_ptr(), sch["posterior_log_variance_clipped"].data_ptr(), 1, out.data_ptr(), B, n, None, s),
+            "posterior")
+    assert float(out.abs().max()) == 0.0

@@ -20,8 +20,10 @@ torch.manual_seed(0)
 model = vm.Unet3D(**bench.LAGRANGIAN).to(dev)
 diff = vm.GaussianDiffusion(model, image_size=bench.HW, num_frames=bench.T, channels=3, timesteps=bench.TIMESTEPS, loss_type="l1",
                             use_dynamic_thres=True, sampling_timesteps=bench.TIMESTEPS).to(dev)
-if os.environ.get("VMM_X3_WGRAD"):
-    model.use_x3_wgrad = True  # opt-in split-bf16 weight-gradient kernel (default: the exact-fp32 one in both modes)
+if os.environ.get("VMM_X3_WGRAD") == "0":
+    model.use_x3_wgrad = False  # exact-fp32 weight gradients everywhere (default in bf16x3 mode: the 3 x 3 layers on the nine-tap split-bf16 kernel)
+if os.environ.get("VMM_X3_WGRAD") == "generic":
+    model.use_x3_wgrad_generic = True  # the generic split-bf16 kernel for the remaining shapes (measured slower than fp32)
 print(bench.bench_training(vm, model, diff, dev, None, 1, 0, steps, precision))
 
 if os.environ.get("VMM_TRAIN_DETAIL"):

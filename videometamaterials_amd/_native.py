@@ -86,6 +86,8 @@ SIGNATURES = {
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_conv3x3_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv3x3_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],
@@ -159,12 +161,14 @@ SIGNATURES = {
     "vmm_predict_x0": [c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_ptr],
     "vmm_quantile_rows": [c_ptr, c_i32, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
     "vmm_posterior_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr],
+    "vmm_posterior_step_rng": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr, c_ptr],
+    "vmm_step_inputs": [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_ptr],
     "vmm_loss_reduce": [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_cfg_combine": [c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr],
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
-RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

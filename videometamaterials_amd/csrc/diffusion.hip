@@ -72,6 +72,79 @@ __global__ void posterior_step_kernel(const float* __restrict__ x0, const float*
 #undef BODY
 }
 
+// ---- step noise generated in the kernel (torch.randn_like of vddp.py:960): Philox4x32-10, key = the sample() call's 64-bit seed,
+// counter = (group of four elements: low / high word, timestep, sample).  One block call gives four uniform words = four standard normals
+// (two Box-Muller pairs).  The noise tensor (4.9 MB per step at 4 x 3 x 11 x 96 x 96) is never written or read.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& z0, float& z1) {
+  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 bits, never 0
+  const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+// posterior step with in-kernel noise; thread = four consecutive elements (per_sample % 4 == 0, 16-byte accesses).  Block (0, b) also leaves
+// t_next[b] = t[b] - 1 for the next replay of a captured step (t itself stays untouched while other blocks read it).
+__global__ __launch_bounds__(256) void posterior_step_rng_kernel(const float* __restrict__ x0, const float* __restrict__ x, const int64_t* __restrict__ rng,
+                                                                 const float* __restrict__ sthr, const int64_t* __restrict__ t,
+                                                                 const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                 const float* __restrict__ logvar, int clip_mode, float* __restrict__ out,
+                                                                 long long per_sample, int64_t* __restrict__ t_next) {
+  const int64_t tb = t[blockIdx.y];
+  const float k1 = c1[tb], k2 = c2[tb];
+  const float sig = (tb == 0) ? 0.f : expf(0.5f * logvar[tb]);
+  const float s = (clip_mode == 2) ? sthr[blockIdx.y] : 1.0f;
+  const unsigned long long seed = (unsigned long long)rng[0];
+  const long long base = (long long)blockIdx.y * per_sample, n4 = per_sample >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x0 + base + 4 * i), b = *reinterpret_cast<const f32x4*>(x + base + 4 * i);
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)tb, blockIdx.y, (unsigned)seed, (unsigned)(seed >> 32), r);
+    f32x4 z;
+    box_muller(r[0], r[1], z[0], z[1]);
+    box_muller(r[2], r[3], z[2], z[3]);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float c = a[j];
+      if (clip_mode) c = fminf(fmaxf(c, -s), s) / s;
+      o[j] = (k1 * c + k2 * b[j]) + sig * z[j];
+    }
+    *reinterpret_cast<f32x4*>(out + base + 4 * i) = o;
+  }
+  if (t_next && blockIdx.x == 0 && threadIdx.x == 0) t_next[blockIdx.y] = tb - 1;
+}
+
+// inputs of a captured guided step, one launch (they were four torch elementwise kernels and a fill): t[b] = t_src[b]; time_in[b] (and
+// time_in[B + b] when two_halves) = t_src[b]; x_in[first half] (and the second half unless the plan is mirrored) = img
+__global__ __launch_bounds__(256) void step_inputs_kernel(const float* __restrict__ img, const int64_t* __restrict__ t_src, float* __restrict__ x_in,
+                                                          int copy_second, int64_t* __restrict__ t, int64_t* __restrict__ time_in, int B, long long n4) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 < B) {
+    const int64_t v = t_src[i0];
+    t[i0] = v;
+    time_in[i0] = v;
+    time_in[B + i0] = v;
+  }
+  for (long long i = i0; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(img)[i];
+    reinterpret_cast<f32x4*>(x_in)[i] = v;
+    if (copy_second) reinterpret_cast<f32x4*>(x_in)[n4 + i] = v;
+  }
+}
+
 __global__ void lincomb_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, float a, float b,
                                float c, float d, float* __restrict__ out, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -233,6 +306,26 @@ extern "C" int vmm_posterior_step(const float* x0, const float* x, const float* 
   if (clip_mode == 2 && !s) return -1;
   hipLaunchKernelGGL(posterior_step_kernel, ew_grid(per_sample, B), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0, x, noise, s, t, coef1,
                      coef2, logvar, clip_mode, out, (long long)per_sample);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_posterior_step_rng(const float* x0, const float* x, const int64_t* rng_seed, const float* s, const int64_t* t, const float* coef1,
+                                      const float* coef2, const float* logvar, int32_t clip_mode, float* out, int32_t B, int64_t per_sample,
+                                      int64_t* t_next, vmm_stream_t stream) {
+  if ((clip_mode == 2 && !s) || !rng_seed || (per_sample & 3) || (((uintptr_t)x0 | (uintptr_t)x | (uintptr_t)out) & 15)) return -1;
+  hipLaunchKernelGGL(posterior_step_rng_kernel, ew_grid(per_sample / 4, B), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0, x, rng_seed, s, t, coef1, coef2,
+                     logvar, clip_mode, out, (long long)per_sample, t_next);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_step_inputs(const float* img, const int64_t* t_src, float* x_in, int32_t copy_second_half, int64_t* t, int64_t* time_in, int32_t B,
+                               int64_t n, vmm_stream_t stream) {
+  if (!img || !t_src || !x_in || !t || !time_in || B < 1 || (n & 3) || (((uintptr_t)img | (uintptr_t)x_in) & 15)) return -1;
+  const int blocks = (int)min((long long)cdiv(n / 4, 256), 4096LL);
+  hipLaunchKernelGGL(step_inputs_kernel, dim3(max(blocks, cdiv(B, 256))), dim3(256), 0, (hipStream_t)stream, img, t_src, x_in, copy_second_half, t, time_in, B,
+                     (long long)(n / 4));
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -18,6 +18,7 @@
 // the gathered loads are not covered.  Kept as the starting point for a deeper-pipelined version.
 // Row slices (blockIdx.z) combine with fp32 atomics, as in the fp32 kernel; the bias gradient (column sums of dY) leaves as one
 // partial row per slice.
+#include <stdlib.h>
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
@@ -224,6 +225,13 @@ extern "C" int vmm_conv_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, i
                                      float* bias_scratch, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   if (nsplit < 1 || (dbias && !bias_scratch) || (d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || (lddy & 3)) return -1;
+  {  // the 3 x 3 "same" convolutions: nine taps per workgroup, x staged once (wgrad3x3_bf16x3.hip); VMM_WGRAD3X3=0 keeps this kernel (A/B runs)
+    static const bool use3 = [] { const char* e = getenv("VMM_WGRAD3X3"); return !e || e[0] != '0'; }();
+    if (use3) {
+      const int rc = vmm_conv3x3_wgrad_bf16x3(dp, dy, lddy, dw_packed, dbias, nullptr, stream);
+      if (rc != 1) return rc;
+    }
+  }
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   if (M <= 0) return 0;
   const int Ktot = d.KH * d.KW * (d.C1 + d.C2);

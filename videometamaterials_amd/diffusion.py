@@ -177,6 +177,9 @@ class GaussianDiffusion(nn.Module):
         try:
             if self.use_graph and noises is None and cond is not None and guidance_scale != 1:
                 stepper = self._graphed_step(tuple(shape), cond, float(guidance_scale))
+                if self.use_graph == "eager" and not stepper.captured:
+                    stepper.captured = True  # the step's launch list without the capture (same kernels, same in-kernel noise)
+                stepper.reseed()
             for j, i in enumerate(reversed(range(0, self.num_timesteps))):
                 if stepper is not None:
                     img = stepper(img, i)
@@ -267,13 +270,14 @@ class _GraphedStep:
         B = shape[0]
         self.B = B
         self.img = torch.zeros(shape, device=dev)
-        self.t = torch.zeros(B, dtype=torch.long, device=dev)
-        self.t2 = torch.zeros(2 * B, dtype=torch.long, device=dev)
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)       # the step's timestep (every kernel of the step reads it)
+        self.t_src = torch.zeros(B, dtype=torch.long, device=dev)   # where the step takes it from: the previous step left t - 1 here
+        self.t_expect = None                                        # host mirror of t_src (None = unknown)
+        self.rng = torch.zeros(2, dtype=torch.long, device=dev)     # [0] = Philox key of the step noise (vmm_posterior_step_rng)
         self.cond2 = torch.zeros(2 * B, cond_len, device=dev)
         self.mask2 = torch.cat([torch.zeros(B, dtype=torch.uint8, device=dev), torch.ones(B, dtype=torch.uint8, device=dev)])
         self.x0 = torch.empty(shape, device=dev)
         self.ax0 = torch.empty(shape, device=dev)
-        self.noise = torch.empty(shape, device=dev)
         self.s = torch.empty(B, device=dev)
         self.scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=dev)
         n = self.img.numel() // B
@@ -295,17 +299,18 @@ class _GraphedStep:
         self.plan.cond_in.copy_(self.cond2)
         self.plan.mask_in.copy_(self.mask2)
 
+    def reseed(self):
+        """A new Philox key for the step noise, drawn from torch's device generator (so torch.manual_seed governs it, and no host
+        synchronisation): once per sample() call."""
+        torch.randint(-2 ** 62, 2 ** 62, (1,), dtype=torch.long, device=self.rng.device, out=self.rng[:1])
+
     def _body(self):
         d, lib, B = self.diff, N.lib(), self.B
         pl = self.plan
-        # elementwise kernels, not copy_(): a same-dtype contiguous copy_ is a hipMemcpyAsync, i.e. a memcpy NODE once captured, and a
-        # memset node of this graph was observed to run unordered with its neighbouring kernels -- the captured
-        # step consists of kernel nodes only
-        torch.add(self.img, 0, out=pl.x_in[:B])
-        if not pl.mirrored:  # (a mirrored plan reads the first half only: both guidance branches see the same x)
-            torch.add(self.img, 0, out=pl.x_in[B:])
-        torch.add(self.t, 0, out=pl.time_in[:B])
-        torch.add(self.t, 0, out=pl.time_in[B:])
+        # kernel nodes only (a same-dtype contiguous copy_ would be a memcpy NODE once captured, and a memset node of this graph was
+        # observed to run unordered with its neighbouring kernels, DESIGN.md section 6); no torch kernels either: inputs in one launch
+        N.check(lib.vmm_step_inputs(_ptr(self.img), _ptr(self.t_src), _ptr(pl.x_in), 0 if pl.mirrored else 1, _ptr(self.t), _ptr(pl.time_in), B,
+                                    self.img.numel(), _stream()), "vmm_step_inputs")
         pl.launch()
         n = self.img.numel() // B
         dyn = d.use_dynamic_thres
@@ -313,10 +318,10 @@ class _GraphedStep:
                                    _ptr(d.sqrt_recipm1_alphas_cumprod), _ptr(self.x0), _ptr(self.ax0) if dyn else None, B, n, _stream()), "vmm_predict_x0")
         if dyn:
             N.check(lib.vmm_quantile_rows(_ptr(self.ax0), B, n, self.k_lo, self.frac, 1.0, _ptr(self.s), _ptr(self.scratch), _stream()), "vmm_quantile_rows")
-        self.noise.normal_()
-        N.check(lib.vmm_posterior_step(_ptr(self.x0), _ptr(self.img), _ptr(self.noise), _ptr(self.s), _ptr(self.t), _ptr(d.posterior_mean_coef1),
-                                       _ptr(d.posterior_mean_coef2), _ptr(d.posterior_log_variance_clipped), 2 if dyn else 1, _ptr(self.img), B, n,
-                                       _stream()), "vmm_posterior_step")
+        # posterior mean + sigma * noise with the noise generated in the kernel (Philox keyed by self.rng); leaves t - 1 in t_src
+        N.check(lib.vmm_posterior_step_rng(_ptr(self.x0), _ptr(self.img), _ptr(self.rng), _ptr(self.s), _ptr(self.t), _ptr(d.posterior_mean_coef1),
+                                           _ptr(d.posterior_mean_coef2), _ptr(d.posterior_log_variance_clipped), 2 if dyn else 1, _ptr(self.img), B, n,
+                                           _ptr(self.t_src), _stream()), "vmm_posterior_step_rng")
 
     def _capture(self):
         side = torch.cuda.Stream()
@@ -332,15 +337,18 @@ class _GraphedStep:
     def __call__(self, img, i: int):
         if self.img.data_ptr() != img.data_ptr():
             self.img.copy_(img)
-        self.t.fill_(i)
         if not self.captured:
             saved = self.img.clone()
+            self.t_src.fill_(i)
             self._capture()  # a capture failure is an error, not a reason to go eager silently (use_graph = False is the opt-out)
             self.captured = True
             self.img.copy_(saved)
-            self.t.fill_(i)
+            self.t_expect = None
+        if self.t_expect != i:  # (inside a sampling loop the previous step has already left i here: no launch)
+            self.t_src.fill_(i)
         if self.graph is not None:
             self.graph.replay()
         else:
             self._body()
+        self.t_expect = i - 1
         return self.img

@@ -24,6 +24,41 @@ from . import hostmath
 from .plan import _stream
 
 
+def _device_collectives_ok(t: torch.Tensor, group=None) -> bool:
+    """RCCL takes device buffers.  The gloo rehearsal backend (several ranks sharing one GPU on a single-GPU box; CPU tests) may lack
+    device-tensor support in this build: then collectives on device tensors are staged through host memory."""
+    if not t.is_cuda or dist.get_backend(group) != "gloo":
+        return True
+    try:
+        probe = torch.zeros(4, device=t.device)
+        dist.all_reduce(probe, group=group)
+        torch.cuda.synchronize()
+        return True
+    except RuntimeError:
+        return False
+
+
+def broadcast_tensor(t: torch.Tensor, src: int = 0, group=None) -> None:
+    """In-place broadcast that also works for device tensors under the gloo rehearsal backend."""
+    if _device_collectives_ok(t, group):
+        dist.broadcast(t, src=src, group=group)
+    else:
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+
+
+def all_gather_tensor(t: torch.Tensor, world: int, group=None) -> List[torch.Tensor]:
+    if _device_collectives_ok(t, group):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+        return out
+    host = t.detach().cpu()
+    out = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(out, host, group=group)
+    return [o.to(t.device) for o in out]
+
+
 class BucketedAllReduce:
     """Sum-all-reduce of a flat gradient buffer in contiguous buckets, driven by "tail is final" marks.
 
@@ -42,18 +77,43 @@ class BucketedAllReduce:
         self.launched: List[Tuple[int, int]] = []
         # RCCL reduces device buffers in place.  The gloo rehearsal backend (several ranks sharing one GPU on a single-GPU box; CPU
         # tests) may lack device-tensor support in this build: then slices are staged through pinned host memory on the side stream.
-        self.host_staged = False
-        if self.cuda and self.world > 1 and dist.get_backend(group) == "gloo":
-            try:
-                probe = torch.zeros(4, device=flat.device)
-                dist.all_reduce(probe, group=group)
-                torch.cuda.synchronize()
-            except RuntimeError:
-                self.host_staged = True
+        self.host_staged = bool(self.cuda and self.world > 1 and not _device_collectives_ok(flat, group))
+        # timing of the last step (events with timing on the compute / side stream): bench.py reports allreduce_ms / overlap_frac from them
+        self.timing = False
+        self._ev_buckets: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self._ev_window: List[torch.cuda.Event] = []
 
     def start(self) -> None:
         self.hi = self.n
         self.works, self.launched = [], []
+        self._ev_buckets, self._ev_window = [], []
+        if self.timing and self.comm_stream is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()  # the backward window opens here (compute stream)
+            self._ev_window.append(e)
+
+    def backward_done(self) -> None:
+        """Call when the last backward launch has been enqueued: closes the window overlap_frac is measured against."""
+        if self.timing and self.comm_stream is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev_window.append(e)
+
+    def last_step_timing(self) -> Optional[dict]:
+        """(after a synchronize) side-stream busy time of the last step's buckets and the share of it inside the backward window."""
+        if len(self._ev_window) < 2 or not self._ev_buckets:
+            return None
+        w0, w1 = self._ev_window
+        win = w0.elapsed_time(w1)
+        busy = inside = 0.0
+        spans = []
+        for a, b in self._ev_buckets:
+            s0, s1 = w0.elapsed_time(a), w0.elapsed_time(b)
+            busy += s1 - s0
+            inside += max(0.0, min(s1, win) - max(s0, 0.0))
+            spans.append((round(s0, 3), round(s1, 3)))
+        return {"allreduce_ms": round(busy, 3), "overlap_frac": round(inside / busy, 4) if busy > 0 else None, "backward_ms": round(win, 3),
+                "bucket_spans_ms": spans, "buckets_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.launched]}
 
     def _reduce(self, lo: int, hi: int) -> None:
         if hi <= lo or self.world == 1:
@@ -65,6 +125,9 @@ class BucketedAllReduce:
             ev.record()  # everything enqueued so far on the compute stream produced flat[lo:hi]
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 if self.host_staged:
                     host = torch.empty(hi - lo, dtype=sl.dtype, pin_memory=True)
                     host.copy_(sl, non_blocking=True)
@@ -73,7 +136,14 @@ class BucketedAllReduce:
                     sl.copy_(host, non_blocking=True)
                     self._pinned = getattr(self, "_pinned", []) + [host]  # alive until finish()
                 else:
-                    self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    w = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self.timing:
+                        w.wait()  # orders the side stream behind the collective (no host block): e1 then stamps its completion
+                    else:
+                        self.works.append(w)
+                if self.timing:
+                    e1.record()
+                    self._ev_buckets.append((e0, e1))
         else:
             self.works.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -122,10 +192,87 @@ class DataParallelTrainer:
             self.broadcast_parameters()
 
     def broadcast_parameters(self) -> None:
-        """DDP's constructor broadcast (rank 0 -> all), SURVEY C1."""
-        for p in list(self.model.parameters()) + list(self.model.buffers()):
-            dist.broadcast(p.data, src=0, group=self.group)
+        """DDP's constructor broadcast (rank 0 -> all), SURVEY C1: ONE flat broadcast per dtype (the ~400 tensors of the model are
+        158 MB in all; tensor by tensor that is ~400 latency-bound collectives), copied back into the live tensors in place."""
+        by_dtype = {}
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            by_dtype.setdefault(t.dtype, []).append(t.data)
+        for dt in sorted(by_dtype, key=str):  # same order on every rank
+            ts = by_dtype[dt]
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            broadcast_tensor(flat, 0, self.group)
+            o = 0
+            for t in ts:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
+        self.unet.bump_generation()
         self.ema_model.load_state_dict(self.model.state_dict())
+
+    def rccl_selfcheck(self) -> dict:
+        """First contact with the collective library: the all-reduce of the rank ids must be N (N - 1) / 2 on every rank."""
+        dev = next(self.model.parameters()).device
+        t = torch.full((1,), float(self.rank), device=dev)
+        if self.world > 1:
+            if _device_collectives_ok(t, self.group):
+                dist.all_reduce(t, group=self.group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t = h.to(dev)
+        got, want = float(t.item()), self.world * (self.world - 1) / 2
+        return {"sum_of_rank_ids": got, "expected": want, "ok": got == want, "backend": dist.get_backend(self.group) if self.world > 1 else None}
+
+    # ------------------------------------------------------------------ checkpoints in the reference's layout (vddp.py:1548-1585)
+    def state_dict(self) -> dict:
+        """{model, optimizer, steps, ema} as Trainer.save writes it: `optimizer` in torch.optim.Adam's format over
+        GaussianDiffusion.parameters() (index = position in that list; parameters that never received a gradient have no state)."""
+        named = list(self.unet.named_parameters())
+        names = [n for n, _ in named]
+        moments = getattr(self, "_moments", {})
+        state = {}
+        for i, (n, prm) in enumerate(named):
+            if n in moments:
+                m, v = moments[n]
+                shape = prm.shape
+                state[i] = {"step": torch.tensor(float(self.step)), "exp_avg": m.detach().clone().view(shape).cpu(),
+                            "exp_avg_sq": v.detach().clone().view(shape).cpu()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        return {"model": self.model.state_dict(), "optimizer": {"state": state, "param_groups": [group]}, "steps": self.step,
+                "ema": self.ema_model.state_dict()}
+
+    def load_state_dict(self, obj: dict, strict: bool = True) -> None:
+        self.model.load_state_dict(obj["model"], strict=strict)
+        if "ema" in obj:
+            self.ema_model.load_state_dict(obj["ema"], strict=strict)
+        self.step = int(obj.get("steps", 0))
+        opt = obj.get("optimizer")
+        if opt:
+            names = [n for n, _ in self.unet.named_parameters()]
+            dev = next(self.unet.parameters()).device
+            if not hasattr(self, "_moments"):
+                self._moments = {}
+            for i, st in opt["state"].items():
+                n = names[int(i)]
+                if n in self._moments:  # keep the storage the device job tables point at
+                    self._moments[n][0].copy_(st["exp_avg"].reshape(-1))
+                    self._moments[n][1].copy_(st["exp_avg_sq"].reshape(-1))
+                else:
+                    self._moments[n] = (st["exp_avg"].detach().to(dev, torch.float32).reshape(-1).clone(),
+                                        st["exp_avg_sq"].detach().to(dev, torch.float32).reshape(-1).clone())
+                if "steps" not in obj and "step" in st:
+                    self.step = max(self.step, int(float(st["step"])))
+            g = opt["param_groups"][0]
+            self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self._ptr_sig = None  # parameters may have been re-homed: rebuild the job tables at the next step
+
+    def save(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load(self, path: str, strict: bool = True) -> dict:
+        obj = torch.load(path, map_location="cpu")
+        self.load_state_dict(obj, strict=strict)
+        return obj
 
     # ------------------------------------------------------------------ setup for one input shape
     def _pointer_signature(self) -> tuple:
@@ -210,6 +357,7 @@ class DataParallelTrainer:
         N.check(lib.vmm_loss_grad(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, None, pl.dout.data_ptr(), _stream()), "loss grad")
         self._reducer.start()
         pl.backward(None, on_mark=self._reducer.mark if self.world > 1 else None)
+        self._reducer.backward_done()
         self._reducer.finish()
         b1, b2 = self.betas
         tab, n = self._adam_table
@@ -224,25 +372,31 @@ class DataParallelTrainer:
 
     # ------------------------------------------------------------------ sharded sampling (vddp.py:1506-1532, 1816-1845)
     @torch.no_grad()
-    def sample_sharded(self, cond_all: torch.Tensor, guidance_scale: float = 5.0, batch: int = 2, use_ema: bool = True) -> Optional[torch.Tensor]:
-        """Every rank samples its contiguous block of rows; rank 0 returns the (N, C, T, H, W) result, others None."""
+    def sample_sharded(self, cond_all: torch.Tensor, guidance_scale: float = 5.0, batch: int = 2, use_ema: bool = True,
+                       seed: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Every rank samples its contiguous block of rows; rank 0 returns the (N, C, T, H, W) result, others None.
+        seed: re-seed the generator with seed + (first row of the batch) before every batch -- the noise of a row then does not depend on
+        which rank samples it (with batch = 1 the result is independent of the world size; the tests use that)."""
         model = self.ema_model if use_ema else self.model
         dev = next(model.parameters()).device
         if self.world > 1:  # the reference broadcasts the conditioning matrix as a pickled object; here: one raw tensor
             cond_all = cond_all.to(dev).contiguous()
-            dist.broadcast(cond_all, src=0, group=self.group)
-        outs = [model.sample(cond=cond_all[a:b].to(dev), guidance_scale=guidance_scale) for a, b in
-                hostmath.shard_rows(cond_all.shape[0], self.rank, self.world, batch)]
+            broadcast_tensor(cond_all, 0, self.group)
+        n_rows = cond_all.shape[0]
+        outs = []
+        for a, b in hostmath.shard_rows(n_rows, self.rank, self.world, batch):
+            if seed is not None:
+                torch.manual_seed(seed + a)
+            outs.append(model.sample(cond=cond_all[a:b].to(dev), guidance_scale=guidance_scale))
         shp = (model.channels, model.num_frames, model.image_size, model.image_size)
         mine = torch.cat(outs, dim=0) if outs else torch.zeros((0,) + shp, device=dev)
         if self.world == 1:
             return mine
-        lengths = [len(range(*r)) for rk in range(self.world) for r in [(0, sum(b - a for a, b in hostmath.shard_rows(cond_all.shape[0], rk, self.world, batch)))]]
+        lengths = [sum(b - a for a, b in hostmath.shard_rows(n_rows, rk, self.world, batch)) for rk in range(self.world)]
         max_len = max(lengths)
         padded = torch.zeros((max_len,) + shp, device=dev)
         padded[: mine.shape[0]] = mine
-        gathered = [torch.empty_like(padded) for _ in range(self.world)]
-        dist.all_gather(gathered, padded, group=self.group)
+        gathered = all_gather_tensor(padded, self.world, self.group)
         if self.rank != 0:
             return None
         return hostmath.strip_padding(torch.cat(gathered, dim=0), lengths, max_len)

@@ -541,7 +541,17 @@ class _Builder:
             return
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
-        if self.x3 and getattr(self.m, "use_x3_wgrad", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
+        wbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout)
+        if self.x3 and getattr(self.m, "use_x3_wgrad", True):
+            # the 3 x 3 layers: nine taps per workgroup on the split-bf16 matrix cores, partial blocks in a workspace + fixed-order reduction
+            ws_n = int(self.lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), lddy))
+            if ws_n:
+                ws = self.alloc(ws_n)
+                self.step(self.lib.vmm_conv3x3_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                          flops=2.0 * M * K * d.Cout, nbytes=wbytes)
+                self.tmp_free((ws, ws_n))
+                return
+        if self.x3 and getattr(self.m, "use_x3_wgrad_generic", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
             fn = self.lib.vmm_conv_wgrad_bf16x3
             tiles = -(-K // 128) * -(-d.Cout // 128)
             nsplit = max(1, min(-(-1024 // tiles), max(1, M // 512)))
