@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void posterior_step_rng_kernel(const float* __
     const f32x4 a = *reinterpret_cast<const f32x4*>(x0 + base + 4 * i), b = *reinterpret_cast<const f32x4*>(x + base + 4 * i);
     unsigned r[4];
     philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)tb, blockIdx.y, (unsigned)seed, (unsigned)(seed >> 32), r);
-    f32x4 z;
+    float z[4];
     box_muller(r[0], r[1], z[0], z[1]);
     box_muller(r[2], r[3], z[2], z[3]);
     f32x4 o;
