@@ -192,9 +192,21 @@ def test_trainer_checkpoint_round_trip_in_the_reference_layout(gpu, tmp_path):
     assert tr2.step == 2
     tr2.train_step(x, cond, t=t, noise=noise, mask=mask)
     torch.cuda.synchronize()
+    # (a handful of gradients -- the relative-position bias, the token keys -- are summed with atomics: equal up to summation order, which Adam's
+    # m / sqrt(v) turns into at most an lr-sized difference where |g| ~ 0)
+    def close(a, b, k):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2e-3 and float(d.mean()) <= 1e-5, (k, float(d.max()), float(d.mean()))
     for (k, a), (_, b) in zip(tr.unet.state_dict().items(), tr2.unet.state_dict().items()):
-        assert torch.equal(a, b), k
+        close(a, b, k)
     for (k, a), (_, b) in zip(tr.ema_model.state_dict().items(), tr2.ema_model.state_dict().items()):
-        assert torch.equal(a, b), k
+        close(a, b, k)
     for k, (m, v) in tr._moments.items():
-        assert torch.equal(m, tr2._moments[k][0]) and torch.equal(v, tr2._moments[k][1]), k
+        assert torch.allclose(m, tr2._moments[k][0], rtol=1e-3, atol=1e-7) and torch.allclose(v, tr2._moments[k][1], rtol=1e-3, atol=1e-10), k
+    # a trainer that did NOT load the optimizer state takes a different step (the moments matter)
+    tr3 = _trainer(gpu)
+    tr3.model.load_state_dict(obj["model"])
+    tr3.train_step(x, cond, t=t, noise=noise, mask=mask)
+    torch.cuda.synchronize()
+    k0 = "downs.0.0.block1.proj.weight"
+    assert float((dict(tr3.unet.named_parameters())[k0] - dict(tr.unet.named_parameters())[k0]).abs().mean()) > 1e-5

@@ -608,6 +608,46 @@ def test_conv3x3_weight_gradient_nine_taps_bf16x3(gpu, nimg, H, W, C1, C2, Cout)
     assert lib.vmm_conv3x3_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), None, None, _s()) == 1
 
 
+def test_weight_gradient_scatter_batched(gpu):
+    """vmm_pack_weights direction 1: packed [(th, tw, c)][n] weight gradients -> torch layout (N, C, TH, TW), = or +=, several jobs per launch.  The plain
+    conv / linear layouts leave through the LDS-tiled kernel, everything else (N not a multiple of 64, a strided tap subset) element-wise; both paths
+    in one table."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(77)
+    specs = [(3, 3, 32, 64, 1, None), (1, 1, 64, 128, 0, None), (4, 4, 16, 64, 1, None), (3, 3, 128, 192, 1, None), (1, 1, 32, 48, 1, None),
+             (2, 2, 16, 64, 1, (1, 2, 0, 2))]  # last: the (h0, hs, w0, ws) tap subset of a 4 x 4 kernel (transposed-convolution phase)
+    jobs = (N.PackJob * len(specs))()
+    keep, want = [], []
+    mx = 0
+    for j, (th, tw, c, n, acc, sub) in zip(jobs, specs):
+        kh, kw = (4, 4) if sub else (th, tw)
+        torch_w = torch.randn(n, c, kh, kw, generator=g).to(gpu)
+        packed = torch.randn(th * tw * c, n, generator=g).to(gpu)
+        ref = torch_w.clone().cpu() if acc else torch.zeros(n, c, kh, kw)
+        upd = packed.cpu().reshape(th, tw, c, n).permute(3, 2, 0, 1)
+        if sub:
+            h0, hs, w0, ws = sub
+            ref = torch_w.clone().cpu()
+            if acc:
+                ref[:, :, h0::hs, w0::ws] += upd
+            else:
+                ref[:, :, h0::hs, w0::ws] = upd
+        else:
+            h0, hs, w0, ws = 0, 1, 0, 1
+            ref = ref + upd
+        j.torch_w, j.packed = torch_w.data_ptr(), packed.data_ptr()
+        j.TH, j.TW, j.C, j.Cp, j.N = th, tw, c, c, n
+        j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = c * kh * kw, kh * kw, kw, 1, h0, hs, w0, ws, acc, 0
+        keep.append((torch_w, packed))
+        want.append(ref)
+        mx = max(mx, th * tw * c * n)
+    tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), len(specs), mx, 1, _s()), "unpack")
+    torch.cuda.synchronize()
+    for (tw_, _), ref, spec in zip(keep, want, specs):
+        assert torch.equal(tw_.cpu(), ref), spec
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

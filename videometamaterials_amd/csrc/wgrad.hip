@@ -254,9 +254,54 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
 }
 
+// Gradient scatter (direction 1) of the plain layouts -- torch (N, C, TH, TW) contiguous, i.e. torch index n C T + c T + t with T = TH TW -- through
+// an LDS tile: packed[(t, c)][n] is read in 256-byte runs along n, torch is written in runs of CB T floats along (c, t).  (The element-wise
+// path below reads the packed buffer coalesced but scatters 4-byte read-modify-writes T or C T floats apart: 1.2 ms per training step.)
+__device__ __forceinline__ int unpack_tile_cb(const vmm_pack_job& jb) {
+  const int T = jb.TH * jb.TW;
+  const bool plain = jb.fmt == 0 && jb.Cp == jb.C && jb.h0 == 0 && jb.w0 == 0 && jb.hs == 1 && jb.ws == 1 && jb.sw == 1 && jb.sh == jb.TW && jb.sc == T &&
+                     jb.sn == jb.C * T && jb.N % 64 == 0 && (((uintptr_t)jb.torch_w | (uintptr_t)jb.packed) & 15) == 0;
+  if (!plain) return 0;
+  const int cb = T == 1 ? 64 : (T <= 16 ? 16 : 0);
+  return (cb && jb.C % cb == 0) ? cb : 0;
+}
+constexpr int UNPACK_TILE_FLOATS = 16 * 16 * 64;  // T * CB * 64 <= this (T = 9 / 16 with CB = 16, T = 1 with CB = 64)
+
+__global__ __launch_bounds__(256) void unpack_tiled_kernel(const vmm_pack_job* __restrict__ jobs) {
+  __shared__ float tile[UNPACK_TILE_FLOATS + 64];
+  const vmm_pack_job jb = jobs[blockIdx.y];
+  const int CB = unpack_tile_cb(jb);
+  if (!CB) return;
+  const int T = jb.TH * jb.TW, run = CB * T;            // floats per (n, c block) run in torch layout; a multiple of 16
+  const int nb = jb.N / 64, ntiles = nb * (jb.C / CB);
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int n0 = (tl % nb) * 64, c0 = (tl / nb) * CB;
+    // packed rows (t, c0 + c): 64 floats at n0 -> tile[(c T + t)][n]  (+1 padding per 64: the transposed reads below walk the rows)
+    for (int i = threadIdx.x; i < run * 16; i += 256) {
+      const int n4 = i & 15, r = i >> 4;                // r = t * CB + c
+      const int t = r / CB, c = r - t * CB;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(jb.packed + ((long long)t * jb.Cp + c0 + c) * jb.N + n0 + 4 * n4);
+      float* d = tile + (c * T + t) * 65 + 4 * n4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // torch run of sample n: run floats at n sn + c0 T; thread = (n, 16-byte piece)
+    const int pieces = run / 4;
+    for (int i = threadIdx.x; i < 64 * pieces; i += 256) {
+      const int n = i / pieces, q = i - n * pieces;
+      float* o = jb.torch_w + (long long)(n0 + n) * jb.sn + (long long)c0 * T + 4 * q;
+      f32x4 v = {tile[(4 * q) * 65 + n], tile[(4 * q + 1) * 65 + n], tile[(4 * q + 2) * 65 + n], tile[(4 * q + 3) * 65 + n]};
+      if (jb.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = v;
+    }
+    __syncthreads();
+  }
+}
+
 // batched (un)pack: packed[(th*TW + tw)*Cp + c][n]  <->  torch[ n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw ]
 __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
   const vmm_pack_job jb = jobs[blockIdx.y];
+  if (direction == 1 && unpack_tile_cb(jb)) return;  // (scattered by unpack_tiled_kernel)
   if (jb.fmt == 1) {
     // split-bf16 operand for igemm_bf16x3.hip: [N][Kpad] hi plane then lo plane, K = (th, tw, c) padded to a multiple of 32
     if (direction != 0) return;
@@ -448,5 +493,10 @@ extern "C" int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int
   const int bx = (int)max(1LL, min((long long)cdiv(max_elems, 256 * 4), cap));
   hipLaunchKernelGGL(pack_kernel, dim3(bx, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, direction);
   VMM_LAUNCH_CHECK();
+  if (direction == 1) {  // the plain conv / linear layouts leave through LDS tiles (jobs outside that envelope were handled above)
+    const int tx = (int)max(1LL, min((long long)cdiv(max_elems, 64 * 144), cap));
+    hipLaunchKernelGGL(unpack_tiled_kernel, dim3(tx, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    VMM_LAUNCH_CHECK();
+  }
   return 0;
 }
