@@ -211,6 +211,16 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
                            const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
                            int32_t heads, int32_t dh, float* lse /* [rows][heads] logsumexp for the backward, or NULL */,
                            vmm_stream_t stream);
+/* ---- cond_attention = 'cross-attention' (vddp.py:354-363, 476-485): queries from to_q, keys / values = the conditioning tokens alone.
+ * Softmax flavour (mid spatial site: bias NULL; temporal sites: bias [heads][T][T] added to the (frames x tokens) scores, ntok == T as in the
+ * reference): out[row, head*dh + e] = sum_j softmax_j(q[row, head] . ek[b][j][head] (+ bias[head][t][j])) ev[b][j][head*dh + e]; q rows
+ * [(b, t, pixel)] x heads*dh (ldq), pre-scaled / pre-rotated by the projection epilogue; ek / ev [B][ntok][heads*dh], ntok <= 32. */
+int vmm_cross_attention(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* bias, float* out, int32_t ldo,
+                        int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+/* linear flavour: the context ctx[(b, t, head)][dh][dh] = softmax_j(ek[b][j])^T ev[b][j] / HW of the tokens alone (every frame of a sample gets
+ * the same block); vmm_linattn_apply then runs on the q rows (ldqkv = heads*dh).  kstat as in vmm_linattn_context (or NULL). */
+int vmm_linattn_cross_context(const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, float* ctx,
+                              float* kstat, vmm_stream_t stream);
 /* the path vmm_temporal_attention takes where it applies (heads = 8, dh = 32, T <= 16, ntok <= 16; returns 1 and launches nothing
  * otherwise): one workgroup per pixel, the T rows of k | v staged once in LDS */
 int vmm_temporal_attention_staged(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,

@@ -213,8 +213,15 @@ def linear_attention(sd, p: str, x: Tensor, tokens: Optional[Tensor], cfg: UnetC
 
         k = torch.cat([per_frame(ek), k], dim=-1)
         v = torch.cat([per_frame(ev), v], dim=-1)
-    elif cfg.cond_attention not in ("none", "self-stacked"):
-        raise ValueError("oracle covers cond_attention in {'none','self-stacked'}")
+    elif cfg.cond_attention == "cross-attention" and tokens is not None:
+        # vddp.py:354-363: queries from their own projection (to_q), keys / values are the conditioning tokens alone, the same for every frame
+        q = torch.einsum("oc,bcn->bon", sd[p + ".to_q.weight"][:, :, 0, 0], xf).reshape(B * T, heads, dh, H * W)
+        ek = F.linear(tokens, sd[p + ".to_k.weight"])
+        ev = F.linear(tokens, sd[p + ".to_v.weight"])
+        n_tok = ek.shape[1]
+        k, v = (t.reshape(B, 1, n_tok, heads, dh).expand(B, T, n_tok, heads, dh).permute(0, 1, 3, 4, 2).reshape(B * T, heads, dh, n_tok) for t in (ek, ev))
+    elif cfg.cond_attention not in ("none", "self-stacked", "cross-attention"):
+        raise ValueError("cond_attention must be none, self-stacked or cross-attention")
     q = q.softmax(dim=-2) * dh ** -0.5
     k = k.softmax(dim=-1)
     v = v / (H * W)
@@ -260,8 +267,15 @@ def softmax_attention(
             ek = rotary_rotate(ek)
         k = torch.cat([ek, k], dim=-2)
         v = torch.cat([ev, v], dim=-2)
-    elif cfg.cond_attention not in ("none", "self-stacked"):
-        raise ValueError("oracle covers cond_attention in {'none','self-stacked'}")
+    elif cfg.cond_attention == "cross-attention" and tokens is not None:
+        # vddp.py:476-485: q = to_q(x); k, v = the tokens alone (every b2 sees all of them), keys not rotated; the positional bias below is
+        # added to the (n x tokens) scores as it is, which only broadcasts when tokens == n
+        q = F.linear(x, sd[p + ".to_q.weight"]).reshape(b, b2, n, heads, dh).transpose(2, 3)
+        ek = F.linear(tokens, sd[p + ".to_k.weight"])
+        ev = F.linear(tokens, sd[p + ".to_v.weight"])
+        k, v = (t[:, None].expand(b, b2, *t.shape[1:]).reshape(b, b2, t.shape[1], heads, dh).transpose(2, 3) for t in (ek, ev))
+    elif cfg.cond_attention not in ("none", "self-stacked", "cross-attention"):
+        raise ValueError("cond_attention must be none, self-stacked or cross-attention")
     q = q * dh ** -0.5
     if rotary:
         q = rotary_rotate(q)

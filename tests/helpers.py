@@ -37,6 +37,15 @@ CONFIGS = {
     # below; Upsample = CircularUpsample), 'circular_1d' at dim 16 (horizontal axis periodic; every convolution wrapped in a helper module)
     "circ64": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                     per_frame_cond=True, cond_bias=True, padding_mode="circular"), (1, 11, 32, 32), 11),
+    # cond_attention = 'cross-attention' (vddp.py:354-363, 476-485; north_star's "cross-attention on the stress-strain conditioning"): queries from
+    # to_q, keys / values = the conditioning tokens alone; the temporal sites add the (frames x frames) positional bias to the (frames x tokens)
+    # scores, so tokens == frames.  dim 16, and the real widths (where self-stacked would take the fused kernels)
+    "cross16": (dict(dim=16, channels=3, cond_attention="cross-attention", cond_attention_tokens=6, use_temporal_attention_cond=True,
+                     per_frame_cond=False), (2, 6, 16, 16), 51),
+    "cross64": (dict(dim=64, channels=3, cond_attention="cross-attention", cond_attention_tokens=11, use_temporal_attention_cond=True,
+                     per_frame_cond=False), (2, 11, 16, 16), 40),
+    "cross16s": (dict(dim=16, channels=3, cond_attention="cross-attention", cond_attention_tokens=9, use_temporal_attention_cond=False,
+                      per_frame_cond=False), (2, 5, 16, 16), 51),  # spatial sites only: any number of tokens
     "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
 }

@@ -648,6 +648,50 @@ def test_weight_gradient_scatter_batched(gpu):
         assert torch.equal(tw_.cpu(), ref), spec
 
 
+@pytest.mark.parametrize("B,T,HW,ntok,with_bias", [(2, 6, 20, 6, True), (3, 4, 33, 9, False), (1, 11, 64, 11, True), (2, 3, 7, 32, False), (2, 5, 16, 1, False)])
+def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias):
+    """cond_attention = 'cross-attention' (vddp.py:354-363, 476-485): softmax attention of every (row, head) over the sample's conditioning tokens
+    (+ the relative-position bias on the temporal sites, tokens == frames), and the linear-attention context of the tokens alone followed by
+    the unchanged apply pass; both against the einsum restatement of the reference lines."""
+    N, lib = _lib()
+    heads, dh = 8, 32
+    hid = heads * dh
+    g = torch.Generator().manual_seed(31 + ntok)
+    rows = B * T * HW
+    q = torch.randn(rows, hid, generator=g)
+    ek = torch.randn(B, ntok, hid, generator=g)
+    ev = torch.randn(B, ntok, hid, generator=g)
+    bias = torch.randn(heads, T, T, generator=g) if with_bias else None
+    qg, ekg, evg = q.to(gpu), ek.to(gpu), ev.to(gpu)
+    out = torch.full((rows, hid), 7.0, device=gpu)
+    bg = bias.to(gpu) if with_bias else None
+    rc = lib.vmm_cross_attention(qg.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), ntok, bg.data_ptr() if with_bias else None, out.data_ptr(), hid, B, T, HW,
+                                 heads, dh, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    q5 = q.reshape(B, T, HW, heads, dh)
+    k5, v5 = ek.reshape(B, ntok, heads, dh), ev.reshape(B, ntok, heads, dh)
+    sim = torch.einsum("btphd,bjhd->btphj", q5, k5)
+    if with_bias:
+        sim = sim + bias.permute(1, 0, 2)[None, :, None]  # bias[h][t][j] -> (1, t, 1, h, j)
+    want = torch.einsum("btphj,bjhd->btphd", sim.softmax(-1), v5).reshape(rows, hid)
+    assert relerr(out.cpu(), want) < 3e-6
+    if with_bias:  # a bias that cannot broadcast is rejected like the reference's addition would fail
+        assert lib.vmm_cross_attention(qg.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), ntok, bg.data_ptr(), out.data_ptr(), hid, B, T + 1, HW, heads, dh, _s()) == -1
+    # linear flavour: q.softmax(d) * scale, k.softmax(tokens), v / HW, ctx = k v^T, out = ctx^T q
+    ctx = torch.empty(B * T * heads, dh, dh, device=gpu)
+    assert lib.vmm_linattn_cross_context(ekg.data_ptr(), evg.data_ptr(), ntok, B, T, HW, heads, dh, ctx.data_ptr(), None, _s()) == 0
+    o2 = torch.full((rows, hid), 7.0, device=gpu)
+    assert lib.vmm_linattn_apply(qg.data_ptr(), hid, ctx.data_ptr(), o2.data_ptr(), hid, B, T, HW, heads, dh, _s()) == 0
+    torch.cuda.synchronize()
+    ks = k5.softmax(dim=1)
+    cw = torch.einsum("bjhd,bjhe->bhde", ks, v5 / HW)
+    assert relerr(ctx.cpu().reshape(B, T, heads, dh, dh), cw[:, None].expand(B, T, heads, dh, dh)) < 3e-6
+    qs = q5.softmax(-1) * dh ** -0.5
+    want2 = torch.einsum("bhde,btphd->btphe", cw, qs).reshape(rows, hid)
+    assert relerr(o2.cpu(), want2) < 3e-6
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -32,7 +32,10 @@ def diagnose(cfg_name, model, x, t, cond, mask_val, dev):
     B, _, T, H, W = x.shape
     with torch.no_grad():
         uo.unet3d_forward(sd, cfg, x, t, cond, torch.full((B,), bool(mask_val)), taps=taps)
-    pl = model.get_plan(B, T, H, W, cond.shape[-1], dev, training=True)  # keep_all plan: every intermediate stays resident
+    try:
+        pl = model.get_plan(B, T, H, W, cond.shape[-1], dev, training=True)  # keep_all plan: every intermediate stays resident
+    except NotImplementedError as e:  # (configurations without a training plan)
+        return f"(no per-block diagnosis: {e})"
     mask = torch.full((B,), int(mask_val), dtype=torch.uint8, device=dev)
     pl.run(x.to(dev), t.to(dev), cond.to(dev), mask)
     torch.cuda.synchronize()

@@ -315,6 +315,16 @@ extern "C" int vmm_linattn_context(const float* qkv, int32_t ldqkv, const float*
   return 0;
 }
 
+// cond_attention = 'cross-attention' (vddp.py:354-363): keys / values are the conditioning tokens alone, so the context of a (frame, head) is
+// the merge above with no pixel partials -- ctx[d][e] = sum_j softmax_j(ek[j][d]) ev[j][e] / (h w), identical for the frames of a sample
+extern "C" int vmm_linattn_cross_context(const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh,
+                                         float* ctx, float* kstat, vmm_stream_t stream) {
+  if (dh != DH || !ek || !ev || ntok < 1) return -1;
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * T * heads), dim3(256), 0, (hipStream_t)stream, nullptr, 0, ek, ev, ntok, T, HW, heads, ctx, kstat);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 // the same with pass 1 on the split-bf16 matrix cores (temporal_core.hip); inference
 extern "C" int vmm_linattn_context_bf16x3(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, int32_t B,
                                           int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t nsplit, float* part, float* ctx,

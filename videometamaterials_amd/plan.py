@@ -497,7 +497,7 @@ class _Builder:
         if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
             return False
         kp = (k + 31) // 32 * 32
-        if kp == 256 and cout <= 64:  # one 64-row tile per CU and a single column slice: the streaming implicit GEMM is faster (measured)
+        if kp == 256 and cout <= 64 and not os.environ.get("VMM_PROJ_K256N64"):  # one 64-row tile per CU and a single column slice: the streaming implicit GEMM is faster (measured)
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
@@ -773,6 +773,8 @@ class _Builder:
         hid = 32 * heads
         HW = x.H * x.W
         rows = B * T * HW
+        if site and self.m.cond_attention == "cross-attention":
+            return self.cross_attn_block(name, x, site, name + ".fn.fn", linear=True)
         if self.x3 and not self.training and x.C == 64 and heads == 8 and HW % 32 == 0 and getattr(self.m, "use_fused_linattn", True):
             # full-resolution level: q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
             wq, _ = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2)
@@ -859,6 +861,8 @@ class _Builder:
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
+        if site and self.m.cond_attention == "cross-attention":
+            return self.cross_attn_block(name, x, site, p, linear=False, temporal=temporal)
         if (temporal and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
                 and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
             # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
@@ -948,6 +952,51 @@ class _Builder:
             if site:
                 self.token_kv_bwd(site)
         self.on_backward(bwd, pg_start, uj_start)
+        return out
+
+    def cross_attn_block(self, name: str, x: Act, site: str, p: str, *, linear: bool, temporal: bool = False) -> Act:
+        """Residual(PreNorm(attention)) with cond_attention = 'cross-attention' (vddp.py:354-363 linear, 476-485 softmax): q = to_q(LayerNorm(x)),
+        keys / values = the conditioning tokens alone (to_k / to_v rows from the batched embedding launch), then to_out + residual."""
+        if self.training:
+            raise NotImplementedError("training with cond_attention='cross-attention' is not built (forward / sampling only)")
+        B, T, heads = self.B, self.T, self.heads
+        hid = 32 * heads
+        HW = x.H * x.W
+        rows = B * T * HW
+        ek, ev = self.ekv_info[site][1], self.ekv_info[site][2]
+        ntok = self.ntok
+        if temporal and ntok != T:
+            raise ValueError(f"cross-attention at the temporal sites adds the ({T} x {T}) positional bias to the ({T} x {ntok}) scores: "
+                             "cond_attention_tokens must equal the number of frames (vddp.py:513)")
+        if ntok > 32:
+            raise NotImplementedError("cross-attention with more than 32 conditioning tokens")
+        pj = self.proj_ok(x.C, hid)
+        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
+        wq, _ = self.pack_linear(p + ".to_q.weight", frag=2 if pj else False)
+        q = self.act(hid, x.H, x.W)
+        epi = {} if linear else dict(q_scale=32 ** -0.5, q_ncols=hid, rot_tab=self.rot_ptr if temporal else 0, rot_ncols=hid if temporal else 0)
+        self.conv(a1=y, w=wq, Cout=hid, out_ptr=q.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_q", proj=pj,
+                  ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0, **epi)
+        if not pj:
+            self.free_act(y)
+        o = self.act(hid, x.H, x.W)
+        if linear:
+            ctx_n = B * T * heads * 1024
+            ctx = self.alloc(ctx_n)
+            self.step(self.lib.vmm_linattn_cross_context, (ek, ev, ntok, B, T, HW, heads, 32, self.ptr(ctx), None), name + " context (tokens)")
+            self.step(self.lib.vmm_linattn_apply, (q.ptr, hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply", nbytes=4.0 * rows * 2 * hid)
+            self.free(ctx, ctx_n)
+        else:
+            self.step(self.lib.vmm_cross_attention, (q.ptr, hid, ek, ev, ntok, self.bias_ptr if temporal else None, o.ptr, hid, B, T, HW, heads, 32),
+                      name + " core (tokens)", nbytes=4.0 * rows * 2 * hid)
+        self.free_act(q)
+        pjo = self.proj_ok(hid, x.C)
+        wo, _ = self.pack_linear(p + ".to_out.weight", frag=2 if pjo else False)
+        out = self.act(x.C, x.H, x.W)
+        self.conv(a1=o, w=wo, bias=self.wraw(p + ".to_out.bias") if linear else 0, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr,
+                  ldres=x.ld, what=name + " to_out", proj=pjo)
+        self.free_act(o)
+        self.plan.named[name] = out
         return out
 
     # ---------------------------------------------------------------- job tables

@@ -84,8 +84,6 @@ class Unet3D(nn.Module):
         self.cond_attention_tokens = cond_attention_tokens if not per_frame_cond else 11  # vddp.py:603
         if self.cond_attention not in ("none", "self-stacked", "cross-attention"):
             raise ValueError("cond_attention must be none, self-stacked or cross-attention")
-        if self.cond_attention == "cross-attention":
-            raise NotImplementedError("cond_attention='cross-attention' is unreachable with the shipped configs and not built")
         self.cond_att_GRU = cond_att_GRU
         self.cond_dim = self.time_dim
         self.use_temporal_attention_cond = use_temporal_attention_cond
