@@ -55,12 +55,6 @@ typedef struct vmm_conv_desc {
    * output (+ bias) in gn_part[B * gn_groups][n][2] = n fp32 (sum x, sum x^2) pairs per (sample, group), every slot written exactly
    * once (vddp.py:274-279; vmm_groupnorm_coef totals them in a fixed order); samples are runs of a_imgs_per_sample frames. */
   float* gn_part; int32_t gn_groups;
-  /* vmm_conv3x3_bf16x3 / vmm_conv3x3_f32 only, with gn_part: when gn_coef is non-NULL and vmm_conv3x3_finalises_gn(d) == 1, the LAST workgroup
-   * to contribute to a sample also totals that sample's partial sums (fixed order, fp64) and writes the fused GroupNorm * FiLM
-   * coefficients gn_coef[B][Cout][2] = (a, b') exactly as vmm_groupnorm_coef would (gamma / beta [Cout], film rows [B][gn_ldfilm] =
-   * (scale | shift) or NULL, eps): the separate vmm_groupnorm_coef launch disappears.  Uses split_tickets[0 .. B) as arrival counters
-   * (left zero again). */
-  const float* gn_gamma; const float* gn_beta; const float* gn_film; int32_t gn_ldfilm; float gn_eps; float* gn_coef;
   /* periodic ("circular") padding instead of zero padding along h / w (vddp.py:163-243: padding_mode 'circular' = both, 'circular_1d' =
    * w only): taps that leave the frame read the opposite border.  Honoured by the implicit-GEMM kernels, vmm_conv_wgrad_f32 and the 2-D-tiled
    * instances of the 3 x 3 halo kernels (flat row tiles, the persistent kernel, vmm_conv_s2 / vmm_stem_conv return 1 / are not used). */
@@ -82,14 +76,14 @@ int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_str
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
  * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
-/* 1 when the launch described by d (gn_part set, vmm_conv3x3_fuses_gn(d) > 0) can also finalise the GroupNorm coefficients (d->gn_coef) */
-int vmm_conv3x3_finalises_gn(const vmm_conv_desc* d);
 /* the same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32; the "fp32" arithmetic mode): d->w = fmt-4 output of
  * vmm_pack_weights; same envelope, tickets and GroupNorm partials */
 int vmm_conv3x3_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* host-only query: the number n of partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part
  * (unsplit 2-D-tiled layers), or 0 when it will not produce them */
 int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
+/* host-only query: 1 when vmm_conv3x3_bf16x3 / vmm_conv3x3_f32 would take d as it stands (a_mode, a_img_mod, wrap_h / wrap_w, res ...), else 0 */
+int vmm_conv3x3_accepts(const vmm_conv_desc* d);
 /* 1x1 / Linear specialisation (to_qkv, to_out vddp.py:319,325,413,421; res_conv vddp.py:297): a workgroup stages its rows' full K
  * extent once in LDS and sweeps all output columns, weights read straight into registers in MFMA fragment order (d->w = fmt-2 output
  * of vmm_pack_weights), 16-byte epilogue stores; same epilogue options as vmm_conv_igemm_*.  ln_gamma != NULL: the rows pass through

@@ -131,12 +131,20 @@ def diffusion_goldens():
     return nograd
 
 
+def relpos_rows():
+    """The bucket of every signed frame distance -40 .. 40 (the table of n frames is bucket[j - i]): pins the whole envelope of the fused kernels
+    (T <= 32) and beyond, including the logarithmic branch whose fp32 log decides the bucket boundaries."""
+    rel = torch.arange(-40, 41)[None, :]
+    return RelativePositionBias._relative_position_bucket(rel, num_buckets=32, max_distance=32)[0].tolist()
+
+
 def table_goldens(nograd):
     tabs = {"nograd_params_lagr16": nograd}
     for n in (4, 11, 22):
         q = torch.arange(n)
         rel = q[None, :] - q[:, None]
         tabs[f"bucket_{n}"] = RelativePositionBias._relative_position_bucket(rel, num_buckets=32, max_distance=32).tolist()
+    tabs["bucket_by_distance_m40_40"] = relpos_rows()
     tabs["ddim_times_256_10"] = list(reversed(torch.linspace(-1, 255, steps=11).int().tolist()))
     tabs["ddim_times_256_256_head"] = list(reversed(torch.linspace(-1, 255, steps=257).int().tolist()))[:5]
     tabs["ddim_times_8_4"] = list(reversed(torch.linspace(-1, 7, steps=5).int().tolist()))
@@ -162,7 +170,13 @@ def table_goldens(nograd):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:  # python make_golden.py <config> [...]: only the Unet3D goldens of the named configs (adding one leaves the rest untouched)
+    if sys.argv[1:] == ["--relpos"]:  # only (re)write the all-distances bucket row into tables.json
+        path = os.path.join(HERE, "tables.json")
+        tabs = json.load(open(path))
+        tabs["bucket_by_distance_m40_40"] = relpos_rows()
+        json.dump(tabs, open(path, "w"))
+        print("relpos row written")
+    elif len(sys.argv) > 1:  # python make_golden.py <config> [...]: only the Unet3D goldens of the named configs (adding one leaves the rest untouched)
         unet_goldens(only=sys.argv[1:])
     else:
         unet_goldens()

@@ -37,6 +37,31 @@ def test_minibatch_assembly_matches_reference_dataset(gpu, name):
     assert np.array_equal(xi.cpu().numpy(), want[1]) and np.array_equal(li.cpu().numpy(), gold["labels"][1])
     with pytest.raises(IndexError):
         ds.batch([N])
+    # negative indices count from the end (the reference indexes Python lists); device-resident index tensors take the no-sync path
+    x3, _ = ds.batch([-1, -N])
+    assert np.array_equal(x3.cpu().numpy(), want[[N - 1, 0]])
+    x4, lab4 = ds.batch(torch.tensor([1, -1], device=gpu))
+    assert np.array_equal(x4.cpu().numpy(), want[[1, N - 1]]) and np.array_equal(lab4.cpu().numpy(), gold["labels"][[1, N - 1]])
+    with pytest.raises(IndexError):
+        ds.batch([-N - 1])
+
+
+def test_min_max_values_csv_like_the_reference(gpu, tmp_path):
+    """<folder>/min_max_values.csv (vddp.py:1210-1246): the rows, their order and values of the reference's constructor."""
+    import csv
+    import videometamaterials_amd as vm
+    for frame, names in (("lagrangian", ["min_u_1", "max_u_1", "min_u_2", "max_u_2", "max_s_mises", "min_s_22", "max_s_22", "max_strain_energy"]),
+                         ("eulerian", ["max_s_mises", "min_s_22", "max_s_22", "max_strain_energy"])):
+        frames, fr, curves = helpers.synth_dataset(5, frame, 4, 3, 8)
+        ds = vm.Dataset(torch.from_numpy(frames), fr, curves, reference_frame=frame, selected_channels=[0, 1], num_frames=3, device=gpu)
+        path = ds.write_min_max_values(str(tmp_path))
+        rows = list(csv.reader(open(path)))
+        assert [r[0] for r in rows] == names
+        fr = np.asarray(fr, dtype=np.float64)
+        cols = dict(zip(names, range(8))) if frame == "lagrangian" else dict(zip(names, range(4)))
+        for k, v in rows:
+            col = fr[:, cols[k]]
+            assert float(v) == (col.min() if k.startswith("min") else col.max()), k
 
 
 @pytest.mark.parametrize("P,frame", [(15, "lagrangian"), (96, "lagrangian"), (7, "eulerian")])

@@ -195,22 +195,6 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
         want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], -1)
         assert relerr(out.cpu(), ref - res) < tol
         assert relerr(part.cpu().double().sum(1).reshape(B, G, 2), want) < 2e-5  # every slot written exactly once (no NaN left)
-        # the coefficients themselves from the convolution's last workgroup per sample (arrival counters = the ticket array) against
-        # vmm_groupnorm_coef on the same partial sums
-        gamma, beta, film = torch.randn(Cout, generator=g).to(gpu), torch.randn(Cout, generator=g).to(gpu), torch.randn(B, 2 * Cout, generator=g).to(gpu)
-        coef_ref = torch.zeros(B, Cout, 2, device=gpu)
-        N.check(lib.vmm_groupnorm_coef(None, T * H * W * (Cout // G), C.c_float(1e-5), gamma.data_ptr(), beta.data_ptr(), film.data_ptr(), 2 * Cout, B, Cout, G,
-                                       coef_ref.data_ptr(), None, part.data_ptr(), n_part, None, 0, _s()), "gn coef")
-        d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
-        if lib.vmm_conv3x3_finalises_gn(C.byref(d)):
-            coef = torch.full((B, Cout, 2), float("nan"), device=gpu)
-            d.gn_gamma, d.gn_beta, d.gn_film, d.gn_ldfilm, d.gn_eps, d.gn_coef = gamma.data_ptr(), beta.data_ptr(), film.data_ptr(), 2 * Cout, 1e-5, coef.data_ptr()
-            for _ in range(2):  # twice: the counters must be back at zero
-                coef.fill_(float("nan"))
-                N.check(kernel(C.byref(d), _s()), "conv3x3 halo + gn coefficients")
-                torch.cuda.synchronize()
-                assert relerr(coef.cpu(), coef_ref.cpu()) < 1e-6
-            assert int(tickets.abs().sum()) == 0
     else:  # only flat row tiles longer than a sample (a tile would touch three samples) go without the fused sums
         assert not (W >= 32 and W % 16 == 0 and H % 16 == 0)
         if os.environ.get("VMM_C3_PERSISTENT") != "2":  # (2 = the persistent kernel for every shape: it fuses the sums for 2-D tiles only)
@@ -1282,17 +1266,6 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
     if ntok:
         assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 2e-5
         assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
-
-
-def test_in_kernel_groupnorm_finalisation_variant(gpu):
-    """VMM_GN_FINAL=1 (opt-in): the plans drop the 38 coefficient launches, the convolutions' trailing workgroups write the
-    coefficients; the denoiser goldens and a guided sampling step again in a process built that way."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_unet.py", "-k",
-                        "forward_matches_reference_golden or graphed_sampler or sampling_loops"], cwd=root, env=dict(os.environ, VMM_GN_FINAL="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])

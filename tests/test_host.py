@@ -42,6 +42,11 @@ def test_hostmath_integer_tables_bit_exact():
     tabs = _gold_tables()
     for n in (4, 11, 22):
         assert hm.relpos_buckets(n).tolist() == tabs[f"bucket_{n}"]
+    # every frame count up to 40 (the fused kernels' envelope is T <= 32): the reference's bucket of every signed distance -40 .. 40, the
+    # logarithmic branch included (hostmath evaluates it with numpy's fp32 log, the reference with torch's)
+    by_dist = tabs["bucket_by_distance_m40_40"]
+    for n in range(1, 41):
+        assert hm.relpos_buckets(n).tolist() == [[by_dist[40 + j - i] for j in range(n)] for i in range(n)], n
     assert [p[0] for p in hm.ddim_time_pairs(256, 10)] + [-1] == tabs["ddim_times_256_10"]
     assert [p[0] for p in hm.ddim_time_pairs(8, 4)] + [-1] == tabs["ddim_times_8_4"]
     for key, want in tabs["num_to_groups"].items():

@@ -49,6 +49,9 @@ def test_integer_tables_bit_exact():
         tabs = json.load(f)
     for n in (4, 11, 22):
         assert uo.rel_pos_bucket_table(n).tolist() == tabs[f"bucket_{n}"]
+    by_dist = tabs["bucket_by_distance_m40_40"]
+    for n in range(1, 41):
+        assert uo.rel_pos_bucket_table(n).tolist() == [[by_dist[40 + j - i] for j in range(n)] for i in range(n)], n
     # literal rows quoted in SURVEY 8a row a4
     assert uo.rel_pos_bucket_table(11)[0].tolist() == [0, 17, 18, 19, 20, 21, 22, 23, 24, 24, 25]
     assert uo.rel_pos_bucket_table(11)[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 8, 9]

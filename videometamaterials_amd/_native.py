@@ -39,7 +39,6 @@ class ConvDesc(C.Structure):
         ("a_mode", c_i32), ("a_coef", c_ptr), ("a_imgs_per_sample", c_i32),
         ("split_tickets", c_ptr), ("n_tickets", c_i32),
         ("gn_part", c_ptr), ("gn_groups", c_i32),
-        ("gn_gamma", c_ptr), ("gn_beta", c_ptr), ("gn_film", c_ptr), ("gn_ldfilm", c_i32), ("gn_eps", c_f32), ("gn_coef", c_ptr),
         ("wrap_h", c_i32), ("wrap_w", c_i32), ("a_img_mod", c_i32),
     ]
 
@@ -81,8 +80,8 @@ SIGNATURES = {
     "vmm_conv_igemm_bf16x3_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
-    "vmm_conv3x3_finalises_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
+    "vmm_conv3x3_accepts": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
@@ -183,12 +182,13 @@ def lib() -> C.CDLL:
     """Load (once) and type the shared library; raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("VMM_LIB_PATH", LIB_PATH)  # (VMM_LIB_PATH: A/B measurements of two builds on one box; read once)
+        if not os.path.exists(path):
             raise NativeError(
-                f"{LIB_PATH} is missing: the HIP extension must be built (python -m videometamaterials_amd.build); "
+                f"{path} is missing: the HIP extension must be built (python -m videometamaterials_amd.build); "
                 "there is no CPU/PyTorch fallback for the hot path"
             )
-        handle = C.CDLL(os.environ.get("VMM_LIB_PATH", LIB_PATH))  # (VMM_LIB_PATH: A/B measurements of two builds on one box)
+        handle = C.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes

@@ -56,82 +56,10 @@ struct C3Args {
   int cps_shift;                 // TS == 2: log2(channel chunks per sub-pixel)
   unsigned tpf_magic, tx_magic;  // floor(2^32 / d) + 1 for d = tiles_per_frame, tiles_x: n / d = mulhi(n, magic) for n d < 2^32 -- a run-time
                                  // division is expanded on the VECTOR unit (v_rcp_iflag) and leaves the wave-uniform tile coordinates in VGPRs
-  int n_final;                   // trailing workgroups that finalise the GroupNorm coefficients, one per sample (p.gn_coef), else 0
   unsigned long long* trace = nullptr;  // VMM_C3_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (16 slots per workgroup)
 };
 
 __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
-
-// GroupNorm * FiLM coefficients of sample `smp` from the partial sums every tile of the sample has left in p.gn_part -- run by the last
-// workgroup to arrive for that sample (all 256 threads).  The same arithmetic as gn_coef_kernel (norm.hip): fp64 totals in a fixed
-// order (32 threads per group stride the slot list, then one thread adds the 32 partial totals in order), biased variance clamped at
-// zero, a = rstd * gamma * (scale + 1), b' = (beta - mean * rstd * gamma) * (scale + 1) + shift.  The slots were written with
-// agent-scope (write-through) stores by workgroups on other XCDs and are read with agent-scope loads.
-__device__ __forceinline__ void gn_finalise(const vmm_conv_desc& p, int smp, int n_contrib, double inv_count, double* red /* LDS, 2400 doubles */, int tid) {
-  const int G = p.gn_groups, C = p.Cout, cpg = C / G;
-  double* red2 = red + 2048;  // [8][32]
-  double* tot = red2 + 256;   // [8]: (sum, sum of squares) of four groups, then (mean, rstd)
-  for (int g0 = 0; g0 < G; g0 += 4) {
-    // four groups at a time: thread tid takes slots tid, tid + 256, ... of each -- eight independent loads per round, all in flight together
-    // (a dependent chain of agent-scope loads costs a memory round trip per link)
-    double acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    for (int k = tid; k < n_contrib; k += 256) {
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int g = min(g0 + (q >> 1), G - 1);
-        v[q] = __hip_atomic_load(p.gn_part + ((long long)(smp * G + g) * n_contrib + k) * 2 + (q & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += (double)v[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) red[q * 256 + tid] = acc[q];
-    __syncthreads();
-    {  // fixed order: 8 strided partial totals per (value, lane of 32), then 32 in sequence
-      const int q = tid >> 5, l = tid & 31;
-      double t = 0.0;
-#pragma unroll
-      for (int i2 = 0; i2 < 8; ++i2) t += red[q * 256 + l + 32 * i2];
-      red2[q * 32 + l] = t;
-    }
-    __syncthreads();
-    if (tid < 8) {
-      double t = 0.0;
-      for (int k = 0; k < 32; ++k) t += red2[tid * 32 + k];
-      tot[tid] = t;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      const double mean = tot[2 * tid] * inv_count;
-      double var = tot[2 * tid + 1] * inv_count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      red2[2 * tid] = mean;
-      red2[2 * tid + 1] = 1.0 / sqrt(var + (double)p.gn_eps);
-    }
-    __syncthreads();
-    for (int i2 = tid; i2 < 4 * cpg; i2 += 256) {
-      const int gq = i2 / cpg, g = g0 + gq;
-      if (g < G) {
-        const int c = g * cpg + (i2 - gq * cpg);
-        const float meanf = (float)red2[2 * gq], rstd = (float)red2[2 * gq + 1];
-        float a = rstd * p.gn_gamma[c];
-        float bb = p.gn_beta[c] - meanf * a;
-        if (p.gn_film) {
-          const float sc = p.gn_film[(long long)smp * p.gn_ldfilm + c] + 1.0f;
-          const float sh = p.gn_film[(long long)smp * p.gn_ldfilm + C + c];
-          a *= sc;
-          bb = bb * sc + sh;
-        }
-        p.gn_coef[((long long)smp * C + c) * 2] = a;
-        p.gn_coef[((long long)smp * C + c) * 2 + 1] = bb;
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // TS ("tap subsets"): the stride-2 resampling layers as 3 x 3 neighbourhood convolutions of which every unit uses a 2 x 2 corner:
 //   TS == 1  ConvTranspose (1,4,4) stride 2 pad 1 (Upsample, vddp.py:155): output pixel (2y + py, 2x + px) is a 2 x 2 convolution over the
@@ -146,6 +74,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   constexpr int BM = WM * 64;
   constexpr int NQ = TS ? 8 : 18;  // k16 steps per chunk
   static_assert(!TS || (!SPLIT && !F32), "tap-subset layers: unsplit split-bf16 only");
+  static_assert(MAXP <= 16, "the source-row exchange below has every lane of an 8-lane group compute two of the MAXP patch items (ps = k4, k4 + 8)");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ph = smem;
   const vmm_conv_desc& p = a.p;
@@ -165,34 +94,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
   // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in
   // one L2 instead of being fetched once per XCD.
-  const int G = gridDim.x - a.n_final, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  if (!SPLIT && !TS && (int)blockIdx.x >= G) {
-    // Finaliser of sample blockIdx.x - G (p.gn_coef): dispatched after every tile workgroup (so they are all resident or done: no
-    // deadlock), it waits until the sample's arrival counter says that all its tiles have left their partial sums -- each tile signals
-    // with a fire-and-forget atomic after its stores are acknowledged, nobody waits for a returned value on the tiles' way out -- then
-    // totals them and writes the GroupNorm * FiLM coefficients the next kernel's loaders read (gn_finalise), and zeroes the counter.
-    const int smp = (int)blockIdx.x - G;
-    const int R = p.Hin * p.Win * p.a_imgs_per_sample;
-    const int cpg = p.Cout / p.gn_groups, rpg = cpg >> 3;
-    int expect, n_contrib;
-    if (MODE) {
-      expect = p.a_imgs_per_sample * a.tiles_per_frame * a.n_tiles;
-      n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * rpg;
-    } else {
-      const int first_t = (int)(((long long)smp * R) / BM), last_t = (int)((((long long)smp + 1) * R - 1) / BM);
-      expect = (last_t - first_t + 1) * a.n_tiles;
-      n_contrib = ((R + BM - 1) / BM + 1) * rpg;
-    }
-    if (threadIdx.x == 0) {
-      // (bounded: a protocol error must end as wrong coefficients that the tests catch, not as a workgroup spinning for ever)
-      for (int spins = 0; __hip_atomic_load(p.split_tickets + smp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect && spins < (1 << 24); ++spins)
-        __builtin_amdgcn_s_sleep(8);
-      __hip_atomic_store(p.split_tickets + smp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    gn_finalise(p, smp, n_contrib, 1.0 / ((double)R * (double)cpg), reinterpret_cast<double*>(smem), threadIdx.x);
-    return;
-  }
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int tile_id = C3_XCD_ORDER ? xcd * (G >> 3) + min(xcd, G & 7) + jx : (int)blockIdx.x;
   const int mtile = tile_id / a.n_tiles;
   const int n0 = (tile_id % a.n_tiles) * (WN * 64);
@@ -736,13 +638,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         sc[64 + wave * 16 + (lane >> 2)] = totB;
       }
       __syncthreads();
-      // p.gn_coef: the slots go out as agent-scope (write-through) stores, every workgroup then counts itself in on its sample's arrival
-      // counter, and the last one totals the sample's slots and writes the coefficients (gn_finalise)
-      const bool fin = p.gn_coef != nullptr;
-      auto put_slot = [&](float* q, float v) {
-        if (fin) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *q = v;
-      };
+      auto put_slot = [&](float* q, float v) { *q = v; };
       if (tid < WN * 16) {
         const int wn2 = tid >> 4, slot = tid & 15, run = slot >> 1;
         float vA = 0.f, vB = 0.f;
@@ -771,15 +667,6 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
           };
           put(smpA, vA);
           if (straddle) put(smpA + 1, vB);
-        }
-      }
-      if (fin && tid < WN * 16) {
-        // the slot stores above come from these threads only: once THEY are acknowledged (s_waitcnt vmcnt(0) -- the tile's output stores of
-        // this wave went out before them and are long on their way) the tile counts itself in, without waiting for an answer
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (tid == 0) {
-          __hip_atomic_fetch_add(p.split_tickets + smpA, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (straddle) __hip_atomic_fetch_add(p.split_tickets + smpA + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -1477,7 +1364,7 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   // VMM_C3_TRACE=<k>: the k-th launch of this process dumps its workgroups' phase stamps to VMM_C3_TRACE_FILE (tools/trace_c3.py reads them)
   static const int trace_launch = [] { const char* e = getenv("VMM_C3_TRACE"); return e ? atoi(e) : -1; }();
   static int* launch_no = c3_launch_counter();
-  const unsigned nwg = (unsigned)(mtiles * a.n_tiles + (SPLIT ? 0 : a.n_final));
+  const unsigned nwg = (unsigned)(mtiles * a.n_tiles);
   if (trace_launch >= 0 && (*launch_no)++ == trace_launch) {
     C3Args at = a;
     const size_t n = (size_t)nwg * ksplit * 16;
@@ -1532,7 +1419,6 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   const bool wide = d.Cout >= 128;  // 2 x 2 waves, 128 pixels x 128 columns; else 4 x 1 waves, 256 pixels x 64 columns
   const int BM = wide ? 128 : 256, TH = BM / 16;
   a.p = d;
-  a.n_final = 0;
   a.cps_shift = 0;
   a.n_tiles = wide ? d.Cout / 128 : 1;
   a.total_rows = (int)M;
@@ -1576,9 +1462,6 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
        (d.Cout / d.gn_groups) % 8 == 0 && d.nimg % d.a_imgs_per_sample == 0 &&
        (a.mode == 1 || (long long)d.Hin * d.Win * d.a_imgs_per_sample >= BM);
   if (!gn) a.p.gn_part = nullptr;
-  // in-kernel coefficient finalisation: needs the fused statistics and one arrival counter per sample
-  if (!gn || !d.gn_gamma || !d.gn_beta || !d.split_tickets || d.n_tickets < d.nimg / max(d.a_imgs_per_sample, 1)) a.p.gn_coef = nullptr;
-  a.n_final = a.p.gn_coef ? d.nimg / d.a_imgs_per_sample : 0;
   return 0;
 }
 
@@ -1618,7 +1501,6 @@ int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t 
   PWArgs pa;
   if (c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
     pa.p.gn_part = pa.mode == 1 ? a.p.gn_part : nullptr;  // (cleared by plan_c3 when the statistics are not fused; the persistent kernel fuses them for 2-D tiles only)
-    pa.p.gn_coef = nullptr;                               // (it never finalises the coefficients: vmm_conv3x3_finalises_gn says 0 for its launches)
     if (getenv("VMM_PW_LOG")) fprintf(stderr, "[pw] Cin %d+%d Cout %d %dx%d nimg %d mode %d units %d a_mode %d gn %p res %p lda %d %d ldo %d\n", a.p.C1, a.p.C2, a.p.Cout, a.p.Hin,
                                       a.p.Win, a.p.nimg, pa.mode, pa.n_units, a.p.a_mode, (void*)pa.p.gn_part, (void*)a.p.res, a.p.lda1, a.p.lda2, a.p.ldo);
     return pa.mode ? launch_pw<1, F32>(pa, s) : launch_pw<0, F32>(pa, s);
@@ -1652,19 +1534,14 @@ extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
   return (int)((R + BM - 1) / BM + 1) * rpg;  // flat row tiles: the most tiles a sample can touch
 }
 
-extern "C" int vmm_conv3x3_finalises_gn(const vmm_conv_desc* dp) {
-  if (getenv("VMM_NO_GN_FUSE") || getenv("VMM_NO_GN_FINAL")) return 0;  // measurement aids
+// host-only query: 1 when vmm_conv3x3_bf16x3 / vmm_conv3x3_f32 would take this descriptor as it stands (fused operand transform, a_img_mod, periodic
+// padding, residual ...), 0 when the launcher would return non-zero.  Lets a plan builder decide on optional features (shared source frames)
+// without restating the kernel's envelope.
+extern "C" int vmm_conv3x3_accepts(const vmm_conv_desc* dp) {
   C3Args a;
   int mtiles, ksplit;
   bool gn = false;
-  vmm_conv_desc d = *dp;
-  static float dummy;
-  d.gn_coef = &dummy;  // (the query is about the shape: would a non-NULL gn_coef survive plan_c3?)
-  if (!d.gn_gamma) d.gn_gamma = &dummy;
-  if (!d.gn_beta) d.gn_beta = &dummy;
-  if (plan_c3(d, a, mtiles, ksplit, gn) != 0 || !gn || !a.p.gn_coef) return 0;
-  PWArgs pa;
-  return c3_use_pw(d, ksplit, pa) ? 0 : 1;
+  return plan_c3(*dp, a, mtiles, ksplit, gn) == 0 ? 1 : 0;
 }
 
 // Weights: vmm_pack_weights fmt 2 (MFMA fragment order).  Returns 1 (nothing launched) when the descriptor is outside this

@@ -118,10 +118,22 @@ class Dataset:
 
     def batch(self, indices) -> Tuple[torch.Tensor, torch.Tensor]:
         """(B, channels, T, H, W) fp32 in [0, 1] and the (B, L) labels of dataset rows ``indices``, on the device, in one launch."""
-        idx = torch.as_tensor(indices, device=self.device).to(torch.int32).reshape(-1).contiguous()
         n, nf, f, H, W = self.frames.shape
-        if idx.numel() == 0 or int(idx.min()) < 0 or int(idx.max()) >= n:
-            raise IndexError("dataset index out of range")
+        if isinstance(indices, torch.Tensor) and indices.is_cuda:
+            # device-resident indices (a device sampler): wrapped and range-checked without a host round trip -- an index outside
+            # [-n, n) is clamped into range on the device and reported by the check below only in debug runs (VMM_DEBUG_SYNC)
+            idx = indices.to(torch.int64).reshape(-1)
+            if os.environ.get("VMM_DEBUG_SYNC") and (idx.numel() == 0 or int(idx.min()) < -n or int(idx.max()) >= n):
+                raise IndexError("dataset index out of range")
+            idx = torch.where(idx < 0, idx + n, idx).clamp_(0, n - 1).to(torch.int32).contiguous()
+        else:
+            # the usual case, a sampler's list / numpy array: validated on the host (no device -> host synchronisation on the training
+            # stream), negative indices count from the end like the reference's list indexing
+            host = np.asarray(indices.cpu() if isinstance(indices, torch.Tensor) else indices, dtype=np.int64).reshape(-1)
+            if host.size == 0 or host.min() < -n or host.max() >= n:
+                raise IndexError("dataset index out of range")
+            host = np.where(host < 0, host + n, host).astype(np.int32)
+            idx = torch.from_numpy(host).to(self.device, non_blocking=True)
         T = self.num_frames if self.force_num_frames else f
         nch = len(self.selected_channels)
         out = torch.empty((idx.numel(), nch, T, H, W), dtype=torch.float32, device=self.device)
@@ -138,7 +150,20 @@ class Dataset:
     def from_folder(cls, folder: str, image_size: int, exts: Sequence[str] = ("gif",), **kw) -> "Dataset":
         """The reference's constructor signature (folder, image_size, ...): read_folder, then upload."""
         frames, fr, curves = read_folder(folder, image_size, exts, kw.get("reference_frame", "eulerian"))
-        return cls(frames, fr, curves, **kw)
+        ds = cls(frames, fr, curves, **kw)
+        ds.write_min_max_values(folder)
+        return ds
+
+    def write_min_max_values(self, folder: str) -> str:
+        """<folder>/min_max_values.csv exactly as the reference's constructor leaves it (vddp.py:1210-1246; same rows, same order): the
+        constants its README points to for rescaling predictions to physical units."""
+        import csv
+        names = (["min_u_1", "max_u_1", "min_u_2", "max_u_2"] if self.reference_frame == "lagrangian" else []) + \
+                ["max_s_mises", "min_s_22", "max_s_22", "max_strain_energy"]
+        path = os.path.join(folder, "min_max_values.csv")
+        with open(path, "w", newline="") as f:
+            csv.writer(f).writerows([[k, getattr(self, k).item()] for k in names])
+        return path
 
 
 def read_folder(folder: str, image_size: int, exts: Sequence[str] = ("gif",), reference_frame: str = "eulerian"):
@@ -149,12 +174,15 @@ def read_folder(folder: str, image_size: int, exts: Sequence[str] = ("gif",), re
     from pathlib import Path
     from PIL import Image
     frame = reference_frame
-    stacks = []
-    for field in FIELDS[frame]:
+    out = None  # (N, n_fields, f, H, W) uint8, allocated once the first GIF is decoded and filled in place (the 53 k-sample training set
+    #             is 27 GB decoded: per-sample lists + two np.stack copies would double that on the host)
+    n_fields = len(FIELDS[frame])
+    for fi, field in enumerate(FIELDS[frame]):
         paths = sorted((p for ext in exts for p in Path(os.path.join(folder, "gifs", field)).glob(f"**/*.{ext}")), key=lambda p: int(p.name.split(".")[0]))
         assert all(int(p.stem) == i for i, p in enumerate(paths)), "file position is not equal to index"
-        per_sample = []
-        for p in paths:
+        if out is not None and len(paths) != out.shape[0]:
+            raise ValueError("number of files / frames in the field folders are not equal")
+        for si, p in enumerate(paths):
             img, planes, i = Image.open(p), [], 0
             while True:  # seek_all_images, vddp.py:1077-1088
                 try:
@@ -163,11 +191,15 @@ def read_folder(folder: str, image_size: int, exts: Sequence[str] = ("gif",), re
                     break
                 planes.append(np.asarray(img.convert("L"), dtype=np.uint8))
                 i += 1
-            per_sample.append(np.stack(planes))
-        stacks.append(np.stack(per_sample))
-    if len({s.shape for s in stacks}) != 1:
-        raise ValueError("number of files / frames in the field folders are not equal")
-    frames = torch.from_numpy(np.stack(stacks, 1))
+            if out is None:
+                out = np.empty((len(paths), n_fields, len(planes)) + planes[0].shape, dtype=np.uint8)
+            if len(planes) != out.shape[2] or planes[0].shape != out.shape[3:]:
+                raise ValueError("number of files / frames in the field folders are not equal")
+            for k, pl in enumerate(planes):
+                out[si, fi, k] = pl
+    if out is None:
+        raise ValueError(f"no {exts} files under {folder}/gifs")
+    frames = torch.from_numpy(out)
     if frames.shape[-1] != image_size or frames.shape[-2] != image_size:
         raise NotImplementedError(f"GIFs are {frames.shape[-2]} x {frames.shape[-1]}, image_size is {image_size}: resize them offline")
     fr = np.genfromtxt(os.path.join(folder, "frame_range_data.csv"), delimiter=",")

@@ -497,7 +497,7 @@ class _Builder:
         if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
             return False
         kp = (k + 31) // 32 * 32
-        if kp == 256 and cout <= 64 and not os.environ.get("VMM_PROJ_K256N64"):  # one 64-row tile per CU and a single column slice: the streaming implicit GEMM is faster (measured)
+        if kp == 256 and cout <= 64:  # one 64-row tile per CU and a single column slice: no faster than the streaming implicit GEMM (measured twice)
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
@@ -589,20 +589,11 @@ class _Builder:
         if n_part:
             part_off = self.alloc(B * G * n_part * 2)
             conv_desc.gn_part = self.ptr(part_off)
-            if not self.training and os.environ.get("VMM_GN_FINAL") == "1" and int(self.lib.vmm_conv3x3_finalises_gn(C.byref(conv_desc))):
-                # Opt-in: one trailing workgroup per sample of the convolution itself totals the partial sums and writes the coefficients --
-                # no coefficient launch: 162 -> 124 launches per guided step, and the step 0.15-0.2 ms SLOWER in every same-box A/B (a
-                # dependent ~5 us tail inside each of 38 kernels against ~3 us for a 64-workgroup launch inside the hipGraph): the launch
-                # count is not what bounds the step
-                conv_desc.gn_gamma, conv_desc.gn_beta = self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias")
-                conv_desc.gn_film, conv_desc.gn_ldfilm, conv_desc.gn_eps = film_ptr or None, ldfilm, 1e-5
-                conv_desc.gn_coef = self.ptr(coef_off)
-            else:
-                self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
-                if mirror:
-                    args2 = (rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
-                             (film_ptr + 4 * B * ldfilm) if film_ptr else None, ldfilm, B, C_, G, self.ptr(coef_off + B * C_ * 2), None)
-                    self.step(self.lib.vmm_groupnorm_coef, (None, *args2, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef (second half)")
+            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef")
+            if mirror:
+                args2 = (rows_ps * (C_ // G), C.c_float(1e-5), self.wraw(prefix + ".norm.weight"), self.wraw(prefix + ".norm.bias"),
+                         (film_ptr + 4 * B * ldfilm) if film_ptr else None, ldfilm, B, C_, G, self.ptr(coef_off + B * C_ * 2), None)
+                self.step(self.lib.vmm_groupnorm_coef, (None, *args2, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef (second half)")
             self.free(part_off, B * G * n_part * 2)
         elif rows_ps * (C_ // G) <= GN_DIRECT_MAX and (C_ // G) % 4 == 0:
             # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
@@ -613,7 +604,8 @@ class _Builder:
             self.step(self.lib.vmm_groupnorm_stats_partials, (h.ptr, h.ld, B, rows_ps, C_, G, self.ptr(part_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
             self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), nslots, None, 0), prefix + ".norm coef")
             self.free(part_off, B * G * nslots * 2)
-        assert not mirror or (n_part and not (os.environ.get("VMM_GN_FINAL") == "1"))
+        if mirror and not n_part:
+            raise RuntimeError("mirrored ResnetBlock without fused GroupNorm partial sums (vmm_conv3x3_accepts and vmm_conv3x3_fuses_gn disagree)")
         return coef_off, (2 if mirror else 1) * B * C_ * 2, self.ptr(coef_off), stats_ptr
 
     def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
@@ -644,8 +636,18 @@ class _Builder:
         # are too -- time and conditioning enter with the FiLM rows of the coefficients.  The convolution runs on one half; block2's loader
         # reads that half for both (a_img_mod) under each sample's own coefficients.  Needs the 2-D-tiled unsplit 3 x 3 kernel on both.
         half = self.B // 2
-        mirror_in = bool(mirror_in and halo1 and halo2 and x2 is None and W >= 32 and W % 16 == 0 and H % 16 == 0
-                         and half * self.T * H * W >= 128 * 256 and os.environ.get("VMM_GN_FINAL") != "1" and _enabled("mirror_conv"))
+        mirror_in = bool(mirror_in and halo1 and halo2 and x2 is None and half * self.T * H * W >= 128 * 256 and _enabled("mirror_conv"))
+        if mirror_in:
+            # the kernel's own envelope for shared source frames (unsplit 2-D tiles), asked of the library instead of restated here: a
+            # throw-away descriptor of block2's launch (any non-NULL pointers; nothing is launched)
+            probe = N.ConvDesc()
+            probe.a1, probe.C1, probe.lda1, probe.w, probe.out, probe.ldo, probe.Cout = self.base, Cout, Cout, self.wbase, self.base, Cout, Cout
+            probe.nimg, probe.Hin, probe.Win, probe.Hv, probe.Wv, probe.stride = self.B * self.T, H, W, H, W, 1
+            probe.KH, probe.KW, probe.off_h, probe.off_w, probe.sgn_h, probe.sgn_w = 3, 3, -1, -1, 1, 1
+            probe.Hout, probe.Wout, probe.oscale = H, W, 1
+            probe.a_mode, probe.a_coef, probe.a_imgs_per_sample, probe.a_img_mod = 1, self.base, self.T, half * self.T
+            probe.wrap_h, probe.wrap_w = self.wrap_h, self.wrap_w
+            mirror_in = bool(self.lib.vmm_conv3x3_accepts(C.byref(probe)))
         if mirror_in:
             self.B = half
         h1 = self.act(Cout, H, W)

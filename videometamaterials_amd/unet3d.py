@@ -14,6 +14,7 @@ plain tensors) but ``forward`` raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -293,7 +294,10 @@ class Unet3D(nn.Module):
 
     def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False) -> "_plan.Plan":
         """mirrored: the caller feeds x[B/2:] == x[:B/2] (guidance: both branches in one batch) -- the conditioning-free prefix is shared."""
-        key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision, bool(mirrored))
+        # (the measurement switches that change a plan's structure are part of its identity: flipping VMM_DISABLE between calls must not
+        # hand back a plan built under the other setting)
+        key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision, bool(mirrored),
+               os.environ.get("VMM_DISABLE", ""), bool(getattr(self, "use_x3_wgrad", True)), bool(getattr(self, "use_x3_wgrad_generic", False)))
         pl = self._plans.get(key)
         if pl is None:
             pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training, mirrored=mirrored)
