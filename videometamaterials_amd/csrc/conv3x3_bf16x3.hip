@@ -675,7 +675,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 }
 
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const C3Args a) {
+#ifndef VMM_C3_WGS
+#define VMM_C3_WGS 2
+#endif
+__global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Args a) {
   conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0>(a);
 }
 
