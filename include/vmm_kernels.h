@@ -94,6 +94,12 @@ int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps,
 /* ResnetBlock tail (vddp.py:311) in one launch: out = silu(res * a + b') + proj(x); res = d->res = the pre-norm output of block2's
  * convolution (may alias d->out), (a, b') = res_coef [B][Cout][2] from vmm_groupnorm_coef, proj = res_conv.  Envelope of vmm_proj_bf16x3. */
 int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* d, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream);
+/* wide contraction, 64 output columns (to_out K = 256 -> 64, the to_qkv data gradient K = 768 -> 64 at the 96 x 96 level: HBM-bound sweeps):
+ * activations as the MFMA's B operand straight from global memory into registers (a lane = a row, 32 contiguous bytes per k16 step), fmt-2
+ * weights straight from L1 / L2, a wave owns 64 rows x 64 columns, no LDS and no barrier (narrow_proj.hip).  Envelope: KH = KW = 1, stride 1,
+ * identity rows, Cout == 64, C1 / C2 multiples of 16, K = C1 + C2 >= 64 and a multiple of 32, no fused operand transform, no rotary / q-scale;
+ * bias / residual epilogue.  Returns 1 (nothing launched) outside it. */
+int vmm_proj_narrow_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
 /* exact-fp32 variant (d->w = fmt-4 output of vmm_pack_weights) */
 int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
 

@@ -676,6 +676,42 @@ def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias):
     assert relerr(o2.cpu(), want2) < 3e-6
 
 
+@pytest.mark.parametrize("rows,C1,C2,bias,res", [(5000, 256, 0, True, True), (333, 768, 0, False, True), (64, 64, 64, True, False), (1, 256, 0, False, False),
+                                                 (40000, 768, 0, False, False), (257, 128, 128, True, True)])
+def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):
+    """vmm_proj_narrow_bf16x3 (wide contraction -> 64 columns: activations and fmt-2 weights straight into registers, no LDS): to_out K = 256 -> 64
+    and the to_qkv data gradient K = 768 -> 64, against x @ W (+ bias + residual, in place); row counts that are no multiple of the 64-row wave
+    tile, two concatenated sources."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(rows + C1)
+    K = C1 + C2
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(64, K, generator=g) / math.sqrt(K)  # (out, in)
+    b = torch.randn(64, generator=g) if bias else None
+    r = torch.randn(rows, 64, generator=g) if res else None
+    want = x @ w.t() + (b if bias else 0) + (r if res else 0)
+    wp = _pack_frag(N, lib, gpu, w, 2)
+    x1 = x[:, :C1].contiguous().to(gpu)
+    x2 = x[:, C1:].contiguous().to(gpu) if C2 else None
+    out = r.clone().to(gpu) if res else torch.full((rows, 64), 7.0, device=gpu)  # the residual is read from the output buffer (in place)
+    bg = b.to(gpu) if bias else None
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = x1.data_ptr(), C1, C1
+    if C2:
+        d.a2, d.C2, d.lda2 = x2.data_ptr(), C2, C2
+    d.w, d.bias = wp.data_ptr(), bg.data_ptr() if bias else None
+    d.out, d.ldo, d.Cout = out.data_ptr(), 64, 64
+    if res:
+        d.res, d.ldres = out.data_ptr(), 64
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = 1, 1, rows, 1, rows, 1
+    d.KH, d.KW, d.sgn_h, d.sgn_w, d.Hout, d.Wout, d.oscale = 1, 1, 1, 1, 1, rows, 1
+    assert lib.vmm_proj_narrow_bf16x3(C.byref(d), _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), want) < 5e-5
+    d.Cout = 128
+    assert lib.vmm_proj_narrow_bf16x3(C.byref(d), _s()) == 1  # outside the envelope: nothing launched
+
+
 def test_projection_rotary_epilogue(gpu):
     """q*scale then interleaved-pair rotation of q,k by the frame index (vddp.py:449,491-496)."""
     from videometamaterials_amd import hostmath

@@ -1,0 +1,145 @@
+// 1x1 / Linear with a wide contraction and 64 output columns -- the training step's to_out (K = 256 -> 64, vddp.py:325, 421) and the data gradient
+// of to_qkv (K = 768 -> 64, autograd of vddp.py:319, 413) at the 96 x 96 level -- on the split-bf16 matrix cores, gfx950.
+//
+//   out[row][0..64) = sum_k a[row][k] w[k][.] (+ bias) (+ res[row][.])
+//
+// These are HBM-bound sweeps: 1-3 KB read per row for 256 bytes written, 2 K 64 flops per row = a tenth of the matrix pipes' time at the
+// HBM rate.  The generic implicit GEMM stages both operands through LDS behind barriers and reaches 1.6-2.6 TB/s on them; the A-stationary
+// projection kernel fits one row tile per CU at K = 256.  Here nothing is staged at all:
+//   * activations are the MFMA's B operand (lane = row, eight consecutive k): a lane's fragment is 32 contiguous bytes of its row, loaded
+//     straight into registers (the two lane halves read adjacent 32-byte pieces: every 128-byte line is used in full over two k16 steps) and
+//     split there;
+//   * weights are the A operand in the fragment order vmm_pack_weights fmt 2 leaves them in: 16 bytes per lane, plane and step straight from
+//     L1 / L2 (K 64 x 4 bytes = 64-192 KB, shared by every wave of the launch);
+//   * a wave owns 64 rows x 64 columns (four 32 x 32 accumulators; lane = row, a register quad = four consecutive columns -> 16-byte
+//     stores), walks K with its loads three k16 steps ahead, and never meets another wave: no LDS, no barrier.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int DEPTH = 3;  // k16 steps of loads in flight per wave
+
+struct NPArgs {
+  vmm_conv_desc p;
+  long long rows;
+  int ksteps;  // K / 16
+};
+
+__global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) {
+  const vmm_conv_desc& p = a.p;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (row0 >= a.rows) return;
+  // this lane's two rows (row fragments 0 and 1); rows past the end re-read the last row and are not stored
+  const long long r0 = min(row0 + l31, a.rows - 1), r1 = min(row0 + 32 + l31, a.rows - 1);
+  const int KS = a.ksteps, KS1 = p.C1 >> 4;
+  auto src = [&](long long r, int ks) -> const float* {  // 8 floats of row r at k = ks * 16 + half * 8 (two sources: concatenated channels)
+    return ks < KS1 ? p.a1 + r * p.lda1 + ks * 16 + half * 8 : p.a2 + r * p.lda2 + (ks - KS1) * 16 + half * 8;
+  };
+  // weights: plane (nt, ks, hi | lo) = 64 lanes x 16 bytes
+  const uint4* wq = reinterpret_cast<const uint4*>(p.w) + lane;
+  auto wplane = [&](int nt, int ks, int lo) -> const uint4* { return wq + ((long long)(nt * KS + ks) * 2 + lo) * 64; };
+
+  f32x4 xa[DEPTH][2][2];   // [stage][row fragment][first / second four floats]
+  uint4 wv[DEPTH][2][2];   // [stage][column tile][hi | lo]
+  auto request = [&](int st, int ks) {
+    const int k = min(ks, KS - 1);  // (the tail re-requests the last step: unconditional loads, no branch in the step)
+    const float* s0 = src(r0, k);
+    const float* s1 = src(r1, k);
+    xa[st][0][0] = *reinterpret_cast<const f32x4*>(s0);
+    xa[st][0][1] = *reinterpret_cast<const f32x4*>(s0 + 4);
+    xa[st][1][0] = *reinterpret_cast<const f32x4*>(s1);
+    xa[st][1][1] = *reinterpret_cast<const f32x4*>(s1 + 4);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      wv[st][nt][0] = *wplane(nt, k, 0);
+      wv[st][nt][1] = *wplane(nt, k, 1);
+    }
+  };
+  f32x16 acc[2][2];  // [column tile][row fragment]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) request(s, s);
+  for (int ks0 = 0; ks0 < KS; ks0 += DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const int ks = ks0 + s;
+      if (ks < KS) {  // (wave-uniform)
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf) {
+          uint4 h, l;
+          h.x = split_bf16_pair(xa[s][rf][0].x, xa[s][rf][0].y, l.x);
+          h.y = split_bf16_pair(xa[s][rf][0].z, xa[s][rf][0].w, l.y);
+          h.z = split_bf16_pair(xa[s][rf][1].x, xa[s][rf][1].y, l.z);
+          h.w = split_bf16_pair(xa[s][rf][1].z, xa[s][rf][1].w, l.w);
+          bh[rf] = __builtin_bit_cast(bf16x8, h);
+          bl[rf] = __builtin_bit_cast(bf16x8, l);
+        }
+        const bf16x8 ah0 = __builtin_bit_cast(bf16x8, wv[s][0][0]), al0 = __builtin_bit_cast(bf16x8, wv[s][0][1]);
+        const bf16x8 ah1 = __builtin_bit_cast(bf16x8, wv[s][1][0]), al1 = __builtin_bit_cast(bf16x8, wv[s][1][1]);
+        request(s, ks + DEPTH);
+        // pass-major, lo products first
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+  // acc[nt][rf][r]: column nt * 32 + (r & 3) + 8 (r >> 2) + 4 half, row = row fragment rf, lane l31
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf) {
+    const long long row = row0 + rf * 32 + l31;
+    if (row >= a.rows) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = nt * 32 + 8 * q + 4 * half;
+        f32x4 v = {acc[nt][rf][4 * q], acc[nt][rf][4 * q + 1], acc[nt][rf][4 * q + 2], acc[nt][rf][4 * q + 3]};
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + c);
+        *reinterpret_cast<f32x4*>(p.out + row * p.ldo + c) = v;
+      }
+  }
+}
+
+}  // namespace
+
+// d->w = vmm_pack_weights fmt 2 of the (K, 64) operand.  Envelope: KH = KW = 1, stride 1, identity row mapping, Cout == 64, C1 (and C2)
+// multiples of 16 with K = C1 + C2 >= 64, no fused operand transform, no rotary / q-scale epilogue; bias / residual as in vmm_conv_igemm_*
+// (res may alias out).  Returns 1 (nothing launched) outside it.
+extern "C" int vmm_proj_narrow_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 &&
+                        d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0 && !d.a_img_mod && !d.rot_ncols && !d.q_ncols;
+  const int K = d.C1 + d.C2;
+  const bool chan_ok = d.Cout == 64 && d.C1 > 0 && d.C1 % 16 == 0 && d.C2 % 16 == 0 && K >= 64 && K % 32 == 0 && (d.lda1 & 3) == 0 && (!d.C2 || (d.lda2 & 3) == 0) &&
+                       (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
+  if (!shape_ok || !chan_ok) return 1;
+  NPArgs a;
+  a.p = d;
+  a.rows = (long long)d.nimg * d.Hv * d.Wv;
+  a.ksteps = K / 16;
+  if (a.rows <= 0) return 0;
+  hipLaunchKernelGGL(narrow_proj_x3_kernel, dim3((unsigned)cdiv(a.rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

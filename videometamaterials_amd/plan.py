@@ -497,9 +497,15 @@ class _Builder:
         if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
             return False
         kp = (k + 31) // 32 * 32
+        if self.narrow_ok(k, cout):  # wide contraction, 64 output columns: the barrier-free streaming kernel (narrow_proj.hip), same fmt-2 weights
+            return True
         if kp == 256 and cout <= 64:  # one 64-row tile per CU and a single column slice: no faster than the streaming implicit GEMM (measured twice)
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
+
+    def narrow_ok(self, k: int, cout: int) -> bool:
+        """Envelope of vmm_proj_narrow_bf16x3 (K >= 256 -> 64 columns, split-bf16 only): to_out and the to_qkv data gradient at the C = 64 levels."""
+        return bool(self.x3 and cout == 64 and k >= 256 and k % 32 == 0 and getattr(self.m, "use_proj_kernel", True) and _enabled("narrow"))
 
     def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
@@ -508,6 +514,9 @@ class _Builder:
         # algorithmic work: every input element, weight and output element touched once
         nbytes = 4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + K * d.Cout + M * d.Cout + (M * d.Cout if kw.get("res_ptr") else 0))
         if proj:  # weights were packed in fragment order for it (proj_ok); ln_gamma: PreNorm LayerNorm fused into the row staging
+            if self.narrow_ok(K, d.Cout) and not ln_gamma and not d.rot_ncols and not d.q_ncols:
+                self.step(self.lib.vmm_proj_narrow_bf16x3, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+                return d
             fn = self.lib.vmm_proj_bf16x3 if self.x3 else self.lib.vmm_proj_f32
             self.step(fn, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
             return d
