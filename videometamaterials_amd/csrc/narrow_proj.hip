@@ -7,24 +7,24 @@
 // HBM rate.  The generic implicit GEMM stages both operands through LDS behind barriers and reaches 1.6-2.6 TB/s on them; the A-stationary
 // projection kernel fits one row tile per CU at K = 256.  Here nothing is staged at all:
 //   * activations are the MFMA's B operand (lane = row, eight consecutive k): a lane's fragment is 32 contiguous bytes of its row, loaded
-//     straight into registers (the two lane halves read adjacent 32-byte pieces: every 128-byte line is used in full over two k16 steps) and
-//     split there;
+//     straight into registers (the two lane halves read adjacent 32-byte pieces; two k16 steps are requested together, so every 128-byte line
+//     of a row is consumed by four back-to-back loads) and split there;
 //   * weights are the A operand in the fragment order vmm_pack_weights fmt 2 leaves them in: 16 bytes per lane, plane and step straight from
 //     L1 / L2 (K 64 x 4 bytes = 64-192 KB, shared by every wave of the launch);
 //   * a wave owns 64 rows x 64 columns (four 32 x 32 accumulators; lane = row, a register quad = four consecutive columns -> 16-byte
-//     stores), walks K with its loads three k16 steps ahead, and never meets another wave: no LDS, no barrier.
+//     stores), walks K with two double steps of loads in flight, and never meets another wave: no LDS, no barrier.
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int DEPTH = 3;  // k16 steps of loads in flight per wave
+constexpr int DEPTH = 2;  // double steps (2 x k16 = 128 bytes of every row) of loads in flight per wave
 
 struct NPArgs {
   vmm_conv_desc p;
   long long rows;
-  int ksteps;  // K / 16
+  int ksteps;  // K / 16 (even)
 };
 
 __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) {
@@ -43,21 +43,28 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
   const uint4* wq = reinterpret_cast<const uint4*>(p.w) + lane;
   auto wplane = [&](int nt, int ks, int lo) -> const uint4* { return wq + ((long long)(nt * KS + ks) * 2 + lo) * 64; };
 
-  f32x4 xa[DEPTH][2][2];   // [stage][row fragment][first / second four floats]
-  uint4 wv[DEPTH][2][2];   // [stage][column tile][hi | lo]
-  auto request = [&](int st, int ks) {
-    const int k = min(ks, KS - 1);  // (the tail re-requests the last step: unconditional loads, no branch in the step)
-    const float* s0 = src(r0, k);
-    const float* s1 = src(r1, k);
-    xa[st][0][0] = *reinterpret_cast<const f32x4*>(s0);
-    xa[st][0][1] = *reinterpret_cast<const f32x4*>(s0 + 4);
-    xa[st][1][0] = *reinterpret_cast<const f32x4*>(s1);
-    xa[st][1][1] = *reinterpret_cast<const f32x4*>(s1 + 4);
+  // A request covers TWO k16 steps: the four 16-byte loads of a row fragment then touch one whole 128-byte line of every row back to back
+  // (requested one step at a time the second half of a line came ~300 cycles later, after the CU's other waves had pushed it out of the L1)
+  f32x4 xa[DEPTH][2][2][2];   // [stage][step of the pair][row fragment][first / second four floats]
+  uint4 wv[DEPTH][2][2][2];   // [stage][step of the pair][column tile][hi | lo]
+  auto request = [&](int st, int kd) {
+    const int k = min(2 * kd, KS - 2);  // (the tail re-requests the last pair: unconditional loads, no branch in the step)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      wv[st][nt][0] = *wplane(nt, k, 0);
-      wv[st][nt][1] = *wplane(nt, k, 1);
+    for (int u = 0; u < 2; ++u) {
+      const float* s0 = src(r0, k + u);
+      const float* s1 = src(r1, k + u);
+      xa[st][u][0][0] = *reinterpret_cast<const f32x4*>(s0);
+      xa[st][u][0][1] = *reinterpret_cast<const f32x4*>(s0 + 4);
+      xa[st][u][1][0] = *reinterpret_cast<const f32x4*>(s1);
+      xa[st][u][1][1] = *reinterpret_cast<const f32x4*>(s1 + 4);
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        wv[st][u][nt][0] = *wplane(nt, k + u, 0);
+        wv[st][u][nt][1] = *wplane(nt, k + u, 1);
+      }
   };
   f32x16 acc[2][2];  // [column tile][row fragment]
 #pragma unroll
@@ -66,40 +73,49 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int KD = KS / 2;
 #pragma unroll
   for (int s = 0; s < DEPTH; ++s) request(s, s);
-  for (int ks0 = 0; ks0 < KS; ks0 += DEPTH) {
+  for (int kd0 = 0; kd0 < KD; kd0 += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
-      const int ks = ks0 + s;
-      if (ks < KS) {  // (wave-uniform)
-        bf16x8 bh[2], bl[2];
+      if (kd0 + s < KD) {  // (wave-uniform)
+        bf16x8 bh[2][2], bl[2][2], ah[2][2], al[2][2];
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf) {
-          uint4 h, l;
-          h.x = split_bf16_pair(xa[s][rf][0].x, xa[s][rf][0].y, l.x);
-          h.y = split_bf16_pair(xa[s][rf][0].z, xa[s][rf][0].w, l.y);
-          h.z = split_bf16_pair(xa[s][rf][1].x, xa[s][rf][1].y, l.z);
-          h.w = split_bf16_pair(xa[s][rf][1].z, xa[s][rf][1].w, l.w);
-          bh[rf] = __builtin_bit_cast(bf16x8, h);
-          bl[rf] = __builtin_bit_cast(bf16x8, l);
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int rf = 0; rf < 2; ++rf) {
+            uint4 h, l;
+            h.x = split_bf16_pair(xa[s][u][rf][0].x, xa[s][u][rf][0].y, l.x);
+            h.y = split_bf16_pair(xa[s][u][rf][0].z, xa[s][u][rf][0].w, l.y);
+            h.z = split_bf16_pair(xa[s][u][rf][1].x, xa[s][u][rf][1].y, l.z);
+            h.w = split_bf16_pair(xa[s][u][rf][1].z, xa[s][u][rf][1].w, l.w);
+            bh[u][rf] = __builtin_bit_cast(bf16x8, h);
+            bl[u][rf] = __builtin_bit_cast(bf16x8, l);
+          }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            ah[u][nt] = __builtin_bit_cast(bf16x8, wv[s][u][nt][0]);
+            al[u][nt] = __builtin_bit_cast(bf16x8, wv[s][u][nt][1]);
+          }
         }
-        const bf16x8 ah0 = __builtin_bit_cast(bf16x8, wv[s][0][0]), al0 = __builtin_bit_cast(bf16x8, wv[s][0][1]);
-        const bf16x8 ah1 = __builtin_bit_cast(bf16x8, wv[s][1][0]), al1 = __builtin_bit_cast(bf16x8, wv[s][1][1]);
-        request(s, ks + DEPTH);
-        // pass-major, lo products first
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1], acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1], acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1], acc[1][1], 0, 0, 0);
+        request(s, kd0 + s + DEPTH);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          // pass-major, lo products first
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][nt], bl[u][rf], acc[nt][rf], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u][nt], bh[u][rf], acc[nt][rf], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][nt], bh[u][rf], acc[nt][rf], 0, 0, 0);
+        }
       }
     }
   }
