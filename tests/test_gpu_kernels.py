@@ -676,6 +676,43 @@ def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias):
     assert relerr(o2.cpu(), want2) < 3e-6
 
 
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 3, 24, 24, 64, 128), (3, 2, 6, 12, 128, 64), (1, 5, 16, 96, 64, 64)])
+def test_conv3x3_weight_gradient_fused_operand_bf16x3(gpu, B, T, H, W, Cin, Cout):
+    """a_mode 1 of the nine-tap split-bf16 weight-gradient kernel: the layer's input is silu(h * ga[b, c] + gb[b, c]) -- GroupNorm * FiLM -> SiLU of the
+    producing block with per-(sample, channel) coefficients (vddp.py:279-285) -- formed in the loader; against torch autograd on the
+    materialised operand.  Samples = runs of T frames; zero padding stays zero (it is applied after the activation)."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(400 + W)
+    nimg = B * T
+    h = torch.randn(nimg, Cin, H, W, generator=g)
+    coef = torch.stack([1 + 0.3 * torch.randn(B, Cin, generator=g), 0.3 * torch.randn(B, Cin, generator=g)], -1)  # (B, C, 2) = (ga, gb)
+    ga = coef[:, :, 0].repeat_interleave(T, 0)[:, :, None, None]
+    gb = coef[:, :, 1].repeat_interleave(T, 0)[:, :, None, None]
+    x = F.silu(h * ga + gb)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    dy = torch.randn(nimg, Cout, H, W, generator=g)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    want_w = w.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout)
+    hg = h.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(gpu)
+    dyg = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(gpu)
+    cg = coef.contiguous().to(gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = hg.data_ptr(), Cin, Cin
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout = H, W, 1, Cout
+    d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
+    n_ws = int(lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), Cout))
+    assert n_ws > 0
+    ws = torch.empty(n_ws, device=gpu)
+    dw = torch.zeros(9 * Cin, Cout, device=gpu)
+    assert lib.vmm_conv3x3_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), None, ws.data_ptr(), _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), want_w) < 5e-5
+    d.a_coef = None
+    assert lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0  # a fused transform without coefficients is refused
+
+
 @pytest.mark.parametrize("rows,C1,C2,bias,res", [(5000, 256, 0, True, True), (333, 768, 0, False, True), (64, 64, 64, True, False), (1, 256, 0, False, False),
                                                  (40000, 768, 0, False, False), (257, 128, 128, True, True)])
 def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):

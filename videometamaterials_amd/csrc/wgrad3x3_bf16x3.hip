@@ -85,6 +85,14 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
   f32x2 rv[8], nv[2];
   unsigned lmask = 0;
   f32x2 bsum = {0.f, 0.f};
+  // a_mode 1: x = silu(a1 * ga + gb), the GroupNorm * FiLM -> SiLU of the producing block (vddp.py:279-285) applied while the fragments are built --
+  // every x element passes here once per (64 output channels), so the activated operand is never materialised.  (ga, gb) per (sample, channel):
+  // an eight-position piece lies inside one frame, hence one sample: one 16-byte coefficient load per item.
+  const bool fused = p.a_mode == 1 && src1;
+  f32x4 cf = {1.f, 0.f, 1.f, 0.f};
+  auto coef_of = [&](unsigned img) -> const f32x4* {
+    return reinterpret_cast<const f32x4*>(p.a_coef + ((long long)(img / (unsigned)p.a_imgs_per_sample) * p.C1 + ci0 + 2 * cp) * 2);
+  };
 
   // request the eight positions P0 .. P0 + 7 (dY: and the neighbours P0 - 1, P0 + 8) of this thread's channel pair; every load is
   // unconditional (a safe address where the position is padding): a lane-dependent branch around a load costs a vmcnt(0) at its first use
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
       m |= (v ? 1u : 0u) << i;
       rv[i] = *reinterpret_cast<const f32x2*>(v ? base + (long long)i * lld : lsrc);
     }
+    if (fused && !is_dy) cf = *coef_of(ok ? img : 0u);
     if (is_dy) {
       const bool vp = ok && col0 > 0 && col0 - 1 < W, vn = ok && col0 + 8 < W;
       m |= (vp ? 1u : 0u) << 8 | (vn ? 1u : 0u) << 9;
@@ -120,6 +129,11 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
       float e[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) e[i] = (lmask >> i & 1) ? rv[i][c] : 0.f;
+      if (fused && !is_dy) {
+        const float ga = c ? cf.z : cf.x, gb = c ? cf.w : cf.y;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (lmask >> i & 1) ? silu_rcp(e[i] * ga + gb) : 0.f;
+      }
       uint4 h, l;
       h.x = split_bf16_pair(e[0], e[1], l.x);
       h.y = split_bf16_pair(e[2], e[3], l.y);
@@ -170,10 +184,12 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
     ok = ok && y < H;
     const float* base = xsrc + ((long long)((int)img * H + y) * W + col0) * xld;
     f32x2 t[8];
+    const f32x4 pcf = fused ? *coef_of(ok ? img : 0u) : f32x4{1.f, 0.f, 1.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const bool v = ok && col0 + i < W;
       t[i] = *reinterpret_cast<const f32x2*>(v ? base + (long long)i * xld : xsrc);
+      if (fused) t[i] = f32x2{silu_rcp(t[i][0] * pcf.x + pcf.y), silu_rcp(t[i][1] * pcf.z + pcf.w)};
       if (!v) t[i] = f32x2{0.f, 0.f};
     }
     const int slot = (j * CH) % R;
@@ -368,7 +384,8 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float* __restr
 // Geometry shared by the launcher and the workspace query.  Returns false outside the envelope.
 static bool w9_setup(const vmm_conv_desc& d, int32_t lddy, W9Args& a, int& gz) {
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 && d.Hv == d.Hin &&
-                        d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0 && !d.wrap_h && !d.wrap_w;
+                        d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && (d.a_mode == 0 || (d.a_mode == 1 && d.a_coef && d.a_imgs_per_sample > 0)) && !d.a_img_mod && !d.wrap_h &&
+                        !d.wrap_w;
   const bool chan_ok = d.C1 > 0 && d.C1 % 64 == 0 && d.C2 % 64 == 0 && d.Cout % 64 == 0 && (d.lda1 & 1) == 0 && (!d.C2 || (d.lda2 & 1) == 0) && (lddy & 1) == 0;
   if (!shape_ok || !chan_ok || d.nimg <= 0 || d.Hin <= 0 || d.Win <= 0) return false;
   a.p = d;
@@ -392,7 +409,8 @@ static bool w9_setup(const vmm_conv_desc& d, int32_t lddy, W9Args& a, int& gz) {
 }
 
 // floats of workspace vmm_conv3x3_wgrad_bf16x3 wants for this layer (partial blocks of every row slice + one bias row per slice); 0 = the
-// layer is outside the kernel's envelope (3 x 3 / stride 1 / pad 1, zero padding, no fused operand transform, C1 / C2 / Cout multiples of 64)
+// layer is outside the kernel's envelope (3 x 3 / stride 1 / pad 1, zero padding, C1 / C2 / Cout multiples of 64; a_mode 1 = the producer's
+// GroupNorm * FiLM -> SiLU on source a1 is applied in the loader)
 extern "C" int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, int32_t lddy) {
   W9Args a;
   int gz = 0;

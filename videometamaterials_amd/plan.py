@@ -457,8 +457,14 @@ class _Builder:
         self.gwritten.add(a.off)
         return g, acc
 
-    def add_into(self, dst: Act, src_ptr: int) -> None:
-        """grad(dst) += src (or = src for the first writer)."""
+    def add_into(self, dst: Act, src_ptr: int, src_act: Optional[Act] = None) -> None:
+        """grad(dst) += src (or = src for the first writer).  src_act: src is the COMPLETE gradient buffer of a residual block's output that
+        nobody reads after this block's own backward launches -- when dst has no gradient yet it simply takes that buffer over (the block's
+        last kernel accumulates into it in place, after every read of it): one 12-byte-per-element pass less per residual block."""
+        if src_act is not None and dst.off not in self.gacts and src_act.n == dst.n and _enabled("grad_alias"):
+            self.gacts[dst.off] = src_act
+            self.gwritten.add(dst.off)
+            return
         g, acc = self.grad_of(dst)
         self.step(self.lib.vmm_lincomb, (src_ptr, g.ptr if acc else None, None, 1.0, 1.0, 0.0, 0.0, g.ptr, g.n), "grad accumulate", nbytes=12.0 * g.n)
 
@@ -726,20 +732,26 @@ class _Builder:
                     self.dgrad_1x1(name + ".res_conv.weight", c0, xs.C, name + ".res_conv dgrad", a1=gout, out_ptr=gx.ptr, ldo=xs.C, Hv=H, Wv=W,
                                    res_ptr=gx.ptr if acc else 0, ldres=xs.C)
             else:
-                self.add_into(x1, gout.ptr)
+                self.add_into(x1, gout.ptr, gout)
             # main branch: GN2+SiLU, conv2, GN1+FiLM+SiLU, conv1
             dh2 = self.act(Cout, H, W)
             self.gn_bwd(name + ".block2", gout.ptr, h2, c2_ptr, st2, 0, 0, dh2.ptr, 0)
-            # block2's operand silu(GN1(h1)) is materialised once for the weight gradient: fused into the wgrad loader it would be
-            # recomputed by every tap / channel tile of the weight (measured 61-68 vs 84-88 TFLOP/s for the same shapes)
-            a1m = self.act(Cout, H, W)
-            self.step(self.lib.vmm_affine_silu, (h1.ptr, Cout, c1_ptr, None, 0, a1m.ptr, Cout, rows, self.T * H * W, Cout), name + " block2 operand",
-                      nbytes=8.0 * h1.n)
-            d2m = N.ConvDesc.from_buffer_copy(d2)
-            d2m.a1, d2m.a_mode, d2m.a_coef = a1m.ptr, 0, None
-            self.plan.keepalive.append(d2m)
-            self.wgrad(d2m, dh2.ptr, Cout, gw2, name + ".block2.proj", gb_ptr=self.pg(name + ".block2.proj.bias"))
-            self.tmp_free(a1m)
+            if (self.x3 and getattr(self.m, "use_x3_wgrad", True) and _enabled("wgrad_fused_operand")
+                    and int(self.lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d2), Cout))):
+                # the nine-tap split-bf16 kernel stages every x element once per 64 output channels: block2's operand silu(GN1(h1)) is
+                # formed in its loader (a_mode 1 of the forward descriptor), never materialised
+                self.wgrad(d2, dh2.ptr, Cout, gw2, name + ".block2.proj", gb_ptr=self.pg(name + ".block2.proj.bias"))
+            else:
+                # materialised once for the generic weight-gradient kernels: fused into their loaders it would be recomputed by every tap /
+                # channel tile of the weight (measured 61-68 vs 84-88 TFLOP/s for the same shapes)
+                a1m = self.act(Cout, H, W)
+                self.step(self.lib.vmm_affine_silu, (h1.ptr, Cout, c1_ptr, None, 0, a1m.ptr, Cout, rows, self.T * H * W, Cout), name + " block2 operand",
+                          nbytes=8.0 * h1.n)
+                d2m = N.ConvDesc.from_buffer_copy(d2)
+                d2m.a1, d2m.a_mode, d2m.a_coef = a1m.ptr, 0, None
+                self.plan.keepalive.append(d2m)
+                self.wgrad(d2m, dh2.ptr, Cout, gw2, name + ".block2.proj", gb_ptr=self.pg(name + ".block2.proj.bias"))
+                self.tmp_free(a1m)
             da1 = self.act(Cout, H, W)
             self.dgrad_3x3(name + ".block2.proj.weight", 0, Cout, name + ".block2.proj dgrad", a1=dh2, out_ptr=da1.ptr, ldo=Cout, Hv=H, Wv=W)
             self.tmp_free(dh2)
@@ -842,7 +854,7 @@ class _Builder:
 
         def bwd():
             gout, _ = self.grad_of(out)
-            self.add_into(x, gout.ptr)  # residual
+            self.add_into(x, gout.ptr, gout)  # residual
             self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out", gb_ptr=self.pg(name + ".fn.fn.to_out.bias"))
             go = self.act(hid, x.H, x.W)
             self.dgrad_1x1(name + ".fn.fn.to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
@@ -940,7 +952,7 @@ class _Builder:
 
         def bwd():
             gout, _ = self.grad_of(out)
-            self.add_into(x, gout.ptr)
+            self.add_into(x, gout.ptr, gout)
             self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out")
             go = self.act(hid, x.H, x.W)
             self.dgrad_1x1(p + ".to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
