@@ -31,10 +31,16 @@ if os.environ.get("VMM_TRAIN_DETAIL"):
     pl = model.get_plan(bench.B_PER_GPU, bench.T, bench.HW, bench.HW, 11, dev, training=True)
     pl.launch()
     pl.pgrad.zero_(); pl.gscratch.zero_()
+    fam = {}
     for name, steps, meta in (("fwd", pl.steps, pl.meta), ("bwd", pl.bwd_steps, pl.bwd_meta)):
         ms = pl.launch_timed(steps)
+        for t, (fn, _, _) in zip(ms, steps):
+            f = fam.setdefault(fn.__name__, [0.0, 0])
+            f[0] += t
+            f[1] += 1
         rows = sorted(zip(ms, steps, meta), key=lambda r: -r[0])
         print(f"== {name}: {sum(ms):.2f} ms over {len(ms)} launches", file=sys.stderr)
         for t, (fn, _, what), (_, fl, nb) in rows[:60]:
             print(f"{t:8.3f} ms {fl / t / 1e9 if t > 0 else 0:8.1f} TFLOP/s {nb / t / 1e6 if t > 0 else 0:8.1f} GB/s  {fn.__name__:32s} {what}", file=sys.stderr)
 
+    print("== families (ms, launches): " + ", ".join(f"{k} {v[0]:.2f}/{v[1]}" for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])), file=sys.stderr)

@@ -1337,10 +1337,11 @@ class _Builder:
                     for ph in range(2):
                         for pw in range(2):
                             # dIn[2c+ph] = sum_kh' dOut[c + ph - kh'] W[(1-ph)+2kh']^T : [(kh', kw', co)][ci]
-                            wp = self.pack(nm + ".weight", 4 * co_ * ci_, want_grad=False, TH=2, TW=2, C=co_, Cp=co_, N=ci_, sn=16, sc=ci_ * 16, sh=4, sw=1,
-                                           h0=1 - ph, hs=2, w0=1 - pw, ws=2)[0]
+                            wp = self.pack(nm + ".weight", 4 * co_ * ci_, want_grad=False, gemm=self.x3, TH=2, TW=2, C=co_, Cp=co_, N=ci_, sn=16, sc=ci_ * 16, sh=4,
+                                           sw=1, h0=1 - ph, hs=2, w0=1 - pw, ws=2)[0]
                             self.conv(a1=gd, w=wp, Cout=ci_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=gx.ptr, ldo=ci_, Hv=d.H, Wv=d.W, Hout=xs.H,
-                                      Wout=xs.W, oscale=2, oo=(ph, pw), res_ptr=gx.ptr if acc else 0, ldres=ci_, what=nm + f" dgrad phase {ph}{pw}")
+                                      Wout=xs.W, oscale=2, oo=(ph, pw), res_ptr=gx.ptr if acc else 0, ldres=ci_, what=nm + f" dgrad phase {ph}{pw}",
+                                      x3w=self.x3)
                 self.on_backward(down_bwd, pg_start, uj_start)
                 x = d
         # the deepest skip is also the mid input: keep it alive, do not free through `stage`
@@ -1390,9 +1391,10 @@ class _Builder:
                         self.wgrad(du, gu.ptr, co_, gwp, nm, gb_ptr=self.pg(nm + ".bias"))
                     gx, acc = self.grad_of(xs)
                     # dX[a][ci] = sum_{kh,kw,co} dU[2a-1+kh][co] W[ci][co][kh][kw]: a stride-2 conv over dU with [(kh,kw,co)][ci]
-                    wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1, hs=1, ws=1)[0]
+                    wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, gemm=self.x3, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1,
+                                   hs=1, ws=1)[0]
                     self.conv(a1=gu, w=wp, Cout=ci_, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=gx.ptr, ldo=ci_, Hv=xs.H, Wv=xs.W, res_ptr=gx.ptr if acc else 0,
-                              ldres=ci_, what=nm + " dgrad")
+                              ldres=ci_, what=nm + " dgrad", x3w=self.x3)
                 self.on_backward(up_bwd, pg_start, uj_start)
                 self.free_act(xs)
                 x = u
