@@ -129,6 +129,13 @@ int vmm_conv3x3_wgrad_f32(const vmm_conv_desc* d, const float* dy, int32_t lddy,
 int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* d, int32_t lddy);
 int vmm_conv3x3_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
                              vmm_stream_t stream);
+/* the 1 x 1 / Linear case (to_qkv, to_out, res_conv): dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] on the split-bf16 matrix cores, a 128 x 128
+ * channel block per workgroup, [channel][row] fragment images in LDS, partial blocks + fixed-order reduction (wgrad1x1_bf16x3.hip).  Envelope:
+ * KH = KW = 1, stride 1, identity rows, no fused operand transform, C1 / C2 / Cout multiples of 64; workspace =
+ * vmm_conv1x1_wgrad_bf16x3_workspace(d, lddy) floats (0 = outside the envelope).  Returns 1 (nothing launched) outside it or without workspace. */
+int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* d, int32_t lddy);
+int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                             vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);

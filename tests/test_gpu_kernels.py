@@ -713,6 +713,46 @@ def test_conv3x3_weight_gradient_fused_operand_bf16x3(gpu, B, T, H, W, Cin, Cout
     assert lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0  # a fused transform without coefficients is refused
 
 
+@pytest.mark.parametrize("rows,C1,C2,Cout,bias", [(5000, 64, 0, 768, False), (777, 256, 0, 64, True), (64, 128, 128, 128, True), (20000, 128, 0, 768, False),
+                                                  (3, 512, 0, 192, True), (130000, 64, 64, 64, False)])
+def test_conv1x1_weight_gradient_bf16x3(gpu, rows, C1, C2, Cout, bias):
+    """vmm_conv1x1_wgrad_bf16x3 (128 x 128 channel blocks, [channel][row] fragment images, partial blocks + fixed-order reduction) against x^T dY and
+    the column sums of dY: channel counts that fill half a block, two concatenated sources, row counts that are no multiple of the 64-row chunk,
+    more workgroups than chunks; += semantics and bit-reproducibility."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(rows + Cout)
+    Cin = C1 + C2
+    x = torch.randn(rows, Cin, generator=g)
+    dy = torch.randn(rows, Cout, generator=g)
+    want_w = x.double().t() @ dy.double()
+    want_b = dy.double().sum(0)
+    x1 = x[:, :C1].contiguous().to(gpu)
+    x2 = x[:, C1:].contiguous().to(gpu) if C2 else None
+    dyg = dy.to(gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1 = x1.data_ptr(), C1, C1
+    if C2:
+        d.a2, d.C2, d.lda2 = x2.data_ptr(), C2, C2
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = 1, 1, rows, 1, rows, 1
+    d.KH, d.KW, d.sgn_h, d.sgn_w, d.Hout, d.Wout, d.oscale, d.Cout = 1, 1, 1, 1, 1, rows, 1, Cout
+    n_ws = int(lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout))
+    assert n_ws > 0
+    outs = []
+    for _ in range(2):
+        ws = torch.full((n_ws,), float("nan"), device=gpu)
+        dw = torch.ones(Cin, Cout, device=gpu)  # += : starts from one
+        db = torch.ones(Cout, device=gpu)
+        assert lib.vmm_conv1x1_wgrad_bf16x3(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), db.data_ptr() if bias else None, ws.data_ptr(), _s()) == 0
+        torch.cuda.synchronize()
+        assert relerr(dw.cpu().double() - 1, want_w) < 5e-5
+        if bias:
+            assert relerr(db.cpu().double() - 1, want_b) < 3e-6
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    d.KH = 3
+    assert lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0
+
+
 @pytest.mark.parametrize("rows,C1,C2,bias,res", [(5000, 256, 0, True, True), (333, 768, 0, False, True), (64, 64, 64, True, False), (1, 256, 0, False, False),
                                                  (40000, 768, 0, False, False), (257, 128, 128, True, True)])
 def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):

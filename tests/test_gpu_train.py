@@ -141,6 +141,7 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     assert "vmm_proj_bf16x3" in used and ("vmm_conv3x3_bf16x3" in used or cfg_name == "lagr16")
     assert ("vmm_conv_wgrad_bf16x3" in used) == (x3_wgrad == "x3+generic") and ("vmm_conv_wgrad_f32" in used) == (x3_wgrad != "x3+generic")
     assert ("vmm_conv3x3_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name == "lagr64")
+    assert ("vmm_conv1x1_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name in ("lagr64", "circ64"))
 
 
 def test_trainer_step_matches_torch_adam(gpu):

@@ -1,0 +1,274 @@
+// Weight gradient of the 1 x 1 convolutions / Linear layers (to_qkv, to_out, res_conv: autograd of vddp.py:297, 319, 325, 413, 421) on the bf16
+// matrix cores with split (hi + lo) operands, gfx950 -- the one-tap sibling of wgrad3x3_bf16x3.hip.
+//
+//   dWp[ci][co] += sum over rows r   x[r][ci] * dY[r][co]
+//
+// The contraction runs over rows, so both MFMA operands need eight consecutive rows of one channel per lane while memory holds rows x
+// channels.  As in the nine-tap kernel the loader's thread = (8 rows, 2 channels) reads eight 8-byte pieces (64 lanes cover 512 contiguous
+// bytes of a row), splits them and writes one 16-byte hi and lo fragment per channel into an LDS image [channel][row] whose row pitch is an
+// odd multiple of 16 bytes: exactly what a lane of the MFMA reads back with one ds_read_b128, conflict-free both ways.  A workgroup owns a
+// 128 x 128 channel block and walks its row slice in chunks of 64 rows (double-buffered LDS, the next chunk's rows in flight in registers);
+// 8 waves = 2 groups x 2 x 2 quadrants of 64 x 64 (four 32 x 32 accumulators each); the groups take alternate halves of a chunk and stage the
+// next chunk before (group 0) / after (group 1) their MFMAs, one barrier per chunk.  Row slices leave partial blocks in a workspace with
+// 16-byte stores, a second launch totals them in a fixed order (bit-reproducible; no atomics).  Channel counts need only be multiples of 64:
+// the half of a 128-wide block that lies beyond C1 + C2 / Cout is neither loaded nor stored.
+// The bias gradient (exact fp32 column sums of dY) leaves as one partial row per slice from the ci-block-0 workgroups.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CH = 64;               // rows per chunk (four k16 steps, two per wave group)
+constexpr int PITCH = 2 * CH + 16;   // bytes per channel row of a plane (144 = 9 x 16)
+constexpr int PLANE = 128 * PITCH;   // one plane (hi or lo) of one operand: 128 channels
+constexpr int BUF = 4 * PLANE;       // x hi | x lo | dY hi | dY lo
+constexpr int BLOCK_FLOATS = 128 * 128;
+
+struct W1Args {
+  vmm_conv_desc p;
+  const float* dy; int lddy;
+  float* part;        // [gridDim.z][tiles][BLOCK_FLOATS]
+  float* bias_part;   // [gridDim.z][Cout] or NULL
+  long long rows;
+  int nchunks, chunks_per_wg;
+};
+
+__global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const vmm_conv_desc& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3, wu = wq >> 1, wv = wq & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int Cin = p.C1 + p.C2;
+  const int ci0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+  const int c_begin = blockIdx.z * a.chunks_per_wg;
+  const int n_it = min(a.chunks_per_wg, a.nchunks - c_begin);
+  if (n_it <= 0) return;
+  const long long r_begin = (long long)c_begin * CH;
+
+  // ---------------------------------------------------------------- loader: thread = (8-row piece `oct`, channel pair `cp`) of BOTH operands
+  const int oct = tid >> 6, cp = tid & 63;
+  const int xc = ci0 + 2 * cp, yc = co0 + 2 * cp;
+  const bool x_ok = xc < Cin, y_ok = yc < p.Cout;
+  const bool x_src1 = xc < p.C1;
+  const float* xsrc = x_src1 ? p.a1 + xc : p.a2 + (xc - p.C1);
+  const int xld = x_src1 ? p.lda1 : p.lda2;
+  const float* ysrc = a.dy + yc;
+  f32x2 xv[8], yv[8];
+  f32x2 bsum = {0.f, 0.f};
+  // (every load is unconditional: rows past the end and channels past the layer re-read row 0 / channel 0 and are zeroed when staged)
+  auto request = [&](long long r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long r = r0 + i;
+      const bool v = r < a.rows;
+      xv[i] = *reinterpret_cast<const f32x2*>((v && x_ok) ? xsrc + r * xld : p.a1);
+      yv[i] = *reinterpret_cast<const f32x2*>((v && y_ok) ? ysrc + r * a.lddy : a.dy);
+    }
+  };
+  auto stage = [&](long long r0, int buf) {
+    unsigned char* base = sm + buf * BUF + oct * 16;
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const bool ok = op ? y_ok : x_ok;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows) ? (op ? yv[i][c] : xv[i][c]) : 0.f;
+        uint4 h, l;
+        h.x = split_bf16_pair(e[0], e[1], l.x);
+        h.y = split_bf16_pair(e[2], e[3], l.y);
+        h.z = split_bf16_pair(e[4], e[5], l.z);
+        h.w = split_bf16_pair(e[6], e[7], l.w);
+        unsigned char* dst = base + op * 2 * PLANE + (2 * cp + c) * PITCH;
+        *reinterpret_cast<uint4*>(dst) = h;
+        *reinterpret_cast<uint4*>(dst + PLANE) = l;
+        if (op) bsum[c] += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+      }
+    }
+  };
+
+  f32x16 acc[2][2];  // [ci fragment of the quadrant][co fragment]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  request(r_begin + 8 * oct);
+  stage(r_begin + 8 * oct, 0);
+  if (n_it > 1) request(r_begin + CH + 8 * oct);
+  __syncthreads();
+
+  const int a_lane = (wu * 64 + l31) * PITCH + half * 16, b_lane = 2 * PLANE + (wv * 64 + l31) * PITCH + half * 16;
+  auto loader_phase = [&](int it) {
+    if (it + 1 < n_it) {
+      stage(r_begin + (long long)(it + 1) * CH + 8 * oct, (it + 1) & 1);
+      if (it + 2 < n_it) request(r_begin + (long long)(it + 2) * CH + 8 * oct);
+    }
+  };
+  for (int it = 0; it < n_it; ++it) {
+    if (grp == 0) loader_phase(it);
+    const unsigned char* buf = sm + (it & 1) * BUF;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int s = 2 * grp + ss;
+      bf16x8 Ah[2], Al[2], Bh[2], Bl[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        Ah[f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_lane + f * 32 * PITCH + s * 32));
+        Al[f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + PLANE + a_lane + f * 32 * PITCH + s * 32));
+        Bh[f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + b_lane + f * 32 * PITCH + s * 32));
+        Bl[f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + PLANE + b_lane + f * 32 * PITCH + s * 32));
+      }
+      // pass-major, lo products first
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bh[j], acc[i][j], 0, 0, 0);
+    }
+    if (grp == 1) loader_phase(it);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue: group 1 hands its accumulators over through LDS, group 0 adds them
+  // and stores the workgroup's partial block: layout [quadrant][i][j][q][lane] x 4 floats (coalesced 16-byte stores; the reduction undoes it)
+  uint4* xch = reinterpret_cast<uint4*>(sm);
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          xch[(((wq * 2 + i) * 2 + j) * 4 + q) * 64 + lane] = uint4{__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]),
+                                                                    __float_as_uint(acc[i][j][4 * q + 2]), __float_as_uint(acc[i][j][4 * q + 3])};
+  }
+  __syncthreads();
+  if (grp == 0) {
+    f32x4* dst = reinterpret_cast<f32x4*>(a.part) + ((long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (BLOCK_FLOATS / 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = (((wq * 2 + i) * 2 + j) * 4 + q) * 64 + lane;
+          const uint4 v = xch[k];
+          dst[k] = f32x4{acc[i][j][4 * q] + __uint_as_float(v.x), acc[i][j][4 * q + 1] + __uint_as_float(v.y), acc[i][j][4 * q + 2] + __uint_as_float(v.z),
+                         acc[i][j][4 * q + 3] + __uint_as_float(v.w)};
+        }
+  }
+  if (a.bias_part && blockIdx.x == 0) {  // (workgroup-uniform) eight pieces x 128 channels of partial column sums -> one value per channel
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sm);
+    red[oct * 128 + 2 * cp] = bsum[0];
+    red[oct * 128 + 2 * cp + 1] = bsum[1];
+    __syncthreads();
+    if (tid < 128 && co0 + tid < p.Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) s += red[o * 128 + tid];
+      a.bias_part[(long long)blockIdx.z * p.Cout + co0 + tid] = s;
+    }
+  }
+}
+
+// dw[ci][co] += sum over row slices z of the partial blocks (fixed order).  A workgroup takes 32 consecutive 16-byte pieces of one block
+// position and all slices: thread = (piece, slice lane), eight slice lanes, LDS tree at the end.
+__global__ __launch_bounds__(256) void wgrad1_reduce_kernel(const float* __restrict__ part, int nz, int tiles_x, int tiles_y, float* __restrict__ dw, int Cin,
+                                                            int Cout) {
+  __shared__ f32x4 red[8][32];
+  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int tile = blockIdx.y;                       // = by * tiles_x + bx
+  const int piece = blockIdx.x * 32 + e;             // ((((wq * 2 + i) * 2 + j) * 4 + q) * 64 + lane
+  const long long zstride = (long long)tiles_x * tiles_y * (BLOCK_FLOATS / 4);
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (long long)tile * (BLOCK_FLOATS / 4) + piece;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int z = zl; z < nz; z += 8) s += src[z * zstride];
+  red[zl][e] = s;
+  __syncthreads();
+  if (zl == 0) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][e];
+    const int lane = piece & 63, q = (piece >> 6) & 3, j = (piece >> 8) & 1, i = (piece >> 9) & 1, wq = piece >> 10;
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    // accumulator register 4 q + k of lane: row (ci) = k + 8 q + 4 (lane >> 5) of fragment i, column (co) = lane & 31 of fragment j
+    const int ci = bx * 128 + (wq >> 1) * 64 + i * 32 + 8 * q + 4 * (lane >> 5), co = by * 128 + (wq & 1) * 64 + j * 32 + (lane & 31);
+    if (ci < Cin && co < Cout) {  // (ci is a multiple of 4 and Cin of 64: the four rows are inside or outside together)
+      float* o = dw + (long long)ci * Cout + co;
+      o[0] += s.x;
+      o[Cout] += s.y;
+      o[2 * Cout] += s.z;
+      o[3 * Cout] += s.w;
+    }
+  }
+}
+
+static bool w1_setup(const vmm_conv_desc& d, int32_t lddy, W1Args& a, int& gz, int& tx, int& ty) {
+  const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 &&
+                        d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0 && !d.a_img_mod;
+  const bool chan_ok = d.C1 > 0 && d.C1 % 64 == 0 && d.C2 % 64 == 0 && d.Cout % 64 == 0 && (d.lda1 & 1) == 0 && (!d.C2 || (d.lda2 & 1) == 0) && (lddy & 1) == 0;
+  if (!shape_ok || !chan_ok || d.nimg <= 0 || d.Hin <= 0 || d.Win <= 0) return false;
+  a.p = d;
+  a.rows = (long long)d.nimg * d.Hv * d.Wv;
+  if (a.rows >= (1ll << 31) * CH) return false;
+  a.nchunks = (int)((a.rows + CH - 1) / CH);
+  tx = (d.C1 + d.C2 + 127) / 128;
+  ty = (d.Cout + 127) / 128;
+  const int nz = max(1, min(a.nchunks, 256 / (tx * ty)));  // one round of workgroups, one per CU
+  a.chunks_per_wg = (a.nchunks + nz - 1) / nz;
+  gz = (a.nchunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  return true;
+}
+
+}  // namespace
+
+// floats of workspace vmm_conv1x1_wgrad_bf16x3 wants for this layer; 0 = outside the kernel's envelope (1 x 1, stride 1, identity rows, no fused
+// operand transform, C1 / C2 / Cout multiples of 64)
+extern "C" int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, int32_t lddy) {
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!w1_setup(*dp, lddy, a, gz, tx, ty)) return 0;
+  return (int64_t)gz * tx * ty * BLOCK_FLOATS + (int64_t)gz * dp->Cout;
+}
+
+// dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] (and dbias[co] += sum_r dY[r][co] when dbias != NULL); d = the FORWARD descriptor of the layer;
+// workspace = vmm_conv1x1_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant).  Returns 1 (nothing launched) outside the envelope.
+extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                                        vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!workspace || !w1_setup(d, lddy, a, gz, tx, ty)) return 1;
+  a.dy = dy; a.lddy = lddy;
+  a.part = workspace;
+  a.bias_part = dbias ? workspace + (long long)gz * tx * ty * BLOCK_FLOATS : nullptr;
+  const size_t shm = 2 * (size_t)BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad1_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad1_reduce_kernel, dim3(BLOCK_FLOATS / 4 / 32, tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed, d.C1 + d.C2,
+                     d.Cout);
+  VMM_LAUNCH_CHECK();
+  if (dbias) return vmm_sum_partials(a.bias_part, gz, d.Cout, d.Cout, dbias, stream);
+  return 0;
+}

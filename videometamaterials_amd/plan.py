@@ -566,6 +566,14 @@ class _Builder:
                           flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
+            # the 1 x 1 layers (to_qkv, to_out, res_conv): 128 x 128 channel blocks on the split-bf16 matrix cores, same reduction scheme
+            ws_n = int(self.lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), lddy)) if _enabled("wgrad1x1") else 0
+            if ws_n:
+                ws = self.alloc(ws_n)
+                self.step(self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                          flops=2.0 * M * K * d.Cout, nbytes=wbytes)
+                self.tmp_free((ws, ws_n))
+                return
         if self.x3 and getattr(self.m, "use_x3_wgrad_generic", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
             fn = self.lib.vmm_conv_wgrad_bf16x3
             tiles = -(-K // 128) * -(-d.Cout // 128)
