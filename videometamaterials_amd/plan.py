@@ -835,7 +835,9 @@ class _Builder:
                            ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
         if not fuse_ln:
             self.free_act(y)
-        la_mfma = self.x3 and not self.training and _enabled("la_mfma")
+        # (pass 1 on the split-bf16 matrix cores in both inference and bf16x3 training: the merge pass, which also leaves the softmax statistics the
+        # backward reads, is the same kernel either way)
+        la_mfma = self.x3 and _enabled("la_mfma")
         # (position slices per (frame, head); swept for the matrix-core pass -- one wave per slice -- too: 2048 / 4096 / 8192 / 16384 slices
         # gave 0.122 / 0.145 / 0.157 / 0.173 ms at the C = 128 level, the partial records and their merge grow with the slices)
         nsplit = max(1, min((HW + 63) // 64, -(-2048 // (B * T * heads))))
