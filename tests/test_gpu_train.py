@@ -144,6 +144,44 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     assert ("vmm_conv1x1_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name in ("lagr64", "circ64"))
 
 
+@pytest.mark.parametrize("cfg_name", ["lagr16", "lagr64"])
+def test_split_bf16_l1_gradients_inside_the_reference_autocast_deviation(gpu, cfg_name):
+    """Why split-bf16 is the measured training arithmetic.  The reference trains with an l1 loss under fp16 autocast (main.py:34); its OWN gradients
+    then move by 1.3e-2 (median over the parameters; 5e-3 .. 3e-2 for the middle 80 %) against fp32 -- measured by running the real reference under
+    torch.autocast(float16) on the CPU (tests/golden/make_golden_autocast.py -> autocast_lagr16.json).  The split-bf16 mode (fp32-class products,
+    1.5e-5 forward) moves the l1 gradients through the sign flips of sign(pred - noise) only: an order of magnitude less, parameter by
+    parameter.  lagr64: the same comparison at the real widths (where the nine-tap / 1 x 1 split-bf16 weight-gradient kernels take their
+    layers) against the dim-16 budget."""
+    with open(os.path.join(helpers.GOLDEN_DIR, "autocast_lagr16.json")) as f:
+        ref_dev = json.load(f)["fp16"]
+    kw, sd, model, diff = _setup(cfg_name, gpu)
+    model.train_precision = "bf16x3"
+    _, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    _, t, cond = helpers.synth_inputs(cfg_name)
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand((B, 3, T, H, W), generator=g) * 2 - 1
+    noise = torch.randn((B, 3, T, H, W), generator=g)
+    _, want = _oracle_grads(cfg_name, kw, sd, x0, t, cond, noise)
+    loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
+    loss.backward()
+    got = {model._ref_key(k): p.grad for k, p in model.named_parameters()}
+    ours = {}
+    for k, w in want.items():
+        if w is not None and float(w.double().norm()) > 0 and got.get(k) is not None:
+            ours[k] = float((got[k].double().cpu() - w.double()).norm() / w.double().norm())
+    vals = np.array(list(ours.values()))
+    assert len(vals) > 300
+    # in aggregate: an order of magnitude inside what the reference's own mixed precision does to the same gradients
+    assert float(np.median(vals)) < 0.1 * ref_dev["median"], (float(np.median(vals)), ref_dev["median"])
+    assert float(np.percentile(vals, 90)) < 0.25 * ref_dev["p90"], (float(np.percentile(vals, 90)), ref_dev["p90"])
+    assert float(vals.max()) < ref_dev["p90"], float(vals.max())
+    if cfg_name == "lagr16":  # parameter by parameter (same names, same inputs as the reference run)
+        worse = [(k, v, ref_dev["rel"][k]) for k, v in ours.items() if k in ref_dev["rel"] and v > max(ref_dev["rel"][k], 2e-3)]
+        assert not worse, worse[:10]
+    print(f"{cfg_name}: split-bf16 l1 gradient deviation median {np.median(vals):.2e} p90 {np.percentile(vals, 90):.2e} max {vals.max():.2e}; "
+          f"reference fp16 autocast median {ref_dev['median']:.2e} p90 {ref_dev['p90']:.2e}")
+
+
 def test_trainer_step_matches_torch_adam(gpu):
     """DataParallelTrainer (world 1): fused q_sample -> forward -> loss -> backward -> multi-tensor Adam -> EMA copy."""
     from videometamaterials_amd.dp import DataParallelTrainer
