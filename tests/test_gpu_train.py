@@ -182,6 +182,32 @@ def test_split_bf16_l1_gradients_inside_the_reference_autocast_deviation(gpu, cf
           f"reference fp16 autocast median {ref_dev['median']:.2e} p90 {ref_dev['p90']:.2e}")
 
 
+@pytest.mark.parametrize("cfg_name,precision", [("lagr16", "fp32"), ("plumb16", "fp32"), ("lagr64", "bf16x3")])
+def test_input_gradient_matches_oracle(gpu, cfg_name, precision):
+    """the gradient of a scalar of the denoiser output with respect to the network INPUT (the stem's data gradient on top of the
+    backward list), against autograd through the oracle; 1 and 3 input channels."""
+    import videometamaterials_amd as vm
+    from oracle import unet3d_oracle as uo
+    kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    sd = helpers.synth_state_dict(helpers.load_shapes(cfg_name))
+    model = vm.Unet3D(**kw)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    model.train_precision = precision
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    wgt = torch.randn(x.shape[0], kw.get("out_dim") or kw["channels"], *x.shape[2:], generator=torch.Generator().manual_seed(3))
+    xo = x.clone().requires_grad_(True)
+    (uo.unet3d_forward(sd, uo.UnetCfg(**kw), xo, t, cond, torch.zeros(B, dtype=torch.bool)) * wgt).sum().backward()
+    xg = x.to(gpu).requires_grad_(True)
+    (model(xg, t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0) * wgt.to(gpu)).sum().backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape
+    assert helpers.rel_err(xg.grad.cpu(), xo.grad) < (1e-3 if precision == "bf16x3" else 1e-4)
+    # a second backward without an input that requires grad does not run the extra launch and still fills the parameter gradients
+    model.zero_grad()
+    (model(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0) * wgt.to(gpu)).sum().backward()
+    assert model.get_parameter("init_conv.weight").grad is not None
+
+
 def test_trainer_step_matches_torch_adam(gpu):
     """DataParallelTrainer (world 1): fused q_sample -> forward -> loss -> backward -> multi-tensor Adam -> EMA copy."""
     from videometamaterials_amd.dp import DataParallelTrainer

@@ -22,10 +22,11 @@ class _UnetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         pl = ctx.plan
-        pl.backward(dout.contiguous())
+        want_dx = bool(ctx.needs_input_grad[3])  # d loss / d x: one extra launch (the stem's data gradient), only when x requires grad
+        pl.backward(dout.contiguous(), want_dx=want_dx)
         views = pl.grad_views(dict(ctx.model.named_parameters()))
         grads = tuple(views[n].clone() if n in views else None for n in ctx.names)
-        return (None, None, None, None, None, None, None) + grads
+        return (None, None, None, pl.dx.clone() if want_dx else None, None, None, None) + grads
 
 
 def unet_forward_with_grad(model, x, time, cond, mask):

@@ -367,6 +367,65 @@ extern "C" int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t
   VMM_LAUNCH_CHECK();
   return 0;
 }
+// Data gradient of the stem (init_conv: Conv3d(Cx <= 4, Cout, (1, k, k)) pad k / 2, vddp.py:600) straight into the NCTHW layout of the network
+// input: dx[b, c, t, y, x] = sum_{kh, kw, co} g[(b, t, y + pad - kh, x + pad - kw)][co] w[co][c][kh][kw] (zero padding).  Only autograd users that ask
+// for the input gradient run it (the training step never does): a plain vector-unit kernel -- a thread per (pixel, c) with the k x k x Cx x Cout weights
+// in LDS as [tap][c][co] -- for 3.8 GFLOP at the Lagrangian sizes.
+__global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ w, float* __restrict__ dx, int Cx, int T,
+                                                         int H, int W, int Cout, int k, long long nrows) {
+  extern __shared__ float ws[];  // [k*k][Cx][Cout]
+  const int kk = k * k;
+  for (int i = threadIdx.x; i < kk * Cx * Cout; i += blockDim.x) {
+    const int co = i % Cout, c = (i / Cout) % Cx, tap = i / (Cout * Cx);
+    ws[i] = w[((long long)co * Cx + c) * kk + tap];
+  }
+  __syncthreads();
+  const int pad = k / 2, HW = H * W;
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, c), c fastest
+  if (item >= nrows * Cx) return;
+  const int c = (int)(item % Cx);
+  const long long r = item / Cx;
+  const int px = (int)(r % W), py = (int)((r / W) % H);
+  const long long img = r / HW;
+  float acc = 0.f;
+  for (int kh = 0; kh < k; ++kh) {
+    const int yy = py + pad - kh;
+    if (yy < 0 || yy >= H) continue;
+    for (int kw = 0; kw < k; ++kw) {
+      const int xx = px + pad - kw;
+      if (xx < 0 || xx >= W) continue;
+      const float* gp = g + ((img * H + yy) * W + xx) * ldg;
+      const float* wp = ws + ((kh * k + kw) * Cx + c) * Cout;
+      for (int co = 0; co < Cout; co += 4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + co);
+        acc = fmaf(gv.x, wp[co], acc);
+        acc = fmaf(gv.y, wp[co + 1], acc);
+        acc = fmaf(gv.z, wp[co + 2], acc);
+        acc = fmaf(gv.w, wp[co + 3], acc);
+      }
+    }
+  }
+  const long long b = img / T;
+  const int t = (int)(img % T);
+  dx[((b * Cx + c) * T + t) * HW + (long long)py * W + px] = acc;
+}
+
+extern "C" int vmm_stem_conv_dgrad(const float* g, int32_t ldg, const float* w, float* dx, int32_t B, int32_t Cx, int32_t T, int32_t H, int32_t W, int32_t Cout,
+                                   int32_t k, vmm_stream_t stream) {
+  if (Cx < 1 || Cout % 4 || (ldg & 3) || k < 1 || !(k & 1) || (size_t)k * k * Cx * Cout * sizeof(float) > 64 * 1024) return -1;
+  const long long nrows = (long long)B * T * H * W;
+  if (nrows <= 0) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(stem_dgrad_kernel, dim3((unsigned)cdiv(nrows * Cx, 256)), dim3(256), sizeof(float) * k * k * Cx * Cout, (hipStream_t)stream, g, ldg, w, dx, Cx, T, H, W,
+                     Cout, k, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int vmm_loss_grad(const float* noise, const float* pred, int64_t n, int32_t squared, const float* gscale, float* dpred,
                              vmm_stream_t stream) {
   const int blocks = (int)max(1LL, min((long long)cdiv(n, 256), 4096LL));

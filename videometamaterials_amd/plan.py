@@ -137,6 +137,8 @@ class Plan:
         self.bwd_steps: List[Tuple[Callable, tuple, str]] = []
         self.bwd_meta: List[Tuple[str, float, float]] = []
         self.bwd_marks: List[Tuple[int, int]] = []  # (index into bwd_steps, X): gradients at float offsets >= X are final after that step
+        self.dx_steps: List[Tuple[Callable, tuple, str]] = []  # gradient with respect to the network input (run on request, after bwd_steps)
+        self.dx: Optional[torch.Tensor] = None
         self.arena: Optional[torch.Tensor] = None
         self.wbuf: Optional[torch.Tensor] = None
         self.pgrad: Optional[torch.Tensor] = None  # flat parameter gradients, torch layouts, first-use order
@@ -200,7 +202,7 @@ class Plan:
         return self.out
 
     # ------------------------------------------------------------------ backward (training plans)
-    def backward(self, dout: Optional[torch.Tensor] = None, on_mark: Optional[Callable[[int], None]] = None) -> torch.Tensor:
+    def backward(self, dout: Optional[torch.Tensor] = None, on_mark: Optional[Callable[[int], None]] = None, want_dx: bool = False) -> torch.Tensor:
         """Run the backward launch list for the forward just executed.  `dout` = d loss / d output (B,C,T,H,W)
         (or already written to self.dout).  Returns the flat gradient buffer; `on_mark(X)` is called as soon as every
         gradient at float offsets >= X is final (dp.py starts the all-reduce of that slice on its own stream)."""
@@ -222,6 +224,11 @@ class Plan:
                 torch.cuda.synchronize()
             if on_mark is not None and i in marks:
                 on_mark(marks[i])
+        if want_dx:  # d loss / d x into self.dx (B, C, T, H, W)
+            if not self.dx_steps:
+                raise NotImplementedError("the input gradient is not built for periodic padding")
+            for fn, args, what in self.dx_steps:
+                N.check(fn(*args, s), what)
         return self.pgrad
 
     def backward_timed(self) -> List[float]:
@@ -1098,6 +1105,7 @@ class _Builder:
         mask_off = self.alloc((B + 3) // 4)
         out_off = self.alloc(B * m.out_dim * T * H * W)
         dout_off = self.alloc(B * m.out_dim * T * H * W) if tr else 0
+        self.dx_off = self.alloc(B * Cx * T * H * W) if tr else 0
         self.io = (x_in_off, time_off, cond_off, mask_off, out_off, dout_off)
         # constant tables
         rot = hostmath.rotary_table(T, 32)
@@ -1285,6 +1293,10 @@ class _Builder:
         def init_bwd():
             g0, _ = self.grad_of(x0)
             self.wgrad(dinit, g0.ptr, m.init_dim, gwi, "init_conv", gb_ptr=self.pg("init_conv.bias"))
+            # d loss / d x: a launch of its own list -- Plan.backward runs it only when the input gradient is asked for
+            if not wrap:
+                self.plan.dx_steps.append((lib.vmm_stem_conv_dgrad, (g0.ptr, m.init_dim, self.wraw("init_conv.weight"), self.ptr(self.dx_off), B, Cx, T, H, W,
+                                                                     m.init_dim, k), "init_conv dgrad (input gradient)"))
         self.on_backward(init_bwd, pg_start, uj_start)
         x_new = self.softmax_attn_block("init_temporal_attn", x, None, temporal=True)
         self.free_act(x)
@@ -1490,6 +1502,7 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     plan.out = arena[o_off:o_off + B * model.out_dim * T * H * W].view(B, model.out_dim, T, H, W)
     plan.arena_floats = sizing.arena.peak
     if training:
+        plan.dx = arena[b.dx_off:b.dx_off + B * Cx * T * H * W].view(B, Cx, T, H, W)
         plan.dout = arena[do_off:do_off + B * model.out_dim * T * H * W].view(B, model.out_dim, T, H, W)
         plan.pgrad_floats = sizing.pgtop
     return plan
