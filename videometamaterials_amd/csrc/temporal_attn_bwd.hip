@@ -73,12 +73,11 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
     const long long row0 = (long long)b * T * a.HW + pix;  // row of frame t = row0 + t * HW
     const long long rc = row0 + (long long)c * a.HW;       // this lane's row in the row layouts
     const float* qrow = a.qkv + rc * a.ldqkv + head * DH + 8 * g;
-    float qr[8], kr[8], vr[8], gr[8], orr[8];
+    float qr[8], kr[8], vr[8], gr[8];
     load_row8(qr, qrow, cT);
     load_row8(kr, qrow + HID, cT);
     load_row8(vr, qrow + 2 * HID, cT);
     load_row8(gr, a.dO + rc * a.ldo + head * DH + 8 * g, cT);
-    load_row8(orr, a.O + rc * a.ldo + head * DH + 8 * g, cT);
     const float Lq = cT ? a.lse[rc * HEADS + head] : 0.f;
     // column layouts (lane = channel c + 16 h, register = frame 4 g + r) of k (for dQ), q (for dK) and dO (for dV)
     float kc[2][4], qc[2][4], gc[2][4];
@@ -94,18 +93,9 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
         gc[h][r] = ok ? a.dO[rt * a.ldo + head * DH + c + 16 * h] : 0.f;
       }
     }
-    // D_i = dO_i . O_i: this lane's 8 channels, then across the 4 lane groups
-    float Dq = 0.f;
+    float LA[4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) Dq = fmaf(gr[s], orr[s], Dq);
-    Dq += __shfl_xor(Dq, 16, 64);
-    Dq += __shfl_xor(Dq, 32, 64);
-    float LA[4], DA[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      LA[r] = __shfl(Lq, 4 * g + r, 64);  // lanes 0..15 hold the values of queries 0..15
-      DA[r] = __shfl(Dq, 4 * g + r, 64);
-    }
+    for (int r = 0; r < 4; ++r) LA[r] = __shfl(Lq, 4 * g + r, 64);  // lanes 0..15 hold the values of queries 0..15
     // ---- scores and dP against the frame keys and the token keys (accumulator layout: register = query 4 g + r, lane = key c)
     f32x4 S = zero4, dP = zero4, St = zero4, dPt = zero4;
 #pragma unroll
@@ -115,14 +105,17 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
       St = mm(qr[s], ekr[s], St);
       dPt = mm(gr[s], evr[s], dPt);
     }
+    // D_i = dO_i . O_i = sum_j p_ij dP_ij over the frame and token keys: the probabilities and dP are in registers anyway (register = query,
+    // lane = key: a 16-lane row sum), so the attention output O (1 KB per row) is not read at all
     float p[4], ds[4], pt[4], dst[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool qok = 4 * g + r < T;
       p[r] = (qok && cT) ? __expf(S[r] + bA[r] - LA[r]) : 0.f;
-      ds[r] = p[r] * (dP[r] - DA[r]);
       pt[r] = (qok && cN) ? __expf(St[r] + (tok_bias ? bA[r] : 0.f) - LA[r]) : 0.f;
-      dst[r] = pt[r] * (dPt[r] - DA[r]);
+      const float DA = row_sum16(fmaf(p[r], dP[r], pt[r] * dPt[r]));
+      ds[r] = p[r] * (dP[r] - DA);
+      dst[r] = pt[r] * (dPt[r] - DA);
       bacc[r] += ds[r] + (tok_bias ? dst[r] : 0.f);
       tile[0][4 * g + r][c] = ds[r];
       tile[1][4 * g + r][c] = dst[r];
