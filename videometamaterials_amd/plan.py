@@ -1340,12 +1340,15 @@ class _Builder:
                 nm = f"downs.{i}.4"
                 d = self.act(x.C, x.H // 2, x.W // 2)
                 co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
-                if self.x3 and not tr and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
+                if self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
                     self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0), nm,
                               flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
                     dd = gwd = None
+                    if tr:  # the weight gradient wants the layer's descriptor and a k-major gradient slot (no forward launch from them)
+                        _, gwd = self.pack_conv(nm + ".weight")
+                        dd = self.conv_desc(a1=xs, w=wd, Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C, Hv=xs.H // 2, Wv=xs.W // 2)
                 else:
                     wd, gwd = self.pack_conv(nm + ".weight")
                     dd = self.conv(a1=xs, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C,
@@ -1385,20 +1388,20 @@ class _Builder:
                 u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
                 one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
-                s2 = self.x3 and not tr and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
+                s2 = self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
                     wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
                     self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wu, self.wraw(nm + ".bias"), u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1), nm,
                               flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
-                for ph in range(2 if not s2 else 0):
+                for ph in range(2 if (not s2 or tr) else 0):  # (training: the phase descriptors feed the weight gradients even when the forward is one s2 launch)
                     for pw in range(2):
                         # ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'
                         wp, gwp = self.pack(nm + ".weight", 4 * ci_ * co_, TH=2, TW=2, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, h0=1 - ph, hs=2,
                                             w0=1 - pw, ws=2)
                         kw_ = dict(a1=xs, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
                                    Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw))
-                        du = self.conv_desc(**kw_) if one_launch else self.conv(what=nm + f" phase {ph}{pw}", **kw_)
+                        du = self.conv_desc(**kw_) if (one_launch or s2) else self.conv(what=nm + f" phase {ph}{pw}", **kw_)
                         phases.append((du, gwp))
                 if one_launch and not s2:
                     arr = (N.ConvDesc * 4)(*[du for du, _ in phases])
