@@ -354,8 +354,17 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
 // dw[(tap, ci)][co] += sum over row slices z of the partial blocks (fixed order: bit-reproducible).  A workgroup takes 32 consecutive 16-byte
 // pieces of one block position and all slices: thread = (piece, slice lane), eight slice lanes, LDS tree at the end.
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float* __restrict__ part, int nz, int tiles_x, int tiles_y, float* __restrict__ dw, int Cin,
-                                                            int Cout) {
+                                                            int Cout, const float* __restrict__ bias_part, float* __restrict__ dbias, int n_main) {
   __shared__ f32x4 red[8][32];
+  if ((int)blockIdx.x >= n_main) {  // trailing workgroups of tile 0: dbias[co] += the slices' partial rows, fixed order (was a launch of its own)
+    const int co = ((int)blockIdx.x - n_main) * 256 + threadIdx.x;
+    if (blockIdx.y == 0 && bias_part && co < Cout) {
+      float s = 0.f;
+      for (int z = 0; z < nz; ++z) s += bias_part[(long long)z * Cout + co];
+      dbias[co] += s;
+    }
+    return;
+  }
   const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
   const int tile = blockIdx.y;                       // = by * tiles_x + bx
   const int piece = blockIdx.x * 32 + e;             // 16-byte piece inside the block: ((t * 4 + wq) * 4 + j) * 64 + lane
@@ -441,10 +450,10 @@ extern "C" int vmm_conv3x3_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy
   hipLaunchKernelGGL(wgrad9_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   if (workspace) {
-    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(PART_FLOATS / 4 / 32, tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed,
-                       d.C1 + d.C2, d.Cout);
+    const int n_main = PART_FLOATS / 4 / 32;
+    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 256) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty,
+                       dw_packed, d.C1 + d.C2, d.Cout, dbias ? a.bias_part : nullptr, dbias, n_main);
     VMM_LAUNCH_CHECK();
-    if (dbias) return vmm_sum_partials(a.bias_part, gz, d.Cout, d.Cout, dbias, stream);
   }
   return 0;
 }
