@@ -194,10 +194,17 @@ __global__ __launch_bounds__(256) void wgrad1_reduce_kernel(const float* __restr
                                                             int Cout, const float* __restrict__ bias_part, float* __restrict__ dbias, int n_main) {
   __shared__ f32x4 red[8][32];
   if ((int)blockIdx.x >= n_main) {  // trailing workgroups of tile 0: dbias[co] += the slices' partial rows, fixed order (was a launch of its own)
-    const int co = ((int)blockIdx.x - n_main) * 256 + threadIdx.x;
-    if (blockIdx.y == 0 && bias_part && co < Cout) {
-      float s = 0.f;
-      for (int z = 0; z < nz; ++z) s += bias_part[(long long)z * Cout + co];
+    if (blockIdx.y != 0 || !bias_part) return;  // (workgroup-uniform)
+    const int co = ((int)blockIdx.x - n_main) * 32 + (threadIdx.x & 31), zq = threadIdx.x >> 5;  // 32 channels x 8 slice lanes
+    float s = 0.f;
+    if (co < Cout)
+      for (int z = zq; z < nz; z += 8) s += bias_part[(long long)z * Cout + co];
+    float* redf = reinterpret_cast<float*>(&red[0][0]);
+    redf[zq * 32 + (threadIdx.x & 31)] = s;
+    __syncthreads();
+    if (zq == 0 && co < Cout) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += redf[k * 32 + threadIdx.x];
       dbias[co] += s;
     }
     return;
@@ -276,7 +283,7 @@ extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy
   hipLaunchKernelGGL(wgrad1_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   const int n_main = BLOCK_FLOATS / 4 / 32;
-  hipLaunchKernelGGL(wgrad1_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 256) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed,
+  hipLaunchKernelGGL(wgrad1_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 32) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed,
                      d.C1 + d.C2, d.Cout, a.bias_part, dbias, n_main);
   VMM_LAUNCH_CHECK();
   return 0;
