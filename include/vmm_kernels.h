@@ -91,6 +91,9 @@ int vmm_conv3x3_accepts(const vmm_conv_desc* d);
  * separate vmm_channel_layernorm pass.  Envelope: KH = KW = 1, stride 1, identity row mapping, K = C1 + C2 padded to 32 in
  * {32, 64, 128, 256}; returns 1 (nothing launched) otherwise. */
 int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
+/* the same, also leaving the LayerNorm statistics of every row in ln_stats [rows][2] = (mean, 1 / sqrt(var + eps)): the training forward of to_qkv
+ * (the normalised rows are never materialised; vmm_conv1x1_wgrad_bf16x3_ln re-normalises from these) */
+int vmm_proj_bf16x3_ln_stats(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, float* ln_stats, vmm_stream_t stream);
 /* ResnetBlock tail (vddp.py:311) in one launch: out = silu(res * a + b') + proj(x); res = d->res = the pre-norm output of block2's
  * convolution (may alias d->out), (a, b') = res_coef [B][Cout][2] from vmm_groupnorm_coef, proj = res_conv.  Envelope of vmm_proj_bf16x3. */
 int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* d, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream);
@@ -136,6 +139,10 @@ int vmm_conv3x3_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t ld
 int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* d, int32_t lddy);
 int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
                              vmm_stream_t stream);
+/* the same for a PreNorm(to_qkv) whose forward fused the channel LayerNorm (vmm_proj_bf16x3_ln_stats): the layer's input is re-normalised while
+ * it is staged, x[r][ci] = (a1[r][ci] - mean[r]) * rstd[r] * ln_gamma[ci] with (mean, rstd) = ln_stats[r][2]; single source (C2 == 0) */
+int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
+                                const float* ln_gamma, vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);

@@ -753,6 +753,42 @@ def test_conv1x1_weight_gradient_bf16x3(gpu, rows, C1, C2, Cout, bias):
     assert lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0
 
 
+@pytest.mark.parametrize("rows,Cc,Cout", [(3000, 64, 768), (515, 128, 256), (64, 256, 64)])
+def test_layernorm_fused_projection_statistics_and_weight_gradient(gpu, rows, Cc, Cout):
+    """Training forward of PreNorm(to_qkv): vmm_proj_bf16x3_ln_stats = the LayerNorm-fused projection that also leaves (mean, rstd) per row, and
+    vmm_conv1x1_wgrad_bf16x3_ln = the weight gradient that re-normalises x from those statistics while it stages it; against LayerNorm -> Linear
+    under torch autograd (vddp.py:245-254: biased variance, eps inside the sqrt, gamma only)."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, Cc, generator=g) * 2 + 0.5
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    w = (torch.randn(Cout, Cc, generator=g) / math.sqrt(Cc)).requires_grad_(True)
+    dy = torch.randn(rows, Cout, generator=g)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    y = (x - mean) / (var + 1e-5).sqrt() * gamma
+    out = y @ w.t()
+    out.backward(dy)
+    xg, gg, dyg = x.to(gpu), gamma.to(gpu), dy.to(gpu)
+    wp = _pack_frag(N, lib, gpu, w.detach(), 2)
+    og = torch.full((rows, Cout), 7.0, device=gpu)
+    stats = torch.full((rows, 2), float("nan"), device=gpu)
+    d = N.ConvDesc()
+    d.a1, d.C1, d.lda1, d.w, d.out, d.ldo, d.Cout = xg.data_ptr(), Cc, Cc, wp.data_ptr(), og.data_ptr(), Cout, Cout
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = 1, 1, rows, 1, rows, 1
+    d.KH, d.KW, d.sgn_h, d.sgn_w, d.Hout, d.Wout, d.oscale, d.rot_dh, d.q_scale = 1, 1, 1, 1, 1, rows, 1, 32, 1.0
+    assert lib.vmm_proj_bf16x3_ln_stats(C.byref(d), gg.data_ptr(), C.c_float(1e-5), stats.data_ptr(), _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(og.cpu(), out.detach()) < 5e-5
+    assert relerr(stats[:, 0].cpu(), mean[:, 0]) < 1e-5 and relerr(stats[:, 1].cpu(), 1 / (var[:, 0] + 1e-5).sqrt()) < 1e-5
+    n_ws = int(lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout))
+    assert n_ws > 0
+    ws = torch.empty(n_ws, device=gpu)
+    dw = torch.zeros(Cc, Cout, device=gpu)
+    assert lib.vmm_conv1x1_wgrad_bf16x3_ln(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), ws.data_ptr(), stats.data_ptr(), gg.data_ptr(), _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), w.grad.t()) < 5e-5
+
+
 @pytest.mark.parametrize("rows,C1,C2,bias,res", [(5000, 256, 0, True, True), (333, 768, 0, False, True), (64, 64, 64, True, False), (1, 256, 0, False, False),
                                                  (40000, 768, 0, False, False), (257, 128, 128, True, True)])
 def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vmm_conv3x3_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
     "vmm_conv1x1_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv1x1_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
+    "vmm_conv1x1_wgrad_bf16x3_ln": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_proj_bf16x3_ln_stats": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr, c_ptr],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
     "vmm_pack_weights": [c_ptr, c_i32, c_i32, c_i32, c_ptr],

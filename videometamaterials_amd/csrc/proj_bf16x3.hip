@@ -33,6 +33,7 @@ struct PJArgs {
   unsigned long long* trace = nullptr;  // VMM_PJ_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (18 slots)
   const float* res_coef;  // non-NULL: the residual enters as silu(res * a + b'), (a, b') = res_coef[sample][column][2] (vmm_proj_bf16x3_res_silu)
   int res_rps;            // rows per sample
+  float* ln_stats = nullptr;  // a_mode 2: (mean, 1 / sqrt(var + eps)) of every row leave here as well [M][2] (the weight gradient normalises x with them)
 };
 
 __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { return split_bf16_pair(a, b, lo); }
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         }
         q = row_sum16(q);
         const float rstd = __builtin_amdgcn_rsqf(q / (float)K + a.eps);
+        if (a.ln_stats && l16 == 0 && blockIdx.y == 0 && m0 + ps * 16 + r0 < a.M)
+          *reinterpret_cast<float2*>(a.ln_stats + 2LL * (m0 + ps * 16 + r0)) = make_float2(mean, rstd);
 #pragma unroll
         for (int i = 0; i < IPL; ++i) {
           const int c = (l16 + 16 * i) * 4;
@@ -432,7 +435,8 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
 // channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
 // identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 32; returns 1 (nothing launched) otherwise.
 template <bool F32>
-static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream, const float* res_coef = nullptr, int res_rps = 1) {
+static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream, const float* res_coef = nullptr, int res_rps = 1,
+                    float* ln_stats = nullptr) {
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
                         d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0;
   const int K = d.C1 + d.C2;
@@ -451,6 +455,7 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   a.eps = ln_eps;
   a.res_coef = res_coef;
   a.res_rps = res_rps;
+  a.ln_stats = ln_gamma ? ln_stats : nullptr;
   a.M = (int)M;
   const int KP = (K + 31) / 32 * 32;
   // workgroup shape: as many rows as fit 80 KB of LDS; column chunk = 256 / rows * 64
@@ -473,6 +478,13 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
 
 extern "C" int vmm_proj_bf16x3(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
   return run_proj<false>(*dp, ln_gamma, ln_eps, stream);
+}
+
+// The same with the LayerNorm statistics of every row left in ln_stats [rows][2] = (mean, 1 / sqrt(var + eps)): the training forward of to_qkv --
+// the normalised rows are never materialised, the weight gradient (vmm_conv1x1_wgrad_bf16x3_ln) re-normalises x from these while it stages it.
+extern "C" int vmm_proj_bf16x3_ln_stats(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, float* ln_stats, vmm_stream_t stream) {
+  if (!ln_gamma || !ln_stats) return -1;
+  return run_proj<false>(*dp, ln_gamma, ln_eps, stream, nullptr, 1, ln_stats);
 }
 
 // ResnetBlock tail (vddp.py:311): out = silu(res * a + b') + proj(x) in one launch -- res = the pre-norm output of block2's convolution

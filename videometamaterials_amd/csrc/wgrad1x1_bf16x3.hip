@@ -34,6 +34,8 @@ struct W1Args {
   float* bias_part;   // [gridDim.z][Cout] or NULL
   long long rows;
   int nchunks, chunks_per_wg;
+  const float* ln_stats;  // non-NULL: x = (a1 - mean[r]) * rstd[r] * ln_gamma[ci], (mean, rstd) = ln_stats[r][2] (PreNorm LayerNorm, vddp.py:245-254)
+  const float* ln_gamma;
 };
 
 __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
@@ -58,8 +60,10 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   const float* xsrc = x_src1 ? p.a1 + xc : p.a2 + (xc - p.C1);
   const int xld = x_src1 ? p.lda1 : p.lda2;
   const float* ysrc = a.dy + yc;
-  f32x2 xv[8], yv[8];
+  f32x2 xv[8], yv[8], sv[8];
   f32x2 bsum = {0.f, 0.f};
+  const bool ln = a.ln_stats != nullptr;  // (workgroup-uniform)
+  const f32x2 lg = (ln && x_ok) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + xc) : f32x2{1.f, 1.f};
   // (every load is unconditional: rows past the end and channels past the layer re-read row 0 / channel 0 and are zeroed when staged)
   auto request = [&](long long r0) {
 #pragma unroll
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
       const bool v = r < a.rows;
       xv[i] = *reinterpret_cast<const f32x2*>((v && x_ok) ? xsrc + r * xld : p.a1);
       yv[i] = *reinterpret_cast<const f32x2*>((v && y_ok) ? ysrc + r * a.lddy : a.dy);
+      if (ln) sv[i] = *reinterpret_cast<const f32x2*>(a.ln_stats + 2 * (v ? r : 0));
     }
   };
   auto stage = [&](long long r0, int buf) {
@@ -80,6 +85,10 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
         float e[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows) ? (op ? yv[i][c] : xv[i][c]) : 0.f;
+        if (ln && !op) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows) ? (e[i] - sv[i][0]) * (sv[i][1] * lg[c]) : 0.f;
+        }
         uint4 h, l;
         h.x = split_bf16_pair(e[0], e[1], l.x);
         h.y = split_bf16_pair(e[2], e[3], l.y);
@@ -265,12 +274,14 @@ extern "C" int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, i
 
 // dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] (and dbias[co] += sum_r dY[r][co] when dbias != NULL); d = the FORWARD descriptor of the layer;
 // workspace = vmm_conv1x1_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant).  Returns 1 (nothing launched) outside the envelope.
-extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
-                                        vmm_stream_t stream) {
+static int w1_launch(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace, const float* ln_stats,
+                     const float* ln_gamma, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   W1Args a;
   int gz = 0, tx = 0, ty = 0;
   if (!workspace || !w1_setup(d, lddy, a, gz, tx, ty)) return 1;
+  a.ln_stats = ln_stats;
+  a.ln_gamma = ln_gamma;
   a.dy = dy; a.lddy = lddy;
   a.part = workspace;
   a.bias_part = dbias ? workspace + (long long)gz * tx * ty * BLOCK_FLOATS : nullptr;
@@ -287,4 +298,17 @@ extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy
                      d.C1 + d.C2, d.Cout, a.bias_part, dbias, n_main);
   VMM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                                        vmm_stream_t stream) {
+  return w1_launch(dp, dy, lddy, dw_packed, dbias, workspace, nullptr, nullptr, stream);
+}
+
+// The same with the layer's input normalised on the way in: x[r][ci] = (a1[r][ci] - mean[r]) * rstd[r] * ln_gamma[ci], (mean, rstd) = ln_stats[r][2] as
+// vmm_proj_bf16x3_ln_stats left them -- the weight gradient of a PreNorm(to_qkv) whose forward fused the LayerNorm (single source: C2 == 0).
+extern "C" int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
+                                           const float* ln_gamma, vmm_stream_t stream) {
+  if (!ln_stats || !ln_gamma || dp->C2) return -1;
+  return w1_launch(dp, dy, lddy, dw_packed, nullptr, workspace, ln_stats, ln_gamma, stream);
 }

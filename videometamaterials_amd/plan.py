@@ -516,11 +516,17 @@ class _Builder:
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
+    def ln_fused_training_ok(self, k: int, cout: int) -> bool:
+        """Training forward of PreNorm(to_qkv / to_q) with the LayerNorm fused into the projection's row staging (statistics kept, vmm_proj_bf16x3_ln_stats):
+        possible when the 1 x 1 split-bf16 weight-gradient kernel (which re-normalises x from those statistics) takes the layer."""
+        return bool(self.training and self.x3 and getattr(self.m, "use_x3_wgrad", True) and _enabled("wgrad1x1") and _enabled("ln_fused_training")
+                    and k % 64 == 0 and cout % 64 == 0 and self.proj_ok(k, cout) and not self.narrow_ok(k, cout))
+
     def narrow_ok(self, k: int, cout: int) -> bool:
         """Envelope of vmm_proj_narrow_bf16x3 (K >= 256 -> 64 columns, split-bf16 only): to_out and the to_qkv data gradient at the C = 64 levels."""
         return bool(self.x3 and cout == 64 and k >= 256 and k % 32 == 0 and getattr(self.m, "use_proj_kernel", True) and _enabled("narrow"))
 
-    def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, **kw) -> "N.ConvDesc":
+    def conv(self, what: str = "conv", halo: bool = False, proj: bool = False, ln_gamma: int = 0, x3w: bool = False, ln_stats: int = 0, **kw) -> "N.ConvDesc":
         d = self.conv_desc(**kw)
         M = d.nimg * d.Hv * d.Wv
         K = d.KH * d.KW * (d.C1 + d.C2)
@@ -529,6 +535,10 @@ class _Builder:
         if proj:  # weights were packed in fragment order for it (proj_ok); ln_gamma: PreNorm LayerNorm fused into the row staging
             if self.narrow_ok(K, d.Cout) and not ln_gamma and not d.rot_ncols and not d.q_ncols:
                 self.step(self.lib.vmm_proj_narrow_bf16x3, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
+                return d
+            if ln_stats:  # training forward: the statistics stay for the weight gradient
+                d._ln = (ln_stats, ln_gamma)
+                self.step(self.lib.vmm_proj_bf16x3_ln_stats, (C.byref(d), ln_gamma, C.c_float(1e-5), ln_stats), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
                 return d
             fn = self.lib.vmm_proj_bf16x3 if self.x3 else self.lib.vmm_proj_f32
             self.step(fn, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
@@ -575,10 +585,18 @@ class _Builder:
                 return
             # the 1 x 1 layers (to_qkv, to_out, res_conv): 128 x 128 channel blocks on the split-bf16 matrix cores, same reduction scheme
             ws_n = int(self.lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), lddy)) if _enabled("wgrad1x1") else 0
+            ln = getattr(d, "_ln", None)  # the forward fused the PreNorm LayerNorm: d.a1 is the un-normalised x
+            if ln and not ws_n:
+                raise RuntimeError("LayerNorm-fused training forward without the 1 x 1 split-bf16 weight-gradient kernel")
             if ws_n:
                 ws = self.alloc(ws_n)
-                self.step(self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
-                          flops=2.0 * M * K * d.Cout, nbytes=wbytes)
+                if ln:
+                    assert not gb_ptr
+                    self.step(self.lib.vmm_conv1x1_wgrad_bf16x3_ln, (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
+                              flops=2.0 * M * K * d.Cout, nbytes=wbytes)
+                else:
+                    self.step(self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                              flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
         if self.x3 and getattr(self.m, "use_x3_wgrad_generic", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
@@ -830,7 +848,8 @@ class _Builder:
             self.plan.named[name] = out
             return out
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
-        fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
+        ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
+        fuse_ln = pj and (not self.training or ln_tr)  # ... with the PreNorm LayerNorm run while the rows are staged (training: statistics kept for the wgrad)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         qkv = self.act(3 * hid, x.H, x.W)
         if not pj and self.split_k_ok(x.C, 3 * hid):
@@ -839,7 +858,7 @@ class _Builder:
         else:
             wq, gwq = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2 if pj else False)
             dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, what=name + " to_qkv", proj=pj,
-                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0)
         if not fuse_ln:
             self.free_act(y)
         # (pass 1 on the split-bf16 matrix cores in both inference and bf16x3 training: the merge pass, which also leaves the softmax statistics the
@@ -918,7 +937,8 @@ class _Builder:
             self.plan.named[name] = out
             return out
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
-        fuse_ln = pj and not self.training  # ... with the PreNorm LayerNorm run while the rows are staged (training keeps y for the wgrad)
+        ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
+        fuse_ln = pj and (not self.training or ln_tr)  # ... with the PreNorm LayerNorm run while the rows are staged (training: statistics kept for the wgrad)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         qkv = self.act(3 * hid, x.H, x.W)
         q_scale = 32 ** -0.5
@@ -930,7 +950,7 @@ class _Builder:
             wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
             dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
                            rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
-                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0)
+                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0)
         if not fuse_ln:
             self.free_act(y)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
