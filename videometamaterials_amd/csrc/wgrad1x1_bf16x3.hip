@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   const long long r_begin = (long long)c_begin * CH;
 
   // ---------------------------------------------------------------- loader: thread = (8-row piece `oct`, channel pair `cp`) of BOTH operands
-  const int oct = tid >> 6, cp = tid & 63;
+  const int oct = wave, cp = tid & 63;  // (oct = tid >> 6 is the wave: wave-uniform, so the per-row LayerNorm statistics below are scalar loads)
   const int xc = ci0 + 2 * cp, yc = co0 + 2 * cp;
   const bool x_ok = xc < Cin, y_ok = yc < p.Cout;
   const bool x_src1 = xc < p.C1;
