@@ -143,6 +143,15 @@ int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t ld
  * it is staged, x[r][ci] = (a1[r][ci] - mean[r]) * rstd[r] * ln_gamma[ci] with (mean, rstd) = ln_stats[r][2]; single source (C2 == 0) */
 int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
                                 const float* ln_gamma, vmm_stream_t stream);
+/* Backward of to_qkv at the C = 64 levels in ONE pass over the gradient g of the qkv rows (rows x 768): gy = g W (rows x 64, plain store) and
+ * dw_packed[c][n] += sum_r g[r][n] y[r][c], y = x (ln_stats NULL) or the channel LayerNorm of x re-formed from ln_stats [rows][2] = (mean, rstd) and
+ * ln_gamma [64] (vmm_proj_bf16x3_ln_stats).  w_frag = vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand, i.e. the torch weight (768, 64) as the
+ * data gradient's "input-major" matrix.  Both LDS images a piece of g needs ([column][row] for the weight gradient, [row][column] for the data
+ * gradient) are written by the one loader pass (qkv_bwd.hip).  workspace = vmm_qkv_bwd_workspace(rows, C, Nq) floats (0 = outside the envelope:
+ * C == 64, Nq == 768, rows a multiple of 64).  Returns 1 (nothing launched) outside the envelope. */
+int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq);
+int vmm_qkv_bwd_bf16x3(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                       float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);

@@ -789,6 +789,44 @@ def test_layernorm_fused_projection_statistics_and_weight_gradient(gpu, rows, Cc
     assert relerr(dw.cpu(), w.grad.t()) < 5e-5
 
 
+@pytest.mark.parametrize("rows,with_ln", [(64, False), (1920, True), (70400, True), (20032, False)])
+def test_fused_to_qkv_backward(gpu, rows, with_ln):
+    """vmm_qkv_bwd_bf16x3: data gradient gy = g W and weight gradient dW += g^T y of to_qkv (768 x 64) from ONE pass over g, y = x or LayerNorm(x)
+    re-formed from the forward's row statistics; against the two matrix products in fp64.  One chunk, fewer chunks than workgroups, many chunks per
+    workgroup; += semantics of dW, plain store of gy, bit-reproducible."""
+    N, lib = _lib()
+    g_ = torch.Generator().manual_seed(rows)
+    Cc, Nq = 64, 768
+    x = torch.randn(rows, Cc, generator=g_) * 1.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g_)
+    w = torch.randn(Nq, Cc, generator=g_) / 8          # torch layout of to_qkv.weight: (out = 768, in = 64)
+    g = torch.randn(rows, Nq, generator=g_)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = 1 / (var + 1e-5).sqrt()
+    y = (x - mean) * rstd * gamma if with_ln else x
+    want_gy = g.double() @ w.double()
+    want_dw = y.double().t() @ g.double()             # packed k-major [c][n]
+    wp = _pack_frag(N, lib, gpu, w.t().contiguous(), 2)  # the (K = 768, N = 64) operand: "weight (out = 64, in = 768)" = W^T
+    xg, gg = x.to(gpu), g.to(gpu)
+    stats = torch.cat([mean, rstd], 1).contiguous().to(gpu)
+    gam = gamma.to(gpu)
+    n_ws = int(lib.vmm_qkv_bwd_workspace(rows, Cc, Nq))
+    assert n_ws > 0 and lib.vmm_qkv_bwd_workspace(rows + 1, Cc, Nq) == 0 and lib.vmm_qkv_bwd_workspace(rows, 128, Nq) == 0
+    outs = []
+    for _ in range(2):
+        ws = torch.full((n_ws,), float("nan"), device=gpu)
+        gy = torch.full((rows, Cc), 7.0, device=gpu)
+        dw = torch.ones(Cc, Nq, device=gpu)
+        rc = lib.vmm_qkv_bwd_bf16x3(xg.data_ptr(), Cc, stats.data_ptr() if with_ln else None, gam.data_ptr() if with_ln else None, gg.data_ptr(), Nq,
+                                    wp.data_ptr(), gy.data_ptr(), Cc, dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, _s())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert relerr(gy.cpu().double(), want_gy) < 5e-5
+        assert relerr(dw.cpu().double() - 1, want_dw) < 5e-5
+        outs.append((gy, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("rows,C1,C2,bias,res", [(5000, 256, 0, True, True), (333, 768, 0, False, True), (64, 64, 64, True, False), (1, 256, 0, False, False),
                                                  (40000, 768, 0, False, False), (257, 128, 128, True, True)])
 def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):

@@ -90,6 +90,8 @@ SIGNATURES = {
     "vmm_conv1x1_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv1x1_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
     "vmm_conv1x1_wgrad_bf16x3_ln": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_qkv_bwd_workspace": [c_i64, c_i32, c_i32],
+    "vmm_qkv_bwd_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3_ln_stats": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr, c_ptr],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
@@ -175,7 +177,7 @@ SIGNATURES = {
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
-RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

@@ -1,0 +1,316 @@
+// Backward of to_qkv at the C = 64 levels (autograd of vddp.py:319, 413: qkv = LayerNorm(x) W^T, W (768, 64)) in ONE pass over the gradient of
+// the qkv rows, split-bf16 matrix cores, gfx950:
+//
+//   gy[r][c]  = sum_n g[r][n] W[n][c]            (data gradient, 768 -> 64)
+//   dW[n][c] += sum_r g[r][n] y[r][c]            (weight gradient; y = LayerNorm(x) re-formed from the forward's row statistics, or y itself)
+//
+// Run separately (narrow_proj.hip + wgrad1x1_bf16x3.hip) each of the two reads the 3 KB rows of g once: 2 x 1.25 GB at the 96 x 96 level, and
+// both are HBM-bound.  Here a workgroup streams 64-row chunks of g in eight pieces of 96 columns; a loader thread (8 rows x 2 columns) splits
+// its values once and writes them into BOTH LDS images a piece needs:
+//   GT [column][row]  (16-byte fragments, rows contiguous)  -> "A" operand of the weight gradient  (contraction over rows)
+//   GR [row][column]  (4-byte pairs, columns contiguous)    -> "B" operand of the data gradient    (contraction over columns)
+// The weight gradient's 768 x 64 accumulators live in registers for the whole kernel (wave w owns the three column fragments of piece w: 96 registers);
+// the data gradient's 64 x 64 tile of a chunk is sixteen 16 x 16 accumulators (two per wave, v_mfma_f32_16x16x32_bf16 with W^T fragments
+// straight from L1 / L2 as the A operand), stored with 16-byte pieces when the chunk's eight pieces are done.  One barrier per piece,
+// double-buffered images; per workgroup partial weight-gradient blocks + a fixed-order reduction, like the other weight-gradient kernels.
+#include "vmm_common.h"
+#include "../../include/vmm_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CH = 64;                  // rows per chunk
+constexpr int NP = 96;                  // columns of g per piece (three 32-column fragments)
+constexpr int NPIECE = 8;               // 768 / 96
+constexpr int NQ = 768, CC = 64;
+constexpr int TP = 2 * CH + 16;         // GT / YT: bytes per column (channel) row of a plane: 144 = 9 x 16
+constexpr int RP = 2 * NP + 16;         // GR: bytes per row of a plane: 208 = 13 x 16
+constexpr int GT_PLANE = NP * TP, GR_PLANE = CH * RP;
+constexpr int PIECE_BUF = 2 * GT_PLANE + 2 * GR_PLANE;   // GT hi | GT lo | GR hi | GR lo = 54 272 bytes
+constexpr int YT_PLANE = CC * TP, YT_BUF = 2 * YT_PLANE;  // 18 432 bytes
+constexpr int LDS_BYTES = 2 * PIECE_BUF + 2 * YT_BUF;     // 145 408 bytes
+constexpr int PART_FLOATS = NQ * CC;
+
+struct QBArgs {
+  const float* x; int ldx;           // rows x 64: y itself, or (ln_stats != NULL) the un-normalised x
+  const float* ln_stats;             // [rows][2] (mean, rstd) or NULL
+  const float* ln_gamma;             // [64]
+  const float* g; int ldg;           // rows x 768
+  const unsigned char* wfrag;        // vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand W
+  float* gy; int ldgy;               // rows x 64 (=)
+  float* part;                       // [gridDim.x][PART_FLOATS]
+  long long rows;
+  int nchunks, chunks_per_wg;
+};
+
+__global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, oct4 = lane >> 4;
+  const int c_begin = blockIdx.x * a.chunks_per_wg;
+  const int n_ch = min(a.chunks_per_wg, a.nchunks - c_begin);
+  if (n_ch <= 0) return;
+  const long long r_begin = (long long)c_begin * CH;
+  unsigned char* const ybuf = sm + 2 * PIECE_BUF;
+
+  // ---------------------------------------------------------------- loaders
+  // g pieces: threads 0..383 (waves 0-5): item = (8 rows `go`, column pair `gp`) of the piece; y chunks: threads 384..511 (waves 6-7): two items
+  // (8 rows, channel pair) per chunk, staged with pieces 0 and 1
+  const bool g_role = wave < 6;
+  const int go = g_role ? tid / 48 : 0, gp = g_role ? tid % 48 : 0;   // 8 row groups x 48 column pairs
+  const int yt = tid - 384, yo0 = (yt >> 5) & 3, ycp = yt & 31;        // item k (0 / 1): row group yo0 + 4 k, channel pair ycp
+  f32x2 gv[8];  // the role's rows in flight (g pieces for waves 0-5, y items for waves 6-7)
+  const f32x2 lg = (!g_role && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
+  // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform base + a 32-bit per-thread offset, so that the row pointers of the eight loads
+  // are not sixteen loop-invariant 64-bit registers per role -- hoisted and spilled by the compiler in the first version)
+  const int g_toff = (8 * go) * a.ldg + 2 * gp, y_toff0 = 8 * yo0 * a.ldx + 2 * ycp;
+  auto g_request = [&](long long r0, int piece) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
+    const float* gb = a.g + r0 * a.ldg + piece * NP;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(gb + (g_toff + i * a.ldg));
+  };
+  auto g_stage = [&](long long r0, int buf) {
+    (void)r0;
+    unsigned char* base = sm + buf * PIECE_BUF;
+    float e0[8], e1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      e0[i] = gv[i][0];
+      e1[i] = gv[i][1];
+    }
+    // GT: one 16-byte fragment (eight rows) per column and plane
+    uint4 h, l;
+    h.x = split_bf16_pair(e0[0], e0[1], l.x); h.y = split_bf16_pair(e0[2], e0[3], l.y);
+    h.z = split_bf16_pair(e0[4], e0[5], l.z); h.w = split_bf16_pair(e0[6], e0[7], l.w);
+    *reinterpret_cast<uint4*>(base + (2 * gp) * TP + go * 16) = h;
+    *reinterpret_cast<uint4*>(base + GT_PLANE + (2 * gp) * TP + go * 16) = l;
+    uint4 h1, l1;
+    h1.x = split_bf16_pair(e1[0], e1[1], l1.x); h1.y = split_bf16_pair(e1[2], e1[3], l1.y);
+    h1.z = split_bf16_pair(e1[4], e1[5], l1.z); h1.w = split_bf16_pair(e1[6], e1[7], l1.w);
+    *reinterpret_cast<uint4*>(base + (2 * gp + 1) * TP + go * 16) = h1;
+    *reinterpret_cast<uint4*>(base + GT_PLANE + (2 * gp + 1) * TP + go * 16) = l1;
+    // GR: per row the column pair as one dword per plane (the same hi / lo values regrouped by row: one v_perm per dword)
+    unsigned char* gr = base + 2 * GT_PLANE + (8 * go) * RP + gp * 4;
+    const unsigned hq[4] = {h.x, h.y, h.z, h.w}, h1q[4] = {h1.x, h1.y, h1.z, h1.w}, lq[4] = {l.x, l.y, l.z, l.w}, l1q[4] = {l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned sel = (i & 1) ? 0x07060302u : 0x05040100u;  // row i of column 2 gp in the low half, of column 2 gp + 1 in the high half
+      *reinterpret_cast<unsigned*>(gr + i * RP) = __builtin_amdgcn_perm(h1q[i >> 1], hq[i >> 1], sel);
+      *reinterpret_cast<unsigned*>(gr + GR_PLANE + i * RP) = __builtin_amdgcn_perm(l1q[i >> 1], lq[i >> 1], sel);
+    }
+  };
+  auto y_request = [&](long long r0, int k) {
+    const float* yb = a.x + (r0 + 32 * k) * a.ldx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(yb + (y_toff0 + i * a.ldx));
+  };
+  auto y_stage = [&](long long r0, int k, int buf) {
+    unsigned char* base = ybuf + buf * YT_BUF + (yo0 + 4 * k) * 16;
+    f32x2 st[8];
+    if (a.ln_stats) {
+      const float* sb = a.ln_stats + 2 * (r0 + 32 * k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const f32x2*>(sb + 2 * (8 * yo0 + i));
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = a.ln_stats ? (gv[i][c] - st[i][0]) * (st[i][1] * lg[c]) : gv[i][c];
+      uint4 h, l;
+      h.x = split_bf16_pair(e[0], e[1], l.x); h.y = split_bf16_pair(e[2], e[3], l.y);
+      h.z = split_bf16_pair(e[4], e[5], l.z); h.w = split_bf16_pair(e[6], e[7], l.w);
+      *reinterpret_cast<uint4*>(base + (2 * ycp + c) * TP) = h;
+      *reinterpret_cast<uint4*>(base + YT_PLANE + (2 * ycp + c) * TP) = l;
+    }
+  };
+
+  // ---------------------------------------------------------------- accumulators
+  f32x16 dw[3][2];   // [owned column fragment f: global fragment 3 wave + f][channel fragment]
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw[f][j][r] = 0.f;
+  // data-gradient units of this wave: 16 channels cb x 16 rows rb0, rb0 + 1 (the two units share their W^T fragments: six 16-byte loads per piece)
+  const int cb = wave >> 1, rb0 = 2 * (wave & 1);
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wfrag);
+  constexpr int KS = NQ / 16;  // k16 planes per column tile of the fmt-2 weights
+  // W^T fragment for 16 x 16 x 32: lane = channel cb * 16 + l15, k = kk * 32 + oct4 * 8 .. + 7  <->  fmt-2 plane (nt = channel / 32, ks = 2 kk + (oct4 >> 1)),
+  // lane' = (oct4 & 1) * 32 + channel % 32
+  const int wch = cb * 16 + l15;
+  const uint4* wbase = wq + ((long long)((wch >> 5) * KS + (oct4 >> 1)) * 2) * 64 + (oct4 & 1) * 32 + (wch & 31);  // + (2 kk * 2 + lo) * 64
+  // The fragments of piece p + 1 are requested at the END of piece p, BEFORE the loader's next global loads: vmcnt retires in order, so a wait
+  // for these never waits for the HBM loads issued after them (requested inside the piece they would queue behind the g prefetch).
+  uint4 wf[3][2];
+  auto w_request = [&](int piece) {
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      wf[kk][0] = wbase[(long long)(2 * (3 * piece + kk) * 2) * 64];
+      wf[kk][1] = wbase[(long long)(2 * (3 * piece + kk) * 2 + 1) * 64];
+    }
+  };
+
+  // ---------------------------------------------------------------- prologue: piece 0 of chunk 0, y of chunk 0
+  if (g_role) {
+    g_request(r_begin, 0);
+    g_stage(r_begin, 0);
+    w_request(0);
+    g_request(r_begin, 1);
+  } else {
+    y_request(r_begin, 0);
+    y_stage(r_begin, 0, 0);
+    y_request(r_begin, 1);
+    y_stage(r_begin, 1, 0);
+    w_request(0);
+  }
+  __syncthreads();
+
+  for (int ch = 0; ch < n_ch; ++ch) {
+    const long long r0 = r_begin + (long long)ch * CH;
+    const bool more_ch = ch + 1 < n_ch;
+    f32x4 gyacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // [row block rb0 + u]
+    const unsigned char* yb = ybuf + (ch & 1) * YT_BUF;
+#pragma unroll 1
+    for (int p = 0; p < NPIECE; ++p) {  // (a real loop: unrolled eight times the kernel needs 400-500 bytes of scratch per lane)
+      const int buf = p & 1;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
+      const unsigned char* pb = sm + buf * PIECE_BUF;
+      // ---- weight gradient: the piece's three column fragments 3 p + j all belong to wave p (72 MFMAs once per chunk and wave: under the ~3.8 k
+      // cycles a piece takes at the HBM rate, and the eight waves take turns)
+      if (wave == p) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int f = j;
+#pragma unroll 1
+          for (int s = 0; s < 4; ++s) {  // (a real loop: unrolled, the compiler hoists the operand reads of all twelve steps and spills)
+            const unsigned char* ap = pb + (j * 32 + l31) * TP + s * 32 + half * 16;
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+            const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
+            bf16x8 Bh[2], Bl[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const unsigned char* bp = yb + (c * 32 + l31) * TP + s * 32 + half * 16;
+              Bh[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+              Bl[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + YT_PLANE));
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[c], dw[f][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[c], dw[f][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[f][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[c], dw[f][c], 0, 0, 0);
+          }
+        }
+      }
+      // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over the piece's 96 columns (three k32 steps)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const bf16x8 Wh = __builtin_bit_cast(bf16x8, wf[kk][0]), Wl = __builtin_bit_cast(bf16x8, wf[kk][1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned char* bp = pb + 2 * GT_PLANE + ((rb0 + u) * 16 + l15) * RP + (kk * 32 + oct4 * 8) * 2;
+          const bf16x8 Gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+          const bf16x8 Gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + GR_PLANE));
+          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gl, gyacc[u], 0, 0, 0);
+          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Gh, gyacc[u], 0, 0, 0);
+          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gh, gyacc[u], 0, 0, 0);
+        }
+      }
+      // ---- loaders.  First the W^T fragments of the next piece (see w_request), then the next piece (already in registers) goes to the other
+      // buffer and the one after it is requested
+      const bool last_piece = p == NPIECE - 1;
+      if (!last_piece || more_ch) w_request((p + 1) % NPIECE);
+      if (g_role) {
+        if (!last_piece || more_ch) {
+          g_stage(last_piece ? r0 + CH : r0, buf ^ 1);
+          const int pn = (p + 2) % NPIECE;
+          const bool next_chunk = p + 2 >= NPIECE;
+          if (!next_chunk || more_ch) g_request(next_chunk ? r0 + CH : r0, pn);
+        }
+      } else if (more_ch) {  // the next chunk's y: one item at a time through the one register set
+        if (p == 0) y_request(r0 + CH, 0);
+        if (p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
+        if (p == 3) y_request(r0 + CH, 1);
+        if (p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
+      }
+      __syncthreads();
+    }
+    // ---- the chunk's data gradient: lane = row (rb0 + u) * 16 + l15, registers = channels cb * 16 + 4 oct4 .. + 3
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long row = r0 + (rb0 + u) * 16 + l15;
+      *reinterpret_cast<f32x4*>(a.gy + row * a.ldgy + cb * 16 + 4 * oct4) = gyacc[u];
+    }
+  }
+
+  // ---------------------------------------------------------------- the workgroup's partial weight-gradient block: [wave][f][c][q][lane] x 4 floats
+  f32x4* dst = reinterpret_cast<f32x4*>(a.part) + (long long)blockIdx.x * (PART_FLOATS / 4);
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[(((wave * 3 + f) * 2 + c) * 4 + q) * 64 + lane] = f32x4{dw[f][c][4 * q], dw[f][c][4 * q + 1], dw[f][c][4 * q + 2], dw[f][c][4 * q + 3]};
+}
+
+// dw_packed[c][n] += sum over workgroups of the partial blocks (fixed order).  thread = (16-byte piece, slice lane)
+__global__ __launch_bounds__(256) void qkv_bwd_reduce_kernel(const float* __restrict__ part, int nz, float* __restrict__ dwp) {
+  __shared__ f32x4 red[8][32];
+  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int piece = blockIdx.x * 32 + e;  // (((wave * 3 + f) * 2 + c) * 4 + q) * 64 + lane
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + piece;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int z = zl; z < nz; z += 8) s += src[(long long)z * (PART_FLOATS / 4)];
+  red[zl][e] = s;
+  __syncthreads();
+  if (zl == 0) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][e];
+    const int lane = piece & 63, q = (piece >> 6) & 3, c = (piece >> 8) & 1, wf = piece >> 9;  // wf = wave * 3 + f
+    const int wave = wf / 3, f = wf - wave * 3;
+    // accumulator register 4 q + k of the lane: row (column n of W) = (3 wave + f) * 32 + k + 8 q + 4 (lane >> 5), column (channel) = c * 32 + (lane & 31)
+    const int n = (wave * 3 + f) * 32 + 8 * q + 4 * (lane >> 5), cc = c * 32 + (lane & 31);
+    f32x4* o = reinterpret_cast<f32x4*>(dwp + (long long)cc * NQ + n);
+    *o += s;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq) {
+  if (C != CC || Nq != NQ || rows <= 0 || rows % CH) return 0;
+  const long long nchunks = (rows + CH - 1) / CH;
+  const long long nwg = nchunks < 256 ? nchunks : 256;
+  return nwg * PART_FLOATS;
+}
+
+// gy = g W (rows x 64, plain store) and dw_packed[c][n] += g^T y in one pass over g (rows x 768).  x / ln_stats / ln_gamma: y = x when ln_stats is
+// NULL, else y = (x - mean) rstd gamma with (mean, rstd) = ln_stats[r][2].  w_frag = vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand
+// (the to_qkv weight (768, 64) as it lies in torch).  Returns 1 (nothing launched) unless C == 64, Nq == 768 and rows is a multiple of 64.
+extern "C" int vmm_qkv_bwd_bf16x3(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                                  float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream) {
+  if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 1) || (ldg & 1) || (ldgy & 3) || (ln_stats && !ln_gamma)) return 1;
+  if (rows <= 0) return 0;
+  QBArgs a;
+  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = g; a.ldg = ldg;
+  a.wfrag = reinterpret_cast<const unsigned char*>(w_frag);
+  a.gy = gy; a.ldgy = ldgy; a.part = workspace; a.rows = rows;
+  a.nchunks = (int)((rows + CH - 1) / CH);
+  const int nwg = a.nchunks < 256 ? a.nchunks : 256;
+  a.chunks_per_wg = (a.nchunks + nwg - 1) / nwg;
+  const int gx = (a.nchunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_bwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(qkv_bwd_x3_kernel, dim3(gx), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qkv_bwd_reduce_kernel, dim3(PART_FLOATS / 4 / 32), dim3(256), 0, (hipStream_t)stream, workspace, gx, dw_packed);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}

@@ -516,6 +516,27 @@ class _Builder:
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
+    def qkv_backward(self, dq: "N.ConvDesc", wname: str, x: Act, gqkv: Act, gwq: int, what: str) -> Act:
+        """Backward of to_qkv: the weight gradient into gwq and the data gradient gy (returned; the caller's LayerNorm backward consumes and frees it).
+        At the C = 64 levels both come from ONE pass over the 3 KB rows of gqkv (qkv_bwd.hip); elsewhere a weight-gradient and a data-gradient launch."""
+        rows = self.B * self.T * x.H * x.W
+        n_out = gqkv.C
+        gy = self.act(x.C, x.H, x.W)
+        ws_n = int(self.lib.vmm_qkv_bwd_workspace(rows, x.C, n_out)) if (self.x3 and gwq and dq is not None and getattr(self.m, "use_x3_wgrad", True)
+                                                                          and _enabled("qkv_bwd")) else 0
+        if ws_n:
+            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
+            ws = self.alloc(ws_n)
+            ln = getattr(dq, "_ln", None)
+            self.step(self.lib.vmm_qkv_bwd_bf16x3, (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
+                                                    self.ptr(ws), rows, x.C, n_out), what + " backward (data + weight gradient)",
+                      flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 2 * x.C))
+            self.tmp_free((ws, ws_n))
+            return gy
+        self.wgrad(dq, gqkv.ptr, n_out, gwq, what)
+        self.dgrad_1x1(wname, 0, x.C, what + " dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
+        return gy
+
     def ln_fused_training_ok(self, k: int, cout: int) -> bool:
         """Training forward of PreNorm(to_qkv / to_q) with the LayerNorm fused into the projection's row staging (statistics kept, vmm_proj_bf16x3_ln_stats):
         possible when the 1 x 1 split-bf16 weight-gradient kernel (which re-normalises x from those statistics) takes the layer."""
@@ -901,9 +922,7 @@ class _Builder:
                                                  geo or None, gvo or None, B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 7 * hid)
             self.tmp_free(go)
             self.tmp_free((dctx, ctx_n))
-            self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
-            gy = self.act(x.C, x.H, x.W)
-            self.dgrad_1x1(name + ".fn.fn.to_qkv.weight", 0, x.C, name + " to_qkv dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
+            gy = self.qkv_backward(dq, name + ".fn.fn.to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
             self.tmp_free(gqkv)
             self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
             self.tmp_free(gy)
@@ -1003,9 +1022,7 @@ class _Builder:
                        gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
             self.tmp_free(go)
             self.tmp_free((dbuf, ndbuf))
-            self.wgrad(dq, gqkv.ptr, 3 * hid, gwq, name + " to_qkv")
-            gy = self.act(x.C, x.H, x.W)
-            self.dgrad_1x1(p + ".to_qkv.weight", 0, x.C, name + " to_qkv dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
+            gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
             self.tmp_free(gqkv)
             self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
             self.tmp_free(gy)
