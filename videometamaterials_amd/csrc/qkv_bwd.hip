@@ -182,9 +182,9 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
       // ---- weight gradient: the piece's three column fragments 3 p + j all belong to wave p (72 MFMAs once per chunk and wave: under the ~3.8 k
       // cycles a piece takes at the HBM rate, and the eight waves take turns)
       if (wave == p) {
-#pragma unroll 2
-        for (int s = 0; s < 4; ++s) {  // (unrolled by two: the operand reads of two k16 steps are in flight together; by four the accumulators spill)
-          bf16x8 Bh[2], Bl[2];
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {  // (a real loop over the k16 steps: the step's five fragment pairs are read together, then 18 MFMAs pass-major
+          bf16x8 Bh[2], Bl[2], Ah[3], Al[3];  // over six accumulators -- with two accumulators per read batch every other MFMA waited for its predecessor)
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const unsigned char* bp = yb + (c * 32 + l31) * TP + s * 32 + half * 16;
@@ -194,15 +194,21 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const unsigned char* ap = pb + (j * 32 + l31) * TP + s * 32 + half * 16;
-            const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-            const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[c], dw[j][c], 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[c], dw[j][c], 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[c], dw[j][c], 0, 0, 0);
+            Ah[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+            Al[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
           }
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl[c], dw[j][c], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh[c], dw[j][c], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh[c], dw[j][c], 0, 0, 0);
         }
       }
       // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over the piece's 96 columns (three k32 steps)
