@@ -9,7 +9,8 @@
 // its values once and writes them into BOTH LDS images a piece needs:
 //   GT [column][row]  (16-byte fragments, rows contiguous)  -> "A" operand of the weight gradient  (contraction over rows)
 //   GR [row][column]  (4-byte pairs, columns contiguous)    -> "B" operand of the data gradient    (contraction over columns)
-// The weight gradient's 768 x 64 accumulators live in registers for the whole kernel (wave w owns the three column fragments of piece w: 96 registers);
+// The weight gradient's 768 x 64 accumulators live in registers for the whole kernel (wave w owns channel fragment 0 of piece w and channel fragment 1 of
+// piece w - 1: 96 registers);
 // the data gradient's 64 x 64 tile of a chunk is sixteen 16 x 16 accumulators (two per wave, v_mfma_f32_16x16x32_bf16 with W^T fragments
 // straight from L1 / L2 as the A operand), stored with 16-byte pieces when the chunk's eight pieces are done.  One barrier per piece,
 // double-buffered images; per workgroup partial weight-gradient blocks + a fixed-order reduction, like the other weight-gradient kernels.
@@ -129,13 +130,13 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
   };
 
   // ---------------------------------------------------------------- accumulators
-  f32x16 dw[3][2];   // [owned column fragment f: global fragment 3 wave + f][channel fragment]
+  // piece p's 96 x 64 block is shared by TWO waves: wave p owns channel fragment 0 (dwA), wave p + 1 channel fragment 1 (dwB) -- each piece then costs
+  // its owners 36 MFMAs, not one wave 72
+  f32x16 dwA[3], dwB[3];   // [column fragment j of the piece]
 #pragma unroll
   for (int f = 0; f < 3; ++f)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dw[f][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) dwA[f][r] = dwB[f][r] = 0.f;
   // data-gradient units of this wave: 16 channels cb x 16 rows rb0, rb0 + 1 (the two units share their W^T fragments: six 16-byte loads per piece)
   const int cb = wave >> 1, rb0 = 2 * (wave & 1);
   const uint4* wq = reinterpret_cast<const uint4*>(a.wfrag);
@@ -179,18 +180,15 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
     for (int p = 0; p < NPIECE; ++p) {  // (a real loop: unrolled eight times the kernel needs 400-500 bytes of scratch per lane)
       const int buf = p & 1;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
       const unsigned char* pb = sm + buf * PIECE_BUF;
-      // ---- weight gradient: the piece's three column fragments 3 p + j all belong to wave p (72 MFMAs once per chunk and wave: under the ~3.8 k
-      // cycles a piece takes at the HBM rate, and the eight waves take turns)
-      if (wave == p) {
+      // ---- weight gradient: the piece's three column fragments x channel fragment c (36 MFMAs per owner and piece: well under the ~3.8 k cycles a
+      // piece takes at the HBM rate, and the eight waves take turns)
+      auto wgrad_half = [&](f32x16 (&acc)[3], int c) {
 #pragma unroll 1
-        for (int s = 0; s < 4; ++s) {  // (a real loop over the k16 steps: the step's five fragment pairs are read together, then 18 MFMAs pass-major
-          bf16x8 Bh[2], Bl[2], Ah[3], Al[3];  // over six accumulators -- with two accumulators per read batch every other MFMA waited for its predecessor)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const unsigned char* bp = yb + (c * 32 + l31) * TP + s * 32 + half * 16;
-            Bh[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
-            Bl[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + YT_PLANE));
-          }
+        for (int s = 0; s < 4; ++s) {  // (a real loop over the k16 steps: the step's four fragment pairs are read together, then 9 MFMAs pass-major)
+          bf16x8 Ah[3], Al[3];
+          const unsigned char* bp = yb + (c * 32 + l31) * TP + s * 32 + half * 16;
+          const bf16x8 Bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+          const bf16x8 Bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + YT_PLANE));
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const unsigned char* ap = pb + (j * 32 + l31) * TP + s * 32 + half * 16;
@@ -198,19 +196,15 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
             Al[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
           }
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
+          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl[c], dw[j][c], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh, acc[j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh[c], dw[j][c], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dw[j][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh[c], dw[j][c], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh, acc[j], 0, 0, 0);
         }
-      }
+      };
+      if (wave == p) wgrad_half(dwA, 0);
+      if (wave == ((p + 1) & 7)) wgrad_half(dwB, 1);
       // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over the piece's 96 columns (three k32 steps)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
@@ -254,12 +248,14 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
 
   // ---------------------------------------------------------------- the workgroup's partial weight-gradient block: [wave][f][c][q][lane] x 4 floats
   f32x4* dst = reinterpret_cast<f32x4*>(a.part) + (long long)blockIdx.x * (PART_FLOATS / 4);
+  const int wprev = (wave + 7) & 7;  // the piece whose channel fragment 1 this wave accumulated
 #pragma unroll
   for (int f = 0; f < 3; ++f)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dst[(((wave * 3 + f) * 2 + c) * 4 + q) * 64 + lane] = f32x4{dw[f][c][4 * q], dw[f][c][4 * q + 1], dw[f][c][4 * q + 2], dw[f][c][4 * q + 3]};
+    for (int q = 0; q < 4; ++q) {
+      dst[(((wave * 3 + f) * 2 + 0) * 4 + q) * 64 + lane] = f32x4{dwA[f][4 * q], dwA[f][4 * q + 1], dwA[f][4 * q + 2], dwA[f][4 * q + 3]};
+      dst[(((wprev * 3 + f) * 2 + 1) * 4 + q) * 64 + lane] = f32x4{dwB[f][4 * q], dwB[f][4 * q + 1], dwB[f][4 * q + 2], dwB[f][4 * q + 3]};
+    }
 }
 
 // dw_packed[c][n] += sum over workgroups of the partial blocks (fixed order).  thread = (16-byte piece, slice lane)
