@@ -84,6 +84,16 @@ int vmm_conv3x3_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
 /* host-only query: 1 when vmm_conv3x3_bf16x3 / vmm_conv3x3_f32 would take d as it stands (a_mode, a_img_mod, wrap_h / wrap_w, res ...), else 0 */
 int vmm_conv3x3_accepts(const vmm_conv_desc* d);
+/* The same convolution as Winograd F(2x2, 3x3) on the split-bf16 matrix cores (conv3x3_wino.hip): 16 transform-domain products per 2 x 2 output
+ * tile and (cin, cout) instead of 36, input / output transforms in fp32 (exact constants), operands split after the transform: fp32-class
+ * results (7e-6 relative against 4.7e-6 for the direct kernel on the same data).  d->w = fmt-8 output of vmm_pack_weights.  Envelope: 3 x 3 /
+ * stride 1 / zero padding 1, even H and W whose tile grid (H / 2 x W / 2) divides into blocks of 32..64 tiles with an input patch of at most 324
+ * pixels, C1 / C2 multiples of 16, Cout a multiple of 64; fused operand transform (a_mode 1), a_img_mod, bias, residual as in
+ * vmm_conv3x3_bf16x3; GroupNorm partial sums in d->gn_part with n = vmm_conv3x3_wino_fuses_gn(d) slots per (sample, group) (0 = not produced).
+ * Returns 1 (nothing launched) outside the envelope; vmm_conv3x3_wino_accepts is the host-only query for that. */
+int vmm_conv3x3_wino_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+int vmm_conv3x3_wino_fuses_gn(const vmm_conv_desc* d);
+int vmm_conv3x3_wino_accepts(const vmm_conv_desc* d);
 /* 1x1 / Linear specialisation (to_qkv, to_out vddp.py:319,325,413,421; res_conv vddp.py:297): a workgroup stages its rows' full K
  * extent once in LDS and sweeps all output columns, weights read straight into registers in MFMA fragment order (d->w = fmt-2 output
  * of vmm_pack_weights), 16-byte epilogue stores; same epilogue options as vmm_conv_igemm_*.  ln_gamma != NULL: the rows pass through
@@ -173,7 +183,10 @@ typedef struct vmm_pack_job {
                 *    6 = ConvTranspose3d (C, N, 1, 4, 4) with the four output phases as 4 N columns: [4N/32][9*C/16][hi|lo][64][8];
                 * 7: the stem convolution (N, C <= 4, 1, k, k), k <= 8, for vmm_stem_conv_bf16x3: fragment order of 2 with
                 *    K = (kernel row, tap 0..7, channel 0..3), zero beyond tap k - 1 and channel C - 1: [N/32][2k][hi|lo][64][8] (TH = TW = k);
-                *    1-7: direction 0 only. */
+                * 8: the 3 x 3 kernel (N, C, 1, 3, 3) as Winograd F(2x2, 3x3) weights U = G g G^T for vmm_conv3x3_wino_bf16x3, split, in "A" fragment order:
+ *    [N/64][Cp/16][position xi*4+nu][column fragment 0..1][hi|lo][64 lanes][8], lane l = column nb*64 + mf*32 + (l & 31),
+ *    channels ks*16 + (l >> 5)*8 .. +7 (TH = TW = 3, Cp a multiple of 16, N of 64; 64 (N/64) Cp bytes);
+ *    1-8: direction 0 only. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 

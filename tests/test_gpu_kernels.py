@@ -117,6 +117,77 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
     assert relerr(out.cpu(), ref_rows) < 5e-5
 
 
+@pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 96, 96, 64, 0, 64, False), (2, 1, 96, 96, 64, 0, 64, True), (2, 3, 48, 48, 64, 64, 128, True),
+                                                      (1, 2, 48, 48, 128, 0, 128, False), (2, 2, 24, 24, 256, 0, 256, True), (1, 3, 24, 24, 256, 256, 128, False),
+                                                      (2, 1, 12, 12, 512, 0, 512, True), (2, 3, 10, 20, 64, 16, 64, True), (1, 1, 16, 16, 16, 0, 64, False),
+                                                      (3, 11, 48, 48, 64, 0, 128, True)])
+def test_conv3x3_winograd_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
+    """Winograd F(2x2, 3x3) form of the 3x3 convolution (weights G g G^T in fragment order, fmt 8): image borders, partial tile blocks (48 / 36 / 50 of 64
+    tiles), two sources, fused per-sample GN+SiLU operand, bias, residual, the GroupNorm partial sums of the epilogue; same tolerance as the direct kernel."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(21)
+    Cin = C1 + C2
+    x1 = torch.randn(B, C1, T, H, W, generator=g)
+    x2 = torch.randn(B, C2, T, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B * T * H * W, Cout, generator=g)
+    xa, coef = x1, None
+    if fused:
+        coef = torch.randn(B, C1, 2, generator=g)
+        xa = F.silu(x1 * coef[:, :, 0][:, :, None, None, None] + coef[:, :, 1][:, :, None, None, None])
+    xin = torch.cat([xa, x2], 1) if C2 else xa
+    ref = F.conv2d(xin.double().permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, Cout).float() + res
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros(16 * Cin * Cout, device=gpu)  # 64 bytes per (channel, column)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 8
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Cin * 16, 0, _s()), "pack")
+    d = N.ConvDesc()
+    x1r, bg, rg = rows_of(x1).to(gpu), b.to(gpu), res.to(gpu)
+    x2r = rows_of(x2).to(gpu) if C2 else None
+    cg = coef.to(gpu) if fused else None
+    out = torch.zeros(B * T * H * W, Cout, device=gpu)
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = x1r.data_ptr(), C1, C1, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout
+    if C2:
+        d.a2, d.C2, d.lda2 = x2r.data_ptr(), C2, C2
+    d.res, d.ldres = rg.data_ptr(), Cout
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, W, 1, Cout, 32, 1.0
+    if fused:
+        d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
+    assert lib.vmm_conv3x3_wino_accepts(C.byref(d)) == 1
+    N.check(lib.vmm_conv3x3_wino_bf16x3(C.byref(d), _s()), "conv3x3 winograd")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 5e-5
+    first = out.clone()
+    out.fill_(7.0)
+    N.check(lib.vmm_conv3x3_wino_bf16x3(C.byref(d), _s()), "conv3x3 winograd")
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
+    # GroupNorm sums of the output (+ bias) from the epilogue
+    G = 8
+    d.res, d.ldres = None, 0
+    d.gn_part, d.gn_groups, d.a_imgs_per_sample = 1, G, T
+    n_part = lib.vmm_conv3x3_wino_fuses_gn(C.byref(d))
+    assert n_part > 0
+    part = torch.full((B * G, n_part, 2), float("nan"), device=gpu)
+    d.gn_part = part.data_ptr()
+    N.check(lib.vmm_conv3x3_wino_bf16x3(C.byref(d), _s()), "conv3x3 winograd + gn sums")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref - res) < 5e-5
+    y = (ref - res).reshape(B, T * H * W, G, Cout // G).double()
+    want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], -1).reshape(B * G, 2)
+    got = part.double().sum(1).cpu()
+    assert not torch.isnan(got).any()
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+
+
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 12, 12, 64, 0, 64, False), (2, 1, 24, 24, 32, 32, 128, False), (1, 2, 96, 96, 64, 0, 64, True),
                                                       (1, 1, 12, 12, 512, 512, 256, False), (2, 3, 10, 20, 64, 64, 128, True), (2, 1, 32, 32, 64, 0, 64, True),
                                                       (2, 1, 48, 48, 32, 32, 128, True), (1, 11, 12, 12, 256, 0, 512, False),

@@ -82,6 +82,9 @@ SIGNATURES = {
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_accepts": [C.POINTER(ConvDesc)],
+    "vmm_conv3x3_wino_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_wino_fuses_gn": [C.POINTER(ConvDesc)],
+    "vmm_conv3x3_wino_accepts": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],

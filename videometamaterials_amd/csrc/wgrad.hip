@@ -386,6 +386,60 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
     }
     return;
   }
+  if (jb.fmt == 8) {
+    // Winograd F(2x2, 3x3) weights for conv3x3_wino.hip: U = G g G^T (G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]]) per (channel, column),
+    // split, in "A" fragment order: plane (column block nb of 64, k16 step ks, position xi * 4 + nu, column fragment mf, hi | lo) = 64 lanes x 8 bf16,
+    // lane l = column nb * 64 + mf * 32 + (l & 31), channels ks * 16 + (l >> 5) * 8 .. + 7.  thread = (nb, ks, mf, l): 72 loads, 32 16-byte stores.
+    if (direction != 0) return;
+    const int KS = jb.Cp / 16, NB = (jb.N + 63) / 64;
+    uint4* dst = reinterpret_cast<uint4*>(jb.packed);
+    const long long tot = (long long)NB * KS * 2 * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int l = (int)(i & 63), mf = (int)(i >> 6) & 1;
+      const long long pk = i >> 7;  // nb * KS + ks
+      const int ks = (int)(pk % KS), nb = (int)(pk / KS);
+      const int n = nb * 64 + mf * 32 + (l & 31), c0 = ks * 16 + (l >> 5) * 8;
+      float tr[8][4][3];  // G g: [channel][xi][j]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g[3][3];
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+          for (int tw = 0; tw < 3; ++tw)
+            g[th][tw] = (c0 + e < jb.C && n < jb.N) ? jb.torch_w[(long long)n * jb.sn + (long long)(c0 + e) * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh +
+                                                                 (long long)(jb.w0 + tw * jb.ws) * jb.sw]
+                                                    : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          tr[e][0][j] = g[0][j];
+          tr[e][1][j] = 0.5f * ((g[0][j] + g[2][j]) + g[1][j]);
+          tr[e][2][j] = 0.5f * ((g[0][j] + g[2][j]) - g[1][j]);
+          tr[e][3][j] = g[2][j];
+        }
+      }
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          unsigned h[4], lo[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            float u[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float* t = tr[2 * e2 + k][xi];
+              u[k] = nu == 0 ? t[0] : nu == 3 ? t[2] : nu == 1 ? 0.5f * ((t[0] + t[2]) + t[1]) : 0.5f * ((t[0] + t[2]) - t[1]);
+            }
+            h[e2] = split_bf16_pair(u[0], u[1], lo[e2]);
+          }
+          uint4* o = dst + ((((pk * 16 + xi * 4 + nu) * 2 + mf) * 2) * 64 + l);
+          o[0] = uint4{h[0], h[1], h[2], h[3]};
+          o[64] = uint4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+    return;
+  }
   if (jb.fmt == 2 || jb.fmt == 3 || jb.fmt == 4) {
     // split-bf16 operand in MFMA fragment order for conv3x3_bf16x3.hip / proj_bf16x3.hip: plane (column tile nt of 32, k16 step ks, hi|lo)
     // = 64 lanes x 8 bf16; lane l holds column nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 .. +7.  K = (th, tw, c) padded to 32, N to 32.
