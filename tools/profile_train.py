@@ -40,7 +40,7 @@ if os.environ.get("VMM_TRAIN_DETAIL"):
             f[1] += 1
         rows = sorted(zip(ms, steps, meta), key=lambda r: -r[0])
         print(f"== {name}: {sum(ms):.2f} ms over {len(ms)} launches", file=sys.stderr)
-        for t, (fn, _, what), (_, fl, nb) in rows[:60]:
+        for t, (fn, _, what), (_, fl, nb) in rows[:int(os.environ.get('VMM_TRAIN_DETAIL_ROWS', '60'))]:
             print(f"{t:8.3f} ms {fl / t / 1e9 if t > 0 else 0:8.1f} TFLOP/s {nb / t / 1e6 if t > 0 else 0:8.1f} GB/s  {fn.__name__:32s} {what}", file=sys.stderr)
 
     print("== families (ms, launches): " + ", ".join(f"{k} {v[0]:.2f}/{v[1]}" for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])), file=sys.stderr)

@@ -1619,17 +1619,26 @@ extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int
   return s2_plan(nullptr, 0, nullptr, nullptr, nullptr, 0, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide) == 0 ? 1 : 0;
 }
 
-extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
-                                  int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
+// res != NULL: out = convolution (+ bias) + res, res rows indexed like out (may alias it): the layers' DATA gradients accumulating into a gradient
+// buffer that already holds the skip connection's share (autograd of vddp.py:155,158)
+extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
+                                      int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
   C3Args a;
   int mtiles;
   bool wide;
   const int rc = s2_plan(x, ldx, w_frag, bias, out, ldo, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide);
   if (rc) return rc;
+  if (res && (ldres & 3)) return 1;
+  a.p.res = res;
+  a.p.ldres = ldres;
   hipStream_t s = (hipStream_t)stream;
   if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1>(a, mtiles, s);
   if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2>(a, mtiles, s);
   return a.mode ? launch_s2<4, 1, 11, 1, 2>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2>(a, mtiles, s);
+}
+extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
+                                  int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
+  return vmm_conv_s2_acc_bf16x3(x, ldx, w_frag, bias, nullptr, 0, out, ldo, nimg, Hin, Win, Cin, Cout, up, stream);
 }
 
 // The same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32, 1e-6 parity): weights = vmm_pack_weights fmt 4

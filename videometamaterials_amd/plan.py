@@ -1314,12 +1314,16 @@ class _Builder:
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
         x = self.act(m.init_dim, H, W)
-        if self.x3 and not tr and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem"):
+        if self.x3 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")):
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
             self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
                       flops=2.0 * rows0 * k * k * Cx * 64, nbytes=4.0 * rows0 * (4 + 64))
             dinit = gwi = None
+            if tr:  # the weight gradient works from the layer's descriptor and the plain packed layout (the operand copy itself is not used)
+                _, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
+                dinit = self.conv_desc(a1=xin, w=0, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr,
+                                       ldo=m.init_dim, Hv=H, Wv=W)
         else:
             wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
             dinit = self.conv(a1=xin, w=wi, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr,
@@ -1396,6 +1400,13 @@ class _Builder:
                     self.wgrad(dd, gd.ptr, xs.C, gwd, nm, gb_ptr=self.pg(nm + ".bias"))
                     gx, acc = self.grad_of(xs)
                     co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
+                    if self.x3 and not wrap and _enabled("s2_dgrad") and lib.vmm_conv_s2_supported(B * T, d.H, d.W, co_, ci_, 1):
+                        # dIn = ConvTranspose(dOut, W) with the convolution's own (Cout, Cin, 1, 4, 4) tensor read as a (C = Cout, N = Cin) transposed-convolution
+                        # weight: ONE tap-subset launch (the Upsample kernel) instead of four phase GEMMs
+                        wt = self.pack(nm + ".weight", 36 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=16, sc=ci_ * 16, sh=4, sw=1, fmt=6)[0]
+                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gd.ptr, gd.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, d.H, d.W, co_, ci_, 1),
+                                  nm + " dgrad", flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (gd.n + (2 if acc else 1) * gx.n + 16 * ci_ * co_))
+                        return
                     for ph in range(2):
                         for pw in range(2):
                             # dIn[2c+ph] = sum_kh' dOut[c + ph - kh'] W[(1-ph)+2kh']^T : [(kh', kw', co)][ci]
@@ -1453,6 +1464,12 @@ class _Builder:
                         self.wgrad(du, gu.ptr, co_, gwp, nm, gb_ptr=self.pg(nm + ".bias"))
                     gx, acc = self.grad_of(xs)
                     # dX[a][ci] = sum_{kh,kw,co} dU[2a-1+kh][co] W[ci][co][kh][kw]: a stride-2 conv over dU with [(kh,kw,co)][ci]
+                    if self.x3 and not wrap and _enabled("s2_dgrad") and lib.vmm_conv_s2_supported(B * T, gu.H, gu.W, co_, ci_, 0):
+                        # ... i.e. the Downsample kernel over dU with the (Cin, Cout, 1, 4, 4) tensor read as a convolution weight (N = Cin, C = Cout)
+                        wt = self.pack(nm + ".weight", 36 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
+                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gu.ptr, gu.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, gu.H, gu.W, co_, ci_, 0),
+                                  nm + " dgrad", flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (gu.n + (2 if acc else 1) * gx.n + 16 * ci_ * co_))
+                        return
                     wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, gemm=self.x3, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1,
                                    hs=1, ws=1)[0]
                     self.conv(a1=gu, w=wp, Cout=ci_, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=gx.ptr, ldo=ci_, Hv=xs.H, Wv=xs.W, res_ptr=gx.ptr if acc else 0,
