@@ -256,19 +256,23 @@ extern "C" int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const floa
   const int c4 = C >> 2;
   int gs = 1;
   while (gs < 64 && gs < c4) gs <<= 1;
+  // (at least four row groups per workgroup: the epilogue -- LDS atomics, a partial row of C floats, then vmm_sum_partials over all of them -- was
+  // most of the 60 us the 12 x 12 level's launches took)
   const long long want = (rows * gs + 255) / 256;
-  const int blocks = (int)max(1LL, min(want, 2048LL));
+  const int blocks = (int)max(1LL, min((want + 3) / 4, 2048LL));
+#define LNB_LAUNCH(G, V)                                                                                                             \
+  hipLaunchKernelGGL((chan_ln_bwd_kernel<G, V>), dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
+                     (long long)rows, C, eps, accumulate, scratch)
 #define LNB_CASE(G)                                                                                                                  \
   case G:                                                                                                                            \
-    if (c4 <= G)                                                                                                                      \
-      hipLaunchKernelGGL((chan_ln_bwd_kernel<G, 1>), dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
-                         (long long)rows, C, eps, accumulate, scratch);                                                                       \
-    else                                                                                                                             \
-      hipLaunchKernelGGL((chan_ln_bwd_kernel<G, 8>), dim3(blocks), dim3(256), sizeof(float) * C, s, x, ldx, gamma, dy, lddy, dx, lddx, dgamma, \
-                         (long long)rows, C, eps, accumulate, scratch);                                                                       \
+    if (c4 <= G) LNB_LAUNCH(G, 1);                                                                                                   \
+    else if (c4 <= 2 * G) LNB_LAUNCH(G, 2); /* (C = 512: two vectors per lane, not eight slots of which six are idle) */             \
+    else if (c4 <= 4 * G) LNB_LAUNCH(G, 4);                                                                                          \
+    else LNB_LAUNCH(G, 8);                                                                                                           \
     break;
   switch (gs) { LNB_CASE(1) LNB_CASE(2) LNB_CASE(4) LNB_CASE(8) LNB_CASE(16) LNB_CASE(32) LNB_CASE(64) }
 #undef LNB_CASE
+#undef LNB_LAUNCH
   VMM_LAUNCH_CHECK();
   if (scratch) return vmm_sum_partials(scratch, blocks, C, C, dgamma, stream);
   return 0;
