@@ -45,6 +45,7 @@ def run(H, C1, C2, Cout, fused, gn=True):
     x2r = rows_of(x2) if C2 else None
     out = torch.zeros(NIMG * H * H, Cout, device=dev)
     part = torch.zeros(1 << 22, device=dev)
+    tickets = torch.zeros(4096, dtype=torch.int32, device=dev)
     res = {}
     for name, kernel, fmt, nfl, query in (("direct", lib.vmm_conv3x3_bf16x3, 2, (Cout + 31) // 32 * 32 * 9 * Cin, lib.vmm_conv3x3_fuses_gn),
                                           ("wino", lib.vmm_conv3x3_wino_bf16x3, 8, 16 * Cin * Cout, lib.vmm_conv3x3_wino_fuses_gn)):
@@ -57,6 +58,8 @@ def run(H, C1, C2, Cout, fused, gn=True):
         d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
         d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, H, 1, Cout, 32, 1.0
         d.a_imgs_per_sample = NIMG
+        if name == "direct" and os.environ.get("WINO_TICKETS"):
+            d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
         if fused:
             d.a_mode, d.a_coef = 1, coef.data_ptr()
         if gn:

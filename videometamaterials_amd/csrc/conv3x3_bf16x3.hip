@@ -1454,7 +1454,12 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   ksplit = 1;
   // split the channel reduction only when the tiles cannot even half-fill the chip: measured on the Lagrangian sampler (batch 8), splitting
   // below 1024 workgroups cost 1.15 ms per step against splitting below 128 (ordered atomics epilogue, no fused GroupNorm sums)
-  if (blocks < 128 && d.split_tickets && d.n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch, 8), 2048 / max(blocks, 1LL)));
+  // How far: a split keeps at least four 32-channel chunks and there are at most four of them.  (Round 3, tools/bench_wino.py with WINO_TICKETS=1,
+  // 11 / 22 / 44 frames: the earlier "up to eight" was never the best choice -- 256 -> 256 at 12 x 12, 44 frames: 71 us with eight splits, 50 with
+  // two or none; 512 -> 512, 22 frames: 84 / 74 / 92 us with eight / four / none -- the ordered ticket epilogue serialises a tile's splits.)
+  static const int ksplit_max = [] { const char* e = getenv("VMM_C3_KSPLIT_MAX"); return e ? atoi(e) : 4; }();  // (measurement aid)
+  if (blocks < 128 && d.split_tickets && d.n_tickets >= blocks)
+    ksplit = (int)max(1LL, min((long long)min(nch / 4, ksplit_max), 2048 / max(blocks, 1LL)));
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
   if (d.a_img_mod && (a.mode == 0 || ksplit > 1 || d.a_img_mod < 0 || d.a_img_mod >= d.nimg)) return 1;  // shared source frames: unsplit 2-D tiles only
