@@ -209,9 +209,11 @@ int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_packed, const
 /* the same with out = convolution (+ bias) + res (res rows indexed like out, may alias it; ldres a multiple of 4): the layers' data gradients --
  * d Downsample / dx = the Upsample kernel over dOut with the convolution's (Cout, Cin, 1, 4, 4) tensor read as a transposed-convolution weight
  * (fmt 6, C = Cout, N = Cin), d Upsample / dx = the Downsample kernel over dOut with the (Cin, Cout, 1, 4, 4) tensor read as a convolution weight
- * (fmt 5, N = Cin, C = Cout) -- accumulating into a gradient buffer that already holds the skip connection's share */
+ * (fmt 5, N = Cin, C = Cout) -- accumulating into a gradient buffer that already holds the skip connection's share.  split_tickets / n_tickets
+ * (NULL / 0: never split) as in vmm_conv_desc: few-tile up == 0 layers split their channel reduction over several workgroups per tile */
 int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_packed, const float* bias, const float* res, int32_t ldres, float* out,
-                           int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream);
+                           int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                           int32_t n_tickets, vmm_stream_t stream);
 
 /* ---- K6: GroupNorm(groups, C) statistics + fused affine/FiLM/SiLU (vddp.py:274-285) ---- */
 /* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */

@@ -403,6 +403,21 @@ def test_stride2_resampling_as_tap_subset_convolutions(gpu, up, nimg, H, W, Cin,
     assert rc == 0, rc
     torch.cuda.synchronize()
     assert relerr(out.cpu(), ref) < 2e-5
+    # ... accumulating into its output (the layers' data gradients add to a gradient buffer that already holds the skip connection's share), and with the
+    # channel reduction of few-tile Downsample layers split over several workgroups per tile (fixed-order tickets: bit-reproducible, tickets left at zero)
+    res = torch.randn(nimg * Ho * Wo, Cout, generator=g)
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+    first = None
+    for _ in range(3):
+        out.copy_(res.to(gpu))
+        rc = lib.vmm_conv_s2_acc_bf16x3(xg.data_ptr(), Cin, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout, out.data_ptr(), Cout, nimg, H, W, Cin, Cout, up,
+                                        tickets.data_ptr(), tickets.numel(), _s())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert relerr(out.cpu(), ref + res) < 2e-5
+        first = out.clone() if first is None else first
+        assert torch.equal(out, first)
+    assert int(tickets.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("nimg,H,W,Cc,k", [(3, 96, 96, 3, 7), (2, 20, 37, 4, 5), (1, 8, 8, 1, 3), (5, 16, 48, 2, 7)])

@@ -134,7 +134,7 @@ SIGNATURES = {
     "vmm_stem_conv_bf16x3": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_conv_s2_supported": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_conv_s2_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
-    "vmm_conv_s2_acc_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_conv_s2_acc_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_temporal_block_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],

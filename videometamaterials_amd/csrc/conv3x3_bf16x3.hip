@@ -73,7 +73,8 @@ template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int
 __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   constexpr int BM = WM * 64;
   constexpr int NQ = TS ? 8 : 18;  // k16 steps per chunk
-  static_assert(!TS || (!SPLIT && !F32), "tap-subset layers: unsplit split-bf16 only");
+  static_assert(!TS || !F32, "tap-subset layers: split-bf16 only");
+  static_assert(TS != 1 || !SPLIT, "the transposed convolution's phase scatter has no split epilogue");
   static_assert(MAXP <= 16, "the source-row exchange below has every lane of an 8-lane group compute two of the MAXP patch items (ps = k4, k4 + 8)");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ph = smem;
@@ -683,9 +684,9 @@ __global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Arg
 }
 
 // the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
-template <int WM, int WN, int MAXP, int MODE, int TS>
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(const C3Args a) {
-  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, false, false, TS>(a);
+  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1395,15 +1396,15 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
-template <int WM, int WN, int MAXP, int MODE, int TS>
-int launch_s2(const C3Args& a, int mtiles, hipStream_t s) {
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false>
+int launch_s2(const C3Args& a, int mtiles, hipStream_t s, int ksplit = 1) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS>), dim3((unsigned)(mtiles * a.n_tiles)), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT>), dim3((unsigned)(mtiles * a.n_tiles), (unsigned)ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -1625,9 +1626,11 @@ extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int
 }
 
 // res != NULL: out = convolution (+ bias) + res, res rows indexed like out (may alias it): the layers' DATA gradients accumulating into a gradient
-// buffer that already holds the skip connection's share (autograd of vddp.py:155,158)
+// buffer that already holds the skip connection's share (autograd of vddp.py:155,158).  split_tickets / n_tickets as in vmm_conv_desc: the
+// Downsample form (up == 0) of a few-tile layer (12 x 12 outputs: 100 workgroups walking K = 9216) splits its channel reduction like the 3 x 3 kernel.
 extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
-                                      int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
+                                      int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                                      int32_t n_tickets, vmm_stream_t stream) {
   C3Args a;
   int mtiles;
   bool wide;
@@ -1638,12 +1641,27 @@ extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* 
   a.p.ldres = ldres;
   hipStream_t s = (hipStream_t)stream;
   if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1>(a, mtiles, s);
+  const long long blocks = (long long)mtiles * a.n_tiles;
+  const int nch = a.chunks_per_split;  // (s2_plan: all of them)
+  static const int ksplit_max = [] { const char* e = getenv("VMM_C3_KSPLIT_MAX"); return e ? atoi(e) : 4; }();  // (measurement aid)
+  int ksplit = 1;
+  // (below one workgroup per CU, not per half CU as for the 3 x 3 layers: nothing is lost by splitting here -- no fused GroupNorm sums)
+  static const int s2_blocks = [] { const char* e = getenv("VMM_S2_SPLIT_BELOW"); return e ? atoi(e) : 256; }();  // (measurement aid)
+  if (blocks < s2_blocks && split_tickets && n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch / 4, ksplit_max), 2048 / max(blocks, 1LL)));
+  if (ksplit > 1) {
+    a.chunks_per_split = (int)cdiv(nch, ksplit);
+    ksplit = (int)cdiv(nch, a.chunks_per_split);
+    a.p.split_tickets = split_tickets;
+    a.p.n_tickets = n_tickets;
+    if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, true>(a, mtiles, s, ksplit) : launch_s2<2, 2, 6, 0, 2, true>(a, mtiles, s, ksplit);
+    return a.mode ? launch_s2<4, 1, 11, 1, 2, true>(a, mtiles, s, ksplit) : launch_s2<4, 1, 11, 0, 2, true>(a, mtiles, s, ksplit);
+  }
   if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2>(a, mtiles, s);
   return a.mode ? launch_s2<4, 1, 11, 1, 2>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2>(a, mtiles, s);
 }
 extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
                                   int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {
-  return vmm_conv_s2_acc_bf16x3(x, ldx, w_frag, bias, nullptr, 0, out, ldo, nimg, Hin, Win, Cin, Cout, up, stream);
+  return vmm_conv_s2_acc_bf16x3(x, ldx, w_frag, bias, nullptr, 0, out, ldo, nimg, Hin, Win, Cin, Cout, up, nullptr, 0, stream);
 }
 
 // The same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32, 1e-6 parity): weights = vmm_pack_weights fmt 4

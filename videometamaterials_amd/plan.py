@@ -505,6 +505,12 @@ class _Builder:
         self.plan.keepalive.append(d)
         return d
 
+    def tickets(self) -> int:
+        """The plan's zero-initialised split tickets (shared by every launch that may split a channel reduction; one stream)."""
+        if self.tickets_ptr is None:
+            self.tickets_ptr = self.wslot(N_TICKETS)
+        return self.tickets_ptr
+
     def proj_ok(self, k: int, cout: int) -> bool:
         """Envelope of vmm_proj_bf16x3 (1x1 / Linear with an A-stationary LDS row tile and fragment-order weights)."""
         if not ((self.x3 or self.f32frag) and getattr(self.m, "use_proj_kernel", True)):
@@ -1384,7 +1390,8 @@ class _Builder:
                 if self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
-                    self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0), nm,
+                    self.step(lib.vmm_conv_s2_acc_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
+                                                           self.tickets() if _enabled("s2_split") else 0, N_TICKETS), nm,
                               flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
                     dd = gwd = None
                     if tr:  # the weight gradient wants the layer's descriptor and a k-major gradient slot (no forward launch from them)
@@ -1404,7 +1411,7 @@ class _Builder:
                         # dIn = ConvTranspose(dOut, W) with the convolution's own (Cout, Cin, 1, 4, 4) tensor read as a (C = Cout, N = Cin) transposed-convolution
                         # weight: ONE tap-subset launch (the Upsample kernel) instead of four phase GEMMs
                         wt = self.pack(nm + ".weight", 36 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=16, sc=ci_ * 16, sh=4, sw=1, fmt=6)[0]
-                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gd.ptr, gd.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, d.H, d.W, co_, ci_, 1),
+                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gd.ptr, gd.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, d.H, d.W, co_, ci_, 1, 0, 0),
                                   nm + " dgrad", flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (gd.n + (2 if acc else 1) * gx.n + 16 * ci_ * co_))
                         return
                     for ph in range(2):
@@ -1467,7 +1474,7 @@ class _Builder:
                     if self.x3 and not wrap and _enabled("s2_dgrad") and lib.vmm_conv_s2_supported(B * T, gu.H, gu.W, co_, ci_, 0):
                         # ... i.e. the Downsample kernel over dU with the (Cin, Cout, 1, 4, 4) tensor read as a convolution weight (N = Cin, C = Cout)
                         wt = self.pack(nm + ".weight", 36 * co_ * ci_, want_grad=False, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
-                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gu.ptr, gu.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, gu.H, gu.W, co_, ci_, 0),
+                        self.step(lib.vmm_conv_s2_acc_bf16x3, (gu.ptr, gu.ld, wt, 0, gx.ptr if acc else 0, ci_, gx.ptr, ci_, B * T, gu.H, gu.W, co_, ci_, 0, self.tickets(), N_TICKETS),
                                   nm + " dgrad", flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (gu.n + (2 if acc else 1) * gx.n + 16 * ci_ * co_))
                         return
                     wp = self.pack(nm + ".weight", 16 * co_ * ci_, want_grad=False, gemm=self.x3, TH=4, TW=4, C=co_, Cp=co_, N=ci_, sn=co_ * 16, sc=16, sh=4, sw=1,
