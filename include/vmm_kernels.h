@@ -113,6 +113,8 @@ int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* d, const float* res_coef, int3
  * identity rows, Cout == 64, C1 / C2 multiples of 16, K = C1 + C2 >= 64 and a multiple of 32, no fused operand transform, no rotary / q-scale;
  * bias / residual epilogue.  Returns 1 (nothing launched) outside it. */
 int vmm_proj_narrow_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* the ResnetBlock tail (vmm_proj_bf16x3_res_silu's contract: out = silu(res * a + b') + proj(x), res_coef [B][64][2]) on the same kernel */
+int vmm_proj_narrow_bf16x3_res_silu(const vmm_conv_desc* d, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream);
 /* exact-fp32 variant (d->w = fmt-4 output of vmm_pack_weights) */
 int vmm_proj_f32(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
 

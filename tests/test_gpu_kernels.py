@@ -945,6 +945,17 @@ def test_narrow_projection_streaming(gpu, rows, C1, C2, bias, res):
     assert lib.vmm_proj_narrow_bf16x3(C.byref(d), _s()) == 0
     torch.cuda.synchronize()
     assert relerr(out.cpu(), want) < 5e-5
+    if res:  # the ResnetBlock tail on the same kernel: out = silu(res * a + b') + x W (+ bias), per-sample coefficients (vddp.py:311)
+        nsmp = 3
+        rps = (rows + nsmp - 1) // nsmp
+        coef = torch.randn(nsmp, 64, 2, generator=g)
+        smp = torch.arange(rows) // rps
+        want2 = x @ w.t() + (b if bias else 0) + F.silu(r * coef[smp, :, 0] + coef[smp, :, 1])
+        out.copy_(r.to(gpu))
+        cg = coef.to(gpu)
+        assert lib.vmm_proj_narrow_bf16x3_res_silu(C.byref(d), cg.data_ptr(), rps, _s()) == 0
+        torch.cuda.synchronize()
+        assert relerr(out.cpu(), want2) < 5e-5
     d.Cout = 128
     assert lib.vmm_proj_narrow_bf16x3(C.byref(d), _s()) == 1  # outside the envelope: nothing launched
 

@@ -144,6 +144,7 @@ SIGNATURES = {
     "vmm_proj_bf16x3_res_silu": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr],
     "vmm_proj_f32": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
     "vmm_proj_narrow_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_proj_narrow_bf16x3_res_silu": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr],
     "vmm_copy2": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     "vmm_extract_geometry": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr, c_ptr],
     "vmm_fields_to_samples": [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],

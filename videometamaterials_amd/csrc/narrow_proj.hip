@@ -25,6 +25,8 @@ struct NPArgs {
   vmm_conv_desc p;
   long long rows;
   int ksteps;  // K / 16 (even)
+  const float* res_coef;  // non-NULL: the residual enters as silu(res * a + b'), (a, b') = res_coef[sample][column][2] (the ResnetBlock tail, vddp.py:311)
+  int rows_per_sample;
 };
 
 __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) {
@@ -131,7 +133,15 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
         const int c = nt * 32 + 8 * q + 4 * half;
         f32x4 v = {acc[nt][rf][4 * q], acc[nt][rf][4 * q + 1], acc[nt][rf][4 * q + 2], acc[nt][rf][4 * q + 3]};
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + c);
+        if (p.res) {
+          f32x4 r = *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + c);
+          if (a.res_coef) {
+            const float* cf = a.res_coef + ((row / a.rows_per_sample) * 64 + c) * 2;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf), c1 = *reinterpret_cast<const f32x4*>(cf + 4);
+            r = f32x4{silu_rcp(r.x * c0.x + c0.y), silu_rcp(r.y * c0.z + c0.w), silu_rcp(r.z * c1.x + c1.y), silu_rcp(r.w * c1.z + c1.w)};
+          }
+          v += r;
+        }
         *reinterpret_cast<f32x4*>(p.out + row * p.ldo + c) = v;
       }
   }
@@ -142,8 +152,7 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
 // d->w = vmm_pack_weights fmt 2 of the (K, 64) operand.  Envelope: KH = KW = 1, stride 1, identity row mapping, Cout == 64, C1 (and C2)
 // multiples of 16 with K = C1 + C2 >= 64, no fused operand transform, no rotary / q-scale epilogue; bias / residual as in vmm_conv_igemm_*
 // (res may alias out).  Returns 1 (nothing launched) outside it.
-extern "C" int vmm_proj_narrow_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
-  const vmm_conv_desc& d = *dp;
+static int np_launch(const vmm_conv_desc& d, const float* res_coef, int rows_per_sample, vmm_stream_t stream) {
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 &&
                         d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 && d.a_mode == 0 && !d.a_img_mod && !d.rot_ncols && !d.q_ncols;
   const int K = d.C1 + d.C2;
@@ -154,8 +163,17 @@ extern "C" int vmm_proj_narrow_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stre
   a.p = d;
   a.rows = (long long)d.nimg * d.Hv * d.Wv;
   a.ksteps = K / 16;
+  a.res_coef = res_coef;
+  a.rows_per_sample = rows_per_sample;
   if (a.rows <= 0) return 0;
   hipLaunchKernelGGL(narrow_proj_x3_kernel, dim3((unsigned)cdiv(a.rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int vmm_proj_narrow_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) { return np_launch(*dp, nullptr, 1, stream); }
+// ResnetBlock tail (vddp.py:311) on the same kernel: out = silu(res * a + b') + proj(x), (a, b') = res_coef [B][64][2] from vmm_groupnorm_coef
+// (vmm_proj_bf16x3_res_silu's contract; res may alias out)
+extern "C" int vmm_proj_narrow_bf16x3_res_silu(const vmm_conv_desc* dp, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream) {
+  if (!dp->res || !res_coef || rows_per_sample <= 0) return -1;
+  return np_launch(*dp, res_coef, rows_per_sample, stream);
 }

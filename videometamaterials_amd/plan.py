@@ -753,7 +753,8 @@ class _Builder:
             dr = self.conv_desc(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
                                 res_ptr=h2.ptr, ldres=Cout)
             kin = x1.C + (x2.C if x2 is not None else 0)
-            self.step(self.lib.vmm_proj_bf16x3_res_silu, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
+            tail_fn = self.lib.vmm_proj_narrow_bf16x3_res_silu if (self.narrow_ok(kin, Cout) and _enabled("narrow_tail")) else self.lib.vmm_proj_bf16x3_res_silu
+            self.step(tail_fn, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
                       flops=2.0 * rows * kin * Cout, nbytes=4.0 * rows * (kin + 2 * Cout))
             self.free(c2_off, c2_n)
             self.plan.named[name] = h2
