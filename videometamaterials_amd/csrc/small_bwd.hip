@@ -29,14 +29,21 @@ __global__ __launch_bounds__(256) void dense_bwd_w_kernel(const vmm_dense_bwd_jo
   for (int t = 0; t < 16; ++t) dwv[t] = 0.f;
   for (int r0 = 0; r0 < jb.rows; r0 += 64) {
     const int nr = min(64, jb.rows - r0);
+    // dy of the block's rows in ONE load (lane = row) and g back in one store after the loop: with a dy load and a dy store inside the row loop
+    // every row paid two dependent memory round trips and the stores kept the compiler from overlapping the rows' x loads (44 rows: 0.24 ms)
+    const float dyv = lane < nr ? jb.dy[(long long)(r0 + lane) * jb.lddy + o] : 0.f;
+    float gmine = 0.f;
+#pragma unroll 4
     for (int r = 0; r < nr; ++r) {
       float part = 0.f;
       for (int k = lane; k < jb.K; k += 64) part = fmaf(act_f(jb.x[(long long)(r0 + r) * jb.ldx + k], jb.act_in), wrow[k], part);
       const float z = wave_sum(part) + bv;
-      const float g = jb.dy[(long long)(r0 + r) * jb.lddy + o] * act_grad(z, jb.act_out);
+      const float g = __shfl(dyv, r, 64) * act_grad(z, jb.act_out);
       db += g;
-      if (lane == 0) { gsh[wv][r] = g; jb.dy[(long long)(r0 + r) * jb.lddy + o] = g; }
+      if (lane == r) gmine = g;
+      if (lane == 0) gsh[wv][r] = g;
     }
+    if (lane < nr) jb.dy[(long long)(r0 + lane) * jb.lddy + o] = gmine;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
