@@ -76,6 +76,9 @@ int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_str
  * vmm_pack_weights.  Needs C1, C2 multiples of 32, Cout == 64 or a multiple of 128, and W <= 31 or (W % 16 == 0 and H % 16 == 0);
  * returns 1 (nothing launched) when the descriptor is outside that envelope. */
 int vmm_conv3x3_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
+/* the "bf16" THROUGHPUT mode of the same kernel (BASELINE.json configs[3], `precision="bf16"`): same descriptor, same fmt-2 weights, same
+ * envelope, tickets and GroupNorm partials; ONE matrix pass on the operands' bf16 roundings (2^-9 relative per operand), fp32 accumulation */
+int vmm_conv3x3_bf16(const vmm_conv_desc* d, vmm_stream_t stream);
 /* the same kernel on the exact-fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32; the "fp32" arithmetic mode): d->w = fmt-4 output of
  * vmm_pack_weights; same envelope, tickets and GroupNorm partials */
 int vmm_conv3x3_f32(const vmm_conv_desc* d, vmm_stream_t stream);
@@ -291,6 +294,11 @@ int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW);
 int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
                              const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
                              int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
+/* the "bf16" throughput mode of the same block: identical arguments and packed weights, one matrix pass per product on bf16-rounded operands
+ * (LayerNorm, softmax, rotary, residual in fp32) */
+int vmm_linattn_block_bf16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                             const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                             int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
 
 /* Fused temporal-attention BLOCK for the full-resolution level (vddp.py:615,630,680: x + to_out(attn(rotary(to_qkv(LayerNorm(x)))))):
  * x is read once and out written once, qkv / attention outputs never touch HBM.  Projections, scores and value mix all run on the
@@ -299,6 +307,12 @@ int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, co
  * per tile); returns 1 (nothing launched) otherwise.  vmm_temporal_block_supported: 0 = outside, 1 / 2 = which kernel would run. */
 int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads);
 int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
+                              const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                              const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
+                              float q_scale, float eps, vmm_stream_t stream);
+/* the "bf16" throughput mode of the same block: identical arguments and packed weights, one matrix pass per product on bf16-rounded operands
+ * (LayerNorm, softmax, rotary, residual in fp32) */
+int vmm_temporal_block_bf16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
                               const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                               const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
                               float q_scale, float eps, vmm_stream_t stream);

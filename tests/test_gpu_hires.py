@@ -61,7 +61,7 @@ def test_hires_22x192x192_matches_oracle(gpu, monkeypatch):
     monkeypatch.setattr(uo, "signal_cnn", lambda sd_, c: cnn(sd_, torch.cat([c, c]))[:1] if c.shape[0] == 1 else cnn(sd_, c))
     with torch.no_grad():
         want = uo.unet3d_forward(sd, uo.UnetCfg(**KW_HIRES), x, t, cond, torch.zeros(B, dtype=torch.bool))
-        for prec, tol in (("bf16x3", 2e-4), ("fp32", 2e-5)):
+        for prec, tol in (("bf16x3", 2e-4), ("fp32", 2e-5), ("bf16", 2e-2)):  # "bf16": the throughput mode this configuration is specified in (one pass)
             m.precision = prec
             got = m(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0).cpu()
             assert _rel(got, want) < tol, (prec, _rel(got, want))

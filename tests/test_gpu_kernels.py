@@ -117,6 +117,64 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
     assert relerr(out.cpu(), ref_rows) < 5e-5
 
 
+@pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 96, 96, 64, 0, 64, True), (2, 3, 48, 48, 64, 64, 128, False), (2, 2, 24, 24, 256, 0, 256, True),
+                                                      (1, 2, 12, 12, 512, 0, 512, False), (2, 3, 10, 20, 64, 64, 128, True)])
+def test_conv3x3_bf16_single_pass(gpu, B, T, H, W, C1, C2, Cout, fused):
+    """vmm_conv3x3_bf16, the "bf16" throughput mode of the 3x3 kernel (BASELINE.json configs[3]): ONE matrix pass on the operands' bf16 roundings.  What it must
+    compute is therefore known exactly: the fp32-accumulated convolution of bf16(operand) x bf16(weight) -- checked at 1e-5 --, which is 2^-9-class (here
+    < 1e-2) away from the fp32 convolution.  2-D and flat tiles, two sources, fused GN+SiLU operand, bias, residual, split channel chunks."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(12)
+    Cin = C1 + C2
+    x1 = torch.randn(B, C1, T, H, W, generator=g)
+    x2 = torch.randn(B, C2, T, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B * T * H * W, Cout, generator=g)
+    xa, coef = x1, None
+    if fused:
+        coef = torch.randn(B, C1, 2, generator=g)
+        xa = F.silu(x1 * coef[:, :, 0][:, :, None, None, None] + coef[:, :, 1][:, :, None, None, None])
+    xin = torch.cat([xa, x2], 1) if C2 else xa
+    rnd = lambda t: t.to(torch.bfloat16).double()
+    as_rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, Cout)
+    x4 = xin.permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W)
+    want = as_rows(F.conv2d(rnd(x4), rnd(w), b.double(), padding=1)).float() + res
+    full = as_rows(F.conv2d(x4.double(), w.double(), b.double(), padding=1)).float() + res
+    K = 9 * Cin
+    Kpad = (K + 31) // 32 * 32
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros((Cout + 31) // 32 * 32 * Kpad, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 2
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
+    d = N.ConvDesc()
+    x1r, bg, rg = rows_of(x1).to(gpu), b.to(gpu), res.to(gpu)
+    x2r = rows_of(x2).to(gpu) if C2 else None
+    cg = coef.to(gpu) if fused else None
+    out = torch.zeros(B * T * H * W, Cout, device=gpu)
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = x1r.data_ptr(), C1, C1, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout
+    if C2:
+        d.a2, d.C2, d.lda2 = x2r.data_ptr(), C2, C2
+    d.res, d.ldres = rg.data_ptr(), Cout
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, W, 1, Cout, 32, 1.0
+    if fused:
+        d.a_mode, d.a_coef, d.a_imgs_per_sample = 1, cg.data_ptr(), T
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+    d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
+    N.check(lib.vmm_conv3x3_bf16(C.byref(d), _s()), "conv3x3 single pass")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), want) < (1e-5 if not fused else 2e-3)  # (fused: the operand is rounded AFTER silu(x a + b), whose last fp32 bits differ from torch's)
+    assert 1e-4 < relerr(out.cpu(), full) < 1e-2
+    assert int(tickets.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 96, 96, 64, 0, 64, False), (2, 1, 96, 96, 64, 0, 64, True), (2, 3, 48, 48, 64, 64, 128, True),
                                                       (1, 2, 48, 48, 128, 0, 128, False), (2, 2, 24, 24, 256, 0, 256, True), (1, 3, 24, 24, 256, 256, 128, False),
                                                       (2, 1, 12, 12, 512, 0, 512, True), (2, 3, 10, 20, 64, 16, 64, True), (1, 1, 16, 16, 16, 0, 64, False),
@@ -1172,6 +1230,14 @@ def test_fused_temporal_block(gpu, monkeypatch, version, B, T, HW, ntok, bias_on
                                           B, T, HW, Cc, heads, C.c_float(32 ** -0.5), C.c_float(1e-5), _s()), "temporal block")
     torch.cuda.synchronize()
     assert relerr(out.cpu() - x.reshape(B * T * HW, Cc), branch) < 5e-5  # on the attention branch alone (the residual would mask errors)
+    # the "bf16" throughput mode of the same block: one matrix pass per product on bf16-rounded operands
+    out.fill_(7.0)
+    N.check(lib.vmm_temporal_block_bf16(xg.data_ptr(), Cc, gg.data_ptr(), wq.data_ptr(), wo.data_ptr(), ekg.data_ptr() if ntok else None,
+                                        evg.data_ptr() if ntok else None, ntok, bg.data_ptr(), bias_on_cond, rg.data_ptr(), out.data_ptr(), Cc,
+                                        B, T, HW, Cc, heads, C.c_float(32 ** -0.5), C.c_float(1e-5), _s()), "temporal block, bf16 mode")
+    torch.cuda.synchronize()
+    e1 = relerr(out.cpu() - x.reshape(B * T * HW, Cc), branch)
+    assert 1e-4 < e1 < 2e-2, e1
 
 
 @pytest.mark.parametrize("HW,ntok,per_frame", [(144, 5, 1), (16, 6, 0), (300, 0, 0), (144, 16, 0), (576, 11, 0), (33, 1, 0)])
@@ -1320,6 +1386,18 @@ def test_fused_linear_attention_block(gpu, B, T, H, W, ntok):
             "fused linear attention")
     torch.cuda.synchronize()
     assert relerr(out.cpu() - rows_of(x), ref - rows_of(x)) < 5e-5  # on the attention branch alone (the residual would mask errors)
+    out3 = out.clone()
+    out.fill_(7.0)  # the "bf16" throughput mode of the same block
+    N.check(lib.vmm_linattn_block_bf16(xg.data_ptr(), Cc, gam.data_ptr(), wq.data_ptr(), wo.data_ptr(), bo.data_ptr(), ek.data_ptr() if ntok else None,
+                                       ev.data_ptr() if ntok else None, ntok, ws.data_ptr(), out.data_ptr(), Cc, B, T, H * W, Cc, heads, 1e-5, _s()),
+            "fused linear attention, bf16 mode")
+    torch.cuda.synchronize()
+    e1 = relerr(out.cpu() - rows_of(x), ref - rows_of(x))
+    assert e1 < 2e-2, e1
+    # (the branch is dominated by to_out's bias here, so the rounding of the operands barely shows in e1: what proves that the single-pass kernels ran
+    # is that the result differs from the three-pass one, by more than its error and less than bf16's)
+    d13 = relerr(out.cpu() - rows_of(x), out3.cpu() - rows_of(x))
+    assert 0 < d13 < 2e-2, d13
 
 
 @pytest.mark.parametrize("HW,ntok,nsplit", [(144, 11, 1), (1000, 0, 4), (2304, 16, 7)])

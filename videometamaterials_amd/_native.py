@@ -79,6 +79,7 @@ SIGNATURES = {
     "vmm_conv_igemm_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv_igemm_bf16x3_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_conv3x3_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_bf16": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_accepts": [C.POINTER(ConvDesc)],
@@ -138,6 +139,8 @@ SIGNATURES = {
     "vmm_temporal_block_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],
+    "vmm_temporal_block_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  c_i32, c_f32, c_f32, c_ptr],
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_spatial_attention_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
@@ -152,6 +155,8 @@ SIGNATURES = {
                                  c_ptr],
     "vmm_linattn_block_workspace": [c_i32, c_i32, c_i32],
     "vmm_linattn_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_f32, c_ptr],
+    "vmm_linattn_block_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                  c_f32, c_ptr],
     "vmm_linattn_context": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_linattn_context_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],

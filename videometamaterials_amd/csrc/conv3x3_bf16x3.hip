@@ -69,8 +69,11 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
 //            4 x Cin cell channels; the channels of sub-pixel (sy, sx) meet the taps of the corner (1 - sy, 1 - sx) only (fmt 5).  The
 //            tile space (p.Hin x p.Win, patch rows) is the CELL grid, the source image is twice as large.
 // Eight k16 steps per chunk instead of eighteen; every input element is still staged once (the generic kernel gathers it four times).
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS>
+// ONE: the "bf16" throughput mode (BASELINE.json configs[3]): the operands' hi planes only, ONE MFMA pass per product (the lo planes of the patch and of
+// the fmt-2 weights are neither read nor multiplied): bf16-rounded operands, fp32 accumulation.
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false>
 __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
+  static_assert(!ONE || !F32, "single pass: bf16 operands");
   constexpr int BM = WM * 64;
   constexpr int NQ = TS ? 8 : 18;  // k16 steps per chunk
   static_assert(!TS || !F32, "tap-subset layers: split-bf16 only");
@@ -318,7 +321,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     for (int j = 0; j < 2; ++j) {
       const uint4* q = bbase[j] + (long long)ks * 128;
       d[2 * j] = q[0];
-      d[2 * j + 1] = q[64];
+      if constexpr (!ONE) d[2 * j + 1] = q[64];
     }
   };
 
@@ -348,7 +351,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       const unsigned short* q = TS ? Ph + (kh == 0 ? abase[i][0] : kh == 1 ? abase[i][1] : abase[i][2]) + (kw * CROW + s * 16)
                                    : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       uint4 vh = *reinterpret_cast<const uint4*>(q);
-      uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
+      uint4 vl = make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (!ONE) vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
       if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
       d[2 * i] = vh;
       d[2 * i + 1] = vl;
@@ -389,6 +393,13 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       if constexpr (SPLIT) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pix, wgt, c, 0, 0, 0);
       else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0);
     };
+    if constexpr (ONE) {
+      acc[0][0] = mm(ah0, bh0, acc[0][0]);
+      acc[0][1] = mm(ah0, bh1, acc[0][1]);
+      acc[1][0] = mm(ah1, bh0, acc[1][0]);
+      acc[1][1] = mm(ah1, bh1, acc[1][1]);
+      return;
+    }
     acc[0][0] = mm(al0, bh0, acc[0][0]);
     acc[0][1] = mm(al0, bh1, acc[0][1]);
     acc[1][0] = mm(al1, bh0, acc[1][0]);
@@ -451,7 +462,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
       if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[q & 1], bb[q % NB]);
-      if constexpr (C3_INTERLEAVE) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
+      if constexpr (C3_INTERLEAVE && !ONE) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
         // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
         // longest way), not in front of them as one block during which the matrix pipe runs dry
 #pragma unroll
@@ -675,12 +686,12 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   }
 }
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false>
 #ifndef VMM_C3_WGS
 #define VMM_C3_WGS 2
 #endif
 __global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Args a) {
-  conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0>(a);
+  conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0, ONE>(a);
 }
 
 // the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
@@ -1357,12 +1368,12 @@ bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
 
 inline int* c3_launch_counter() { static int n = 0; return &n; }  // one count over all instances
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   // VMM_C3_TRACE=<k>: the k-th launch of this process dumps its workgroups' phase stamps to VMM_C3_TRACE_FILE (tools/trace_c3.py reads them)
@@ -1374,7 +1385,7 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
     const size_t n = (size_t)nwg * ksplit * 16;
     (void)hipMalloc(&at.trace, n * sizeof(unsigned long long));
     (void)hipMemsetAsync(at.trace, 0, n * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3(nwg, ksplit), dim3(256), shm, s, at);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32, ONE>), dim3(nwg, ksplit), dim3(256), shm, s, at);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), at.trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -1391,7 +1402,7 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
     }
     return 0;
   }
-  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32>), dim3(nwg, ksplit), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32, ONE>), dim3(nwg, ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -1505,24 +1516,24 @@ static bool c3_pw_this_launch() {
   return only < 0 || n++ == only;
 }
 
-template <bool F32>
+template <bool F32, bool ONE = false>
 int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t s) {
   PWArgs pa;
-  if (c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
+  if (!ONE && c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
     pa.p.gn_part = pa.mode == 1 ? a.p.gn_part : nullptr;  // (cleared by plan_c3 when the statistics are not fused; the persistent kernel fuses them for 2-D tiles only)
     if (getenv("VMM_PW_LOG")) fprintf(stderr, "[pw] Cin %d+%d Cout %d %dx%d nimg %d mode %d units %d a_mode %d gn %p res %p lda %d %d ldo %d\n", a.p.C1, a.p.C2, a.p.Cout, a.p.Hin,
                                       a.p.Win, a.p.nimg, pa.mode, pa.n_units, a.p.a_mode, (void*)pa.p.gn_part, (void*)a.p.res, a.p.lda1, a.p.lda2, a.p.ldo);
     return pa.mode ? launch_pw<1, F32>(pa, s) : launch_pw<0, F32>(pa, s);
   }
   if (ksplit > 1) {
-    if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32>(a, mtiles, ksplit, s);
-    return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32>(a, mtiles, ksplit, s);
+    if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32, ONE>(a, mtiles, ksplit, s);
+    return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32, ONE>(a, mtiles, ksplit, s);
   }
-  if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32>(a, mtiles, 1, s);
+  if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32, ONE>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32, ONE>(a, mtiles, 1, s);
   // (weight fragments two steps ahead where the registers allow it: with the requests interleaved into the MFMA stream one step is less
   // than an L2 round trip)
   constexpr int PF = F32 ? 1 : 2;
-  return a.mode ? launch_c3<4, 1, 11, 1, PF, false, F32>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, PF, false, F32>(a, mtiles, 1, s);
+  return a.mode ? launch_c3<4, 1, 11, 1, PF, false, F32, ONE>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, PF, false, F32, ONE>(a, mtiles, 1, s);
 }
 
 // Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
@@ -1567,6 +1578,19 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   const bool wide = d.Cout >= 128;
   hipStream_t s = (hipStream_t)stream;
   return dispatch_c3<false>(a, mtiles, ksplit, wide, s);
+}
+
+// The "bf16" throughput mode of the same kernel (BASELINE.json configs[3]): same descriptor, same fmt-2 weights, ONE matrix pass on the operands'
+// bf16 roundings (2^-9 relative per operand; fp32 accumulation, bias / residual / GroupNorm sums in fp32 as before).
+extern "C" int vmm_conv3x3_bf16(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  C3Args a;
+  int mtiles, ksplit;
+  bool gn = false;
+  const int rc = plan_c3(d, a, mtiles, ksplit, gn);
+  if (rc != 0) return rc;
+  if (a.total_rows <= 0) return 0;
+  return dispatch_c3<false, true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
 }
 
 // The resampling layers on the tap-subset variants of the kernel (TS, see there):

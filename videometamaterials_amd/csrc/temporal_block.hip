@@ -68,7 +68,11 @@ __device__ __forceinline__ void split8v(const float (&v)[8], uint4& hi, uint4& l
   hi.w = pack_split(v[6], v[7], lo.w);
 }
 
+// ONE ("bf16" throughput mode, BASELINE.json configs[3]): the hi planes only, one pass; the lo halves of every split in the kernel then have no
+// reader and the compiler drops them (and the lo weight fragments' registers) with it
+template <bool ONE>
 __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
+  if constexpr (ONE) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
@@ -85,6 +89,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // index of the contraction / row slot that element j of lane half lk holds in k16 step s (accumulator register order)
 __device__ __forceinline__ int slot(int s, int lk, int j) { return (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * lk; }
 
+template <bool ONE>
 __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);                     // [8 heads][32 rows][64 channels]
@@ -226,9 +231,9 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
     f32x16 qt = zero16(), kt = zero16(), vt = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qt = mfma3(wqh[s], wql[s], yh[s], yl[s], qt);  // [d][m]
-      kt = mfma3(wkh[s], wkl[s], yh[s], yl[s], kt);  // [d][m]
-      vt = mfma3(yh[s], yl[s], wvh[s], wvl[s], vt);  // [m][d]
+      qt = mfma3<ONE>(wqh[s], wql[s], yh[s], yl[s], qt);  // [d][m]
+      kt = mfma3<ONE>(wkh[s], wkl[s], yh[s], yl[s], kt);  // [d][m]
+      vt = mfma3<ONE>(yh[s], yl[s], wvh[s], wvl[s], vt);  // [m][d]
     }
     rotate2(qt, kt);
     uint4 qh[2], ql[2];
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
     for (int s = 0; s < 2; ++s) {
       uint4 kh, kl;
       split8(kt, s * 8, kh, kl);
-      st = mfma3(kh, kl, qh[s], ql[s], st);
-      if (ntok) sk = mfma3(eks[(s * 2) * 64], eks[(s * 2 + 1) * 64], qh[s], ql[s], sk);
+      st = mfma3<ONE>(kh, kl, qh[s], ql[s], st);
+      if (ntok) sk = mfma3<ONE>(eks[(s * 2) * 64], eks[(s * 2 + 1) * 64], qh[s], ql[s], sk);
     }
     // to_out fragments of this head (8 KB, L2-resident): requested here, a softmax / value phase before their use -- next to their use
     // each (column tile, step) pair paid an L2 round trip of its own; earlier than here the registers do not exist (q/k/v tiles live)
@@ -296,14 +301,14 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
       uint4 vh, vl, ph, pl;
       split8(vt, 0, vh, vl);
       split8v(p0, ph, pl);
-      ot = mfma3(vh, vl, ph, pl, ot);
+      ot = mfma3<ONE>(vh, vl, ph, pl, ot);
       split8(vt, 8, vh, vl);
       split8v(p1, ph, pl);
-      ot = mfma3(vh, vl, ph, pl, ot);
+      ot = mfma3<ONE>(vh, vl, ph, pl, ot);
       if (ntok) {
         const uint4* evs = evf + h * 2 * 64 + lane;
         split8v(g, ph, pl);
-        ot = mfma3(evs[0], evs[64], ph, pl, ot);
+        ot = mfma3<ONE>(evs[0], evs[64], ph, pl, ot);
       }
     }
     // ---- this head's share of to_out
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
       uint4 oh, ol;
       split8(ot, s * 8, oh, ol);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+      for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3<ONE>(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
     }
     float* rb = red + (h * 32) * TC;  // (free: the barrier after the LayerNorm above came after everyone's previous head sum)
 #pragma unroll
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
 //              2j + 2   A: F(j)     2j + 3  A: S(j) -> redA[j & 1]   B: F(j)
 //              2j + 4   B: S(j) -> redB                              2j + 5  head sum(j) + residual -> out    (group A's threads, next to S)
 // Frame slots: SLOTS = 16 (two pixels per 32-row tile, T <= 16) or 32 (one pixel, T <= 32: the 22-frame configuration).
-template <int SLOTS, int PARK>
+template <int SLOTS, int PARK, bool ONE>
 __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a) {
   constexpr int NP = 32 / SLOTS;  // pixels per tile
   constexpr int NK = SLOTS / 2;   // frame keys per lane
@@ -560,9 +565,9 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
-          qt = mfma3(wqh[s], wql[s], yh, yl, qt);  // [d][m]
-          kt = mfma3(wkh[s], wkl[s], yh, yl, kt);  // [d][m]
-          vt = mfma3(yh, yl, wvh[s], s < NREG ? wvl[s < NREG ? s : 0] : wvp[(s < NREG ? 0 : s - NREG) * 512 + tid], vt);  // [m][d]
+          qt = mfma3<ONE>(wqh[s], wql[s], yh, yl, qt);  // [d][m]
+          kt = mfma3<ONE>(wkh[s], wkl[s], yh, yl, kt);  // [d][m]
+          vt = mfma3<ONE>(yh, yl, wvh[s], s < NREG ? wvl[s < NREG ? s : 0] : wvp[(s < NREG ? 0 : s - NREG) * 512 + tid], vt);  // [m][d]
         }
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
@@ -587,8 +592,8 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
         for (int s = 0; s < 2; ++s) {
           uint4 kh, kl;
           split8(kt, s * 8, kh, kl);
-          st = mfma3(kh, kl, qh[s], ql[s], st);
-          if (ntok) sk = mfma3(eks_l[(s * 2) * 32], eks_l[(s * 2 + 1) * 32], qh[s], ql[s], sk);
+          st = mfma3<ONE>(kh, kl, qh[s], ql[s], st);
+          if (ntok) sk = mfma3<ONE>(eks_l[(s * 2) * 32], eks_l[(s * 2 + 1) * 32], qh[s], ql[s], sk);
         }
         // logits of this lane's query: 8 (16) frame keys and 8 tokens per lane half, relative-position bias from LDS
         float bz[NK];
@@ -655,14 +660,14 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
           }
           split8(vt, 0, vh, vl);
           split8v(p0, ph, pl);
-          ot = mfma3(vh, vl, ph, pl, ot);
+          ot = mfma3<ONE>(vh, vl, ph, pl, ot);
           split8(vt, 8, vh, vl);
           split8v(p1, ph, pl);
-          ot = mfma3(vh, vl, ph, pl, ot);
+          ot = mfma3<ONE>(vh, vl, ph, pl, ot);
           if (ntok) {
             const uint4* evs = evf + h * 2 * 64 + lane;
             split8v(g, ph, pl);
-            ot = mfma3(evs[0], evs[64], ph, pl, ot);
+            ot = mfma3<ONE>(evs[0], evs[64], ph, pl, ot);
           }
         }
         f32x16 pc[2] = {zero16(), zero16()};
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
           uint4 oh, ol;
           split8(ot, s * 8, oh, ol);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+          for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3<ONE>(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
         }
         // accumulator rows r of a lane half: frame slots 8 (r >> 2) + 4 lk + (r & 3) -- whole groups of four exist or do not (Tp)
         float* rb0 = red_mine + (grp ? 0 : (j & 1) * 4 * rows * TC) + (4 * lk) * TC + lrow;
@@ -725,10 +730,10 @@ extern "C" int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW,
   return T <= 16 ? 1 : 0;
 }
 
-extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
-                                         const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
-                                         const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
-                                         int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+template <bool ONE>
+static int tb_launch(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* ek, const float* ev,
+                     int32_t ntok, const float* bias, int32_t bias_on_cond, const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
+                     int32_t C, int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
   if ((ldx & 3) || (ldo & 3)) return 1;
   const int kind = vmm_temporal_block_supported(T, ek ? ntok : 0, HW, C, heads);
   if (kind == 0) return 1;
@@ -753,27 +758,27 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
   int ns = max(1, min(units, 256 / B));  // one 512-thread workgroup per CU (LDS), one round of workgroups
   a.tps = (units + ns - 1) / ns;
   a.nsplit = (units + a.tps - 1) / a.tps;
-  static bool attr_set = false;
+  static bool attr_set = false;  // (one flag per instantiation of this launcher)
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 1, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 1, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 3, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 3, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const dim3 grid((unsigned)(B * a.nsplit));
   if (kind == 2) {
     const int park = tb2_lds_bytes(slots, T, a.ntok, 3) <= 160 * 1024 ? 3 : 1;
     const size_t shm = tb2_lds_bytes(slots, T, a.ntok, park);
-    if (slots == 16 && park == 3) hipLaunchKernelGGL((temporal_block2_kernel<16, 3>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else if (slots == 16) hipLaunchKernelGGL((temporal_block2_kernel<16, 1>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else if (park == 3) hipLaunchKernelGGL((temporal_block2_kernel<32, 3>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((temporal_block2_kernel<32, 1>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    if (slots == 16 && park == 3) hipLaunchKernelGGL((temporal_block2_kernel<16, 3, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (slots == 16) hipLaunchKernelGGL((temporal_block2_kernel<16, 1, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (park == 3) hipLaunchKernelGGL((temporal_block2_kernel<32, 3, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((temporal_block2_kernel<32, 1, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
   } else {
     const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
                        sizeof(unsigned short) * 32 * (2 * TC + 8) + sizeof(float) * 2 * 16 * 8 * 2;
-    hipLaunchKernelGGL(temporal_block_kernel, grid, dim3(512), shm, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(temporal_block_kernel<ONE>, grid, dim3(512), shm, (hipStream_t)stream, a);
   }
   VMM_LAUNCH_CHECK();
   if (want_trace) {  // debugging aid: time line of workgroup 0 (ticks of s_memtime relative to the first stamp)
@@ -795,4 +800,19 @@ extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const floa
     }
   }
   return 0;
+}
+
+extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                         const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                         const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
+                                         int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+  return tb_launch<false>(x, ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, out, ldo, B, T, HW, C, heads, q_scale, eps, stream);
+}
+// the "bf16" throughput mode of the same block (BASELINE.json configs[3]): identical arguments and packed weights, one matrix pass per product on
+// the operands' bf16 roundings; LayerNorm, softmax, rotary and the residual stay fp32
+extern "C" int vmm_temporal_block_bf16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                       const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                       const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
+                                       int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+  return tb_launch<true>(x, ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, out, ldo, B, T, HW, C, heads, q_scale, eps, stream);
 }

@@ -280,7 +280,13 @@ class _Builder:
         self.heads = model.attn_heads
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
-        self.x3 = getattr(model, "train_precision" if training else "precision", "fp32") == "bf16x3"
+        prec = getattr(model, "train_precision" if training else "precision", "fp32")
+        if prec == "bf16" and training:
+            raise ValueError("precision 'bf16' is the single-pass THROUGHPUT mode of the sampling path (BASELINE.json configs[3]); training modes: 'fp32', 'bf16x3'")
+        self.x3 = prec in ("bf16x3", "bf16")
+        # "bf16": the 3 x 3 convolutions and the fused attention blocks run ONE matrix pass on the operands' bf16 roundings (same packed weights, same
+        # launch list); the bandwidth-bound kernels keep their three passes, which cost them no time.  fp32 activations in HBM either way.
+        self.one = prec == "bf16"
         # exact-fp32 mode: the 3x3 and projection kernels run their v_mfma_f32_32x32x2_f32 variants on fp32 fragment-order weights (fmt 4)
         self.f32frag = not self.x3 and getattr(model, "use_f32_frag_kernels", True)
         self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
@@ -575,7 +581,7 @@ class _Builder:
         if self.x3 and (x3w or not self.in_bwd):  # x3w: a backward GEMM whose weight operand was packed split-bf16 (pack(..., gemm=True))
             fn = self.lib.vmm_conv_igemm_bf16x3
             if halo:  # weights were packed in fragment order for it (halo_ok)
-                fn = self.lib.vmm_conv3x3_bf16x3
+                fn = self.lib.vmm_conv3x3_bf16 if self.one else self.lib.vmm_conv3x3_bf16x3
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
@@ -868,7 +874,7 @@ class _Builder:
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             out = self.act(x.C, x.H, x.W)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * hid * 32
-            self.step(self.lib.vmm_linattn_block_bf16x3,
+            self.step(self.lib.vmm_linattn_block_bf16 if self.one else self.lib.vmm_linattn_block_bf16x3,
                       (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(name + ".fn.fn.to_out.bias"), ek or None, ev or None,
                        self.ntok if site else 0, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=12.0 * x.n)
@@ -956,7 +962,7 @@ class _Builder:
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             out = self.act(x.C, x.H, x.W)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + (self.ntok if site else 0))
-            self.step(self.lib.vmm_temporal_block_bf16x3,
+            self.step(self.lib.vmm_temporal_block_bf16 if self.one else self.lib.vmm_temporal_block_bf16x3,
                       (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, self.ntok if site else 0, self.bias_ptr,
                        1 if self.m.per_frame_cond else 0, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=8.0 * x.n)

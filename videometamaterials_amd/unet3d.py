@@ -45,7 +45,11 @@ def _uniform(shape, fan_in: int) -> torch.Tensor:
     return (torch.rand(shape) * 2 - 1) * bound
 
 
+PRECISIONS = ("fp32", "bf16x3", "bf16")
+
+
 class Unet3D(nn.Module):
+    PRECISIONS = PRECISIONS  # arithmetic modes of `precision` (sampling); `train_precision` takes the first two
     def __init__(
         self,
         dim,
@@ -112,6 +116,8 @@ class Unet3D(nn.Module):
         # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
         # (forward + data gradients; weight gradients are always exact fp32).  Training defaults to fp32: with the reference's l1 loss
         # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3.
+        # "bf16" (sampling only) = the throughput mode of BASELINE.json configs[3]: one matrix pass on bf16-rounded operands in the 3 x 3 convolutions
+        # and the fused attention blocks (~1e-2 relative on the denoiser output; tests/test_gpu_hires.py states and checks the tolerance).
         self.precision = "bf16x3"
         self.train_precision = "fp32"
 
