@@ -104,6 +104,9 @@ int vmm_conv3x3_wino_accepts(const vmm_conv_desc* d);
  * separate vmm_channel_layernorm pass.  Envelope: KH = KW = 1, stride 1, identity row mapping, K = C1 + C2 padded to 32 in
  * {32, 64, 128, 256}; returns 1 (nothing launched) otherwise. */
 int vmm_proj_bf16x3(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
+/* the "bf16" throughput mode of the same kernel (and of its ResnetBlock-tail form below): one matrix pass on bf16-rounded operands */
+int vmm_proj_bf16(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, vmm_stream_t stream);
+int vmm_proj_bf16_res_silu(const vmm_conv_desc* d, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream);
 /* the same, also leaving the LayerNorm statistics of every row in ln_stats [rows][2] = (mean, 1 / sqrt(var + eps)): the training forward of to_qkv
  * (the normalised rows are never materialised; vmm_conv1x1_wgrad_bf16x3_ln re-normalises from these) */
 int vmm_proj_bf16x3_ln_stats(const vmm_conv_desc* d, const float* ln_gamma, float ln_eps, float* ln_stats, vmm_stream_t stream);
@@ -217,6 +220,10 @@ int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_packed, const
  * (fmt 5, N = Cin, C = Cout) -- accumulating into a gradient buffer that already holds the skip connection's share.  split_tickets / n_tickets
  * (NULL / 0: never split) as in vmm_conv_desc: few-tile up == 0 layers split their channel reduction over several workgroups per tile */
 int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_packed, const float* bias, const float* res, int32_t ldres, float* out,
+                           int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                           int32_t n_tickets, vmm_stream_t stream);
+/* the "bf16" throughput mode of the same layers: one matrix pass on bf16-rounded operands */
+int vmm_conv_s2_acc_bf16(const float* x, int32_t ldx, const float* w_packed, const float* bias, const float* res, int32_t ldres, float* out,
                            int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
                            int32_t n_tickets, vmm_stream_t stream);
 

@@ -136,6 +136,7 @@ SIGNATURES = {
     "vmm_conv_s2_supported": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_conv_s2_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_conv_s2_acc_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_conv_s2_acc_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_temporal_block_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],
@@ -144,6 +145,8 @@ SIGNATURES = {
     "vmm_spatial_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_spatial_attention_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
+    "vmm_proj_bf16": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
+    "vmm_proj_bf16_res_silu": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr],
     "vmm_proj_bf16x3_res_silu": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr],
     "vmm_proj_f32": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr],
     "vmm_proj_narrow_bf16x3": [C.POINTER(ConvDesc), c_ptr],

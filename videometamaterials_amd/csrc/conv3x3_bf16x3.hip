@@ -695,9 +695,9 @@ __global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Arg
 }
 
 // the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
-template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false>
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(const C3Args a) {
-  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS>(a);
+  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS, ONE>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1407,15 +1407,15 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
-template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false>
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false>
 int launch_s2(const C3Args& a, int mtiles, hipStream_t s, int ksplit = 1) {
   const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT>), dim3((unsigned)(mtiles * a.n_tiles), (unsigned)ksplit), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE>), dim3((unsigned)(mtiles * a.n_tiles), (unsigned)ksplit), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -1652,9 +1652,9 @@ extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int
 // res != NULL: out = convolution (+ bias) + res, res rows indexed like out (may alias it): the layers' DATA gradients accumulating into a gradient
 // buffer that already holds the skip connection's share (autograd of vddp.py:155,158).  split_tickets / n_tickets as in vmm_conv_desc: the
 // Downsample form (up == 0) of a few-tile layer (12 x 12 outputs: 100 workgroups walking K = 9216) splits its channel reduction like the 3 x 3 kernel.
-extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
-                                      int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
-                                      int32_t n_tickets, vmm_stream_t stream) {
+template <bool ONE>
+static int s2_run(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out, int32_t ldo, int32_t nimg,
+                  int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets, int32_t n_tickets, vmm_stream_t stream) {
   C3Args a;
   int mtiles;
   bool wide;
@@ -1664,7 +1664,7 @@ extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* 
   a.p.res = res;
   a.p.ldres = ldres;
   hipStream_t s = (hipStream_t)stream;
-  if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1>(a, mtiles, s);
+  if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1, false, ONE>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1, false, ONE>(a, mtiles, s);
   const long long blocks = (long long)mtiles * a.n_tiles;
   const int nch = a.chunks_per_split;  // (s2_plan: all of them)
   static const int ksplit_max = [] { const char* e = getenv("VMM_C3_KSPLIT_MAX"); return e ? atoi(e) : 4; }();  // (measurement aid)
@@ -1677,11 +1677,22 @@ extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* 
     ksplit = (int)cdiv(nch, a.chunks_per_split);
     a.p.split_tickets = split_tickets;
     a.p.n_tickets = n_tickets;
-    if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, true>(a, mtiles, s, ksplit) : launch_s2<2, 2, 6, 0, 2, true>(a, mtiles, s, ksplit);
-    return a.mode ? launch_s2<4, 1, 11, 1, 2, true>(a, mtiles, s, ksplit) : launch_s2<4, 1, 11, 0, 2, true>(a, mtiles, s, ksplit);
+    if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, true, ONE>(a, mtiles, s, ksplit) : launch_s2<2, 2, 6, 0, 2, true, ONE>(a, mtiles, s, ksplit);
+    return a.mode ? launch_s2<4, 1, 11, 1, 2, true, ONE>(a, mtiles, s, ksplit) : launch_s2<4, 1, 11, 0, 2, true, ONE>(a, mtiles, s, ksplit);
   }
-  if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2>(a, mtiles, s);
-  return a.mode ? launch_s2<4, 1, 11, 1, 2>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2>(a, mtiles, s);
+  if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, false, ONE>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2, false, ONE>(a, mtiles, s);
+  return a.mode ? launch_s2<4, 1, 11, 1, 2, false, ONE>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2, false, ONE>(a, mtiles, s);
+}
+extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
+                                      int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                                      int32_t n_tickets, vmm_stream_t stream) {
+  return s2_run<false>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, split_tickets, n_tickets, stream);
+}
+// the "bf16" throughput mode of the same layers (BASELINE.json configs[3]): one matrix pass on bf16-rounded operands
+extern "C" int vmm_conv_s2_acc_bf16(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
+                                    int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                                    int32_t n_tickets, vmm_stream_t stream) {
+  return s2_run<true>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, split_tickets, n_tickets, stream);
 }
 extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
                                   int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {

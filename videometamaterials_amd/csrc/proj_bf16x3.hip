@@ -45,8 +45,10 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { r
 #ifndef VMM_PJ_DBG
 #define VMM_PJ_DBG 0
 #endif
-template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
+// ONE: the "bf16" throughput mode (BASELINE.json configs[3]): hi planes only, one matrix pass per product
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
+  static_assert(!ONE || !F32, "single pass: bf16 operands");
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int KP = KS * 16;         // padded K
   constexpr int PITCH = 2 * KP + 8;   // bf16 per LDS row: hi[KP] | lo[KP] | pad  ((4 KP + 16) / 16 is odd: conflict-free ds_read_b128)
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       const int nt = min((nc * BN + wn * 64) / 32 + j, p.Cout / 32 - 1);
       const uint4* q = wf + ((long long)nt * KS + s) * 128 + lane;
       d[2 * j] = q[0];
-      d[2 * j + 1] = q[64];
+      if constexpr (!ONE) d[2 * j + 1] = q[64];
     }
   };
   int abase[2];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     for (int i = 0; i < 2; ++i) {
       const unsigned short* q = At + abase[i] + s * (F32 ? 32 : 16);
       d[2 * i] = *reinterpret_cast<const uint4*>(q);
-      d[2 * i + 1] = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : KP));
+      if constexpr (!ONE) d[2 * i + 1] = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : KP));
     }
   };
   f32x16 acc[2][2];
@@ -209,6 +211,13 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     asm volatile("" :: "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1), "v"(ah0), "v"(ah1), "v"(al0), "v"(al1));
     return;
 #endif
+    if constexpr (ONE) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah0, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah1, acc[1][1], 0, 0, 0);
+      return;
+    }
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, al0, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, al1, acc[1][0], 0, 0, 0);
@@ -388,13 +397,13 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
 
 inline int* pj_launch_counter() { static int n = 0; return &n; }
 
-template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false>
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false>
 int launch_pj(const PJArgs& a, hipStream_t s) {
   constexpr int BM = WM * 64;
   const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32, KSPLIT4, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int mt = (int)cdiv(a.M, BM);
@@ -406,7 +415,7 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
     const size_t n = (size_t)mt * ny * 18;
     (void)hipMalloc(&at.trace, n * sizeof(unsigned long long));
     (void)hipMemsetAsync(at.trace, 0, n * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, at);
+    hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4, ONE>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, at);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), at.trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -424,7 +433,7 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
     }
     return 0;
   }
-  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, KSPLIT4, ONE>), dim3((unsigned)mt, (unsigned)ny), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -434,7 +443,7 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
 // 1x1 / Linear projection.  d->w = vmm_pack_weights fmt 2 of the (Cout, K) weight.  ln_gamma != NULL: the rows pass through the
 // channel LayerNorm (gamma only, eps inside the sqrt, vddp.py:245-254) while they are staged.  Envelope: KH = KW = 1, stride 1,
 // identity row mapping, K = C1 + C2 <= 256 with C1, C2 multiples of 4, Cout a multiple of 32; returns 1 (nothing launched) otherwise.
-template <bool F32>
+template <bool F32, bool ONE = false>
 static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps, vmm_stream_t stream, const float* res_coef = nullptr, int res_rps = 1,
                     float* ln_stats = nullptr) {
   const bool shape_ok = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.off_h == 0 && d.off_w == 0 && d.Hv == d.Hin && d.Wv == d.Win &&
@@ -466,13 +475,13 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   int ny = (int)max(1LL, min((long long)a.n_chunks, 1024 / max(mt, 1LL)));
   a.chunks_per_y = (int)cdiv(a.n_chunks, ny);
   hipStream_t s = (hipStream_t)stream;
-  if (KP == 32) return launch_pj<4, 1, 2, F32>(a, s);
-  if (KP == 64) return launch_pj<4, 1, 4, F32>(a, s);
+  if (KP == 32) return launch_pj<4, 1, 2, F32, false, ONE>(a, s);
+  if (KP == 64) return launch_pj<4, 1, 4, F32, false, ONE>(a, s);
   if (KP <= 128) {
     if (KP == 96) return 1;
-    return launch_pj<2, 2, 8, F32>(a, s);
+    return launch_pj<2, 2, 8, F32, false, ONE>(a, s);
   }
-  if (KP == 256) return d.Cout <= 64 ? launch_pj<1, 4, 16, F32, true>(a, s) : launch_pj<1, 4, 16, F32, false>(a, s);
+  if (KP == 256) return d.Cout <= 64 ? launch_pj<1, 4, 16, F32, true, ONE>(a, s) : launch_pj<1, 4, 16, F32, false, ONE>(a, s);
   return 1;
 }
 
@@ -498,4 +507,14 @@ extern "C" int vmm_proj_bf16x3_res_silu(const vmm_conv_desc* dp, const float* re
 // The same kernel on the exact-fp32 matrix-core instruction (d->w = vmm_pack_weights fmt 4); the "fp32" arithmetic mode's projections.
 extern "C" int vmm_proj_f32(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
   return run_proj<true>(*dp, ln_gamma, ln_eps, stream);
+}
+
+// The "bf16" throughput mode of the projection kernel (BASELINE.json configs[3]): same descriptor, same fmt-2 weights, one matrix pass on the
+// operands' bf16 roundings; the fused LayerNorm, the q-scale / rotary / bias / residual epilogue stay fp32.
+extern "C" int vmm_proj_bf16(const vmm_conv_desc* dp, const float* ln_gamma, float ln_eps, vmm_stream_t stream) {
+  return run_proj<false, true>(*dp, ln_gamma, ln_eps, stream);
+}
+extern "C" int vmm_proj_bf16_res_silu(const vmm_conv_desc* dp, const float* res_coef, int32_t rows_per_sample, vmm_stream_t stream) {
+  if (!dp->res || !res_coef || rows_per_sample <= 0) return -1;
+  return run_proj<false, true>(*dp, nullptr, 0.f, stream, res_coef, rows_per_sample);
 }

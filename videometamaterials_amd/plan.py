@@ -573,7 +573,7 @@ class _Builder:
                 d._ln = (ln_stats, ln_gamma)
                 self.step(self.lib.vmm_proj_bf16x3_ln_stats, (C.byref(d), ln_gamma, C.c_float(1e-5), ln_stats), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
                 return d
-            fn = self.lib.vmm_proj_bf16x3 if self.x3 else self.lib.vmm_proj_f32
+            fn = (self.lib.vmm_proj_bf16 if self.one else self.lib.vmm_proj_bf16x3) if self.x3 else self.lib.vmm_proj_f32
             self.step(fn, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
             return d
         assert not ln_gamma
@@ -759,7 +759,8 @@ class _Builder:
             dr = self.conv_desc(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
                                 res_ptr=h2.ptr, ldres=Cout)
             kin = x1.C + (x2.C if x2 is not None else 0)
-            tail_fn = self.lib.vmm_proj_narrow_bf16x3_res_silu if (self.narrow_ok(kin, Cout) and _enabled("narrow_tail")) else self.lib.vmm_proj_bf16x3_res_silu
+            tail_fn = (self.lib.vmm_proj_narrow_bf16x3_res_silu if (self.narrow_ok(kin, Cout) and _enabled("narrow_tail"))
+                       else self.lib.vmm_proj_bf16_res_silu if self.one else self.lib.vmm_proj_bf16x3_res_silu)
             self.step(tail_fn, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
                       flops=2.0 * rows * kin * Cout, nbytes=4.0 * rows * (kin + 2 * Cout))
             self.free(c2_off, c2_n)
@@ -1397,7 +1398,8 @@ class _Builder:
                 if self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
-                    self.step(lib.vmm_conv_s2_acc_bf16x3, (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
+                    self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                              (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
                                                            self.tickets() if _enabled("s2_split") else 0, N_TICKETS), nm,
                               flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
                     dd = gwd = None
@@ -1454,7 +1456,8 @@ class _Builder:
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
                     wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
-                    self.step(lib.vmm_conv_s2_bf16x3, (xs.ptr, xs.ld, wu, self.wraw(nm + ".bias"), u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1), nm,
+                    self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                              (xs.ptr, xs.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1, 0, 0), nm,
                               flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
                 for ph in range(2 if (not s2 or tr) else 0):  # (training: the phase descriptors feed the weight gradients even when the forward is one s2 launch)
                     for pw in range(2):
