@@ -285,7 +285,7 @@ def bench_config4(vm, dev, timed_region, world, B: int = 8, frames: int = 22, si
     out = {"workload": f"configs[3]: {frames}x{size}x{size}, batch {B} per GPU, dim 64 (random init), CNN signal embedding + 16 tokens", "batch_per_gpu": B}
     modes = [("bf16x3", "fp32 activations in HBM, split-bf16 MFMA (parity mode, 2e-4 vs the oracle at this size)")]
     if "bf16" in getattr(vm.Unet3D, "PRECISIONS", ()):
-        modes.append(("bf16", "bf16 throughput mode"))
+        modes.append(("bf16", "fp32 activations in HBM, ONE MFMA pass on bf16-rounded operands (throughput mode, 2e-2 vs the oracle at this size)"))
     with torch.no_grad():
         for prec, note in modes:
             m.precision = prec
@@ -417,7 +417,7 @@ def main():
     frames_per_s = world * B_PER_GPU * T * (args.steps / TIMESTEPS) / elapsed
     finite = bool(torch.isfinite(img).all().item())
 
-    full_sample = fp32_exact = None
+    full_sample = fp32_exact = bf16_mode = None
     if not args.no_extras:
         # the public call: GaussianDiffusion.sample() = 256 steps + unnormalise, draws its own x_T (vddp.py:965-984)
         diff.use_graph = not args.no_graph
@@ -433,6 +433,18 @@ def main():
         model.precision = "bf16x3"
         fp32_exact = {"ms_per_step": round(el32 / n32 * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (TIMESTEPS * el32 / n32), 4), "steps": n32,
                       "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1e-6 parity", "hipgraph": st32.graph is not None}
+        # ... and in the single-pass bf16 THROUGHPUT mode (the dtype BASELINE.json states for configs[3]; 2e-2 on the denoiser output, NOT a parity number:
+        # the headline `value` above stays the fp32-class split-bf16 path)
+        bf16_mode = None
+        if "bf16" in getattr(vm.Unet3D, "PRECISIONS", ()):
+            model.precision = "bf16"
+            n16 = max(2, min(args.steps, 32))
+            el16, st16, img16 = sampler_leg(n16, 2)
+            model.precision = "bf16x3"
+            bf16_mode = {"ms_per_step": round(el16 / n16 * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (TIMESTEPS * el16 / n16), 4), "steps": n16,
+                         "arithmetic": "one MFMA pass on bf16-rounded operands in the 3x3 / stride-2 convolutions, projections and fused attention blocks; "
+                                       "fp32 activations and accumulation (2e-2 relative on the denoiser output)",
+                         "hipgraph": st16.graph is not None, "output_finite": bool(torch.isfinite(img16).all().item())}
 
     # ---- second half of BASELINE.json's metric: training denoising steps/s (configs[2]: per-GPU batch 4, fp32, Adam, RCCL all-reduce)
     train = None
@@ -508,7 +520,7 @@ def main():
                        "parallelism": f"independent sampling shards x{world} (no data-path collective)" + ("" if backend == "nccl" or world == 1
                                                                                                            else f" [{backend} rehearsal, not RCCL]")},
             "denoising_sample_steps_per_sec": round(world * B_PER_GPU / (ms_per_step * 1e-3), 3),
-            "full_sample": full_sample, "fp32_exact": fp32_exact,
+            "full_sample": full_sample, "fp32_exact": fp32_exact, "bf16_throughput_mode": bf16_mode,
             "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
             "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
             "training": train, "config4": config4, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
