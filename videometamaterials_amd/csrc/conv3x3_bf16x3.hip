@@ -479,6 +479,19 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the patch prefetch item(s) of this step, if any
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
+      if constexpr (C3_INTERLEAVE && ONE) {  // single pass: four MFMAs, two weight-fragment requests, two LDS fragment reads per step
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     stamp(4 + 2 * (cc - c_begin));
