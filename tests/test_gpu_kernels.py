@@ -476,6 +476,20 @@ def test_stride2_resampling_as_tap_subset_convolutions(gpu, up, nimg, H, W, Cin,
         first = out.clone() if first is None else first
         assert torch.equal(out, first)
     assert int(tickets.abs().sum()) == 0
+    # the "bf16" throughput mode of the same layers: exactly the fp32-accumulated result on bf16-rounded operands
+    rnd = lambda t_: t_.to(torch.bfloat16).double()
+    if up:
+        want1 = F.conv_transpose2d(rnd(x), rnd(w), b.double(), stride=2, padding=1)
+    else:
+        want1 = F.conv2d(rnd(x), rnd(w), b.double(), stride=2, padding=1)
+    want1 = want1.permute(0, 2, 3, 1).reshape(-1, Cout).float()
+    out.fill_(7.0)
+    rc = lib.vmm_conv_s2_acc_bf16(xg.data_ptr(), Cin, packed.data_ptr(), bg.data_ptr(), None, 0, out.data_ptr(), Cout, nimg, H, W, Cin, Cout, up,
+                                  tickets.data_ptr(), tickets.numel(), _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), want1) < 1e-5
+    assert 1e-4 < relerr(out.cpu(), ref) < 1e-2
 
 
 @pytest.mark.parametrize("nimg,H,W,Cc,k", [(3, 96, 96, 3, 7), (2, 20, 37, 4, 5), (1, 8, 8, 1, 3), (5, 16, 48, 2, 7)])

@@ -351,11 +351,15 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       const unsigned short* q = TS ? Ph + (kh == 0 ? abase[i][0] : kh == 1 ? abase[i][1] : abase[i][2]) + (kw * CROW + s * 16)
                                    : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       uint4 vh = *reinterpret_cast<const uint4*>(q);
-      uint4 vl = make_uint4(0u, 0u, 0u, 0u);
-      if constexpr (!ONE) vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
-      if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
-      d[2 * i] = vh;
-      d[2 * i + 1] = vl;
+      if constexpr (ONE) {
+        if (!MODE && !((tapmask[i] >> tap) & 1u)) vh = make_uint4(0u, 0u, 0u, 0u);
+        d[2 * i] = vh;
+      } else {
+        uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
+        if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+        d[2 * i] = vh;
+        d[2 * i + 1] = vl;
+      }
     }
   };
   auto mma_step = [&](const uint4 (&av)[4], const uint4 (&b)[4]) {
