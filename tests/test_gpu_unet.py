@@ -87,6 +87,10 @@ def test_bf16_throughput_mode_against_reference_golden(gpu, cfg_name):
     with pytest.raises(ValueError):
         model.train_precision = "bf16"
         model.get_plan(x.shape[0], x.shape[2], x.shape[3], x.shape[4], cond.shape[1], gpu, training=True)
+    with pytest.raises(ValueError):  # (an unknown mode is an error, not a silent fp32)
+        model.precision = "fp16"
+        model._plans.clear()
+        model(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0)
 
 
 def test_guidance_scales_and_state_dict_roundtrip(gpu):

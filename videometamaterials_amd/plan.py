@@ -281,6 +281,8 @@ class _Builder:
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
         prec = getattr(model, "train_precision" if training else "precision", "fp32")
+        if prec not in ("fp32", "bf16x3", "bf16"):
+            raise ValueError(f"unknown arithmetic mode {prec!r}: 'fp32' (exact), 'bf16x3' (split-bf16, fp32-class), 'bf16' (single pass, sampling only)")
         if prec == "bf16" and training:
             raise ValueError("precision 'bf16' is the single-pass THROUGHPUT mode of the sampling path (BASELINE.json configs[3]); training modes: 'fp32', 'bf16x3'")
         self.x3 = prec in ("bf16x3", "bf16")
