@@ -39,7 +39,12 @@ __device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool 
 }
 
 __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArgs a) {
-  __shared__ float xp[HEADS][2][16][17];  // wave-private transpose tiles: dS and dS(tokens)
+  // wave-private tiles: dS and dS(tokens) [16][17]; and the row <-> column layout changes of q, k, dO on the way in and of dQ, dK, dV on the way out
+  // [16 frames][36]: the column layouts used to be 24 four-byte global loads and 24 four-byte global stores per pixel and head (3.6 TB/s)
+  extern __shared__ __attribute__((aligned(16))) float smem_bw[];
+  float(*xp)[2][16][17] = reinterpret_cast<float(*)[2][16][17]>(smem_bw);
+  constexpr int TPITCH = 36;
+  float* tiles = smem_bw + HEADS * 2 * 16 * 17 + (threadIdx.x >> 6) * 3 * 16 * TPITCH;
   const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, c = lane & 15, g = lane >> 4;
   const int T = a.T, ntok = a.ntok;
   const int b = blockIdx.x / a.blocks_per_sample, blk = blockIdx.x % a.blocks_per_sample;
@@ -69,29 +74,60 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
   f32x4 dEK[2] = {zero4, zero4}, dEV[2] = {zero4, zero4}, bacc = zero4;
   float(*tile)[16][17] = xp[head];
 
+  float nq[8], nk[8], nv[8], ng[8], nL;
+  {
+    const bool ok0 = cT && blk < a.HW;
+    const long long r0 = (long long)b * T * a.HW + min(blk, a.HW - 1) + (long long)c * a.HW;
+    const float* q0 = a.qkv + r0 * a.ldqkv + head * DH + 8 * g;
+    load_row8(nq, q0, ok0);
+    load_row8(nk, q0 + HID, ok0);
+    load_row8(nv, q0 + 2 * HID, ok0);
+    load_row8(ng, a.dO + r0 * a.ldo + head * DH + 8 * g, ok0);
+    nL = ok0 ? a.lse[r0 * HEADS + head] : 0.f;
+  }
   for (int pix = blk; pix < a.HW; pix += a.blocks_per_sample) {
     const long long row0 = (long long)b * T * a.HW + pix;  // row of frame t = row0 + t * HW
     const long long rc = row0 + (long long)c * a.HW;       // this lane's row in the row layouts
-    const float* qrow = a.qkv + rc * a.ldqkv + head * DH + 8 * g;
+    // this pixel's rows were requested during the previous pixel's arithmetic (nq ..); the next pixel's are requested now: without the prefetch a
+    // pixel was load latency + 80 MFMAs + stores in sequence, the same for both waves of a SIMD
     float qr[8], kr[8], vr[8], gr[8];
-    load_row8(qr, qrow, cT);
-    load_row8(kr, qrow + HID, cT);
-    load_row8(vr, qrow + 2 * HID, cT);
-    load_row8(gr, a.dO + rc * a.ldo + head * DH + 8 * g, cT);
-    const float Lq = cT ? a.lse[rc * HEADS + head] : 0.f;
-    // column layouts (lane = channel c + 16 h, register = frame 4 g + r) of k (for dQ), q (for dK) and dO (for dV)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qr[j] = nq[j]; kr[j] = nk[j]; vr[j] = nv[j]; gr[j] = ng[j]; }
+    const float Lq = nL;
+    {
+      const int pn = pix + a.blocks_per_sample;
+      const bool okn = cT && pn < a.HW;
+      const long long rn = (long long)b * T * a.HW + min(pn, a.HW - 1) + (long long)c * a.HW;
+      const float* qn = a.qkv + rn * a.ldqkv + head * DH + 8 * g;
+      load_row8(nq, qn, okn);
+      load_row8(nk, qn + HID, okn);
+      load_row8(nv, qn + 2 * HID, okn);
+      load_row8(ng, a.dO + rn * a.ldo + head * DH + 8 * g, okn);
+      nL = okn ? a.lse[rn * HEADS + head] : 0.f;
+    }
+    // column layouts (lane = channel c + 16 h, register = frame 4 g + r) of k (for dQ), q (for dK) and dO (for dV): through the wave's tiles
+    // (rows of frame slots >= T were loaded as zeros)
     float kc[2][4], qc[2][4], gc[2][4];
+    {
+      float* tq = tiles + (c * TPITCH + 8 * g);
+      *reinterpret_cast<f32x4*>(tq) = f32x4{qr[0], qr[1], qr[2], qr[3]};
+      *reinterpret_cast<f32x4*>(tq + 4) = f32x4{qr[4], qr[5], qr[6], qr[7]};
+      *reinterpret_cast<f32x4*>(tq + 16 * TPITCH) = f32x4{kr[0], kr[1], kr[2], kr[3]};
+      *reinterpret_cast<f32x4*>(tq + 16 * TPITCH + 4) = f32x4{kr[4], kr[5], kr[6], kr[7]};
+      *reinterpret_cast<f32x4*>(tq + 32 * TPITCH) = f32x4{gr[0], gr[1], gr[2], gr[3]};
+      *reinterpret_cast<f32x4*>(tq + 32 * TPITCH + 4) = f32x4{gr[4], gr[5], gr[6], gr[7]};
+      // (the tiles are wave-private; the workgroup barrier orders the wave's own writes before its reads AND keeps the eight head-waves on the same pixel:
+      // with wave-level ordering only, the heads drift apart and the kernel is 8 % slower -- they read neighbouring 128-byte pieces of the same rows)
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = 4 * g + r;
-      const bool ok = t < T;
-      const long long rt = row0 + (long long)t * a.HW;
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        qc[h][r] = ok ? a.qkv[rt * a.ldqkv + head * DH + c + 16 * h] : 0.f;
-        kc[h][r] = ok ? a.qkv[rt * a.ldqkv + HID + head * DH + c + 16 * h] : 0.f;
-        gc[h][r] = ok ? a.dO[rt * a.ldo + head * DH + c + 16 * h] : 0.f;
-      }
+        for (int h = 0; h < 2; ++h) {
+          const float* tr = tiles + ((4 * g + r) * TPITCH + c + 16 * h);
+          qc[h][r] = tr[0];
+          kc[h][r] = tr[16 * TPITCH];
+          gc[h][r] = tr[32 * TPITCH];
+        }
     }
     float LA[4];
 #pragma unroll
@@ -141,7 +177,9 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
         dEK[h] = mm(dst[r], qc[h][r], dEK[h]);  // accumulated over the workgroup's pixels
         dEV[h] = mm(pt[r], gc[h][r], dEV[h]);
       }
-    // ---- store: register r <-> frame 4 g + r, lane <-> channel c + 16 h; undo the interleaved-pair rotation (pairs = adjacent lanes)
+    // ---- store: register r <-> frame 4 g + r, lane <-> channel c + 16 h; undo the interleaved-pair rotation (pairs = adjacent lanes), then back to the
+    // row layout through the tiles: lane = frame c, eight channels 8 g .. + 7 = two 16-byte stores per tensor
+    __syncthreads();  // (the column reads above are done before the tiles are overwritten)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -149,20 +187,29 @@ __global__ __launch_bounds__(512) void temporal_attn_bwd_mfma_kernel(const TMArg
         const int t = 4 * g + r;
         float q = dQ[h][r], k = dK[h][r];
         const float qp = __shfl_xor(q, 1, 64), kp = __shfl_xor(k, 1, 64);
-        if (t < T) {
-          const int d = c + 16 * h;
-          if (a.rot) {
-            const float cs = a.rot[(t * (DH / 2) + (d >> 1)) * 2], sn = a.rot[(t * (DH / 2) + (d >> 1)) * 2 + 1];
-            const float sg = (d & 1) ? -sn : sn;  // even: a c + b s, odd: b c - a s
-            q = q * cs + qp * sg;
-            k = k * cs + kp * sg;
-          }
-          float* o = a.dqkv + (row0 + (long long)t * a.HW) * a.ldqkv + head * DH + d;
-          o[0] = q * a.q_scale;
-          o[HID] = k;
-          o[2 * HID] = dV[h][r];
+        const int d = c + 16 * h;
+        if (a.rot && t < T) {
+          const float cs = a.rot[(t * (DH / 2) + (d >> 1)) * 2], sn = a.rot[(t * (DH / 2) + (d >> 1)) * 2 + 1];
+          const float sg = (d & 1) ? -sn : sn;  // even: a c + b s, odd: b c - a s
+          q = q * cs + qp * sg;
+          k = k * cs + kp * sg;
         }
+        float* tw = tiles + (t * TPITCH + d);
+        tw[0] = q * a.q_scale;
+        tw[16 * TPITCH] = k;
+        tw[32 * TPITCH] = dV[h][r];
       }
+    __syncthreads();
+    if (cT) {
+      const float* tr = tiles + (c * TPITCH + 8 * g);
+      float* o = a.dqkv + rc * a.ldqkv + head * DH + 8 * g;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        *reinterpret_cast<f32x4*>(o + part * HID) = *reinterpret_cast<const f32x4*>(tr + part * 16 * TPITCH);
+        *reinterpret_cast<f32x4*>(o + part * HID + 4) = *reinterpret_cast<const f32x4*>(tr + part * 16 * TPITCH + 4);
+      }
+    }
+    __syncthreads();  // (the row reads are done before the next pixel's writes)
   }
   // ---- per-workgroup partials of the gradients shared by its pixels (summed by temporal_attn_bwd_reduce_kernel)
   float* part = a.part + (long long)blockIdx.x * a.pstride;
@@ -251,7 +298,13 @@ extern "C" int vmm_temporal_attention_bwd(const float* qkv, int32_t ldqkv, const
   const int bps = tb_blocks_per_sample(B, HW), pstride = tb_pstride(ntok, T);
   TMArgs a{qkv, ek, ev, bias, out, dout, lse, rot_tab, dqkv, scratch, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, bps, pstride, q_scale};
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(temporal_attn_bwd_mfma_kernel, dim3((unsigned)(B * bps)), dim3(512), 0, s, a);
+  constexpr size_t shm = sizeof(float) * (HEADS * 2 * 16 * 17 + HEADS * 3 * 16 * 36);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(temporal_attn_bwd_mfma_kernel, dim3((unsigned)(B * bps)), dim3(512), shm, s, a);
   VMM_LAUNCH_CHECK();
   const int nred = B * 2 * ntok * HID + (bias && dbias ? HEADS * T * T : 0);
   if (nred > 0) {
