@@ -200,7 +200,8 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     model.train()
     tr = DataParallelTrainer(diff, train_lr=1e-4)
     assert tr.world == world
-    selfcheck = tr.rccl_selfcheck() if world > 1 else None
+    rehearse = tr.engine is not None or os.environ.get("VMM_DP_FORCE") == "1"  # one rank through the collective path (first contact with RCCL)
+    selfcheck = tr.rccl_selfcheck() if (world > 1 or rehearse) else None
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(B_PER_GPU, 3, T, HW, HW, generator=g).to(dev)
     cond = (torch.rand(B_PER_GPU, 11, generator=g) * 2 - 1).to(dev)
@@ -223,7 +224,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     ms = el / steps * 1e3
     pl = tr._plan
     comm = None
-    if world > 1:
+    if world > 1 or rehearse:
         # one more (untimed) step with events on the side stream: how long the buckets keep it busy and how much of that lies inside the
         # backward window (bucket i starts when the backward marks its tail slice final)
         tr._reducer.timing = True
@@ -236,7 +237,9 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
            "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
            "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32",
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
-           "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if world > 1 else 0}
+           "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if (world > 1 or rehearse) else 0,
+           "dp_engine": (f"native: vmm_dp C ABI over RCCL {tr.engine.rccl_version} (include/vmm_dp.h)" if tr.engine is not None
+                         else f"torch.distributed/{dist.get_backend()}" if dist is not None else "none (single rank)")}
     if comm:
         out.update(allreduce_ms=comm["allreduce_ms"], overlap_frac=comm["overlap_frac"], comm_detail=comm)
     if selfcheck:
@@ -261,6 +264,8 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
         out["roofline_training"] = {"dominant": dom, "kernels": objs, "event_ms_forward": round(sum(fwd_ms), 2), "event_ms_backward": round(sum(bwd_ms), 2),
                                     "ms_by_kernel_family": {k: round(v[0], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]},
                                     "peak_note": "fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32); split-bf16 kernels: 2500 / 3"}
+    if tr.engine is not None:
+        tr.engine.close()  # the next leg builds its own communicator
     return out
 
 
@@ -334,6 +339,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn_under_torchrun(args.gpus)
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner with printf when a communicator is created, other
+    # libraries may do the like.  File descriptor 1 points at stderr for the whole run; the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -351,8 +361,17 @@ def main():
             raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {ndev}): one RCCL rank per GPU")
         dev_index = local_rank % ndev
         torch.cuda.set_device(dev_index)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # (device_id: the communicator is bound to this rank's GPU at once -- no guessing from the global rank at the first barrier)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}))
         assert dist.get_world_size() == args.gpus
+    elif os.environ.get("VMM_DP_FORCE") == "1":
+        # one-GPU rehearsal of the N-rank control flow THROUGH RCCL: a one-rank process group, every collective of the training leg issued
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dev_index = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
     else:
         dist = None
         dev_index = 0
@@ -525,7 +544,8 @@ def main():
             "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
             "training": train, "config4": config4, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,6 +27,27 @@ def test_c_abi_exports_every_declared_symbol():
     lib = N.lib()  # raises if the library is missing or a symbol is not exported (no compute calls here)
     for name in declared:
         assert getattr(lib, name) is not None
+    # the data-parallel engine's surface (include/vmm_dp.h) lives in the same library
+    dp_hdr = open(os.path.join(ROOT, "include", "vmm_dp.h")).read()
+    dp_declared = set(re.findall(r"^(?:int|const char\*) (vmm_dp_\w+)\(", dp_hdr, flags=re.M))
+    assert dp_declared == set(N.DP_SIGNATURES), dp_declared ^ set(N.DP_SIGNATURES)
+    for name in dp_declared:
+        assert getattr(lib, name) is not None
+
+
+def test_dp_engine_rejects_bad_arguments_without_a_gpu():
+    """Argument checks of the engine that need neither a GPU nor RCCL (no collective runs here)."""
+    import ctypes as C
+    from videometamaterials_amd import _native as N
+    lib = N.lib()
+    assert lib.vmm_dp_get_unique_id(None, None) == -1
+    handle = C.c_void_p()
+    ident = (C.c_char * 128)()
+    assert lib.vmm_dp_init(C.byref(handle), None, 3, 2, ident, 0) == -1  # rank outside the world
+    assert lib.vmm_dp_init(C.byref(handle), b"/nonexistent/librccl.so", 0, 1, ident, 0) == -2  # RCCL cannot be loaded: loud, no fallback
+    assert not handle.value
+    assert lib.vmm_dp_wait_all(None, None) == -1 and lib.vmm_dp_finalize(None) == -1
+    assert lib.vmm_dp_world(None) == -1 and lib.vmm_dp_last_error(None) == b"null engine"
 
 
 def test_missing_library_fails_loudly(monkeypatch):

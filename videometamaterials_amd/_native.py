@@ -190,7 +190,28 @@ SIGNATURES = {
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
-RESTYPES = {"vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
+# include/vmm_dp.h: the data-parallel engine (RCCL bound at run time; nothing here runs unless a DP engine is created)
+c_ptrp = C.POINTER(c_ptr)
+DP_SIGNATURES = {
+    "vmm_dp_get_unique_id": [C.c_char_p, c_ptr],
+    "vmm_dp_init": [c_ptrp, C.c_char_p, c_i32, c_i32, c_ptr, c_i32],
+    "vmm_dp_register_buckets": [c_ptr, C.POINTER(c_ptr), C.POINTER(c_i64), c_i32],
+    "vmm_dp_allreduce_bucket_async": [c_ptr, c_i32, c_ptr],
+    "vmm_dp_wait_all": [c_ptr, c_ptr],
+    "vmm_dp_set_timing": [c_ptr, c_i32],
+    "vmm_dp_window_mark": [c_ptr, c_i32, c_ptr],
+    "vmm_dp_timing": [c_ptr, C.POINTER(c_f32)],
+    "vmm_dp_allreduce": [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_dp_broadcast": [c_ptr, c_ptr, c_i64, c_i32, c_ptr],
+    "vmm_dp_all_gather": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
+    "vmm_dp_rank": [c_ptr],
+    "vmm_dp_world": [c_ptr],
+    "vmm_dp_rccl_version": [c_ptr],
+    "vmm_dp_last_error": [c_ptr],
+    "vmm_dp_finalize": [c_ptr],
+}
+
+RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 
@@ -210,7 +231,7 @@ def lib() -> C.CDLL:
                 "there is no CPU/PyTorch fallback for the hot path"
             )
         handle = C.CDLL(path)
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in list(SIGNATURES.items()) + list(DP_SIGNATURES.items()):
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = RESTYPES.get(name, C.c_int)

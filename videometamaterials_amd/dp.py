@@ -19,9 +19,129 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+import ctypes as C
+import os
+
 from . import _native as N
 from . import hostmath
 from .plan import _stream
+
+
+def _host_rccl_path() -> Optional[str]:
+    """The RCCL PyTorch-ROCm ships and maps for its own "nccl" backend: binding the engine to the same file keeps ONE copy of the
+    library in the process (None: the engine's default, librccl.so.1 from the loader path)."""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+class RcclEngine:
+    """The native data-parallel engine (include/vmm_dp.h, csrc/dp_engine.hip): RCCL communicator + side stream + events behind the C ABI.
+    torch.distributed is used for ONE thing only -- handing rank 0's 128-byte rendezvous id to the other ranks (any backend; a host
+    without PyTorch would use a file or its own store)."""
+
+    def __init__(self, rank: int, world: int, device: torch.device, unique_id: bytes, rccl_path: Optional[str] = None):
+        assert len(unique_id) == 128
+        self.lib = N.lib()
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        path = rccl_path if rccl_path is not None else _host_rccl_path()
+        self._h = C.c_void_p()
+        self._id = C.create_string_buffer(unique_id, 128)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        code = self.lib.vmm_dp_init(C.byref(self._h), path.encode() if path else None, rank, world, self._id, idx)
+        if code != 0 or not self._h.value:
+            raise N.NativeError(f"vmm_dp_init failed with code {code} (rank {rank} of {world}, RCCL at {path or 'librccl.so.1'})")
+        self._keep = None  # ctypes arrays of the registered bucket list
+
+    @staticmethod
+    def new_unique_id(rccl_path: Optional[str] = None) -> bytes:
+        buf = C.create_string_buffer(128)
+        path = rccl_path if rccl_path is not None else _host_rccl_path()
+        N.check(N.lib().vmm_dp_get_unique_id(path.encode() if path else None, buf), "vmm_dp_get_unique_id")
+        return buf.raw
+
+    @classmethod
+    def create(cls, device: torch.device, group=None) -> "RcclEngine":
+        """One engine per process.  With torch.distributed initialised: its rank / world, the id broadcast from rank 0 as a Python
+        object; otherwise a single-rank communicator (a one-GPU box still goes through RCCL: first-contact rehearsal)."""
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [cls.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            return cls(rank, world, device, box[0])
+        return cls(0, 1, device, cls.new_unique_id())
+
+    def _check(self, code: int, what: str) -> None:
+        if code != 0:
+            msg = self.lib.vmm_dp_last_error(self._h)
+            raise N.NativeError(f"{what} failed with code {code}: {msg.decode() if msg else ''}")
+
+    @property
+    def rccl_version(self) -> int:
+        return int(self.lib.vmm_dp_rccl_version(self._h))
+
+    def register(self, flat: torch.Tensor, slices: List[Tuple[int, int]]) -> None:
+        n = len(slices)
+        ptrs = (C.c_void_p * max(n, 1))(*[flat.data_ptr() + 4 * lo for lo, _ in slices])
+        counts = (C.c_int64 * max(n, 1))(*[hi - lo for lo, hi in slices])
+        self._keep = (ptrs, counts, flat)
+        self._check(self.lib.vmm_dp_register_buckets(self._h, ptrs, counts, n), "vmm_dp_register_buckets")
+
+    def allreduce_bucket_async(self, i: int) -> None:
+        self._check(self.lib.vmm_dp_allreduce_bucket_async(self._h, i, _stream()), "vmm_dp_allreduce_bucket_async")
+
+    def wait_all(self) -> None:
+        self._check(self.lib.vmm_dp_wait_all(self._h, _stream()), "vmm_dp_wait_all")
+
+    def set_timing(self, on: bool) -> None:
+        self._check(self.lib.vmm_dp_set_timing(self._h, 1 if on else 0), "vmm_dp_set_timing")
+
+    def window_mark(self, which: int) -> None:
+        self._check(self.lib.vmm_dp_window_mark(self._h, which, _stream()), "vmm_dp_window_mark")
+
+    def timing(self) -> Tuple[float, float, float]:
+        out = (C.c_float * 3)()
+        self._check(self.lib.vmm_dp_timing(self._h, out), "vmm_dp_timing")
+        return float(out[0]), float(out[1]), float(out[2])
+
+    _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum") -> None:
+        assert t.is_cuda and t.is_contiguous()
+        self._check(self.lib.vmm_dp_allreduce(self._h, t.data_ptr(), t.numel(), self._DTYPES[t.dtype], {"sum": 0, "max": 1, "min": 2}[op], _stream()),
+                    "vmm_dp_allreduce")
+
+    def broadcast(self, t: torch.Tensor, root: int = 0) -> None:
+        assert t.is_cuda and t.is_contiguous()
+        if t.numel():
+            self._check(self.lib.vmm_dp_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), root, _stream()), "vmm_dp_broadcast")
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        assert t.is_cuda and t.is_contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self._check(self.lib.vmm_dp_all_gather(self._h, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(), _stream()), "vmm_dp_all_gather")
+        return list(out.unbind(0))
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            code = self.lib.vmm_dp_finalize(self._h)
+            self._h = None
+            N.check(code, "vmm_dp_finalize")
+
+
+def plan_buckets(n_valid: int, marks: List[int], bucket_floats: int) -> List[Tuple[int, int]]:
+    """The (lo, hi) slices BucketedAllReduce will reduce for a plan's mark sequence, in issue order (the sequence is static per plan, so the
+    native engine registers them once)."""
+    out, hi = [], n_valid
+    for x in marks:
+        x = max(0, min(x, hi))
+        if hi - x >= bucket_floats or x == 0:
+            if hi > x:
+                out.append((x, hi))
+            hi = x
+    if hi > 0:
+        out.append((0, hi))
+    return out
 
 
 def _device_collectives_ok(t: torch.Tensor, group=None) -> bool:
@@ -66,18 +186,30 @@ class BucketedAllReduce:
     `bucket_floats`, then reduced asynchronously (on `comm_stream` for CUDA tensors).  finish() flushes the rest and
     makes the caller's stream wait for every bucket."""
 
-    def __init__(self, flat: torch.Tensor, n_valid: int, bucket_floats: int = 6_400_000, group=None):
+    def __init__(self, flat: torch.Tensor, n_valid: int, bucket_floats: int = 4_000_000, group=None, engine: Optional[RcclEngine] = None,
+                 marks: Optional[List[int]] = None):
         self.flat, self.n, self.bucket = flat, n_valid, bucket_floats
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.engine = engine
+        self.world = engine.world if engine is not None else (dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        # a single rank normally skips the exchange; the native engine, or VMM_DP_FORCE=1 with an initialised one-rank process group, runs it
+        # anyway (a one-GPU box then meets RCCL through exactly the code path of N ranks)
+        self.active = self.world > 1 or engine is not None or (os.environ.get("VMM_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.active and engine is None) else None
+        self._index = {}
+        if engine is not None:
+            if marks is None:
+                raise ValueError("the native engine registers a static bucket list: pass the plan's marks")
+            slices = plan_buckets(n_valid, marks, bucket_floats)
+            engine.register(flat, slices)
+            self._index = {sl: i for i, sl in enumerate(slices)}
         self.hi = n_valid
         self.works = []
         self.launched: List[Tuple[int, int]] = []
         # RCCL reduces device buffers in place.  The gloo rehearsal backend (several ranks sharing one GPU on a single-GPU box; CPU
         # tests) may lack device-tensor support in this build: then slices are staged through pinned host memory on the side stream.
-        self.host_staged = bool(self.cuda and self.world > 1 and not _device_collectives_ok(flat, group))
+        self.host_staged = bool(self.cuda and self.active and engine is None and not _device_collectives_ok(flat, group))
         # timing of the last step (events with timing on the compute / side stream): bench.py reports allreduce_ms / overlap_frac from them
         self.timing = False
         self._ev_buckets: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
@@ -87,6 +219,11 @@ class BucketedAllReduce:
         self.hi = self.n
         self.works, self.launched = [], []
         self._ev_buckets, self._ev_window = [], []
+        if self.engine is not None:
+            self.engine.set_timing(self.timing)
+            if self.timing:
+                self.engine.window_mark(0)
+            return
         if self.timing and self.comm_stream is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()  # the backward window opens here (compute stream)
@@ -94,6 +231,10 @@ class BucketedAllReduce:
 
     def backward_done(self) -> None:
         """Call when the last backward launch has been enqueued: closes the window overlap_frac is measured against."""
+        if self.engine is not None:
+            if self.timing:
+                self.engine.window_mark(1)
+            return
         if self.timing and self.comm_stream is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -101,6 +242,12 @@ class BucketedAllReduce:
 
     def last_step_timing(self) -> Optional[dict]:
         """(after a synchronize) side-stream busy time of the last step's buckets and the share of it inside the backward window."""
+        if self.engine is not None:
+            if not self.timing or not self.launched:
+                return None
+            busy, inside, win = self.engine.timing()
+            return {"allreduce_ms": round(busy, 3), "overlap_frac": round(inside / busy, 4) if busy > 0 else None, "backward_ms": round(win, 3),
+                    "buckets_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.launched]}
         if len(self._ev_window) < 2 or not self._ev_buckets:
             return None
         w0, w1 = self._ev_window
@@ -116,11 +263,15 @@ class BucketedAllReduce:
                 "bucket_spans_ms": spans, "buckets_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.launched]}
 
     def _reduce(self, lo: int, hi: int) -> None:
-        if hi <= lo or self.world == 1:
+        if hi <= lo or not self.active:
             return
         sl = self.flat[lo:hi]
         self.launched.append((lo, hi))
-        if self.cuda:
+        if self.engine is not None:
+            if (lo, hi) not in self._index:
+                raise RuntimeError(f"gradient slice [{lo}, {hi}) is not in the bucket list registered for this plan")
+            self.engine.allreduce_bucket_async(self._index[(lo, hi)])
+        elif self.cuda:
             ev = torch.cuda.Event()
             ev.record()  # everything enqueued so far on the compute stream produced flat[lo:hi]
             self.comm_stream.wait_event(ev)
@@ -156,7 +307,9 @@ class BucketedAllReduce:
     def finish(self) -> None:
         self._reduce(0, self.hi)
         self.hi = 0
-        if self.comm_stream is not None:
+        if self.engine is not None:
+            self.engine.wait_all()
+        elif self.comm_stream is not None:
             with torch.cuda.stream(self.comm_stream):
                 for w in self.works:
                     w.wait()  # (device collectives: orders the side stream behind the collective, does not block the host)
@@ -173,7 +326,10 @@ class DataParallelTrainer:
     """Minimal counterpart of the reference Trainer's inner loop (vddp.py:1612-1640) for the HIP path."""
 
     def __init__(self, diffusion, *, train_lr: float = 1e-4, ema_decay: float = 0.995, step_start_ema: int = 2000, update_ema_every: int = 10,
-                 null_cond_prob: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8, bucket_floats: int = 6_400_000, group=None):
+                 null_cond_prob: float = 0.1, betas=(0.9, 0.999), eps: float = 1e-8, bucket_floats: int = 4_000_000, group=None,
+                 engine: Optional[str] = None):
+        """engine: "torch" = torch.distributed collectives (backend "nccl" is RCCL on ROCm; the default), "native" = the C-ABI engine of
+        include/vmm_dp.h (its own RCCL communicator and side stream; also at world 1).  Default: $VMM_DP_ENGINE or "torch"."""
         self.model = diffusion
         self.unet = diffusion.denoise_fn
         self.ema_model = copy.deepcopy(diffusion)  # vddp.py:1453
@@ -183,6 +339,15 @@ class DataParallelTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        kind = engine if engine is not None else os.environ.get("VMM_DP_ENGINE", "torch")
+        if kind not in ("torch", "native"):
+            raise ValueError(f"engine must be 'torch' or 'native', got {kind!r}")
+        self.engine: Optional[RcclEngine] = None
+        if kind == "native":
+            dev = next(diffusion.parameters()).device
+            if dev.type != "cuda":
+                raise N.NativeError("the native data-parallel engine runs over RCCL: the model must live on a GPU")
+            self.engine = RcclEngine.create(dev, group)
         self.step = 0
         self.bucket_floats = bucket_floats
         self._plan = None
@@ -200,7 +365,10 @@ class DataParallelTrainer:
         for dt in sorted(by_dtype, key=str):  # same order on every rank
             ts = by_dtype[dt]
             flat = torch.cat([t.reshape(-1) for t in ts])
-            broadcast_tensor(flat, 0, self.group)
+            if self.engine is not None and flat.is_cuda:
+                self.engine.broadcast(flat, 0)
+            else:
+                broadcast_tensor(flat, 0, self.group)
             o = 0
             for t in ts:
                 t.copy_(flat[o:o + t.numel()].view_as(t))
@@ -212,7 +380,12 @@ class DataParallelTrainer:
         """First contact with the collective library: the all-reduce of the rank ids must be N (N - 1) / 2 on every rank."""
         dev = next(self.model.parameters()).device
         t = torch.full((1,), float(self.rank), device=dev)
-        if self.world > 1:
+        if self.engine is not None:
+            self.engine.all_reduce(t)
+            got, want = float(t.item()), self.world * (self.world - 1) / 2
+            return {"sum_of_rank_ids": got, "expected": want, "ok": got == want, "backend": f"vmm_dp (RCCL {self.engine.rccl_version})"}
+        through = self.world > 1 or (os.environ.get("VMM_DP_FORCE") == "1" and dist.is_initialized())
+        if through:
             if _device_collectives_ok(t, self.group):
                 dist.all_reduce(t, group=self.group)
             else:
@@ -220,7 +393,7 @@ class DataParallelTrainer:
                 dist.all_reduce(h, group=self.group)
                 t = h.to(dev)
         got, want = float(t.item()), self.world * (self.world - 1) / 2
-        return {"sum_of_rank_ids": got, "expected": want, "ok": got == want, "backend": dist.get_backend(self.group) if self.world > 1 else None}
+        return {"sum_of_rank_ids": got, "expected": want, "ok": got == want, "backend": dist.get_backend(self.group) if through else None}
 
     # ------------------------------------------------------------------ checkpoints in the reference's layout (vddp.py:1548-1585)
     def state_dict(self) -> dict:
@@ -321,7 +494,10 @@ class DataParallelTrainer:
         if pl is not self._plan:
             self._plan = pl
             self._build_tables(pl, dev)
-            self._reducer = BucketedAllReduce(pl.pgrad, pl.pgrad_floats, self.bucket_floats, self.group)
+            if self._reducer is not None and self.engine is not None:
+                torch.cuda.current_stream().synchronize()  # the engine's bucket list is replaced: nothing of the old plan may be in flight
+            self._reducer = BucketedAllReduce(pl.pgrad, pl.pgrad_floats, self.bucket_floats, self.group, engine=self.engine,
+                                              marks=[x for _, x in sorted(dict(pl.bwd_marks).items())])
             self._acc = torch.empty(1, dtype=torch.float64, device=dev)
             self._loss = torch.empty((), dtype=torch.float32, device=dev)
         elif self._ptr_sig != self._pointer_signature():
@@ -356,7 +532,7 @@ class DataParallelTrainer:
         N.check(lib.vmm_loss_reduce(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, self._acc.data_ptr(), self._loss.data_ptr(), _stream()), "loss")
         N.check(lib.vmm_loss_grad(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, None, pl.dout.data_ptr(), _stream()), "loss grad")
         self._reducer.start()
-        pl.backward(None, on_mark=self._reducer.mark if self.world > 1 else None)
+        pl.backward(None, on_mark=self._reducer.mark if self._reducer.active else None)
         self._reducer.backward_done()
         self._reducer.finish()
         b1, b2 = self.betas
@@ -381,7 +557,10 @@ class DataParallelTrainer:
         dev = next(model.parameters()).device
         if self.world > 1:  # the reference broadcasts the conditioning matrix as a pickled object; here: one raw tensor
             cond_all = cond_all.to(dev).contiguous()
-            broadcast_tensor(cond_all, 0, self.group)
+            if self.engine is not None:
+                self.engine.broadcast(cond_all, 0)
+            else:
+                broadcast_tensor(cond_all, 0, self.group)
         n_rows = cond_all.shape[0]
         outs = []
         for a, b in hostmath.shard_rows(n_rows, self.rank, self.world, batch):
@@ -396,7 +575,7 @@ class DataParallelTrainer:
         max_len = max(lengths)
         padded = torch.zeros((max_len,) + shp, device=dev)
         padded[: mine.shape[0]] = mine
-        gathered = all_gather_tensor(padded, self.world, self.group)
+        gathered = self.engine.all_gather(padded) if self.engine is not None else all_gather_tensor(padded, self.world, self.group)
         if self.rank != 0:
             return None
         return hostmath.strip_padding(torch.cat(gathered, dim=0), lengths, max_len)
