@@ -277,6 +277,17 @@ int vmm_cross_attention(const float* q, int32_t ldq, const float* ek, const floa
  * the same block); vmm_linattn_apply then runs on the q rows (ldqkv = heads*dh).  kstat as in vmm_linattn_context (or NULL). */
 int vmm_linattn_cross_context(const float* ek, const float* ev, int32_t ntok, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, float* ctx,
                               float* kstat, vmm_stream_t stream);
+/* backward of the two (training with cond_attention = 'cross-attention'; loss.backward() through vddp.py:354-363 / 476-485).
+ * vmm_cross_attention_bwd: q = the rows the forward consumed, dout [rows][heads*dh]; writes dq = the gradient of the RAW to_q output (the
+ * projection epilogue's rotation -- rot_tab [T][dh/2][2] (cos, sin) or NULL -- and q_scale are undone here), ADDS the token gradients into
+ * dek / dev [B][ntok][heads*dh] and the bias gradient into dbias [heads][T][T] (NULL allowed).  heads = 8, ntok <= 16.
+ * vmm_linattn_cross_bwd: ctx / kstat as vmm_linattn_cross_context left them, dctx = [B*T*heads][dh*dh] scratch; writes dq, ADDS dek / dev. */
+int vmm_cross_attention_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* bias, const float* dout,
+                            int32_t lddo, const float* rot_tab, float q_scale, float* dq, int32_t lddq, float* dek, float* dev, float* dbias, int32_t B,
+                            int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+int vmm_linattn_cross_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* ctx, const float* kstat,
+                          const float* dout, int32_t lddo, float* dctx, float* dq, int32_t lddq, float* dek, float* dev, int32_t B, int32_t T, int32_t HW,
+                          int32_t heads, int32_t dh, vmm_stream_t stream);
 /* the path vmm_temporal_attention takes where it applies (heads = 8, dh = 32, T <= 16, ntok <= 16; returns 1 and launches nothing
  * otherwise): one workgroup per pixel, the T rows of k | v staged once in LDS */
 int vmm_temporal_attention_staged(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,

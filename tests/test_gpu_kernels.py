@@ -834,6 +834,86 @@ def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias):
     assert relerr(o2.cpu(), want2) < 3e-6
 
 
+@pytest.mark.parametrize("B,T,HW,ntok,with_bias,rotate", [(2, 6, 20, 6, True, True), (3, 4, 33, 9, False, False), (1, 11, 150, 11, True, True),
+                                                         (2, 5, 3400, 16, False, False), (2, 5, 16, 1, False, False)])
+def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate):
+    """Backward of the two cross-attention cores against torch autograd through the einsum restatement of vddp.py:354-363 / 476-485, including what
+    the projection epilogue did to q (scale, rotary rotation by the row's frame): dq is the gradient of the RAW to_q output; token and bias
+    gradients are ADDED to what the buffers hold."""
+    N, lib = _lib()
+    from videometamaterials_amd import hostmath
+    heads, dh = 8, 32
+    hid = heads * dh
+    scale = dh ** -0.5
+    g = torch.Generator().manual_seed(77 + ntok)
+    rows = B * T * HW
+    q_raw = torch.randn(rows, hid, generator=g, requires_grad=True)
+    ek = torch.randn(B, ntok, hid, generator=g, requires_grad=True)
+    ev = torch.randn(B, ntok, hid, generator=g, requires_grad=True)
+    bias = torch.randn(heads, T, T, generator=g, requires_grad=True) if with_bias else None
+    go = torch.randn(rows, hid, generator=g)
+    rot = hostmath.rotary_table(T, dh)  # [T][dh/2][2] (cos, sin)
+    q5 = q_raw.reshape(B, T, HW, heads, dh) * scale
+    if rotate:
+        c, s_ = rot[:, :, 0][None, :, None, None, :], rot[:, :, 1][None, :, None, None, :]
+        x0, x1 = q5[..., 0::2], q5[..., 1::2]
+        q5 = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], -1).reshape(B, T, HW, heads, dh)
+    k5, v5 = ek.reshape(B, ntok, heads, dh), ev.reshape(B, ntok, heads, dh)
+    sim = torch.einsum("btphd,bjhd->btphj", q5, k5)
+    if with_bias:
+        sim = sim + bias.permute(1, 0, 2)[None, :, None]
+    out = torch.einsum("btphj,bjhd->btphd", sim.softmax(-1), v5).reshape(rows, hid)
+    out.backward(go)
+    q_used = q5.detach().reshape(rows, hid).contiguous().to(gpu)
+    ekg, evg, gog = ek.detach().to(gpu), ev.detach().to(gpu), go.to(gpu)
+    bg = bias.detach().to(gpu) if with_bias else None
+    rotg = rot.to(gpu).contiguous()
+    dq = torch.full((rows, hid), 7.0, device=gpu)
+    base = 0.5
+    dek, dev_ = torch.full((B, ntok, hid), base, device=gpu), torch.full((B, ntok, hid), base, device=gpu)
+    dbias = torch.full((heads, T, T), base, device=gpu) if with_bias else None
+    rc = lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), ntok, bg.data_ptr() if with_bias else None, gog.data_ptr(), hid,
+                                     rotg.data_ptr() if rotate else None, scale, dq.data_ptr(), hid, dek.data_ptr(), dev_.data_ptr(),
+                                     dbias.data_ptr() if with_bias else None, B, T, HW, heads, dh, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    if ntok == 1:  # one key: p = 1, ds = 0 -- the scores do not matter
+        assert float(dq.abs().max()) == 0 and float((dek - base).abs().max()) == 0 and float(q_raw.grad.abs().max()) == 0
+    else:
+        assert relerr(dq.cpu(), q_raw.grad) < 2e-5 and relerr(dek.cpu() - base, ek.grad) < 2e-5
+    assert relerr(dev_.cpu() - base, ev.grad) < 2e-5
+    if with_bias:
+        assert relerr(dbias.cpu() - base, bias.grad) < 2e-5
+    assert lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), 17, None, gog.data_ptr(), hid, None, scale, dq.data_ptr(), hid,
+                                       dek.data_ptr(), dev_.data_ptr(), None, B, T, HW, heads, dh, _s()) == -1  # more than 16 tokens
+
+    # linear flavour: forward context + statistics from the library, backward against autograd
+    q2 = torch.randn(rows, hid, generator=g, requires_grad=True)
+    ek2, ev2 = ek.detach().clone().requires_grad_(True), ev.detach().clone().requires_grad_(True)
+    ks = ek2.reshape(B, ntok, heads, dh).softmax(dim=1)
+    cw = torch.einsum("bjhd,bjhe->bhde", ks, ev2.reshape(B, ntok, heads, dh) / HW)
+    qs = q2.reshape(B, T, HW, heads, dh).softmax(-1) * scale
+    o2 = torch.einsum("bhde,btphd->btphe", cw, qs).reshape(rows, hid)
+    o2.backward(go)
+    ctx = torch.empty(B * T * heads, dh, dh, device=gpu)
+    kstat = torch.empty(B * T * heads, 2, dh, device=gpu)
+    dctx = torch.empty_like(ctx)
+    q2g = q2.detach().to(gpu)
+    assert lib.vmm_linattn_cross_context(ekg.data_ptr(), evg.data_ptr(), ntok, B, T, HW, heads, dh, ctx.data_ptr(), kstat.data_ptr(), _s()) == 0
+    dq2 = torch.full((rows, hid), 7.0, device=gpu)
+    base = 0.0  # (these gradients carry a 1 / HW: next to an offset of 0.5 the comparison would measure the offset's rounding)
+    dek2, dev2 = torch.full((B, ntok, hid), base, device=gpu), torch.full((B, ntok, hid), base, device=gpu)
+    rc = lib.vmm_linattn_cross_bwd(q2g.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), ntok, ctx.data_ptr(), kstat.data_ptr(), gog.data_ptr(), hid,
+                                   dctx.data_ptr(), dq2.data_ptr(), hid, dek2.data_ptr(), dev2.data_ptr(), B, T, HW, heads, dh, _s())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    if ntok == 1:  # one key: softmax over the tokens is 1, every context row equals v / HW, sum_d softmax_d(q) = 1 -- q and k do not matter
+        assert float(dq2.abs().max()) < 1e-6 * float(ev2.grad.abs().max()) and float(dek2.abs().max()) < 1e-6 * float(ev2.grad.abs().max())
+    else:
+        assert relerr(dq2.cpu(), q2.grad) < 2e-5 and relerr(dek2.cpu() - base, ek2.grad) < 5e-5
+    assert relerr(dev2.cpu() - base, ev2.grad) < 5e-5
+
+
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 3, 24, 24, 64, 128), (3, 2, 6, 12, 128, 64), (1, 5, 16, 96, 64, 64)])
 def test_conv3x3_weight_gradient_fused_operand_bf16x3(gpu, B, T, H, W, Cin, Cout):
     """a_mode 1 of the nine-tap split-bf16 weight-gradient kernel: the layer's input is silu(h * ga[b, c] + gb[b, c]) -- GroupNorm * FiLM -> SiLU of the

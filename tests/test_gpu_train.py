@@ -40,7 +40,16 @@ def _oracle_grads(cfg_name, kw, sd, x0, t, cond, noise, mask_val=False):
 
 def _report(got, want):
     bad = []
+    # Gradients that are zero in exact arithmetic come out of autograd as rounding noise (cond_attention = 'cross-attention' with the CNN signal
+    # embedding: the tokens are copies of ONE row, vddp.py:767, so the softmax over them is uniform whatever q and k are -- the oracle's
+    # to_q / to_k / PreNorm gamma gradients there are 1e-13 .. 1e-19 of the others).  Such entries must be negligible on the device too.
+    typical = max((float(w.double().norm()) for w in want.values() if w is not None), default=0.0)
     for k, w in want.items():
+        if w is not None and float(w.double().norm()) < 1e-9 * typical:
+            g = got.get(k)
+            if g is not None and float(g.double().norm()) > 1e-6 * typical:
+                bad.append((k, f"expected a vanishing gradient, got |g| {float(g.double().norm()):.3e}"))
+            continue
         g = got.get(k)
         if w is None:
             if g is not None and float(g.abs().max()) != 0:
@@ -85,7 +94,8 @@ def test_backward_matches_reference_golden_gradients(gpu):
 
 
 @pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
-                                               ("hires64t22", False), ("circ64", False), ("circ1d16", False)])
+                                               ("hires64t22", False), ("circ64", False), ("circ1d16", False), ("cross16", False), ("cross64", False),
+                                               ("cross64", True), ("cross16s", False)])
 def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_val):
     kw, sd, model, diff = _setup(cfg_name, gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)
@@ -102,7 +112,7 @@ def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_va
 
 
 @pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", "f32"), ("lagr64", "f32"), ("lagr64", "x3"), ("lagr64", "x3+generic"), ("circ64", "f32"),
-                                               ("circ64", "x3+generic")])
+                                               ("circ64", "x3+generic"), ("cross64", "x3")])
 def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     """train_precision = "bf16x3": forward and data gradients on the split-bf16 matrix cores (3x3 data gradients through the halo kernel
     with reversed taps, 1x1 ones through the projection kernel); weight gradients: "x3" (the default) = the 3 x 3 layers on the nine-tap
@@ -138,6 +148,9 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
     plan = model.get_plan(B, T, H, W, cond.shape[1], gpu, training=True)
     used = {fn.__name__ for fn, _, _ in plan.bwd_steps}
+    if cfg_name == "cross64":  # cond_attention = 'cross-attention': the two token-only cores' backwards ran
+        assert {"vmm_cross_attention_bwd", "vmm_linattn_cross_bwd"} <= used
+        return
     assert "vmm_proj_bf16x3" in used and ("vmm_conv3x3_bf16x3" in used or cfg_name == "lagr16")
     assert ("vmm_conv_wgrad_bf16x3" in used) == (x3_wgrad == "x3+generic") and ("vmm_conv_wgrad_f32" in used) == (x3_wgrad != "x3+generic")
     assert ("vmm_conv3x3_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name == "lagr64")

@@ -167,6 +167,10 @@ SIGNATURES = {
     "vmm_linattn_apply": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_cross_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_cross_context": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
+    "vmm_cross_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_f32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
+                                c_i32, c_i32, c_ptr],
+    "vmm_linattn_cross_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32,
+                              c_i32, c_ptr],
     "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
     "vmm_sinusoidal_embed": [c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr],
     "vmm_cond_tokens": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],

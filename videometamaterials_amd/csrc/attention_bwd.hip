@@ -431,7 +431,76 @@ __global__ void linattn_bwd_tokens_kernel(const float* __restrict__ ek, const fl
   atomicAdd(&dev[((long long)b * ntok + j) * hid + head * DH + d], acc * invHW);
 }
 
+// cond_attention = 'cross-attention': only the queries are rows.  thread per (row, head): g[d] = sum_e ctx[d,e] dout[n,e],
+// dq[n,d] = scale p[d] (g[d] - sum_d' p g), p = softmax_d(q[n,:]); ctx of the frame's heads in LDS as [head][d][33]
+__global__ __launch_bounds__(256) void linattn_bwd_q_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ dout, int lddo,
+                                                            const float* __restrict__ ctx, int HW, int heads, float scale, float* __restrict__ dq,
+                                                            int lddq) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x;
+  const long long frame = blockIdx.y;
+  for (int i = tid; i < heads * DH * DH; i += 256) sm[(i / DH) * (DH + 1) + i % DH] = ctx[frame * heads * DH * DH + i];
+  __syncthreads();
+  const int rows_per_block = 256 / heads;
+  const int head = tid % heads, n = blockIdx.x * rows_per_block + tid / heads;
+  if (n >= HW || tid / heads >= rows_per_block) return;
+  const long long row = frame * HW + n;
+  float qv[DH], go[DH];
+  ld32(qv, q + row * ldq + head * DH);
+  ld32(go, dout + row * lddo + head * DH);
+  float mx = qv[0];
+#pragma unroll
+  for (int d = 1; d < DH; ++d) mx = fmaxf(mx, qv[d]);
+  float sum = 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { qv[d] = __expf(qv[d] - mx); sum += qv[d]; }
+  const float inv = 1.0f / sum;
+  float g[DH], pg = 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    const float* c = sm + (head * DH + d) * (DH + 1);
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < DH; ++e) a = fmaf(c[e], go[e], a);
+    g[d] = a;
+    qv[d] *= inv;
+    pg = fmaf(qv[d], a, pg);
+  }
+#pragma unroll
+  for (int d = 0; d < DH; ++d) g[d] = scale * qv[d] * (g[d] - pg);
+  st32(dq + row * lddq + head * DH, g);
+}
+
 }  // namespace
+
+// Backward of the linear cross-attention core (vddp.py:354-363; forward = vmm_linattn_cross_context + vmm_linattn_apply on the q rows): dq
+// [rows][heads*32] is written, the token gradients are ADDED into dek / dev [B][ntok][heads*32].  ctx / kstat as the forward left them
+// ([B*T*heads][32*32], [B*T*heads][2][32]); dctx: [B*T*heads][32*32] scratch.
+extern "C" int vmm_linattn_cross_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* ctx, const float* kstat,
+                                     const float* dout, int32_t lddo, float* dctx, float* dq, int32_t lddq, float* dek, float* dev, int32_t B, int32_t T,
+                                     int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
+  if (dh != DH || (ldq & 3) || (lddo & 3) || (lddq & 3) || !ek || !ev || ntok < 1 || !kstat || heads < 1 || heads > 32 || 256 % heads) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int nfh = B * T * heads;
+  if (int rc = vmm_zero_async(dctx, sizeof(float) * nfh * DH * DH, s)) return rc;
+  const float scale = 0.17677669529663687f;
+  const int nsplit = max(1, min((HW + LB_TILE - 1) / LB_TILE, cdiv(2048, nfh)));
+  const int rps = cdiv(cdiv(HW, nsplit), LB_TILE) * LB_TILE;
+  hipLaunchKernelGGL(linattn_bwd_dctx_kernel, dim3(cdiv(HW, rps), nfh), dim3(256), 0, s, q, ldq, dout, lddo, HW, heads, rps, scale, dctx);
+  VMM_LAUNCH_CHECK();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linattn_bwd_q_kernel, dim3(cdiv(HW, 256 / heads), B * T), dim3(256), sizeof(float) * heads * DH * (DH + 1), s, q, ldq, dout, lddo, ctx,
+                     HW, heads, scale, dq, lddq);
+  VMM_LAUNCH_CHECK();
+  const long long tot = (long long)nfh * ntok * DH;
+  hipLaunchKernelGGL(linattn_bwd_tokens_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, s, ek, ev, ntok, ctx, dctx, kstat, T, HW, heads, nfh, dek, dev);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                                  int32_t tok_per_frame, const float* bias, int32_t bias_on_cond, const float* out, const float* dout,

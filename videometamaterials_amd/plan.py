@@ -1049,9 +1049,9 @@ class _Builder:
 
     def cross_attn_block(self, name: str, x: Act, site: str, p: str, *, linear: bool, temporal: bool = False) -> Act:
         """Residual(PreNorm(attention)) with cond_attention = 'cross-attention' (vddp.py:354-363 linear, 476-485 softmax): q = to_q(LayerNorm(x)),
-        keys / values = the conditioning tokens alone (to_k / to_v rows from the batched embedding launch), then to_out + residual."""
-        if self.training:
-            raise NotImplementedError("training with cond_attention='cross-attention' is not built (forward / sampling only)")
+        keys / values = the conditioning tokens alone (to_k / to_v rows from the batched embedding launch), then to_out + residual.  Training: the
+        backward of the two cores (vmm_cross_attention_bwd, vmm_linattn_cross_bwd) between the usual projection / LayerNorm / token backwards."""
+        pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         B, T, heads = self.B, self.T, self.heads
         hid = 32 * heads
         HW = x.H * x.W
@@ -1063,20 +1063,28 @@ class _Builder:
                              "cond_attention_tokens must equal the number of frames (vddp.py:513)")
         if ntok > 32:
             raise NotImplementedError("cross-attention with more than 32 conditioning tokens")
+        if self.training and not linear and (ntok > 16 or heads != 8):
+            raise NotImplementedError("training with cond_attention='cross-attention': the softmax core's backward takes 8 heads and at most 16 tokens")
         pj = self.proj_ok(x.C, hid)
-        y = x if pj else self.layernorm(x, name + ".fn.norm.gamma")
-        wq, _ = self.pack_linear(p + ".to_q.weight", frag=2 if pj else False)
+        ln_tr = self.ln_fused_training_ok(x.C, hid)
+        fuse_ln = pj and (not self.training or ln_tr)  # (training: the LayerNorm statistics stay for the weight gradient, as at the to_qkv sites)
+        y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
+        wq, gwq = self.pack_linear(p + ".to_q.weight", frag=2 if pj else False)
         q = self.act(hid, x.H, x.W)
-        epi = {} if linear else dict(q_scale=32 ** -0.5, q_ncols=hid, rot_tab=self.rot_ptr if temporal else 0, rot_ncols=hid if temporal else 0)
-        self.conv(a1=y, w=wq, Cout=hid, out_ptr=q.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_q", proj=pj,
-                  ln_gamma=self.wraw(name + ".fn.norm.gamma") if pj else 0, **epi)
-        if not pj:
+        q_scale = 32 ** -0.5
+        epi = {} if linear else dict(q_scale=q_scale, q_ncols=hid, rot_tab=self.rot_ptr if temporal else 0, rot_ncols=hid if temporal else 0)
+        dq = self.conv(a1=y, w=wq, Cout=hid, out_ptr=q.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_q", proj=pj,
+                       ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0,
+                       **epi)
+        if not fuse_ln:
             self.free_act(y)
         o = self.act(hid, x.H, x.W)
+        ctx_n = B * T * heads * 1024
+        ctx = kstat_ptr = 0
         if linear:
-            ctx_n = B * T * heads * 1024
             ctx = self.alloc(ctx_n)
-            self.step(self.lib.vmm_linattn_cross_context, (ek, ev, ntok, B, T, HW, heads, 32, self.ptr(ctx), None), name + " context (tokens)")
+            kstat_ptr = self.ptr(self.alloc(B * T * heads * 64)) if self.training else 0
+            self.step(self.lib.vmm_linattn_cross_context, (ek, ev, ntok, B, T, HW, heads, 32, self.ptr(ctx), kstat_ptr or None), name + " context (tokens)")
             self.step(self.lib.vmm_linattn_apply, (q.ptr, hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply", nbytes=4.0 * rows * 2 * hid)
             self.free(ctx, ctx_n)
         else:
@@ -1084,12 +1092,38 @@ class _Builder:
                       name + " core (tokens)", nbytes=4.0 * rows * 2 * hid)
         self.free_act(q)
         pjo = self.proj_ok(hid, x.C)
-        wo, _ = self.pack_linear(p + ".to_out.weight", frag=2 if pjo else False)
+        wo, gwo = self.pack_linear(p + ".to_out.weight", frag=2 if pjo else False)
         out = self.act(x.C, x.H, x.W)
-        self.conv(a1=o, w=wo, bias=self.wraw(p + ".to_out.bias") if linear else 0, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr,
-                  ldres=x.ld, what=name + " to_out", proj=pjo)
+        do = self.conv(a1=o, w=wo, bias=self.wraw(p + ".to_out.bias") if linear else 0, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr,
+                       ldres=x.ld, what=name + " to_out", proj=pjo)
         self.free_act(o)
         self.plan.named[name] = out
+
+        def bwd():
+            gout, _ = self.grad_of(out)
+            self.add_into(x, gout.ptr, gout)  # residual
+            self.wgrad(do, gout.ptr, x.C, gwo, name + " to_out", gb_ptr=self.pg(p + ".to_out.bias") if linear else 0)
+            go = self.act(hid, x.H, x.W)
+            self.dgrad_1x1(p + ".to_out.weight", 0, hid, name + " to_out dgrad", a1=gout, out_ptr=go.ptr, ldo=hid, Hv=x.H, Wv=x.W)
+            gq = self.act(hid, x.H, x.W)
+            geo, gvo = self.ekv_info[site][3], self.ekv_info[site][4]
+            if linear:
+                dctx = self.alloc(ctx_n)
+                self.step(self.lib.vmm_linattn_cross_bwd, (q.ptr, hid, ek, ev, ntok, self.ptr(ctx), kstat_ptr, go.ptr, hid, self.ptr(dctx), gq.ptr, hid, geo, gvo,
+                                                           B, T, HW, heads, 32), name + " core bwd (tokens)", nbytes=4.0 * rows * 4 * hid)
+                self.tmp_free((dctx, ctx_n))
+            else:
+                self.step(self.lib.vmm_cross_attention_bwd,
+                          (q.ptr, hid, ek, ev, ntok, self.bias_ptr if temporal else None, go.ptr, hid, self.rot_ptr if temporal else None, C.c_float(q_scale),
+                           gq.ptr, hid, geo, gvo, self.dbias_ptr if temporal else None, B, T, HW, heads, 32), name + " core bwd (tokens)",
+                          nbytes=4.0 * rows * 5 * hid)
+            self.tmp_free(go)
+            gy = self.qkv_backward(dq, p + ".to_q.weight", x, gq, gwq, name + " to_q")
+            self.tmp_free(gq)
+            self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+            self.tmp_free(gy)
+            self.token_kv_bwd(site)
+        self.on_backward(bwd, pg_start, uj_start)
         return out
 
     # ---------------------------------------------------------------- job tables
