@@ -391,6 +391,9 @@ int vmm_rows_layernorm_affine(const float* x, const float* w, const float* b, fl
 /* out[b,:] = mask[b] ? null[:] : x[b,:]   then (+ add[b,:])   (vddp.py:784-788) */
 int vmm_select_add(const float* x, const float* null_row, const uint8_t* mask, const float* add, float* out, int32_t B,
                    int32_t D, vmm_stream_t stream);
+/* cond_to_time = 'concat' (vddp.py:788-789): out[b, :D] = t[b, :], out[b, D:2D] = mask[b] ? null[:] : x[b, :] */
+int vmm_select_concat(const float* x, const float* null_row, const uint8_t* mask, const float* t, float* out, int32_t B, int32_t D,
+                      vmm_stream_t stream);
 /* rotate token keys for temporal attention: ek[b, n, h*dh + d] with position n (vddp.py:470-471) */
 int vmm_rotary_rows(float* x, const float* rot_tab, int32_t B, int32_t N, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* relative position bias (vddp.py:70-108): embedding gather through the INTEGER T5 bucket table [n*n] that the host computes
@@ -503,6 +506,9 @@ int vmm_rows_layernorm_affine_bwd(const float* x, const float* w, const float* d
                                   float eps, vmm_stream_t stream);
 int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dadd, int32_t B, int32_t D,
                        vmm_stream_t stream);
+/* backward of vmm_select_concat: dout [B][2D]; ADDS into dx / dnull_row / dt (each may be NULL) */
+int vmm_select_concat_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dt, int32_t B, int32_t D,
+                          vmm_stream_t stream);
 int vmm_relpos_bias_bwd(const float* dbias, const int32_t* buckets, int32_t n, int32_t heads, float* demb, vmm_stream_t stream);
 int vmm_tokens_from_hidden_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dhidden,
                                float* dnull_token, vmm_stream_t stream);

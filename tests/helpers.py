@@ -46,6 +46,10 @@ CONFIGS = {
                      per_frame_cond=False), (2, 11, 16, 16), 40),
     "cross16s": (dict(dim=16, channels=3, cond_attention="cross-attention", cond_attention_tokens=9, use_temporal_attention_cond=False,
                       per_frame_cond=False), (2, 5, 16, 16), 51),  # spatial sites only: any number of tokens
+    # cond_to_time = 'concat' (vddp.py:670, 788-789): the ResnetBlock mlps read cat(t, hidden); per-frame conditioning and the CNN embedding
+    "concat16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                      per_frame_cond=True, cond_bias=True, cond_to_time="concat"), (2, 11, 16, 16), 11),
+    "concat16c": (dict(dim=16, channels=1, cond_to_time="concat"), (2, 4, 16, 16), 51),
     "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
 }

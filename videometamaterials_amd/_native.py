@@ -115,6 +115,7 @@ SIGNATURES = {
     "vmm_cond_tokens_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_rows_layernorm_affine_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr],
     "vmm_select_add_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_select_concat_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     "vmm_relpos_bias_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_tokens_from_hidden_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv1d_k4s2_silu_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
@@ -176,6 +177,7 @@ SIGNATURES = {
     "vmm_cond_tokens": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_rows_layernorm_affine": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr],
     "vmm_select_add": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_select_concat": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     "vmm_rotary_rows": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_relpos_bias": [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_conv1d_k4s2_silu": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],

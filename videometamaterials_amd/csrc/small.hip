@@ -187,6 +187,16 @@ __global__ void select_add_kernel(const float* __restrict__ x, const float* __re
   out[i] = v;
 }
 
+// cond_to_time = 'concat' (vddp.py:789): out[b, :D] = t[b, :], out[b, D:] = mask ? null : x[b, :]
+__global__ void select_concat_kernel(const float* __restrict__ x, const float* __restrict__ null_row, const uint8_t* __restrict__ mask,
+                                     const float* __restrict__ t, float* __restrict__ out, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  out[(long long)b * 2 * D + d] = t[i];
+  out[(long long)b * 2 * D + D + d] = (mask && mask[b]) ? null_row[d] : x[i];
+}
+
 // in-place interleaved-pair rotation of x[b, n, h*dh + d] by position n; thread per pair
 __global__ void rotary_rows_kernel(float* __restrict__ x, const float* __restrict__ tab, int B, int N, int heads, int dh) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,6 +324,14 @@ extern "C" int vmm_rows_layernorm_affine(const float* x, const float* w, const f
 extern "C" int vmm_select_add(const float* x, const float* null_row, const uint8_t* mask, const float* add, float* out, int32_t B,
                               int32_t D, vmm_stream_t stream) {
   hipLaunchKernelGGL(select_add_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, null_row, mask, add, out, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_select_concat(const float* x, const float* null_row, const uint8_t* mask, const float* t, float* out, int32_t B, int32_t D,
+                                 vmm_stream_t stream) {
+  if (!x || !t || !out || (mask && !null_row)) return -1;
+  hipLaunchKernelGGL(select_concat_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, null_row, mask, t, out, B, D);
   VMM_LAUNCH_CHECK();
   return 0;
 }

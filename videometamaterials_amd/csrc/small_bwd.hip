@@ -154,6 +154,20 @@ __global__ void select_add_bwd_kernel(const float* __restrict__ dout, const uint
   if (dnull) dnull[d] += gn;
 }
 
+// out[b, :D] = t[b, :], out[b, D:] = mask ? null : x[b, :]   (cond_to_time = 'concat')
+__global__ void select_concat_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                         float* __restrict__ dnull, float* __restrict__ dt, int B, int D) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float gn = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = dout[(long long)b * 2 * D + D + d];
+    if (mask && mask[b]) gn += g; else if (dx) dx[b * D + d] += g;
+    if (dt) dt[b * D + d] += dout[(long long)b * 2 * D + d];
+  }
+  if (dnull) dnull[d] += gn;
+}
+
 __global__ void relpos_bias_bwd_kernel(const float* __restrict__ dbias, const int32_t* __restrict__ buckets, int n, int heads,
                                        float* __restrict__ demb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,6 +343,12 @@ extern "C" int vmm_rows_layernorm_affine_bwd(const float* x, const float* w, con
 extern "C" int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dadd, int32_t B, int32_t D,
                                   vmm_stream_t stream) {
   hipLaunchKernelGGL(select_add_bwd_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dout, mask, dx, dnull_row, dadd, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_select_concat_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dt, int32_t B, int32_t D,
+                                     vmm_stream_t stream) {
+  hipLaunchKernelGGL(select_concat_bwd_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dout, mask, dx, dnull_row, dt, B, D);
   VMM_LAUNCH_CHECK();
   return 0;
 }

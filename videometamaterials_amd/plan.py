@@ -1212,8 +1212,11 @@ class _Builder:
         # ---- conditioning / time embedding (vddp.py:745-795)
         se = self.alloc(B * m.dim)
         self.step(lib.vmm_sinusoidal_embed, (self.ptr(time_off), B, m.dim, C.c_float(-(math.log(10000) / (m.dim // 2 - 1))), self.ptr(se)), "time sinusoid")
-        h1, t2, hidden, temb = self.alloc(B * td), self.alloc(B * td), self.alloc(B * td), self.alloc(B * td)
-        gh1, gt2, ghidden, gtemb = [self.scratch(B * td) for _ in range(4)] if tr else (0, 0, 0, 0)
+        concat = getattr(m, "cond_to_time", "add") == "concat"  # vddp.py:786-789: t = cat(t, hidden) instead of t + hidden; the ResnetBlock mlps take 2 td inputs
+        tw = 2 * td if concat else td
+        h1, t2, hidden, temb = self.alloc(B * td), self.alloc(B * td), self.alloc(B * td), self.alloc(B * tw)
+        gh1, gt2, ghidden = [self.scratch(B * td) for _ in range(3)] if tr else (0, 0, 0)
+        gtemb = self.scratch(B * tw) if tr else 0
         ntok = self.ntok = m.cond_attention_tokens
         tokens = self.alloc(B * ntok * D) if m.cond_attention != "none" else None
         self.tokens_ptr = self.ptr(tokens) if tokens is not None else 0
@@ -1286,7 +1289,8 @@ class _Builder:
                 cond_bwd.append(cond_b)
         self.dense_level(lvl1, "embed level 1")
         self.dense_level(lvl2, "embed level 2")
-        self.step(lib.vmm_select_add, (self.ptr(hidden), self.wraw("null_text_hidden"), self.ptr(mask_off), self.ptr(t2), self.ptr(temb), B, td), "t + hidden")
+        self.step(lib.vmm_select_concat if concat else lib.vmm_select_add,
+                  (self.ptr(hidden), self.wraw("null_text_hidden"), self.ptr(mask_off), self.ptr(t2), self.ptr(temb), B, td), "t | hidden" if concat else "t + hidden")
         self._touch("null_text_hidden")
 
         # level 3: every ResnetBlock.mlp and every to_k/to_v on the tokens, one launch
@@ -1300,10 +1304,10 @@ class _Builder:
             fo = self.alloc(B * n_out)
             gfo = self.scratch(B * n_out) if tr else 0
             film[rn] = (self.ptr(fo), gfo)
-            lvl3.append(dict(x=self.ptr(temb), w=self.wraw(rn + ".mlp.1.weight"), b=self.wraw(rn + ".mlp.1.bias"), y=self.ptr(fo), rows=B, K=td, N=n_out, act_in=1))
+            lvl3.append(dict(x=self.ptr(temb), w=self.wraw(rn + ".mlp.1.weight"), b=self.wraw(rn + ".mlp.1.bias"), y=self.ptr(fo), rows=B, K=tw, N=n_out, act_in=1))
             if tr:
                 self.bwd_lvl3.append(dict(x=self.ptr(temb), w=self.wraw(rn + ".mlp.1.weight"), dy=gfo, dx=gtemb, dw=self.pg(rn + ".mlp.1.weight"),
-                                          db=self.pg(rn + ".mlp.1.bias"), rows=B, K=td, N=n_out, act_in=1))
+                                          db=self.pg(rn + ".mlp.1.bias"), rows=B, K=tw, N=n_out, act_in=1))
         self.ekv_info: Dict[str, tuple] = {}
         rot_sites: List[int] = []
 
@@ -1344,7 +1348,8 @@ class _Builder:
 
         def embed_bwd():
             self.dense_bwd_level(self.bwd_lvl3, "embed level 3 bwd")
-            self.step(lib.vmm_select_add_bwd, (gtemb, self.ptr(mask_off), ghidden, self.pg("null_text_hidden") or None, gt2, B, td), "t + hidden bwd")
+            self.step(lib.vmm_select_concat_bwd if concat else lib.vmm_select_add_bwd,
+                      (gtemb, self.ptr(mask_off), ghidden, self.pg("null_text_hidden") or None, gt2, B, td), "t | hidden bwd" if concat else "t + hidden bwd")
             self.dense_bwd_level(bwd_lvl2, "embed level 2 bwd")
             self.dense_bwd_level(bwd_lvl1, "embed level 1 bwd")
             for f_ in cond_bwd:

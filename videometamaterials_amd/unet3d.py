@@ -77,8 +77,8 @@ class Unet3D(nn.Module):
             raise NotImplementedError("cond_att_GRU (ablation-only GRU embedding, vddp.py:546-549) is not built")
         if padding_mode not in ("zeros", "circular", "circular_1d"):
             raise ValueError(f"padding_mode {padding_mode!r}: 'zeros', 'circular' or 'circular_1d' (vddp.py:153-243)")
-        if cond_to_time != "add":
-            raise NotImplementedError("cond_to_time='concat' is not built; model.yaml uses 'add'")
+        if cond_to_time not in ("add", "concat"):
+            raise ValueError("cond_to_time must be 'add' or 'concat' (vddp.py:786-789)")
         if attn_dim_head != 32:
             raise NotImplementedError("attention kernels are specialised for dim_head = 32 (model.yaml:16)")
         self.channels = channels
@@ -169,6 +169,7 @@ class Unet3D(nn.Module):
 
     def _build_parameters(self):
         heads, td, cd = self.attn_heads, self.time_dim, self.cond_dim
+        te = td + cd if self.cond_to_time == "concat" else cd  # ResnetBlock.mlp input width (vddp.py:670)
         _attach(self, "time_rel_pos_bias.relative_attention_bias.weight", torch.randn(32, heads))
         k = self.init_kernel_size
         self._conv("init_conv", self.init_dim, self.channels, k)
@@ -187,21 +188,21 @@ class Unet3D(nn.Module):
             self._linear("cond_token_to_hidden.3", td, cd)
         n_lvl = len(self.in_out)
         for i, (ci, co) in enumerate(self.in_out):
-            self._resnet(f"downs.{i}.0", ci, co, cd)
-            self._resnet(f"downs.{i}.1", co, co, cd)
+            self._resnet(f"downs.{i}.0", ci, co, te)
+            self._resnet(f"downs.{i}.1", co, co, te)
             if self.use_sparse_linear_attn:
                 self._linear_attn(f"downs.{i}.2.fn", co)
             self._softmax_attn(f"downs.{i}.3.fn", co, True, self.attn_dim_head)
             if i < n_lvl - 1:
                 self._conv(f"downs.{i}.4", co, co, 4)
         mid = self.in_out[-1][1]
-        self._resnet("mid_block1", mid, mid, cd)
+        self._resnet("mid_block1", mid, mid, te)
         self._softmax_attn("mid_spatial_attn.fn", mid, False, 32)
         self._softmax_attn("mid_temporal_attn.fn", mid, True, self.attn_dim_head)
-        self._resnet("mid_block2", mid, mid, cd)
+        self._resnet("mid_block2", mid, mid, te)
         for i, (ci, co) in enumerate(reversed(self.in_out)):
-            self._resnet(f"ups.{i}.0", co * 2, ci, cd)
-            self._resnet(f"ups.{i}.1", ci, ci, cd)
+            self._resnet(f"ups.{i}.0", co * 2, ci, te)
+            self._resnet(f"ups.{i}.1", ci, ci, te)
             if self.use_sparse_linear_attn:
                 self._linear_attn(f"ups.{i}.2.fn", ci)
             self._softmax_attn(f"ups.{i}.3.fn", ci, True, self.attn_dim_head)
