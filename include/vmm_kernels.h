@@ -394,6 +394,14 @@ int vmm_select_add(const float* x, const float* null_row, const uint8_t* mask, c
 /* cond_to_time = 'concat' (vddp.py:788-789): out[b, :D] = t[b, :], out[b, D:2D] = mask[b] ? null[:] : x[b, :] */
 int vmm_select_concat(const float* x, const float* null_row, const uint8_t* mask, const float* t, float* out, int32_t B, int32_t D,
                       vmm_stream_t stream);
+/* focus_present_mask (vddp.py:431, 438-443, 514-524; Unet3D.forward's `focus_present_mask` / `prob_focus_present`): a sample that focuses on the
+ * present attends to its own frame only, i.e. its attention output is its value row.  Row patches around the unchanged temporal attention
+ * kernels; sample of a row = row / rows_per_sample; focus [B] bytes; ncols, lda, ldb multiples of 4:
+ *   mode 0: b[row] = a[row] where focus        (forward: a = v third of the qkv rows, b = attention output)
+ *   mode 1: b[row] = focus ? 0 : a[row]         (backward: the dO the core's backward sees)
+ *   mode 2: b[row] += a[row] where focus        (backward: dv += dO) */
+int vmm_focus_rows(int32_t mode, const float* a, int32_t lda, float* b, int32_t ldb, const uint8_t* focus, int32_t B, int32_t rows_per_sample,
+                   int32_t ncols, vmm_stream_t stream);
 /* rotate token keys for temporal attention: ek[b, n, h*dh + d] with position n (vddp.py:470-471) */
 int vmm_rotary_rows(float* x, const float* rot_tab, int32_t B, int32_t N, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* relative position bias (vddp.py:70-108): embedding gather through the INTEGER T5 bucket table [n*n] that the host computes

@@ -241,16 +241,20 @@ def softmax_attention(
     tokens: Optional[Tensor],
     rotary: bool,
     dim_head: int,
+    focus: Optional[Tensor] = None,
 ) -> Tensor:
     """Attention (vddp.py:396-535) on x of shape (b, b2, n, c).
 
     temporal use: b2 = pixels, n = frames, rotary=True, pos_bias given.
     mid spatial use: b2 = frames, n = pixels, rotary=False, pos_bias None.
-    focus_present_mask is inert on every shipped config."""
+    focus: focus_present_mask (b,) bool or None (vddp.py:431, 438-443, 514-524): samples that "focus on the present" attend to their own
+    position only.  Inert on every shipped config (prob_focus_present = 0)."""
     b, b2, n, c = x.shape
     heads, dh = cfg.attn_heads, dim_head
     assert dh <= 32, "rotary restatement rotates the whole head (rot_dim == dim_head <= 32)"
     qkv = F.linear(x, sd[p + ".to_qkv.weight"])
+    if focus is not None and (cfg.cond_attention == "none" or tokens is None) and bool(focus.all()):  # vddp.py:438-443
+        return F.linear(qkv.chunk(3, dim=-1)[-1], sd[p + ".to_out.weight"])
     q, k, v = (t.reshape(b, b2, n, heads, dh).transpose(2, 3) for t in qkv.chunk(3, dim=-1))
     stacked = cfg.cond_attention == "self-stacked" and tokens is not None
     if rotary:
@@ -287,6 +291,10 @@ def softmax_attention(
                 sim[..., :n] = sim[..., :n] + pos_bias
         else:
             sim = sim + pos_bias
+    if focus is not None and bool(focus.any()):  # vddp.py:514-524 (an (n x n) mask: shape-errors against stacked token keys, like the reference)
+        eye = torch.eye(n, dtype=torch.bool)
+        keep = torch.where(focus.reshape(b, 1, 1, 1, 1), eye.reshape(1, 1, 1, n, n), torch.ones(1, 1, 1, n, n, dtype=torch.bool))
+        sim = sim.masked_fill(~keep, -torch.finfo(sim.dtype).max)
     sim = sim - sim.amax(dim=-1, keepdim=True)
     attn = sim.softmax(dim=-1)
     out = torch.einsum("...ij,...jd->...id", attn, v)
@@ -294,12 +302,12 @@ def softmax_attention(
     return F.linear(out, sd[p + ".to_out.weight"])
 
 
-def temporal_attention_block(sd, p: str, x: Tensor, cfg, pos_bias, tokens) -> Tensor:
+def temporal_attention_block(sd, p: str, x: Tensor, cfg, pos_bias, tokens, focus: Optional[Tensor] = None) -> Tensor:
     """Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention))) (vddp.py:615,630,680)."""
     B, C, T, H, W = x.shape
     y = channel_layernorm(x, sd[p + ".fn.norm.gamma"])
     y = y.permute(0, 3, 4, 2, 1).reshape(B, H * W, T, C)
-    y = softmax_attention(sd, p + ".fn.fn.fn", y, cfg, pos_bias=pos_bias, tokens=tokens, rotary=True, dim_head=cfg.attn_dim_head)
+    y = softmax_attention(sd, p + ".fn.fn.fn", y, cfg, pos_bias=pos_bias, tokens=tokens, rotary=True, dim_head=cfg.attn_dim_head, focus=focus)
     y = y.reshape(B, H, W, T, C).permute(0, 4, 3, 1, 2)
     return y + x
 
@@ -351,9 +359,10 @@ def embed_condition(sd, cfg: UnetCfg, cond: Tensor, null_mask: Tensor):
 
 # --------------------------------------------------------------------------- the network
 def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor, cond: Tensor, null_mask: Tensor,
-                   taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                   taps: Optional[Dict[str, Tensor]] = None, focus: Optional[Tensor] = None) -> Tensor:
     """Unet3D.forward (vddp.py:730-821) with the CFG drop mask passed explicitly
     (null_cond_prob=0 -> all False, =1 -> all True; vddp.py:55-61).
+    focus: focus_present_mask (b,) bool -- reaches every temporal attention except init_temporal_attn (vddp.py:743, 803, 809, 817).
     `taps`, if given, receives the output of every block (debug aid for the per-block GPU parity tests)."""
 
     def tap(name, v):
@@ -383,20 +392,20 @@ def unet3d_forward(sd: Dict[str, Tensor], cfg: UnetCfg, x: Tensor, time: Tensor,
         x = tap(f"downs.{i}.0", resnet_block(sd, f"downs.{i}.0", x, t, g, pm))
         x = tap(f"downs.{i}.1", resnet_block(sd, f"downs.{i}.1", x, t, g, pm))
         x = tap(f"downs.{i}.2", linear_attention_block(sd, f"downs.{i}.2", x, cfg, tokens))
-        x = tap(f"downs.{i}.3", temporal_attention_block(sd, f"downs.{i}.3", x, cfg, bias, tokens_t))
+        x = tap(f"downs.{i}.3", temporal_attention_block(sd, f"downs.{i}.3", x, cfg, bias, tokens_t, focus))
         skips.append(x)
         if i < n_lvl - 1:
             x = frame_conv(x, sd[ref_key(pm, f"downs.{i}.4.weight")], sd[ref_key(pm, f"downs.{i}.4.bias")], stride=2, pad=1, mode=pm)
     x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g, pm))
     x = tap("mid_spatial_attn", mid_spatial_attention_block(sd, "mid_spatial_attn", x, cfg, tokens))
-    x = tap("mid_temporal_attn", temporal_attention_block(sd, "mid_temporal_attn", x, cfg, bias, tokens_t))
+    x = tap("mid_temporal_attn", temporal_attention_block(sd, "mid_temporal_attn", x, cfg, bias, tokens_t, focus))
     x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g, pm))
     for i in range(n_lvl):
         x = torch.cat((x, skips.pop()), dim=1)
         x = tap(f"ups.{i}.0", resnet_block(sd, f"ups.{i}.0", x, t, g, pm))
         x = tap(f"ups.{i}.1", resnet_block(sd, f"ups.{i}.1", x, t, g, pm))
         x = tap(f"ups.{i}.2", linear_attention_block(sd, f"ups.{i}.2", x, cfg, tokens))
-        x = tap(f"ups.{i}.3", temporal_attention_block(sd, f"ups.{i}.3", x, cfg, bias, tokens_t))
+        x = tap(f"ups.{i}.3", temporal_attention_block(sd, f"ups.{i}.3", x, cfg, bias, tokens_t, focus))
         if i < n_lvl - 1:
             x = frame_conv_transpose(x, sd[ref_key(pm, f"ups.{i}.4.weight")], sd[ref_key(pm, f"ups.{i}.4.bias")], mode=pm)
     x = torch.cat((x, r), dim=1)

@@ -58,6 +58,26 @@ def unet_goldens(only=None):
         print(cfg_name, {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
 
 
+FOCUS_CASES = {"plumb16": ([1, 0], [1, 1]), "focus16s": ([1, 0, 1], [1, 1, 1], [0, 1, 0])}
+
+
+def focus_goldens():
+    """Non-trivial focus_present_mask (vddp.py:431, 438-443, 514-524) where the reference accepts one: temporal attentions without tokens."""
+    out = {}
+    for cfg_name, masks in FOCUS_CASES.items():
+        model = build(cfg_name)
+        x, t, cond = helpers.synth_inputs(cfg_name)
+        with torch.no_grad():
+            for m in masks:
+                fm = torch.tensor(m, dtype=torch.bool)
+                tag = "".join(str(v) for v in m)
+                out[f"{cfg_name}/{tag}"] = model(x, t, cond=cond, null_cond_prob=0.0, focus_present_mask=fm).numpy()
+                out[f"{cfg_name}/w5_{tag}"] = model.forward_with_guidance_scale(x, t, cond=cond, focus_present_mask=fm).numpy()
+            out[f"{cfg_name}/prob1"] = model(x, t, cond=cond, null_cond_prob=0.0, prob_focus_present=1.0).numpy()
+    np.savez(os.path.join(HERE, "unet_focus.npz"), **out)
+    print({k: float(np.abs(v).mean()) for k, v in out.items()})
+
+
 def diffusion_goldens():
     cfg_name = "lagr16"
     model = build(cfg_name)
@@ -176,6 +196,8 @@ if __name__ == "__main__":
         tabs["bucket_by_distance_m40_40"] = relpos_rows()
         json.dump(tabs, open(path, "w"))
         print("relpos row written")
+    elif sys.argv[1:] == ["--focus"]:
+        focus_goldens()
     elif len(sys.argv) > 1:  # python make_golden.py <config> [...]: only the Unet3D goldens of the named configs (adding one leaves the rest untouched)
         unet_goldens(only=sys.argv[1:])
     else:

@@ -50,6 +50,9 @@ CONFIGS = {
     "concat16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, cond_to_time="concat"), (2, 11, 16, 16), 11),
     "concat16c": (dict(dim=16, channels=1, cond_to_time="concat"), (2, 4, 16, 16), 51),
+    # conditioning tokens at the spatial sites only: the temporal attentions see no tokens, so a non-trivial focus_present_mask is legal (vddp.py:514-524)
+    "focus16s": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=9, use_temporal_attention_cond=False,
+                      per_frame_cond=False), (3, 5, 16, 16), 51),
     "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
 }

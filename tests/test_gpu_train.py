@@ -111,6 +111,39 @@ def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_va
     assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("cfg_name,focus", [("plumb16", [True, False]), ("focus16s", [True, False, True]), ("focus16s", [True, True, True])])
+def test_gradients_with_focus_present_mask_match_oracle_autograd(gpu, cfg_name, focus, precision):
+    """Training with a non-trivial focus_present_mask (vddp.py:1622-1628 passes it through p_losses): the masked samples' attention is the
+    identity on the value rows -- nothing flows into their queries / keys / positional bias, dv = dO.  l2 loss, every parameter."""
+    import videometamaterials_amd as vm
+    from oracle import diffusion_oracle as do
+    from oracle import unet3d_oracle as uo
+    kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    sd = helpers.synth_state_dict(helpers.load_shapes(cfg_name))
+    model = vm.Unet3D(**kw)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(gpu)
+    model.train_precision = precision
+    diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=256, loss_type="l2", sampling_timesteps=256).to(gpu)
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.rand(x.shape, generator=g) * 2 - 1
+    noise = torch.randn(x.shape, generator=g)
+    fm = torch.tensor(focus)
+    cfg = uo.UnetCfg(**kw)
+    sdg = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
+    want_loss = do.p_losses(do.schedule_buffers(256), lambda a, b: uo.unet3d_forward(sdg, cfg, a, b, cond, torch.zeros(B, dtype=torch.bool), focus=fm), x0, t,
+                            noise, loss_type="l2")
+    want_loss.backward()
+    want = {k: v.grad for k, v in sdg.items() if v.requires_grad}
+    loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0, focus_present_mask=fm.to(gpu))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want_loss.detach())) < 1e-4 * abs(float(want_loss.detach()))
+    bad = _report({model._ref_key(k): p.grad for k, p in model.named_parameters()}, want)
+    assert not bad, f"{len(bad)} of {len(want)} parameter gradients off:\n" + "\n".join(f"  {k}: {v}" for k, v in bad[:40])
+
+
 @pytest.mark.parametrize("cfg_name,x3_wgrad", [("lagr16", "f32"), ("lagr64", "f32"), ("lagr64", "x3"), ("lagr64", "x3+generic"), ("circ64", "f32"),
                                                ("circ64", "x3+generic"), ("cross64", "x3")])
 def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):

@@ -93,6 +93,46 @@ def test_bf16_throughput_mode_against_reference_golden(gpu, cfg_name):
         model(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("cfg_name", ["plumb16", "focus16s"])
+def test_focus_present_mask_matches_reference_golden(gpu, cfg_name, precision):
+    """A non-trivial focus_present_mask / prob_focus_present (vddp.py:431, 438-443, 514-524): masked samples attend to their own frame only at every
+    temporal attention except init_temporal_attn.  Outputs of the real reference for partial and full masks, alone and under guidance."""
+    gold = np.load(os.path.join(helpers.GOLDEN_DIR, "unet_focus.npz"))
+    model = make_model(cfg_name, gpu, precision)
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    xg, tg, cg = x.to(gpu), t.to(gpu), cond.to(gpu)
+    tags = sorted(k.split("/")[1] for k in gold.files if k.startswith(cfg_name + "/") and k.split("/")[1][0] in "01")
+    with torch.no_grad():
+        for tag in tags:
+            fm = torch.tensor([c == "1" for c in tag])
+            got = model(xg, tg, cond=cg, null_cond_prob=0.0, focus_present_mask=fm.to(gpu)).cpu()
+            assert helpers.rel_err(got, torch.from_numpy(gold[f"{cfg_name}/{tag}"])) < TOL, tag
+            got = model.forward_with_guidance_scale(xg, tg, cond=cg, focus_present_mask=fm.to(gpu)).cpu()
+            assert helpers.rel_err(got, torch.from_numpy(gold[f"{cfg_name}/w5_{tag}"])) < TOL, tag
+        got = model(xg, tg, cond=cg, null_cond_prob=0.0, prob_focus_present=1.0).cpu()
+        assert helpers.rel_err(got, torch.from_numpy(gold[f"{cfg_name}/prob1"])) < TOL
+        # an all-False mask is the plain forward (and takes the regular plan)
+        plain = model(xg, tg, cond=cg, null_cond_prob=0.0).cpu()
+        got = model(xg, tg, cond=cg, null_cond_prob=0.0, focus_present_mask=torch.zeros(x.shape[0], dtype=torch.bool, device=gpu)).cpu()
+        assert torch.equal(got, plain)
+        with pytest.raises(ValueError):
+            model(xg, tg, cond=cg, focus_present_mask=torch.ones(x.shape[0] + 1, dtype=torch.bool, device=gpu))
+
+
+def test_focus_present_mask_with_temporal_tokens_is_rejected_like_the_reference(gpu):
+    """With conditioning tokens at the temporal attentions the reference's (frames x frames) mask cannot broadcast against the stacked scores
+    (vddp.py:514-524 raises): a ValueError here; an all-False mask stays inert."""
+    model = make_model("lagr16", gpu)
+    x, t, cond = helpers.synth_inputs("lagr16")
+    xg, tg, cg = x.to(gpu), t.to(gpu), cond.to(gpu)
+    with torch.no_grad():
+        plain = model(xg, tg, cond=cg).cpu()
+        assert torch.equal(model(xg, tg, cond=cg, focus_present_mask=torch.zeros(x.shape[0], dtype=torch.bool, device=gpu)).cpu(), plain)
+        with pytest.raises(ValueError, match="focus_present_mask"):
+            model(xg, tg, cond=cg, focus_present_mask=torch.tensor([True, False], device=gpu))
+
+
 def test_guidance_scales_and_state_dict_roundtrip(gpu):
     model = make_model("lagr16", gpu)
     gold = np.load(os.path.join(helpers.GOLDEN_DIR, "unet_lagr16.npz"))

@@ -44,6 +44,30 @@ def test_guidance_scales():
             assert helpers.rel_err(got, torch.from_numpy(gold[key])) < 5 * RTOL
 
 
+@pytest.mark.parametrize("cfg_name", ["plumb16", "focus16s"])
+def test_focus_present_mask_matches_reference(cfg_name):
+    """A non-trivial focus_present_mask (vddp.py:431, 438-443, 514-524) on the configs where the reference accepts one (no tokens at the temporal
+    sites): masked samples attend to their own frame only; all-masked takes the values-only shortcut."""
+    cfg, sd, _ = _load(cfg_name)
+    gold = np.load(os.path.join(helpers.GOLDEN_DIR, "unet_focus.npz"))
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    B = x.shape[0]
+    tags = sorted(k.split("/")[1] for k in gold.files if k.startswith(cfg_name + "/") and k.split("/")[1][0] in "01")
+    assert len(tags) >= 2
+    with torch.no_grad():
+        for tag in tags:
+            fm = torch.tensor([c == "1" for c in tag])
+            e_c = uo.unet3d_forward(sd, cfg, x, t, cond, torch.zeros(B, dtype=torch.bool), focus=fm)
+            assert helpers.rel_err(e_c, torch.from_numpy(gold[f"{cfg_name}/{tag}"])) < RTOL, tag
+            e_n = uo.unet3d_forward(sd, cfg, x, t, cond, torch.ones(B, dtype=torch.bool), focus=fm)
+            assert helpers.rel_err(e_n + (e_c - e_n) * 5.0, torch.from_numpy(gold[f"{cfg_name}/w5_{tag}"])) < 5 * RTOL, tag
+        ones = uo.unet3d_forward(sd, cfg, x, t, cond, torch.zeros(B, dtype=torch.bool), focus=torch.ones(B, dtype=torch.bool))
+        assert helpers.rel_err(ones, torch.from_numpy(gold[f"{cfg_name}/prob1"])) < RTOL
+        # ... and it differs from the unmasked output (the mask is not inert here)
+        plain = uo.unet3d_forward(sd, cfg, x, t, cond, torch.zeros(B, dtype=torch.bool))
+        assert helpers.rel_err(ones, plain) > 1e-2
+
+
 def test_integer_tables_bit_exact():
     with open(os.path.join(helpers.GOLDEN_DIR, "tables.json")) as f:
         tabs = json.load(f)

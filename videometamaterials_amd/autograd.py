@@ -14,9 +14,9 @@ from .plan import _stream
 
 class _UnetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, plan, names, x, time, cond, mask, *params):
+    def forward(ctx, model, plan, names, x, time, cond, mask, focus, *params):
         ctx.plan, ctx.names, ctx.model = plan, names, model
-        out = plan.run(x, time, cond, mask)
+        out = plan.run(x, time, cond, mask, focus)
         return out.clone()
 
     @staticmethod
@@ -26,15 +26,15 @@ class _UnetFn(torch.autograd.Function):
         pl.backward(dout.contiguous(), want_dx=want_dx)
         views = pl.grad_views(dict(ctx.model.named_parameters()))
         grads = tuple(views[n].clone() if n in views else None for n in ctx.names)
-        return (None, None, None, pl.dx.clone() if want_dx else None, None, None, None) + grads
+        return (None, None, None, pl.dx.clone() if want_dx else None, None, None, None, None) + grads
 
 
-def unet_forward_with_grad(model, x, time, cond, mask):
+def unet_forward_with_grad(model, x, time, cond, mask, focus=None):
     B, _, T, H, W = x.shape
-    pl = model.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True)
+    pl = model.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True, focus=focus is not None)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     names = tuple(n for n, _ in named)
-    return _UnetFn.apply(model, pl, names, x.contiguous(), time, cond.contiguous(), mask, *[p for _, p in named])
+    return _UnetFn.apply(model, pl, names, x.contiguous(), time, cond.contiguous(), mask, focus, *[p for _, p in named])
 
 
 class _NoiseLossFn(torch.autograd.Function):

@@ -197,6 +197,31 @@ __global__ void select_concat_kernel(const float* __restrict__ x, const float* _
   out[(long long)b * 2 * D + D + d] = (mask && mask[b]) ? null_row[d] : x[i];
 }
 
+// focus_present_mask (vddp.py:431, 438-443, 514-524): a sample that "focuses on the present" attends to its own frame only -- softmax over
+// one unmasked key is exactly 1, so its attention output IS its value row.  Row-wise patches around the unchanged attention kernels, float4
+// per thread, sample of a row = row / rows_per_sample:
+//   mode 0 (forward):   b[row] = a[row]      where focus[sample]   (a = the v third of the qkv rows, b = the attention output)
+//   mode 1 (backward):  b[row] = focus ? 0 : a[row]                (dO for the core's backward: masked samples contribute nothing through p)
+//   mode 2 (backward):  b[row] += a[row]     where focus[sample]   (dv += dO)
+__global__ void focus_rows_kernel(int mode, const float* __restrict__ a, int lda, float* __restrict__ b, int ldb, const uint8_t* __restrict__ focus,
+                                  long long rows, int rows_per_sample, int ncols4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ncols4) return;
+  const long long row = i / ncols4;
+  const int c = (int)(i - row * ncols4) * 4;
+  const bool f = focus[row / rows_per_sample] != 0;
+  const f32x4* ap = reinterpret_cast<const f32x4*>(a + row * lda + c);
+  f32x4* bp = reinterpret_cast<f32x4*>(b + row * ldb + c);
+  if (mode == 0) {
+    if (f) *bp = *ap;
+  } else if (mode == 1) {
+    *bp = f ? f32x4{0.f, 0.f, 0.f, 0.f} : *ap;
+  } else if (f) {
+    const f32x4 x = *ap, y = *bp;
+    *bp = f32x4{x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+  }
+}
+
 // in-place interleaved-pair rotation of x[b, n, h*dh + d] by position n; thread per pair
 __global__ void rotary_rows_kernel(float* __restrict__ x, const float* __restrict__ tab, int B, int N, int heads, int dh) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,6 +357,16 @@ extern "C" int vmm_select_concat(const float* x, const float* null_row, const ui
                                  vmm_stream_t stream) {
   if (!x || !t || !out || (mask && !null_row)) return -1;
   hipLaunchKernelGGL(select_concat_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, x, null_row, mask, t, out, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_focus_rows(int32_t mode, const float* a, int32_t lda, float* b, int32_t ldb, const uint8_t* focus, int32_t B, int32_t rows_per_sample,
+                              int32_t ncols, vmm_stream_t stream) {
+  if (mode < 0 || mode > 2 || !a || !b || !focus || (lda & 3) || (ldb & 3) || (ncols & 3) || rows_per_sample <= 0) return -1;
+  const long long rows = (long long)B * rows_per_sample;
+  hipLaunchKernelGGL(focus_rows_kernel, dim3(cdiv(rows * (ncols / 4), 256)), dim3(256), 0, (hipStream_t)stream, mode, a, lda, b, ldb, focus, rows,
+                     rows_per_sample, ncols / 4);
   VMM_LAUNCH_CHECK();
   return 0;
 }

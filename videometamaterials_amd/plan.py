@@ -148,6 +148,7 @@ class Plan:
         self.param_slices: Dict[str, Tuple[int, int]] = {}  # name -> (offset, numel) in pgrad
         self.keepalive: list = []
         self.x_in = self.time_in = self.cond_in = self.mask_in = self.out = self.dout = None
+        self.focus_in = None  # (B,) uint8 focus_present_mask slot of plans built with focus=True
         self.weights_version = None
         self.named: Dict[str, Act] = {}  # debug taps (name -> feature map)
         self.shape = None
@@ -192,12 +193,16 @@ class Plan:
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in evs]
 
-    def run(self, x, time, cond, mask) -> torch.Tensor:
+    def run(self, x, time, cond, mask, focus=None) -> torch.Tensor:
         """Copy the inputs into the static slots, replay, return the static (B,C,T,H,W) output view."""
         self.x_in.copy_(x)
         self.time_in.copy_(time)
         self.cond_in.copy_(cond)
         self.mask_in.copy_(mask)
+        if self.focus_in is not None:
+            self.focus_in.copy_(focus)
+        elif focus is not None:
+            raise RuntimeError("this plan was built without a focus_present_mask slot")
         self.launch()
         return self.out
 
@@ -257,8 +262,12 @@ def cfg_combine(eps_c: torch.Tensor, eps_n: torch.Tensor, w: float) -> torch.Ten
 
 # ====================================================================================== builder
 class _Builder:
-    def __init__(self, model, B, T, H, W, cond_len, device, bases: Tuple[int, int, int, int], training: bool, mirrored: bool = False):
+    def __init__(self, model, B, T, H, W, cond_len, device, bases: Tuple[int, int, int, int], training: bool, mirrored: bool = False,
+                 focus: bool = False):
         self.m = model
+        # focus: the plan takes a per-sample focus_present_mask (vddp.py:431): every temporal attention except init_temporal_attn runs its unfused
+        # form with the row patches of vmm_focus_rows around the core (plans without it -- every shipped config -- are unchanged)
+        self.focus = bool(focus)
         # mirrored: the caller guarantees x[B/2:] == x[:B/2] (the two branches of classifier-free guidance as one batch, vddp.py:715-728):
         # what the network computes from x alone -- the stem and init_temporal_attn, before time / conditioning enter -- is computed for
         # one half and duplicated
@@ -955,9 +964,14 @@ class _Builder:
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
+        focus = self.focus and temporal and name != "init_temporal_attn"  # (vddp.py:743: init_temporal_attn is called without the mask)
+        if focus and site:
+            raise ValueError("focus_present_mask with conditioning tokens at the temporal attentions: the reference's (frames x frames) mask does not "
+                             "broadcast against the (frames x (tokens + frames)) scores (vddp.py:514-524); use_temporal_attention_cond=False or "
+                             "cond_attention='none' accept one")
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, p, linear=False, temporal=temporal)
-        if (temporal and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
+        if (temporal and not focus and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
                 and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
             # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
             wq, _ = self.pack_linear(p + ".to_qkv.weight", frag=2)
@@ -991,7 +1005,7 @@ class _Builder:
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
         ntok = self.ntok if site else 0
         pfc = 1 if self.m.per_frame_cond else 0
-        if (temporal and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
+        if (temporal and not focus and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
                 and getattr(self.m, "use_fused_temporal", True)):
             # scores, value mix and to_out on the matrix cores in one kernel: qkv read once, the attention output never stored
             wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
@@ -1007,6 +1021,9 @@ class _Builder:
         if temporal:
             self.step(self.lib.vmm_temporal_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
                                                         lse_ptr or None), name + " core", nbytes=4.0 * rows * 4 * hid)
+            if focus:  # masked samples: softmax over their own frame alone = 1, the output is the value row
+                self.step(self.lib.vmm_focus_rows, (0, qkv.ptr + 8 * hid, 3 * hid, o.ptr, hid, self.focus_ptr, B, T * HW, hid), name + " focus (o = v)",
+                          nbytes=8.0 * rows * hid)
         elif self.x3 and not self.training and ntok <= 32 and (not (ek and pfc) or ntok >= T) and _enabled("sa_mfma"):
             # flash-attention forward on the split-bf16 matrix cores (temporal_core.hip)
             self.step(self.lib.vmm_spatial_attention_bf16x3, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, pfc, o.ptr, hid, B, T, HW, heads, 32),
@@ -1032,10 +1049,19 @@ class _Builder:
             ndbuf = int(self.lib.vmm_attention_bwd_scratch(0 if temporal else 1, B, T, HW, heads, ntok))
             dbuf = self.alloc(ndbuf)
             geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
+            go_core = go
+            if focus:  # the core's backward sees dO = 0 for the masked samples (nothing flows through their p); their dv = dO is added afterwards
+                go_core = self.act(hid, x.H, x.W)
+                self.step(self.lib.vmm_focus_rows, (1, go.ptr, hid, go_core.ptr, hid, self.focus_ptr, B, T * HW, hid), name + " focus (dO of the core)",
+                          nbytes=8.0 * rows * hid)
             self.step(self.lib.vmm_attention_bwd,
                       (0 if temporal else 1, qkv.ptr, 3 * hid, ek or None, ev or None, ntok, 0 if temporal else pfc, self.bias_ptr if temporal else None,
-                       pfc if temporal else 0, o.ptr, go.ptr, hid, lse_ptr, self.rot_ptr if temporal else None, C.c_float(q_scale), gqkv.ptr, geo or None,
+                       pfc if temporal else 0, o.ptr, go_core.ptr, hid, lse_ptr, self.rot_ptr if temporal else None, C.c_float(q_scale), gqkv.ptr, geo or None,
                        gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
+            if focus:
+                self.step(self.lib.vmm_focus_rows, (2, go.ptr, hid, gqkv.ptr + 8 * hid, 3 * hid, self.focus_ptr, B, T * HW, hid), name + " focus (dv += dO)",
+                          nbytes=12.0 * rows * hid)
+                self.tmp_free(go_core)
             self.tmp_free(go)
             self.tmp_free((dbuf, ndbuf))
             gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
@@ -1190,6 +1216,8 @@ class _Builder:
         time_off = self.alloc(B * 2)
         cond_off = self.alloc(B * self.cond_len)
         mask_off = self.alloc((B + 3) // 4)
+        self.focus_off = self.alloc((B + 3) // 4) if self.focus else 0
+        self.focus_ptr = self.ptr(self.focus_off) if self.focus else 0
         out_off = self.alloc(B * m.out_dim * T * H * W)
         dout_off = self.alloc(B * m.out_dim * T * H * W) if tr else 0
         self.dx_off = self.alloc(B * Cx * T * H * W) if tr else 0
@@ -1582,23 +1610,23 @@ class _Builder:
         return self.plan
 
 
-def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False) -> Plan:
+def build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False, focus: bool = False) -> Plan:
     # plan buffers outlive the caller's autograd mode: never create them as inference tensors
     with torch.inference_mode(False), torch.no_grad():
-        return _build_plan(model, B, T, H, W, cond_len, device, training, mirrored)
+        return _build_plan(model, B, T, H, W, cond_len, device, training, mirrored, focus)
 
 
-def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool, mirrored: bool = False) -> Plan:
+def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, training: bool, mirrored: bool = False, focus: bool = False) -> Plan:
     # pass 1: sizes only (addresses relative to 0); pass 2: identical allocation order over real buffers
     # (fake but non-zero bases, so "pointer or None" decisions are identical in both passes)
-    sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training, mirrored)
+    sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training, mirrored, focus)
     sizing.build()
     arena = torch.empty(sizing.arena.peak + ALIGN, dtype=torch.float32, device=device)
     wbuf = torch.zeros(sizing.wtop + ALIGN, dtype=torch.float32, device=device)
     pgrad = torch.zeros(sizing.pgtop + ALIGN, dtype=torch.float32, device=device) if training else None
     gscr = torch.zeros(sizing.gstop + ALIGN, dtype=torch.float32, device=device) if training else None
     bases = (arena.data_ptr(), wbuf.data_ptr(), pgrad.data_ptr() if training else 0, gscr.data_ptr() if training else 0)
-    b = _Builder(model, B, T, H, W, cond_len, device, bases, training, mirrored)
+    b = _Builder(model, B, T, H, W, cond_len, device, bases, training, mirrored, focus)
     plan = b.build()
     assert b.arena.peak == sizing.arena.peak and b.wtop == sizing.wtop and b.pgtop == sizing.pgtop and b.gstop == sizing.gstop
     plan.arena, plan.wbuf, plan.pgrad, plan.gscratch = arena, wbuf, pgrad, gscr
@@ -1614,6 +1642,8 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     plan.time_in = arena[t_off:t_off + B * 2].view(torch.int64)
     plan.cond_in = arena[c_off:c_off + B * cond_len].view(B, cond_len)
     plan.mask_in = arena[m_off:m_off + (B + 3) // 4].view(torch.uint8)[:B]
+    if b.focus:
+        plan.focus_in = arena[b.focus_off:b.focus_off + (B + 3) // 4].view(torch.uint8)[:B]
     plan.out = arena[o_off:o_off + B * model.out_dim * T * H * W].view(B, model.out_dim, T, H, W)
     plan.arena_floats = sizing.arena.peak
     if training:

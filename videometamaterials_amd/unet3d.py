@@ -299,15 +299,17 @@ class Unet3D(nn.Module):
                 pl.refresh_weights(self._params_flat())
                 pl.weights_version = ver
 
-    def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False) -> "_plan.Plan":
-        """mirrored: the caller feeds x[B/2:] == x[:B/2] (guidance: both branches in one batch) -- the conditioning-free prefix is shared."""
+    def get_plan(self, B: int, T: int, H: int, W: int, cond_len: int, device, *, training: bool = False, mirrored: bool = False,
+                 focus: bool = False) -> "_plan.Plan":
+        """mirrored: the caller feeds x[B/2:] == x[:B/2] (guidance: both branches in one batch) -- the conditioning-free prefix is shared.
+        focus: a plan with a focus_present_mask slot (vddp.py:431; the temporal attentions in their unfused form)."""
         # (the measurement switches that change a plan's structure are part of its identity: flipping VMM_DISABLE between calls must not
         # hand back a plan built under the other setting)
         key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision, bool(mirrored),
-               os.environ.get("VMM_DISABLE", ""), bool(getattr(self, "use_x3_wgrad", True)), bool(getattr(self, "use_x3_wgrad_generic", False)))
+               os.environ.get("VMM_DISABLE", ""), bool(getattr(self, "use_x3_wgrad", True)), bool(getattr(self, "use_x3_wgrad_generic", False)), bool(focus))
         pl = self._plans.get(key)
         if pl is None:
-            pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training, mirrored=mirrored)
+            pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training, mirrored=mirrored, focus=focus)
             self._plans[key] = pl
             pl.weights_version = None
         if not (self.static_weights and pl.weights_version is not None):
@@ -330,23 +332,34 @@ class Unet3D(nn.Module):
             raise ValueError(f"expected x of shape (b, {self.channels}, f, h, w), got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("videometamaterials_amd.Unet3D runs on an MI355X only; move the model and inputs to 'cuda'")
-        if prob_focus_present != 0 or (focus_present_mask is not None and bool(focus_present_mask.any())):
-            raise NotImplementedError("focus_present_mask is inert on every shipped config (prob_focus_present = 0, main.py); "
-                                      "a non-trivial mask is not built")
+        if focus_present_mask is not None and tuple(focus_present_mask.shape) != (x.shape[0],):
+            raise ValueError(f"focus_present_mask must have shape ({x.shape[0]},), got {tuple(focus_present_mask.shape)}")
         if cond is None:
             raise ValueError("cond is required (the reference dereferences it unconditionally, vddp.py:753,761)")
         if self.per_frame_cond and x.shape[2] != 11:
             raise ValueError("per_frame_cond is hard-wired to 11 frames (vddp.py:603)")
 
+    def _focus(self, batch: int, focus_present_mask, prob_focus_present: float, device):
+        """vddp.py:740: the caller's mask, else prob_mask_like((batch,), prob_focus_present) -- drawn BEFORE the classifier-free-guidance mask, like
+        the reference.  None when no sample focuses on the present (the case of every shipped config: the regular plans run)."""
+        if focus_present_mask is None:
+            if prob_focus_present == 0:
+                return None
+            f = self._mask(batch, prob_focus_present, device)
+        else:
+            f = focus_present_mask.to(device=device).reshape(batch).ne(0).to(torch.uint8)
+        return f if bool(f.any()) else None
+
     def forward(self, x, time, cond=None, null_cond_prob=0.0, focus_present_mask=None, prob_focus_present=0.0):
         self._check_inputs(x, cond, focus_present_mask, prob_focus_present)
         B, _, T, H, W = x.shape
+        focus = self._focus(B, focus_present_mask, prob_focus_present, x.device)
         mask = self._mask(B, null_cond_prob, x.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import unet_forward_with_grad
-            return unet_forward_with_grad(self, x, time, cond, mask)
-        pl = self.get_plan(B, T, H, W, cond.shape[-1], x.device)
-        return pl.run(x, time, cond, mask).clone()
+            return unet_forward_with_grad(self, x, time, cond, mask, focus)
+        pl = self.get_plan(B, T, H, W, cond.shape[-1], x.device, focus=focus is not None)
+        return pl.run(x, time, cond, mask, focus).clone()
 
     def forward_with_guidance_scale(self, *args, **kwargs):
         """vddp.py:715-728.  Both branches run as ONE batch of 2B (legal: every op is per-sample)."""
@@ -357,15 +370,23 @@ class Unet3D(nn.Module):
         bound = dict(zip(names, args))
         bound.update(kwargs)
         x, time, cond = bound["x"], bound["time"], bound.get("cond")
-        self._check_inputs(x, cond, bound.get("focus_present_mask"), bound.get("prob_focus_present", 0.0))
-        eps_c, eps_n = self.guided_pair(x, time, cond)
+        fpm, pfp = bound.get("focus_present_mask"), bound.get("prob_focus_present", 0.0)
+        self._check_inputs(x, cond, fpm, pfp)
+        B = x.shape[0]
+        # (the reference calls forward twice: with a probability strictly between 0 and 1 each call draws its own mask)
+        f_c, f_n = self._focus(B, fpm, pfp, x.device), self._focus(B, fpm, pfp, x.device)
+        focus = None
+        if f_c is not None or f_n is not None:
+            z = torch.zeros(B, dtype=torch.uint8, device=x.device)
+            focus = torch.cat([z if f_c is None else f_c, z if f_n is None else f_n])
+        eps_c, eps_n = self.guided_pair(x, time, cond, focus)
         return _plan.cfg_combine(eps_c, eps_n, float(guidance_scale))
 
     @torch.no_grad()
-    def guided_pair(self, x, time, cond):
-        """(eps_cond, eps_null) views into the plan's static output (valid until the next call)."""
+    def guided_pair(self, x, time, cond, focus=None):
+        """(eps_cond, eps_null) views into the plan's static output (valid until the next call).  focus: (2B,) uint8 or None."""
         B, _, T, H, W = x.shape
-        pl = self.get_plan(2 * B, T, H, W, cond.shape[-1], x.device, mirrored=True)
+        pl = self.get_plan(2 * B, T, H, W, cond.shape[-1], x.device, mirrored=True, focus=focus is not None)
         mask = torch.cat([torch.zeros(B, dtype=torch.uint8, device=x.device), torch.ones(B, dtype=torch.uint8, device=x.device)])
-        out = pl.run(torch.cat([x, x]), torch.cat([time, time]), torch.cat([cond, cond]), mask)
+        out = pl.run(torch.cat([x, x]), torch.cat([time, time]), torch.cat([cond, cond]), mask, focus)
         return out[:B], out[B:]
