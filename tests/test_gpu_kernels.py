@@ -1448,14 +1448,15 @@ def test_projection_a_stationary_bf16x3(gpu, B, T, HW, C1, C2, Cout, ln, rot, re
     assert relerr(out.cpu(), ref) < (3e-6 if exact else 5e-5)
 
 
+@pytest.mark.parametrize("Cc", [64, 128])
 @pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 16, 16, 11), (1, 2, 96, 96, 0), (3, 1, 8, 12, 6)])
-def test_fused_linear_attention_block(gpu, B, T, H, W, ntok):
+def test_fused_linear_attention_block(gpu, B, T, H, W, ntok, Cc):
     """vmm_linattn_block_bf16x3 (LayerNorm -> to_qkv -> linear attention with stacked tokens -> to_out -> +x in three launches, q/k/v on chip)
     against the oracle's block; several pixel splits per frame, more than one sample (token keys differ per sample)."""
     from oracle import unet3d_oracle as uo
     N, lib = _lib()
     g = torch.Generator().manual_seed(21)
-    Cc, heads, hid = 64, 8, 256
+    heads, hid = 8, 256
     x = torch.randn(B, Cc, T, H, W, generator=g)
     sd = {"a.fn.norm.gamma": 1 + 0.2 * torch.randn(1, Cc, 1, 1, 1, generator=g),
           "a.fn.fn.to_qkv.weight": torch.randn(3 * hid, Cc, 1, 1, generator=g) * 0.3,

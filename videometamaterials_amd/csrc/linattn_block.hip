@@ -1,4 +1,4 @@
-// Fused spatial linear-attention BLOCK for the full-resolution level (C = 64, 8 heads x 32), split-bf16 MFMA, gfx950.
+// Fused spatial linear-attention BLOCK for the two upper levels (C = 64 or 128, 8 heads x 32), split-bf16 MFMA, gfx950.
 //
 //   out = x + to_out( ctx^T . softmax_d(q) * scale ) + bias,   ctx = softmax_n([k_tok | k]) . ([v_tok | v] / HW)^T,   q,k,v = to_qkv(LayerNorm(x))
 //   (vddp.py:313-378 SpatialLinearAttention inside Residual(PreNorm(.)), vddp.py:613/628)
@@ -28,7 +28,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int LC = 64;            // channels
+// CC = channels of the level: 64 (full resolution; every weight fragment of a head stays in its wave's registers) or 128 (the next level: the
+// q / k / v fragments still do -- 128 registers in pass A, 64 in pass B --, the to_out fragments of pass B are streamed from L2 per tile through a
+// two-plane ring, the head sum goes through LDS in two 64-channel halves of the [8][32][128] buffer's worth).
 constexpr int LH = 8;             // heads (= waves per workgroup)
 constexpr int LD = 32;            // dim_head
 constexpr int PART = 64 + LD * LD;  // floats per partial: max[32] | sum[32] | ctx^T[e][d]
@@ -67,33 +69,53 @@ __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const 
   return c;
 }
 
-// The 32 x 64 input tile of a step is read ONCE per workgroup: thread (row tid >> 4, channels (tid & 15) * 4 .. +3) loads one float4 a
-// tile ahead (the HBM latency hides under the previous tile's MFMAs), the 16 lanes of a row normalise it (channel LayerNorm,
+// The 32 x CC input tile of a step is read ONCE per workgroup: thread (row tid >> 4, channels (tid & 15) * 4 .. +3 of every 64-channel group) loads
+// its float4s a tile ahead (the HBM latency hides under the previous tile's MFMAs), the 16 lanes of a row normalise it (channel LayerNorm,
 // vddp.py:245-254) and the bf16 hi | lo rows go to LDS, where the eight head-waves pick up their operand fragments: lane
-// (pixel = lane & 31, lk) owns channels s*16 + lk*8 .. +7 for the four k16 steps s.  The same registers serve as an A operand
+// (pixel = lane & 31, lk) owns channels s*16 + lk*8 .. +7 for the CC / 16 k16 steps s.  The same registers serve as an A operand
 // (rows = pixels) or a B operand (columns = pixels).
-constexpr int YPITCH = 2 * LC + 8;  // bf16 per LDS row: hi 64 | lo 64 | pad (272 bytes = 17 x 16: conflict-free ds_read_b128)
+template <int CC> struct LAGeom {
+  static constexpr int NV = CC / 64;          // float4s per staging thread
+  static constexpr int NS = CC / 16;          // k16 steps of a projection from the channels
+  static constexpr int YPITCH = 2 * CC + 8;   // bf16 per LDS row: hi CC | lo CC | pad (272 / 528 bytes = 17 / 33 x 16: conflict-free ds_read_b128)
+};
 
-__device__ __forceinline__ void stage_norm_row(const LAArgs& a, const f32x4& x, const f32x4& gam, unsigned short* ytile, int tid) {
+template <int CC>
+__device__ __forceinline__ void stage_norm_row(const LAArgs& a, const f32x4 (&x)[CC / 64], const f32x4 (&gam)[CC / 64], unsigned short* ytile, int tid) {
   // (row sums inside the DPP row, v_rsq_f32: the eight ds_bpermute round trips and the IEEE sqrt / divide were ~1k cycles of every tile,
   // in front of the barrier all eight head-waves wait at)
-  const float mean = row_sum16((x.x + x.y) + (x.z + x.w)) * (1.0f / LC);
-  const f32x4 c = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
-  const float rstd = __builtin_amdgcn_rsqf(row_sum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / LC) + a.eps);
-  unsigned l0, l1;
-  const unsigned h0 = pack_split(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
-  const unsigned h1 = pack_split(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
-  unsigned short* row = ytile + (tid >> 4) * YPITCH + (tid & 15) * 4;
-  *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
-  *reinterpret_cast<uint2*>(row + LC) = make_uint2(l0, l1);
+  constexpr int NV = CC / 64, YP = LAGeom<CC>::YPITCH;
+  float s1 = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) s1 += (x[v].x + x[v].y) + (x[v].z + x[v].w);
+  const float mean = row_sum16(s1) * (1.0f / CC);
+  f32x4 c[NV];
+  float s2 = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    c[v] = f32x4{x[v].x - mean, x[v].y - mean, x[v].z - mean, x[v].w - mean};
+    s2 += (c[v].x * c[v].x + c[v].y * c[v].y) + (c[v].z * c[v].z + c[v].w * c[v].w);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(row_sum16(s2) * (1.0f / CC) + a.eps);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    unsigned l0, l1;
+    const unsigned h0 = pack_split(c[v].x * rstd * gam[v].x, c[v].y * rstd * gam[v].y, l0);
+    const unsigned h1 = pack_split(c[v].z * rstd * gam[v].z, c[v].w * rstd * gam[v].w, l1);
+    unsigned short* row = ytile + (tid >> 4) * YP + v * 64 + (tid & 15) * 4;
+    *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(row + CC) = make_uint2(l0, l1);
+  }
 }
 
-__device__ __forceinline__ void read_row_frags(const unsigned short* ytile, int lrow, int lk, uint4 (&yh)[4], uint4 (&yl)[4]) {
+// four k16 steps s0 .. s0 + 3 of the row's fragments
+template <int CC>
+__device__ __forceinline__ void read_row_frags(const unsigned short* ytile, int lrow, int lk, int s0, uint4 (&yh)[4], uint4 (&yl)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned short* q = ytile + lrow * YPITCH + i * 16 + lk * 8;
+    const unsigned short* q = ytile + lrow * LAGeom<CC>::YPITCH + (s0 + i) * 16 + lk * 8;
     yh[i] = *reinterpret_cast<const uint4*>(q);
-    yl[i] = *reinterpret_cast<const uint4*>(q + LC);
+    yl[i] = *reinterpret_cast<const uint4*>(q + CC);
   }
 }
 
@@ -105,45 +127,56 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- pass A
-template <bool ONE>
-__global__ __launch_bounds__(512, 2) void linattn_ctx_kernel(const LAArgs a) {
+template <bool ONE, int CC>
+__global__ __launch_bounds__(512) void linattn_ctx_kernel(const LAArgs a) {
+  constexpr int NV = CC / 64, NS = CC / 16, YP = LAGeom<CC>::YPITCH;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
   const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
   const int tiles = a.HW / 32;
   const int t_begin = split * a.sps, t_end = min(tiles, t_begin + a.sps);
 
-  uint4 wkh[4], wkl[4], wvh[4], wvl[4];
+  uint4 wkh[NS], wkl[NS], wvh[NS], wvl[NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4* qk = a.wqkv + (((long long)(LH + h) * 4 + s) * 2) * 64 + lane;
-    const uint4* qv = a.wqkv + (((long long)(2 * LH + h) * 4 + s) * 2) * 64 + lane;
+  for (int s = 0; s < NS; ++s) {
+    const uint4* qk = a.wqkv + (((long long)(LH + h) * NS + s) * 2) * 64 + lane;
+    const uint4* qv = a.wqkv + (((long long)(2 * LH + h) * NS + s) * 2) * 64 + lane;
     wkh[s] = qk[0]; wkl[s] = qk[64];
     wvh[s] = qv[0]; wvl[s] = qv[64];
   }
-  __shared__ __attribute__((aligned(16))) unsigned short ytile[2][32 * YPITCH];  // double buffer: one barrier per tile
-  const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + (tid & 15) * 4);
-  auto load_x = [&](int t) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < t_end) v = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + (tid & 15) * 4);
-    return v;
+  __shared__ __attribute__((aligned(16))) unsigned short ytile[2][32 * YP];  // double buffer: one barrier per tile
+  f32x4 gam[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) gam[v] = *reinterpret_cast<const f32x4*>(a.gamma + v * 64 + (tid & 15) * 4);
+  auto load_x = [&](int t, f32x4 (&d)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < t_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + v * 64 + (tid & 15) * 4);
+    }
   };
   float m = -INFINITY, ssum = 0.f;
   f32x16 ctx = zero16();  // rows e, column d = lrow
-  f32x4 x_next = load_x(t_begin);
+  f32x4 x_next[NV];
+  load_x(t_begin, x_next);
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
-    const f32x4 x_cur = x_next;
-    x_next = load_x(t + 1);
-    stage_norm_row(a, x_cur, gam, ytile[buf], tid);
+    f32x4 x_cur[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x_cur[v] = x_next[v];
+    load_x(t + 1, x_next);
+    stage_norm_row<CC>(a, x_cur, gam, ytile[buf], tid);
     __syncthreads();
-    uint4 yh[4], yl[4];
-    read_row_frags(ytile[buf], lrow, lk, yh, yl);
     f32x16 kt = zero16(), vt = zero16();  // rows pixels, column d (resp. e) = lrow
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kt = mfma3<ONE>(yh[s], yl[s], wkh[s], wkl[s], kt);
-      vt = mfma3<ONE>(yh[s], yl[s], wvh[s], wvl[s], vt);
+    for (int g = 0; g < NS / 4; ++g) {
+      uint4 yh[4], yl[4];
+      read_row_frags<CC>(ytile[buf], lrow, lk, 4 * g, yh, yl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kt = mfma3<ONE>(yh[i], yl[i], wkh[4 * g + i], wkl[4 * g + i], kt);
+        vt = mfma3<ONE>(yh[i], yl[i], wvh[4 * g + i], wvl[4 * g + i], vt);
+      }
     }
     float tm = kt[0];
 #pragma unroll
@@ -222,56 +255,78 @@ __global__ __launch_bounds__(256) void linattn_combine_kernel(const LAArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- pass B
-template <bool ONE>
-__global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [8 heads][32 pixels][64 channels], then the staged input tile
-  unsigned short* ytile = reinterpret_cast<unsigned short*>(red + LH * 32 * LC);
+template <bool ONE, int CC>
+__global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
+  constexpr int NV = CC / 64, NS = CC / 16, NCT = CC / 32, YP = LAGeom<CC>::YPITCH;
+  constexpr bool HOLD_WO = CC == 64;  // the to_out fragments of the head stay in registers (C = 64) or are streamed per tile (C = 128)
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [8 heads][32 pixels][64 channels] (one 64-channel half at a time), then the staged input tile
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(red + LH * 32 * 64);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
   const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
   const int tiles = a.HW / 32;
   const int t_begin = split * a.sps, t_end = min(tiles, t_begin + a.sps);
 
-  uint4 wqh[4], wql[4], woh[2][2], wol[2][2], ch[2], cl[2];
+  uint4 wqh[NS], wql[NS], woh[HOLD_WO ? NCT : 1][2], wol[HOLD_WO ? NCT : 1][2], ch[2], cl[2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint4* q = a.wqkv + (((long long)h * 4 + s) * 2) * 64 + lane;
+  for (int s = 0; s < NS; ++s) {
+    const uint4* q = a.wqkv + (((long long)h * NS + s) * 2) * 64 + lane;
     wqh[s] = q[0]; wql[s] = q[64];
   }
+  const uint4* wo_base = a.wout + ((long long)(2 * h) * 2) * 64 + lane;  // + (ct * 16 + s) * 128
+  if constexpr (HOLD_WO) {
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const uint4* q = a.wout + (((long long)ct * 16 + 2 * h + s) * 2) * 64 + lane;
-      woh[ct][s] = q[0]; wol[ct][s] = q[64];
-    }
+      for (int s = 0; s < 2; ++s) {
+        const uint4* q = wo_base + (ct * 16 + s) * 128;
+        woh[ct][s] = q[0]; wol[ct][s] = q[64];
+      }
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const uint4* q = a.ctxfrag + ((long long)frame * LH + h) * 256 + (s * 2) * 64 + lane;
     ch[s] = q[0]; cl[s] = q[64];
   }
-  // reduction role: pixel rp, channels rc .. rc+3
+  // reduction role: pixel rp, channels rc .. rc+3 of every 64-channel half
   const int rp = tid >> 4, rc = (tid & 15) * 4;
-  const f32x4 bias = a.bias_out ? *reinterpret_cast<const f32x4*>(a.bias_out + rc) : f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + rc);
-  auto load_x = [&](int t) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < t_end) v = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + rc);
-    return v;
+  f32x4 bias[NV], gam[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    bias[v] = a.bias_out ? *reinterpret_cast<const f32x4*>(a.bias_out + v * 64 + rc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gam[v] = *reinterpret_cast<const f32x4*>(a.gamma + v * 64 + rc);
+  }
+  auto load_x = [&](int t, f32x4 (&d)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < t_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
+    }
   };
-  f32x4 x_next = load_x(t_begin);
+  f32x4 x_next[NV];
+  load_x(t_begin, x_next);
   for (int t = t_begin; t < t_end; ++t) {
     const long long row0 = (long long)frame * a.HW + t * 32;
-    const f32x4 x_cur = x_next;
-    x_next = load_x(t + 1);
-    stage_norm_row(a, x_cur, gam, ytile, tid);
+    f32x4 x_cur[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x_cur[v] = x_next[v];
+    load_x(t + 1, x_next);
+    stage_norm_row<CC>(a, x_cur, gam, ytile, tid);
     __syncthreads();  // tile rows visible; also: every wave has finished the previous tile's head sum (red is free again)
-    uint4 yh[4], yl[4];
-    read_row_frags(ytile, lrow, lk, yh, yl);
+    // streamed to_out fragments: the first channel tile's two steps are requested now and land under the q projection
+    uint4 sh[2][2], sl[2][2];  // [ring slot][step]
+    if constexpr (!HOLD_WO) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { const uint4* q = wo_base + s * 128; sh[0][s] = q[0]; sl[0][s] = q[64]; }
+    }
     f32x16 qt = zero16();  // rows d, column pixel = lrow
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qt = mfma3<ONE>(wqh[s], wql[s], yh[s], yl[s], qt);
+    for (int g = 0; g < NS / 4; ++g) {
+      uint4 yh[4], yl[4];
+      read_row_frags<CC>(ytile, lrow, lk, 4 * g, yh, yl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qt = mfma3<ONE>(wqh[4 * g + i], wql[4 * g + i], yh[i], yl[i], qt);
+    }
     float mx = qt[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
@@ -290,30 +345,44 @@ __global__ __launch_bounds__(512, 2) void linattn_apply_kernel(const LAArgs a) {
       split8(qt, s * 8, qh, ql);
       ot = mfma3<ONE>(ch[s], cl[s], qh, ql, ot);
     }
-    f32x16 pc[2] = {zero16(), zero16()};  // rows pixels, column channel ct*32 + lrow
+    uint4 oh[2], ol[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 oh, ol;
-      split8(ot, s * 8, oh, ol);
+    for (int s = 0; s < 2; ++s) split8(ot, s * 8, oh[s], ol[s]);
+    float* rb = red + (h * 32) * 64;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3<ONE>(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+    for (int half = 0; half < NV; ++half) {  // 64 output channels at a time through the head-sum buffer
+      if (half) __syncthreads();             // the previous half's sums have been read
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int ct = half * 2 + c2;
+        f32x16 pc = zero16();  // rows pixels, column channel ct*32 + lrow
+        if constexpr (HOLD_WO) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) pc = mfma3<ONE>(oh[s], ol[s], woh[ct][s], wol[ct][s], pc);
+        } else {
+          if (ct + 1 < NCT) {  // next channel tile's fragments into the other ring slot
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const uint4* q = wo_base + ((ct + 1) * 16 + s) * 128; sh[(ct + 1) & 1][s] = q[0]; sl[(ct + 1) & 1][s] = q[64]; }
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) pc = mfma3<ONE>(oh[s], ol[s], sh[ct & 1][s], sl[ct & 1][s], pc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          rb[px * 64 + c2 * 32 + lrow] = pc[r];
+        }
+      }
+      __syncthreads();
+      f32x4 acc = bias[half];
+#pragma unroll
+      for (int w = 0; w < LH; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rp) * 64 + rc);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x += x_cur[half].x; acc.y += x_cur[half].y; acc.z += x_cur[half].z; acc.w += x_cur[half].w;  // residual: the element this thread normalised
+      *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + half * 64 + rc) = acc;
     }
-    float* rb = red + (h * 32) * LC;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int px = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      rb[px * LC + lrow] = pc[0][r];
-      rb[px * LC + 32 + lrow] = pc[1][r];
-    }
-    __syncthreads();
-    f32x4 acc = bias;
-#pragma unroll
-    for (int w = 0; w < LH; ++w) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rp) * LC + rc);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    acc.x += x_cur.x; acc.y += x_cur.y; acc.z += x_cur.z; acc.w += x_cur.w;  // residual: the element this thread normalised
-    *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + rc) = acc;
   }
 }
 
@@ -333,12 +402,29 @@ extern "C" int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW)
   return (int64_t)B * T * ns * LH * PART + (int64_t)B * T * LH * 1024;
 }
 
-// Returns 1 (nothing launched) outside the envelope: C == 64, heads == 8, dim_head == 32, HW % 32 == 0.
+template <bool ONE, int CC>
+static int la_run(const LAArgs& a, unsigned blocks, int frames, hipStream_t s) {
+  hipLaunchKernelGGL((linattn_ctx_kernel<ONE, CC>), dim3(blocks), dim3(512), 0, s, a);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(frames * LH)), dim3(256), 0, s, a);
+  VMM_LAUNCH_CHECK();
+  const size_t shm = sizeof(float) * LH * 32 * 64 + sizeof(unsigned short) * 32 * LAGeom<CC>::YPITCH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel<ONE, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((linattn_apply_kernel<ONE, CC>), dim3(blocks), dim3(512), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Returns 1 (nothing launched) outside the envelope: C == 64 or 128, heads == 8, dim_head == 32, HW % 32 == 0.
 template <bool ONE>
 static int la_launch(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* bias_out, const float* ek,
                      const float* ev, int32_t ntok, float* workspace, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
                      float eps, vmm_stream_t stream) {
-  if (C != LC || heads != LH || (HW % 32) || (ldx & 3) || (ldo & 3)) return 1;
+  if ((C != 64 && C != 128) || heads != LH || (HW % 32) || (ldx & 3) || (ldo & 3)) return 1;
   if (B * T <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   LAArgs a;
@@ -354,19 +440,7 @@ static int la_launch(const float* x, int32_t ldx, const float* gamma, const floa
   a.out = out; a.ldo = ldo;
   a.q_scale = 1.0f / sqrtf((float)LD);
   const unsigned blocks = (unsigned)(B * T * a.nsplit);
-  hipLaunchKernelGGL(linattn_ctx_kernel<ONE>, dim3(blocks), dim3(512), 0, s, a);
-  VMM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(B * T * LH)), dim3(256), 0, s, a);
-  VMM_LAUNCH_CHECK();
-  const size_t shm = sizeof(float) * LH * 32 * LC + sizeof(unsigned short) * 32 * YPITCH;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel<ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(linattn_apply_kernel<ONE>, dim3(blocks), dim3(512), shm, s, a);
-  VMM_LAUNCH_CHECK();
-  return 0;
+  return C == 64 ? la_run<ONE, 64>(a, blocks, B * T, s) : la_run<ONE, 128>(a, blocks, B * T, s);
 }
 
 extern "C" int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,

@@ -877,8 +877,9 @@ class _Builder:
         rows = B * T * HW
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, name + ".fn.fn", linear=True)
-        if self.x3 and not self.training and x.C == 64 and heads == 8 and HW % 32 == 0 and getattr(self.m, "use_fused_linattn", True):
-            # full-resolution level: q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
+        if (self.x3 and not self.training and (x.C == 64 or (x.C == 128 and _enabled("la_c128"))) and heads == 8 and HW % 32 == 0
+                and getattr(self.m, "use_fused_linattn", True)):
+            # the two upper levels (C = 64, 128): q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
             wq, _ = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2)
             wo, _ = self.pack_linear(name + ".fn.fn.to_out.weight", frag=3)
             ws_n = int(self.lib.vmm_linattn_block_workspace(B, T, HW))
