@@ -24,6 +24,7 @@
 #include "igemm_common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -342,6 +343,344 @@ __global__ __launch_bounds__(512, 2) void temporal_block_kernel(const TBArgs a) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same block at the C = 128 level (48 x 48 / 24 x 24 frames of the Lagrangian configuration): the unfused path there writes and re-reads
+// the 768-wide qkv rows (623 MB per site at batch 8) for a 128-wide input.  Structure of the first kernel above (eight head-waves in lock step,
+// two pixels x 16 frame slots per tile), with what the doubled contraction changes:
+//   * a head's q / k / v weight fragments are 8 k16 steps x 3 x (hi | lo) = 192 registers -- they do not fit.  All three projections STREAM
+//     their fragments from L2 through a four-step register ring (the fragments of step s + 3 are requested before the MFMAs of step s), one
+//     projection after the other so that only one 32 x 32 accumulator and one ring are live: 48 KB per head and tile, 30 B / clk per CU at
+//     the kernel's pace, half of what the L1 delivers;
+//   * to_out has four 32-channel column tiles: their fragments ride the same ring, and the head sum goes through the [8][32][64] LDS buffer in
+//     two 64-channel halves;
+//   * the LayerNorm row staging handles two float4 per thread.
+constexpr int TC2 = 128;
+
+template <bool ONE>
+__global__ __launch_bounds__(512) void temporal_block128_kernel(const TBArgs a) {
+  constexpr int NS = TC2 / 16, NCT = TC2 / 32, NV = TC2 / 64;
+  constexpr int YPITCH = 2 * TC2 + 8;                                  // 528 bytes = 33 x 16: conflict-free ds_read_b128 over consecutive rows
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);                     // [8 heads][32 rows][64 channels] (one half of the channels at a time)
+  uint4* ekf = reinterpret_cast<uint4*>(red + HEADS * 32 * 64);        // [8 heads][2 steps][hi|lo][64 lanes]
+  uint4* evf = ekf + HEADS * 4 * 64;                                   // [8 heads][hi|lo][64 lanes]
+  float* biasf = reinterpret_cast<float*>(evf + HEADS * 2 * 64);       // [8 heads][2 halves][16 frames][8]
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(biasf + HEADS * 2 * 16 * 8);  // [32 rows][hi 128 | lo 128 | pad 8]
+  float* rotf = reinterpret_cast<float*>(ytile + 32 * YPITCH);          // [2 halves][16 frames][8 pairs][cos, sin]
+
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int pa = lrow >> 4, ft = lrow & 15;  // pixel of the pair, frame slot
+  const int T = a.T, HW = a.HW;
+  const int b = blockIdx.x / a.nsplit, split = blockIdx.x - b * a.nsplit;
+  const int pairs = HW / 2;
+  const int p_begin = split * a.tps, p_end = min(pairs, p_begin + a.tps);
+  const int ntok = a.ek ? a.ntok : 0;
+
+  // ---- per-workgroup tables in LDS (as in the first kernel)
+  {
+    uint4* eks = ekf + h * 4 * 64;
+    uint4* evs = evf + h * 2 * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = lrow < ntok ? a.ek[((long long)b * ntok + lrow) * HID + h * DHd + slot(s, lk, j)] : 0.f;
+      uint4 hi, lo;
+      split8v(v, hi, lo);
+      eks[(s * 2 + 0) * 64 + lane] = hi;
+      eks[(s * 2 + 1) * 64 + lane] = lo;
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      v[j] = tk < ntok ? a.ev[((long long)b * ntok + tk) * HID + h * DHd + lrow] : 0.f;
+    }
+    uint4 hi, lo;
+    split8v(v, hi, lo);
+    evs[lane] = hi;
+    evs[64 + lane] = lo;
+    for (int i = tid; i < HEADS * 2 * 16 * 8; i += 512) {
+      const int j = i & 7, t = (i >> 3) & 15, l2 = (i >> 7) & 1, hh = i >> 8;
+      const int tk = slot(0, l2, j);
+      biasf[i] = (t < T && tk < T) ? a.bias[(hh * T + t) * T + tk] : 0.f;
+    }
+  }
+  for (int i = tid; i < 2 * 16 * 8; i += 512) {
+    const int pr = i & 7, t = (i >> 3) & 15, l2 = i >> 7;
+    const int d = slot(pr >> 2, l2, (2 * pr) & 7);  // feature index of register 2 pr
+    const float2 cs = t < T ? *reinterpret_cast<const float2*>(a.rot + (t * 16 + (d >> 1)) * 2) : make_float2(1.f, 0.f);
+    rotf[i * 2] = cs.x;
+    rotf[i * 2 + 1] = cs.y;
+  }
+  const float* rot_l = rotf + ((lk * 16 + ft) * 8) * 2;
+  auto rotate1 = [&](f32x16& u) {
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(rot_l + i4 * 4);  // pairs 2 i4, 2 i4 + 1
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = 2 * i4 + k;
+        const float c = k ? cs.z : cs.x, sn = k ? cs.w : cs.y;
+        const float e = u[2 * i], o = u[2 * i + 1];
+        u[2 * i] = e * c - o * sn;
+        u[2 * i + 1] = o * c + e * sn;
+      }
+    }
+  };
+  __syncthreads();
+
+  // streamed weight fragments: plane pair (hi, lo) of column tile nt, k16 step ks of a fmt-2 / fmt-3 matrix with KS steps per column tile
+  const uint4* wq_l = a.wqkv + ((long long)h * NS * 2) * 64 + lane;
+  const uint4* wk_l = a.wqkv + ((long long)(HEADS + h) * NS * 2) * 64 + lane;
+  const uint4* wv_l = a.wqkv + ((long long)(2 * HEADS + h) * NS * 2) * 64 + lane;
+  const uint4* wo_l = a.wout + ((long long)2 * h * 2) * 64 + lane;  // + (ct * 16 + s) * 128
+  constexpr int RING = 4, AHEAD = 3;
+
+  const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
+  // reduction role
+  const int rm = tid >> 4, rcol = (tid & 15) * 4;
+  const int rpa = rm >> 4, rft = rm & 15;
+  f32x4 gam[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) gam[v] = *reinterpret_cast<const f32x4*>(a.gamma + v * 64 + rcol);
+  auto load_x = [&](int pp, f32x4 (&d)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rft < T && pp < p_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * T + rft) * HW + pp * 2 + rpa) * a.ldx + v * 64 + rcol);
+    }
+  };
+  // Projections with the weight fragments streamed through the ring.  The group loop stays a LOOP (ring slot = step within the group, RING ==
+  // 4): unrolled, the scheduler hoists every fragment request of the projection to its top -- 64 registers of weights instead of 32 -- and the
+  // kernel spills.  Two accumulators are always in flight (q^T with k^T; the even and the odd steps of v): the three passes of one mfma3 form a
+  // dependent chain, and a single chain leaves the matrix pipe idle for half of every MFMA's latency.
+  static_assert(RING == 4 && AHEAD == 3 && NS % 4 == 0, "ring slot = step & 3");
+  auto read_y = [&](int g, uint4 (&yh)[4], uint4 (&yl)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned short* q = ytile + lrow * YPITCH + (4 * g + i) * 16 + lk * 8;
+      yh[i] = *reinterpret_cast<const uint4*>(q);
+      yl[i] = *reinterpret_cast<const uint4*>(q + TC2);
+    }
+  };
+#ifndef VMM_TB128_HOLD_Q
+#define VMM_TB128_HOLD_Q 0
+#endif
+  constexpr bool HOLD_Q = VMM_TB128_HOLD_Q;  // 1: the q fragments of the head stay in registers (64 of them; 254 registers + 36 bytes of scratch), k and v streamed -- measured equal to streaming all three (2.52 ms for the family either way): the kernel is bound by its lock-step phases, not by the fragment traffic
+  uint4 wqh[HOLD_Q ? NS : 1], wql[HOLD_Q ? NS : 1];
+  if constexpr (HOLD_Q) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { wqh[s] = wq_l[(s * 2) * 64]; wql[s] = wq_l[(s * 2 + 1) * 64]; }
+  }
+  auto project_qk = [&](f32x16& qt, f32x16& kt) {  // both [d][m]: the weights are the A operand
+    uint4 qh_[RING], ql_[RING], kh_[RING], kl_[RING];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) {
+      if constexpr (!HOLD_Q) { qh_[s] = wq_l[(s * 2) * 64]; ql_[s] = wq_l[(s * 2 + 1) * 64]; }
+      kh_[s] = wk_l[(s * 2) * 64]; kl_[s] = wk_l[(s * 2 + 1) * 64];
+    }
+    qt = zero16();
+    kt = zero16();
+    if constexpr (HOLD_Q) {
+#pragma unroll
+      for (int g = 0; g < NS / 4; ++g) {  // (unrolled: the held fragments are indexed statically; the k ring's requests are pinned per step)
+        uint4 yh[4], yl[4];
+        read_y(g, yh, yl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int sn = min(4 * g + i + AHEAD, NS - 1);
+          kh_[(i + AHEAD) & 3] = wk_l[(sn * 2) * 64]; kl_[(i + AHEAD) & 3] = wk_l[(sn * 2 + 1) * 64];
+          qt = mfma3<ONE>(wqh[4 * g + i], wql[4 * g + i], yh[i], yl[i], qt);
+          kt = mfma3<ONE>(kh_[i], kl_[i], yh[i], yl[i], kt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
+#pragma unroll 1
+    for (int g = 0; g < NS / 4; ++g) {
+      uint4 yh[4], yl[4];
+      read_y(g, yh, yl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sn = min(4 * g + i + AHEAD, NS - 1);  // (past the end: re-requests the last step, unused)
+        qh_[(i + AHEAD) & 3] = wq_l[(sn * 2) * 64]; ql_[(i + AHEAD) & 3] = wq_l[(sn * 2 + 1) * 64];
+        kh_[(i + AHEAD) & 3] = wk_l[(sn * 2) * 64]; kl_[(i + AHEAD) & 3] = wk_l[(sn * 2 + 1) * 64];
+        qt = mfma3<ONE>(qh_[i], ql_[i], yh[i], yl[i], qt);
+        kt = mfma3<ONE>(kh_[i], kl_[i], yh[i], yl[i], kt);
+      }
+    }
+  };
+  auto project_v = [&]() -> f32x16 {  // [m][d]: the rows are the A operand
+    uint4 rh[RING], rl[RING];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) { rh[s] = wv_l[(s * 2) * 64]; rl[s] = wv_l[(s * 2 + 1) * 64]; }
+    f32x16 a0 = zero16(), a1 = zero16();
+#pragma unroll 1
+    for (int g = 0; g < NS / 4; ++g) {
+      uint4 yh[4], yl[4];
+      read_y(g, yh, yl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sn = min(4 * g + i + AHEAD, NS - 1);
+        rh[(i + AHEAD) & 3] = wv_l[(sn * 2) * 64];
+        rl[(i + AHEAD) & 3] = wv_l[(sn * 2 + 1) * 64];
+        if (i & 1) a1 = mfma3<ONE>(yh[i], yl[i], rh[i], rl[i], a1);
+        else a0 = mfma3<ONE>(yh[i], yl[i], rh[i], rl[i], a0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] += a1[r];
+    return a0;
+  };
+
+  f32x4 x_next[NV];
+  load_x(p_begin, x_next);
+  for (int pp = p_begin; pp < p_end; ++pp) {
+    f32x4 x_cur[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x_cur[v] = x_next[v];
+    load_x(pp + 1, x_next);
+    // ---- LayerNorm of the 32 rows (16 lanes per row), rows to LDS as bf16 hi | lo
+    {
+      float s1 = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) s1 += (x_cur[v].x + x_cur[v].y) + (x_cur[v].z + x_cur[v].w);
+      const float mean = row_sum16(s1) * (1.0f / TC2);
+      f32x4 c[NV];
+      float s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        c[v] = f32x4{x_cur[v].x - mean, x_cur[v].y - mean, x_cur[v].z - mean, x_cur[v].w - mean};
+        s2 += (c[v].x * c[v].x + c[v].y * c[v].y) + (c[v].z * c[v].z + c[v].w * c[v].w);
+      }
+      const float rstd = __builtin_amdgcn_rsqf(row_sum16(s2) * (1.0f / TC2) + a.eps);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        unsigned l0, l1;
+        const unsigned h0 = pack_split(c[v].x * rstd * gam[v].x, c[v].y * rstd * gam[v].y, l0);
+        const unsigned h1 = pack_split(c[v].z * rstd * gam[v].z, c[v].w * rstd * gam[v].w, l1);
+        *reinterpret_cast<uint2*>(ytile + rm * YPITCH + v * 64 + rcol) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(ytile + rm * YPITCH + TC2 + v * 64 + rcol) = make_uint2(l0, l1);
+      }
+    }
+    __syncthreads();  // tile rows visible; also: every wave has finished the previous tile's head sum (red is free again)
+    // ---- projections: q^T with k^T, then v
+    f32x16 st = zero16(), sk = zero16();
+    {
+      f32x16 qt, kt;
+      project_qk(qt, kt);
+      rotate1(qt);
+      rotate1(kt);
+      const uint4* eks = ekf + h * 4 * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint4 qh, ql, kh, kl;
+        split8(qt, s * 8, qh, ql);
+        split8(kt, s * 8, kh, kl);
+        st = mfma3<ONE>(kh, kl, qh, ql, st);
+        if (ntok) sk = mfma3<ONE>(eks[(s * 2) * 64], eks[(s * 2 + 1) * 64], qh, ql, sk);
+      }
+    }
+    const f32x16 vt = project_v();
+    // ---- softmax over this query's 8 (+8) frame keys and 8 (+8) tokens: lane half lk holds slots {0-3, 8-11} + 4 lk
+    const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_l), bz1 = *reinterpret_cast<const f32x4*>(bias_l + 4);
+    const float bz[8] = {bz0.x, bz0.y, bz0.z, bz0.w, bz1.x, bz1.y, bz1.z, bz1.w};
+    const unsigned pmask = pa ? 0xffffffffu : 0u;
+    float f[8], g[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tk = slot(0, lk, j);
+      const float sv = __uint_as_float((__float_as_uint(st[8 + j]) & pmask) | (__float_as_uint(st[j]) & ~pmask));  // (bit blend: see the first kernel)
+      f[j] = tk < T ? sv * a.q_scale + bz[j] : -INFINITY;
+      g[j] = tk < ntok ? sk[j] * a.q_scale + (a.bias_on_cond ? bz[j] : 0.f) : -INFINITY;
+      mx = fmaxf(mx, fmaxf(f[j], g[j]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = __expf(f[j] - mx);
+      g[j] = __expf(g[j] - mx);
+      sum += f[j] + g[j];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float p0[8], p1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] *= inv;
+      g[j] *= inv;
+      p0[j] = pa ? 0.f : f[j];  // keys of pixel 0 <-> k16 step 0
+      p1[j] = pa ? f[j] : 0.f;  // keys of pixel 1 <-> k16 step 1
+    }
+    // first to_out fragments into the ring while the value mix runs
+    uint4 rh[2][2], rl[2][2];  // [ring slot][step]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { rh[0][s] = wo_l[(s * 2) * 64]; rl[0][s] = wo_l[(s * 2 + 1) * 64]; }
+    // ---- o^T = v^T . p^T (+ token values)
+    f32x16 ot = zero16();
+    {
+      uint4 vh, vl, ph, pl;
+      split8(vt, 0, vh, vl);
+      split8v(p0, ph, pl);
+      ot = mfma3<ONE>(vh, vl, ph, pl, ot);
+      split8(vt, 8, vh, vl);
+      split8v(p1, ph, pl);
+      ot = mfma3<ONE>(vh, vl, ph, pl, ot);
+      if (ntok) {
+        const uint4* evs = evf + h * 2 * 64 + lane;
+        split8v(g, ph, pl);
+        ot = mfma3<ONE>(evs[0], evs[64], ph, pl, ot);
+      }
+    }
+    uint4 oh[2], ol[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) split8(ot, s * 8, oh[s], ol[s]);
+    // ---- this head's share of to_out, 64 output channels at a time through the head-sum buffer
+    float* rb = red + (h * 32) * 64;
+#pragma unroll
+    for (int half = 0; half < NV; ++half) {
+      if (half) __syncthreads();  // the previous half's sums have been read
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int ct = half * 2 + c2;
+        if (ct + 1 < NCT) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            rh[(ct + 1) & 1][s] = wo_l[(((ct + 1) * 16 + s) * 2) * 64];
+            rl[(ct + 1) & 1][s] = wo_l[(((ct + 1) * 16 + s) * 2 + 1) * 64];
+          }
+        }
+        f32x16 pc = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pc = mfma3<ONE>(oh[s], ol[s], rh[ct & 1][s], rl[ct & 1][s], pc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          rb[m * 64 + c2 * 32 + lrow] = pc[r];
+        }
+      }
+      __syncthreads();
+      if (rft < T) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < HEADS; ++w) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * 32 + rm) * 64 + rcol);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
+        acc.x += x_cur[half].x; acc.y += x_cur[half].y; acc.z += x_cur[half].z; acc.w += x_cur[half].w;  // residual: the element this thread normalised
+        *reinterpret_cast<f32x4*>(a.out + row * a.ldo + half * 64 + rcol) = acc;
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Second version: the same products, two tiles in flight, the two waves of a SIMD half a tile apart.
@@ -720,9 +1059,11 @@ int tb_version() {  // read at every call (a host-side getenv per plan build / l
 
 // Weights: wqkv_frag = vmm_pack_weights fmt 2 of to_qkv (768, 64), wout_frag = fmt 3 of to_out (64, 256).
 // Returns 1 (nothing launched) when the shape is outside the envelope: C == 64, heads == 8, dim_head == 32, ntok <= 16, and T <= 16 with an
-// even HW (two pixels per tile) or T <= 32 (one pixel per tile, second kernel only, LDS permitting -- vmm_temporal_block_supported).
-// 0: outside the envelope of both kernels; 1: first kernel only (T <= 16); 2: two-tiles-in-flight kernel (LDS permitting, T <= 32)
+// even HW (two pixels per tile) or T <= 32 (one pixel per tile, second kernel only, LDS permitting -- vmm_temporal_block_supported); or C == 128
+// with T <= 16 and an even HW (wqkv_frag then = fmt 2 of (768, 128), wout_frag = fmt 3 of (128, 256)).
+// 0: outside the envelope of all kernels; 1: first kernel only (T <= 16); 2: two-tiles-in-flight kernel (LDS permitting, T <= 32); 3: C = 128
 extern "C" int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads) {
+  if (C == TC2 && heads == HEADS && T >= 1 && T <= 16 && ntok >= 0 && ntok <= 16 && !(HW & 1)) return 3;  // the C = 128 kernel (streamed weights)
   if (C != TC || heads != HEADS || T < 1 || T > 32 || ntok < 0 || ntok > 16) return 0;
   const int slots = T <= 16 ? 16 : 32;
   if (slots == 16 && (HW & 1)) return 0;
@@ -752,6 +1093,22 @@ static int tb_launch(const float* x, int32_t ldx, const float* gamma, const floa
   if (want_trace) {
     hipMalloc(reinterpret_cast<void**>(&a.trace), sizeof(unsigned long long) * TB_TRACE_N * 8 * 4);
     hipMemset(a.trace, 0, sizeof(unsigned long long) * TB_TRACE_N * 8 * 4);
+  }
+  if (kind == 3) {  // C = 128: one 512-thread workgroup per CU, one round
+    const int units = HW / 2;
+    const int ns = max(1, min(units, 256 / B));
+    a.tps = (units + ns - 1) / ns;
+    a.nsplit = (units + a.tps - 1) / a.tps;
+    static bool attr128 = false;
+    if (!attr128) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block128_kernel<ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr128 = true;
+    }
+    const size_t shm = sizeof(float) * HEADS * 32 * 64 + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
+                       sizeof(unsigned short) * 32 * (2 * TC2 + 8) + sizeof(float) * 2 * 16 * 8 * 2;
+    hipLaunchKernelGGL(temporal_block128_kernel<ONE>, dim3((unsigned)(B * a.nsplit)), dim3(512), shm, (hipStream_t)stream, a);
+    VMM_LAUNCH_CHECK();
+    return 0;
   }
   const int slots = (kind == 2 && T > 16) ? 32 : 16;
   const int units = HW / (32 / slots);

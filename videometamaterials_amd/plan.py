@@ -973,8 +973,8 @@ class _Builder:
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, p, linear=False, temporal=temporal)
         if (temporal and not focus and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
-                and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
-            # full-resolution level: the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
+                and (x.C != 128 or _enabled("tb_c128")) and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
+            # the two upper levels (C = 64, 128): the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
             wq, _ = self.pack_linear(p + ".to_qkv.weight", frag=2)
             wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
