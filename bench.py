@@ -43,7 +43,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (AMD's 5 PF headline includes 2:1 sparsi
 PEAK_HBM_GBS = 8000.0
 # launcher (family) -> device kernel name prefix in rocprofv3 output
 KERNEL_OF = {"vmm_conv3x3_bf16x3": ("conv3x3_x3_kernel", "conv3x3_pw_kernel"), "vmm_conv_igemm_bf16x3": ("igemm_bf16x3_kernel",), "vmm_conv_s2_bf16x3": ("conv_s2_kernel",),
-             "vmm_conv_igemm_f32": ("igemm_f32_kernel",), "vmm_temporal_block_bf16x3": ("temporal_block_kernel", "temporal_block2_kernel"),
+             "vmm_conv_igemm_f32": ("igemm_f32_kernel",), "vmm_temporal_block_bf16x3": ("temporal_block_kernel", "temporal_block2_kernel", "temporal_block128_kernel"),
              "vmm_linattn_block_bf16x3": ("linattn_ctx_kernel", "linattn_combine_kernel", "linattn_apply_kernel"),
              "vmm_temporal_core_bf16x3": ("temporal_core_kernel",), "vmm_proj_bf16x3": ("proj_x3_kernel",), "vmm_conv_wgrad_f32": ("wgrad_f32_kernel",),
              "vmm_conv3x3_f32": ("conv3x3_x3_kernel", "conv3x3_pw_kernel"), "vmm_proj_f32": ("proj_x3_kernel",),
