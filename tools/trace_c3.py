@@ -1,6 +1,7 @@
 """Measurement aid: phase time line of one launch of the one-tile-per-workgroup 3x3 kernel (conv3x3_x3_kernel).
 
-    VMM_C3_TRACE=<k> VMM_C3_TRACE_FILE=gpurun_out/c3_trace.txt python tools/trace_c3.py
+    python tools/build_ab.py conv3x3_bf16x3 -DVMM_C3_TRACE_BUILD=1    # (the stamps are not in the default build: they cost registers)
+    VMM_LIB_PATH=$PWD/videometamaterials_amd/libvmm_hip_ab.so VMM_C3_TRACE=<k> VMM_C3_TRACE_FILE=gpurun_out/c3_trace.txt python tools/trace_c3.py
 
 runs one eager denoiser forward at the bench shape; the k-th 3x3 launch (network order: 0 = downs.0.0.block1, 1 = downs.0.0.block2, ...)
 writes 16 stamps per workgroup (wave 0: entry, loads issued, first patch stored, first barrier, [end of chunk c's steps, next patch

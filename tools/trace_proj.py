@@ -1,6 +1,7 @@
 """Measurement aid: phase time line of one launch of the A-stationary projection kernel (proj_x3_kernel).
 
-    VMM_PJ_TRACE=<k> VMM_PJ_TRACE_FILE=gpurun_out/pj_trace.txt python tools/trace_proj.py
+    python tools/build_ab.py proj_bf16x3 -DVMM_PJ_TRACE_BUILD=1   # (the stamps are not in the default build)
+    VMM_LIB_PATH=$PWD/videometamaterials_amd/libvmm_hip_ab.so VMM_PJ_TRACE=<k> VMM_PJ_TRACE_FILE=gpurun_out/pj_trace.txt python tools/trace_proj.py
 
 runs three eager denoiser forwards at the bench shape; the k-th projection launch of the process writes 18 stamps per workgroup (wave 0:
 entry, row requests issued, rows staged, barrier, then per column chunk: end of the k16 steps, end of the epilogue; exit)."""

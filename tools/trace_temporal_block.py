@@ -1,4 +1,5 @@
-"""VMM_TB_TRACE time line of one fused temporal block launch (workgroup 0): python tools/trace_temporal_block.py [T HW ntok]"""
+"""VMM_TB_TRACE time line of one fused temporal block launch (workgroup 0): python tools/trace_temporal_block.py [T HW ntok]
+(needs a library built with the stamps: python tools/build_ab.py temporal_block -DVMM_TB_TRACE_BUILD=1, then VMM_LIB_PATH=.../libvmm_hip_ab.so)"""
 import os
 import sys
 

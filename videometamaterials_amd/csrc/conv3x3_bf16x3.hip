@@ -87,13 +87,22 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane & 31, lk = lane >> 5;
   const int W = p.Win, H = p.Hin, HW = H * W;
+  // The phase stamps are compiled in only by -DVMM_C3_TRACE_BUILD=1 (tools/build_ab.py conv3x3_bf16x3 -DVMM_C3_TRACE_BUILD=1, then VMM_LIB_PATH): the
+  // run-time test `a.trace != nullptr` alone kept the pointer and the workgroup's slot index alive through the whole kernel -- 15-35 registers in
+  // every instantiation, and 36 bytes of scratch in the 256 x 64 instance of the 96 x 96 layers (256 -> 237 registers without them; the family
+  // 5.93 -> 5.87 ms per guided step on one box).
+#ifndef VMM_C3_TRACE_BUILD
+#define VMM_C3_TRACE_BUILD 0
+#endif
   auto stamp = [&](int k) {  // measurement aid (outside the step loop only)
-    if (a.trace && tid == 0 && k < 14) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = __builtin_readcyclecounter();
+    if constexpr (VMM_C3_TRACE_BUILD)
+      if (a.trace && tid == 0 && k < 14) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = __builtin_readcyclecounter();
   };
-  if (a.trace && tid == 0) {
-    a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
-    a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
-  }
+  if constexpr (VMM_C3_TRACE_BUILD)
+    if (a.trace && tid == 0) {
+      a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
+      a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
+    }
   stamp(0);
   // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
   // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in

@@ -64,8 +64,14 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   const int K = p.C1 + p.C2;
   const int nc_begin = blockIdx.y * a.chunks_per_y, nc_end = min(a.n_chunks, nc_begin + a.chunks_per_y);
   if (nc_begin >= nc_end) return;
+  // (compiled in by -DVMM_PJ_TRACE_BUILD=1 only -- tools/build_ab.py proj_bf16x3 -DVMM_PJ_TRACE_BUILD=1 + VMM_LIB_PATH: the run-time pointer test keeps
+  // the pointer and the slot index in registers for the whole kernel, see conv3x3_bf16x3.hip)
+#ifndef VMM_PJ_TRACE_BUILD
+#define VMM_PJ_TRACE_BUILD 0
+#endif
   auto stamp = [&](int k) {  // measurement aid (tools/trace_proj.py)
-    if (a.trace && tid == 0 && k < 18) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 18 + k] = __builtin_readcyclecounter();
+    if constexpr (VMM_PJ_TRACE_BUILD)
+      if (a.trace && tid == 0 && k < 18) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 18 + k] = __builtin_readcyclecounter();
   };
   stamp(0);
 

@@ -837,9 +837,14 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
   load_x(grp ? 0 : -1, xv);
   __syncthreads();
 
-  const bool tracing = a.trace && blockIdx.x == 0;
+  // (compiled in by -DVMM_TB_TRACE_BUILD=1 only -- tools/build_ab.py temporal_block -DVMM_TB_TRACE_BUILD=1 + VMM_LIB_PATH; see conv3x3_bf16x3.hip)
+#ifndef VMM_TB_TRACE_BUILD
+#define VMM_TB_TRACE_BUILD 0
+#endif
+  const bool tracing = VMM_TB_TRACE_BUILD && a.trace && blockIdx.x == 0;
   auto stamp = [&](int n, int k) {
-    if (tracing && n < TB_TRACE_N && lane == 0) a.trace[(n * 8 + h) * 4 + k] = __builtin_amdgcn_s_memtime();
+    if constexpr (VMM_TB_TRACE_BUILD)
+      if (tracing && n < TB_TRACE_N && lane == 0) a.trace[(n * 8 + h) * 4 + k] = __builtin_amdgcn_s_memtime();
   };
   for (int n = 0; n < 2 * nt + 4; ++n) {
     stamp(n, 0);
