@@ -356,8 +356,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // bf16x3: 8 hi then 8 lo values of channels s*16 + lk*8 .. +7;  fp32: those eight channels as two float4
-      // (TS: the tap is a run-time, wave-uniform value: the kernel-row base is selected, the rest is a scalar offset)
-      const unsigned short* q = TS ? Ph + (kh == 0 ? abase[i][0] : kh == 1 ? abase[i][1] : abase[i][2]) + (kw * CROW + s * 16)
+      // (TS: the tap is a run-time, wave-uniform value: the centre-row base plus ONE scalar offset.  Selecting among the three row bases
+      // -- `kh == 0 ? abase[i][0] : ...` -- was turned back into a run-time index by the compiler: the six bases went to scratch and every k16
+      // step paid two scratch loads on the vector-memory counter its weight fragments wait on; 32 bytes of scratch in every conv_s2 instance)
+      // (family 0.775 -> 0.64 ms per guided step on one box)
+      const unsigned short* q = TS ? Ph + abase[i][1] + (((kh - 1) * pitch + kw) * CROW + s * 16)
                                    : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       uint4 vh = *reinterpret_cast<const uint4*>(q);
       if constexpr (ONE) {
