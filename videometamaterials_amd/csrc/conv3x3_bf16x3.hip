@@ -351,6 +351,14 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) abase[i][kh] = (prow[i] + (kh - 1) * pitch - 1) * CROW + lk * (F32 ? 16 : 8);
+  // Flat row tiles (MODE 0): a tap that leaves the image reads a real patch row of ANOTHER pixel, so it is masked per pixel.  The masked lanes
+  // read three rows of zeros behind the patch instead (one select on the ADDRESS per pixel block; it was eight selects on the fragment's
+  // registers -- 16 v_cndmask per k16 step between the MFMAs, 546 in the kernel).  Immediate offsets stay below 3 * CROW.
+#ifndef VMM_C3_ZERO_ROWS
+#define VMM_C3_ZERO_ROWS 1
+#endif
+  constexpr bool ZROWS = VMM_C3_ZERO_ROWS && !MODE;
+  const int zb = PRc * CROW;  // element offset of the zero rows
   auto load_a = [&](uint4 (&d)[4], int tap, int s) {
     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
@@ -360,15 +368,21 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       // -- `kh == 0 ? abase[i][0] : ...` -- was turned back into a run-time index by the compiler: the six bases went to scratch and every k16
       // step paid two scratch loads on the vector-memory counter its weight fragments wait on; 32 bytes of scratch in every conv_s2 instance)
       // (family 0.775 -> 0.64 ms per guided step on one box)
-      const unsigned short* q = TS ? Ph + abase[i][1] + (((kh - 1) * pitch + kw) * CROW + s * 16)
-                                   : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
+      const bool ok = MODE || ((tapmask[i] >> tap) & 1u);
+      const unsigned short* q;
+      if constexpr (ZROWS) {
+        if (TS) q = Ph + (ok ? abase[i][1] + (((kh - 1) * pitch + kw) * CROW + s * 16) : zb);
+        else q = Ph + (ok ? abase[i][kh] : zb) + (kw * CROW + s * (F32 ? 32 : 16));
+      } else {
+        q = TS ? Ph + abase[i][1] + (((kh - 1) * pitch + kw) * CROW + s * 16) : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
+      }
       uint4 vh = *reinterpret_cast<const uint4*>(q);
       if constexpr (ONE) {
-        if (!MODE && !((tapmask[i] >> tap) & 1u)) vh = make_uint4(0u, 0u, 0u, 0u);
+        if (!ZROWS && !ok) vh = make_uint4(0u, 0u, 0u, 0u);
         d[2 * i] = vh;
       } else {
         uint4 vl = *reinterpret_cast<const uint4*>(q + (F32 ? 8 : CK));
-        if (!MODE && !((tapmask[i] >> tap) & 1u)) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
+        if (!ZROWS && !ok) { vh = make_uint4(0u, 0u, 0u, 0u); vl = vh; }
         d[2 * i] = vh;
         d[2 * i + 1] = vl;
       }
@@ -449,6 +463,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
   stamp(1);
   store_patch(c_begin);
+  if constexpr (ZROWS)
+    for (int i = tid; i < 3 * CROW / 2; i += 256) reinterpret_cast<unsigned*>(Ph + zb)[i] = 0u;  // (stays zero: no patch store reaches row PR)
   stamp(2);
   __syncthreads();
   stamp(3);
@@ -1399,7 +1415,7 @@ inline int* c3_launch_counter() { static int n = 0; return &n; }  // one count o
 
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false>
 int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
-  const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
+  const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;  // (+ three rows of zeros for the masked taps of flat row tiles)
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, SPLIT, F32, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1438,7 +1454,7 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
 
 template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false>
 int launch_s2(const C3Args& a, int mtiles, hipStream_t s, int ksplit = 1) {
-  const size_t shm = sizeof(unsigned short) * (size_t)a.PR * CROW;
+  const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;  // (+ three rows of zeros for the masked taps of flat row tiles)
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
