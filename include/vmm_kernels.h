@@ -402,6 +402,13 @@ int vmm_select_concat(const float* x, const float* null_row, const uint8_t* mask
  *   mode 2: b[row] += a[row] where focus        (backward: dv += dO) */
 int vmm_focus_rows(int32_t mode, const float* a, int32_t lda, float* b, int32_t ldb, const uint8_t* focus, int32_t B, int32_t rows_per_sample,
                    int32_t ncols, vmm_stream_t stream);
+/* cond_att_GRU (vddp.py:546-549, 567-571, 769-770: SignalEmbedding('GRU') = nn.GRU(1, cond_dim, num_layers=3, batch_first=True) over the signal):
+ * the recurrence of ONE layer.  gi [B][L][3H] = W_ih x_t + b_ih for every step (a batched dense launch), whh_t = W_hh transposed [H][3H], bhh [3H];
+ * y [B][L][H] = the layer's states; training also keeps hprev [B][L][H] (the state BEFORE each step) and gates [B][L][4][H] = (r, z, n, W_hn h + b_hn)
+ * (both may be NULL).  Gate order r | z | n as in torch.  vmm_tokens_select: tokens[b, n, :] = mask[b] ? null_token[n, :] : g[b, n, :]. */
+int vmm_gru_recurrent(const float* gi, const float* whh_t, const float* bhh, float* y, float* hprev, float* gates, int32_t B, int32_t L, int32_t H,
+                      vmm_stream_t stream);
+int vmm_tokens_select(const float* g, const float* null_token, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* tokens, vmm_stream_t stream);
 /* rotate token keys for temporal attention: ek[b, n, h*dh + d] with position n (vddp.py:470-471) */
 int vmm_rotary_rows(float* x, const float* rot_tab, int32_t B, int32_t N, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* relative position bias (vddp.py:70-108): embedding gather through the INTEGER T5 bucket table [n*n] that the host computes
@@ -517,6 +524,12 @@ int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float* dx, float*
 /* backward of vmm_select_concat: dout [B][2D]; ADDS into dx / dnull_row / dt (each may be NULL) */
 int vmm_select_concat_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dt, int32_t B, int32_t D,
                           vmm_stream_t stream);
+/* backward of vmm_gru_recurrent through time: dy [B][L][H] = gradient of the layer's states; whh = W_hh in torch layout (3H, H); WRITES dgi / dgh
+ * [B][L][3H] (gradients of the input-side / hidden-side pre-activations: the weight, bias and input gradients are dense backward jobs over them).
+ * vmm_tokens_select_bwd WRITES dg and ADDS into dnull_token. */
+int vmm_gru_recurrent_bwd(const float* dy, const float* gates, const float* hprev, const float* whh, float* dgi, float* dgh, int32_t B, int32_t L, int32_t H,
+                          vmm_stream_t stream);
+int vmm_tokens_select_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dg, float* dnull_token, vmm_stream_t stream);
 int vmm_relpos_bias_bwd(const float* dbias, const int32_t* buckets, int32_t n, int32_t heads, float* demb, vmm_stream_t stream);
 int vmm_tokens_from_hidden_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dhidden,
                                float* dnull_token, vmm_stream_t stream);

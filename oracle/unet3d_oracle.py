@@ -336,6 +336,33 @@ def signal_cnn(sd, cond: Tensor) -> Tensor:
     return torch.squeeze(h)
 
 
+def signal_gru(sd, cond: Tensor) -> Tensor:
+    """SignalEmbedding('GRU') (vddp.py:546-549, 567-571): the (B, L) signal as a length-L sequence of scalars through nn.GRU(1, cond_dim, num_layers=3,
+    batch_first=True); every time step's top-layer state is a token -> (B, L, cond_dim).  nn.GRU's cell (torch documentation), gates in the order
+    (r, z, n) along the 3 H rows of weight_ih / weight_hh:
+        r = sigmoid(W_ir x + b_ir + W_hr h + b_hr),  z = sigmoid(W_iz x + b_iz + W_hz h + b_hz),
+        n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),  h' = (1 - z) * n + z * h,   h_0 = 0."""
+    x = cond[..., None]  # (B, L, 1)
+    B, L, _ = x.shape
+    for layer in range(3):
+        pfx = f"sign_emb_GRU.emb_model."
+        w_ih, w_hh = sd[pfx + f"weight_ih_l{layer}"], sd[pfx + f"weight_hh_l{layer}"]
+        b_ih, b_hh = sd[pfx + f"bias_ih_l{layer}"], sd[pfx + f"bias_hh_l{layer}"]
+        H = w_hh.shape[1]
+        gi_all = F.linear(x, w_ih, b_ih)  # (B, L, 3H)
+        h = torch.zeros(B, H, dtype=x.dtype)
+        outs = []
+        for t in range(L):
+            gi, gh = gi_all[:, t], F.linear(h, w_hh, b_hh)
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            outs.append(h)
+        x = torch.stack(outs, dim=1)
+    return x
+
+
 def embed_condition(sd, cfg: UnetCfg, cond: Tensor, null_mask: Tensor):
     """vddp.py:751-795. Returns (tokens or None, hidden (B,time_dim))."""
     if cfg.per_frame_cond:
@@ -349,8 +376,9 @@ def embed_condition(sd, cfg: UnetCfg, cond: Tensor, null_mask: Tensor):
         tokens = None
         if cfg.cond_attention != "none":
             if cfg.cond_att_GRU:
-                raise ValueError("oracle does not cover the GRU ablation")
-            tokens = hidden[:, None, :].expand(-1, cfg.cond_attention_tokens, -1)
+                tokens = signal_gru(sd, cond)  # vddp.py:769-770: one token per sample of the conditioning signal (cond_attention_tokens == its length)
+            else:
+                tokens = hidden[:, None, :].expand(-1, cfg.cond_attention_tokens, -1)
     if cfg.cond_attention != "none":
         tokens = torch.where(null_mask[:, None, None], sd["null_text_token"], tokens)
     hidden = torch.where(null_mask[:, None], sd["null_text_hidden"], hidden)

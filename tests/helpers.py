@@ -53,6 +53,10 @@ CONFIGS = {
     # conditioning tokens at the spatial sites only: the temporal attentions see no tokens, so a non-trivial focus_present_mask is legal (vddp.py:514-524)
     "focus16s": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=9, use_temporal_attention_cond=False,
                       per_frame_cond=False), (3, 5, 16, 16), 51),
+    # cond_att_GRU (vddp.py:546-549, 646-649, 769-770): the conditioning tokens are the 3-layer GRU's states over the signal, one per sample of it
+    # (cond_attention_tokens == signal length); more tokens than the fused kernels' 16: the generic attention paths at every site
+    "gru16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=34, use_temporal_attention_cond=True, per_frame_cond=False,
+                   cond_att_GRU=True), (2, 5, 16, 16), 34),  # (the CNN embedding of the same signal needs 32 .. 63 samples)
     "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
 }

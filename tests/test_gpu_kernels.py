@@ -914,6 +914,56 @@ def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate
     assert relerr(dev2.cpu() - base, ev2.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,L,H,I", [(2, 34, 64, 1), (3, 7, 300, 300), (1, 12, 512, 512), (2, 5, 256, 1)])
+def test_gru_recurrence_against_torch_gru(gpu, B, L, H, I):
+    """vmm_gru_recurrent / _bwd (cond_att_GRU, vddp.py:546-549: nn.GRU) against torch.nn.GRU itself, one layer: states, and through autograd the
+    gradients of the pre-activations' producers (input, W_ih, W_hh, both biases) assembled the way the plan does -- input side as a dense product,
+    recurrence in the kernel, weight gradients from dgi / dgh."""
+    N, lib = _lib()
+    torch.manual_seed(5 + H)
+    gru = torch.nn.GRU(I, H, num_layers=1, batch_first=True)
+    x = torch.randn(B, L, I, requires_grad=True)
+    dy = torch.randn(B, L, H)
+    y_ref, _ = gru(x)
+    y_ref.backward(dy)
+    w_ih, w_hh, b_ih, b_hh = (p.detach() for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0))
+    gi = (x.detach() @ w_ih.t() + b_ih).to(gpu).contiguous()
+    whh_t = w_hh.t().contiguous().to(gpu)
+    bhh, whh = b_hh.to(gpu), w_hh.contiguous().to(gpu)
+    y = torch.empty(B, L, H, device=gpu)
+    hprev, gates = torch.empty(B, L, H, device=gpu), torch.empty(B, L, 4, H, device=gpu)
+    assert lib.vmm_gru_recurrent(gi.data_ptr(), whh_t.data_ptr(), bhh.data_ptr(), y.data_ptr(), hprev.data_ptr(), gates.data_ptr(), B, L, H, _s()) == 0
+    torch.cuda.synchronize()
+    assert relerr(y.cpu(), y_ref.detach()) < 2e-6
+    assert torch.equal(hprev[:, 1:].cpu(), y[:, :-1].cpu()) and float(hprev[:, 0].abs().max()) == 0
+    dgi, dgh = torch.empty(B, L, 3 * H, device=gpu), torch.empty(B, L, 3 * H, device=gpu)
+    dyg = dy.to(gpu)
+    assert lib.vmm_gru_recurrent_bwd(dyg.data_ptr(), gates.data_ptr(), hprev.data_ptr(), whh.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), B, L, H, _s()) == 0
+    torch.cuda.synchronize()
+    dgi_c, dgh_c, hp_c = dgi.cpu().reshape(B * L, 3 * H), dgh.cpu().reshape(B * L, 3 * H), hprev.cpu().reshape(B * L, H)
+    assert relerr(dgi_c.t() @ x.detach().reshape(B * L, I), gru.weight_ih_l0.grad) < 2e-5
+    assert relerr(dgh_c.t() @ hp_c, gru.weight_hh_l0.grad) < 2e-5
+    assert relerr(dgi_c.sum(0), gru.bias_ih_l0.grad) < 2e-5 and relerr(dgh_c.sum(0), gru.bias_hh_l0.grad) < 2e-5
+    assert relerr((dgi_c @ w_ih).reshape(B, L, I), x.grad) < 2e-5
+    # token select: forward and backward
+    D, Nn = 32, 5
+    g0 = torch.randn(B, Nn, D)
+    null = torch.randn(Nn, D)
+    mask = torch.tensor([b % 2 for b in range(B)], dtype=torch.uint8)
+    out = torch.empty(B, Nn, D, device=gpu)
+    g0g, nullg, maskg = g0.to(gpu), null.to(gpu), mask.to(gpu)
+    assert lib.vmm_tokens_select(g0g.data_ptr(), nullg.data_ptr(), maskg.data_ptr(), B, Nn, D, out.data_ptr(), _s()) == 0
+    want = torch.where(mask.bool()[:, None, None], null[None], g0)
+    dtok = torch.randn(B, Nn, D)
+    dg, dnull = torch.full((B, Nn, D), 7.0, device=gpu), torch.full((Nn, D), 0.25, device=gpu)
+    dtokg = dtok.to(gpu)
+    assert lib.vmm_tokens_select_bwd(dtokg.data_ptr(), maskg.data_ptr(), B, Nn, D, dg.data_ptr(), dnull.data_ptr(), _s()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+    assert torch.equal(dg.cpu(), torch.where(mask.bool()[:, None, None], torch.zeros(()), dtok))
+    assert relerr(dnull.cpu() - 0.25, (dtok * mask.float()[:, None, None]).sum(0)) < 1e-5 or float((dtok * mask.float()[:, None, None]).abs().max()) == 0
+
+
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 3, 24, 24, 64, 128), (3, 2, 6, 12, 128, 64), (1, 5, 16, 96, 64, 64)])
 def test_conv3x3_weight_gradient_fused_operand_bf16x3(gpu, B, T, H, W, Cin, Cout):
     """a_mode 1 of the nine-tap split-bf16 weight-gradient kernel: the layer's input is silu(h * ga[b, c] + gb[b, c]) -- GroupNorm * FiLM -> SiLU of the

@@ -30,6 +30,8 @@ CASES = [
     ("lagr32-mults124-40x40", dict(dim=32, dim_mults=(1, 2, 4), **LAGR), (2, 11, 40, 40), 11, True),
     ("cross64-T11-24x8", dict(dim=64, channels=3, cond_attention="cross-attention", cond_attention_tokens=11, use_temporal_attention_cond=True,
                               per_frame_cond=False), (2, 11, 24, 8), 51, False),
+    ("gru64-8x8", dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=40, use_temporal_attention_cond=True, per_frame_cond=False,
+                       cond_att_GRU=True), (2, 3, 8, 8), 40, True),
     # square frames (GaussianDiffusion.image_size) of awkward sizes: also through the training step
     ("lagr16-40x40-B3", dict(dim=16, **LAGR), (3, 11, 40, 40), 11, True),
     ("cnn64-T5-24x24-B3", dict(dim=64, **CNN), (3, 5, 24, 24), 51, True),

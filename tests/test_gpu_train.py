@@ -95,7 +95,7 @@ def test_backward_matches_reference_golden_gradients(gpu):
 
 @pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
                                                ("hires64t22", False), ("circ64", False), ("circ1d16", False), ("cross16", False), ("cross64", False),
-                                               ("cross64", True), ("cross16s", False), ("concat16", False), ("concat16", True), ("concat16c", False)])
+                                               ("cross64", True), ("cross16s", False), ("concat16", False), ("concat16", True), ("concat16c", False), ("gru16", False), ("gru16", True)])
 def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_val):
     kw, sd, model, diff = _setup(cfg_name, gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)

@@ -178,6 +178,10 @@ SIGNATURES = {
     "vmm_rows_layernorm_affine": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_ptr],
     "vmm_select_add": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     "vmm_select_concat": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    "vmm_gru_recurrent": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_tokens_select": [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_gru_recurrent_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_tokens_select_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_focus_rows": [c_i32, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_ptr],
     "vmm_rotary_rows": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_relpos_bias": [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr],

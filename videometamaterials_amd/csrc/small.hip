@@ -222,6 +222,57 @@ __global__ void focus_rows_kernel(int mode, const float* __restrict__ a, int lda
   }
 }
 
+// cond_att_GRU (vddp.py:546-549, 567-571, 769-770): nn.GRU's recurrence for one layer, one workgroup per sample.  The input-side products
+// gi = W_ih x_t + b_ih of ALL time steps come from one batched dense launch; this kernel walks the time axis: gh = W_hh h + b_hh (the state in LDS,
+// W_hh transposed so that consecutive threads read consecutive addresses), r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z),
+// n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h.  Latency-bound by construction (L x 3 dependent steps); a few hundred microseconds per call.
+__global__ __launch_bounds__(256) void gru_rec_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t, const float* __restrict__ bhh,
+                                                          float* __restrict__ y, float* __restrict__ hprev, float* __restrict__ gates, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) float gru_hs[];  // [2][H]
+  const int tid = threadIdx.x;
+  const long long b = blockIdx.x;
+  for (int j = tid; j < 2 * H; j += 256) gru_hs[j] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < L; ++t) {
+    const float* hc = gru_hs + (t & 1) * H;
+    float* hn = gru_hs + ((t + 1) & 1) * H;
+    const long long bt = b * L + t;
+    for (int j = tid; j < H; j += 256) {
+      float ar = bhh[j], az = bhh[H + j], an = bhh[2 * H + j];
+      for (int k = 0; k < H; ++k) {
+        const float hk = hc[k];
+        const float* w = whh_t + (long long)k * 3 * H;
+        ar = fmaf(w[j], hk, ar);
+        az = fmaf(w[H + j], hk, az);
+        an = fmaf(w[2 * H + j], hk, an);
+      }
+      const float* g = gi + bt * 3 * H;
+      const float r = 1.0f / (1.0f + expf(-(g[j] + ar)));
+      const float z = 1.0f / (1.0f + expf(-(g[H + j] + az)));
+      const float n = tanhf(g[2 * H + j] + r * an);
+      const float hp = hc[j];
+      const float h = (1.0f - z) * n + z * hp;
+      y[bt * H + j] = h;
+      hn[j] = h;
+      if (gates) {
+        float* G = gates + bt * 4 * H;
+        G[j] = r; G[H + j] = z; G[2 * H + j] = n; G[3 * H + j] = an;
+      }
+      if (hprev) hprev[bt * H + j] = hp;
+    }
+    __syncthreads();
+  }
+}
+
+// tokens[b, n, :] = mask[b] ? null[n, :] : g[b, n, :]   (vddp.py:773-778 with per-sample, per-token embeddings)
+__global__ void tokens_select_kernel(const float* __restrict__ g, const float* __restrict__ null_tok, const uint8_t* __restrict__ mask, int B, int N, int D,
+                                     float* __restrict__ tokens) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * N * D) return;
+  const int b = (int)(i / ((long long)N * D));
+  tokens[i] = (mask && mask[b]) ? null_tok[i - (long long)b * N * D] : g[i];
+}
+
 // in-place interleaved-pair rotation of x[b, n, h*dh + d] by position n; thread per pair
 __global__ void rotary_rows_kernel(float* __restrict__ x, const float* __restrict__ tab, int B, int N, int heads, int dh) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +418,23 @@ extern "C" int vmm_focus_rows(int32_t mode, const float* a, int32_t lda, float* 
   const long long rows = (long long)B * rows_per_sample;
   hipLaunchKernelGGL(focus_rows_kernel, dim3(cdiv(rows * (ncols / 4), 256)), dim3(256), 0, (hipStream_t)stream, mode, a, lda, b, ldb, focus, rows,
                      rows_per_sample, ncols / 4);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_gru_recurrent(const float* gi, const float* whh_t, const float* bhh, float* y, float* hprev, float* gates, int32_t B, int32_t L,
+                                 int32_t H, vmm_stream_t stream) {
+  if (!gi || !whh_t || !bhh || !y || H < 1 || H > 4096 || L < 1) return -1;
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(gru_rec_fwd_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * 2 * H, (hipStream_t)stream, gi, whh_t, bhh, y, hprev, gates, L, H);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_tokens_select(const float* g, const float* null_token, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* tokens,
+                                 vmm_stream_t stream) {
+  if (!g || !tokens || (mask && !null_token)) return -1;
+  hipLaunchKernelGGL(tokens_select_kernel, dim3(cdiv((long long)B * N * D, 256)), dim3(256), 0, (hipStream_t)stream, g, null_token, mask, B, N, D, tokens);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -168,6 +168,70 @@ __global__ void select_concat_bwd_kernel(const float* __restrict__ dout, const u
   if (dnull) dnull[d] += gn;
 }
 
+// Backward of gru_rec_fwd_kernel through time, one workgroup per sample: with dh = dy_t + carry,
+//   dn = dh (1 - z), dz = dh (h_prev - n), carry' = dh z + W_hh^T dgh,   dn_pre = dn (1 - n^2), dz_pre = dz z (1 - z), dr_pre = dn_pre gh_n r (1 - r),
+//   dgi = (dr_pre, dz_pre, dn_pre), dgh = (dr_pre, dz_pre, dn_pre r).
+// dgi / dgh of every (sample, step) are left for two batched dense backward jobs (weight / bias gradients, and dgi W_ih = the layer below's dy).
+__global__ __launch_bounds__(256) void gru_rec_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gates, const float* __restrict__ hprev,
+                                                          const float* __restrict__ whh, float* __restrict__ dgi, float* __restrict__ dgh, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) float gru_sm[];  // dgh of the step [3H] | carry [H]
+  float* dghs = gru_sm;
+  float* carry = gru_sm + 3 * H;
+  const int tid = threadIdx.x;
+  const long long b = blockIdx.x;
+  for (int j = tid; j < H; j += 256) carry[j] = 0.f;
+  __syncthreads();
+  for (int t = L - 1; t >= 0; --t) {
+    const long long bt = b * L + t;
+    float direct[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = tid + 256 * i;
+      direct[i] = 0.f;
+      if (j < H) {
+        const float* G = gates + bt * 4 * H;
+        const float r = G[j], z = G[H + j], n = G[2 * H + j], an = G[3 * H + j], hp = hprev[bt * H + j];
+        const float dh = dy[bt * H + j] + carry[j];
+        const float dnp = dh * (1.0f - z) * (1.0f - n * n);
+        const float dzp = dh * (hp - n) * z * (1.0f - z);
+        const float drp = dnp * an * r * (1.0f - r);
+        float* o1 = dgi + bt * 3 * H;
+        float* o2 = dgh + bt * 3 * H;
+        o1[j] = drp; o1[H + j] = dzp; o1[2 * H + j] = dnp;
+        o2[j] = drp; o2[H + j] = dzp; o2[2 * H + j] = dnp * r;
+        dghs[j] = drp; dghs[H + j] = dzp; dghs[2 * H + j] = dnp * r;
+        direct[i] = dh * z;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = tid + 256 * i;
+      if (k < H) {
+        float acc = direct[i];
+        for (int g = 0; g < 3 * H; ++g) acc = fmaf(dghs[g], whh[(long long)g * H + k], acc);
+        carry[k] = acc;  // (only its owner read carry[k] above)
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// tokens[b, n, :] = mask[b] ? null[n, :] : g[b, n, :]: dg is WRITTEN, dnull accumulated; thread per (n, d)
+__global__ void tokens_select_bwd_kernel(const float* __restrict__ dtokens, const uint8_t* __restrict__ mask, int B, int N, int D, float* __restrict__ dg,
+                                         float* __restrict__ dnull) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  float gn = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = dtokens[(long long)b * N * D + i];
+    const bool drop = mask && mask[b];
+    if (drop) gn += g;
+    dg[(long long)b * N * D + i] = drop ? 0.f : g;
+  }
+  if (dnull) dnull[i] += gn;
+}
+
 __global__ void relpos_bias_bwd_kernel(const float* __restrict__ dbias, const int32_t* __restrict__ buckets, int n, int heads,
                                        float* __restrict__ demb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,6 +413,21 @@ extern "C" int vmm_select_add_bwd(const float* dout, const uint8_t* mask, float*
 extern "C" int vmm_select_concat_bwd(const float* dout, const uint8_t* mask, float* dx, float* dnull_row, float* dt, int32_t B, int32_t D,
                                      vmm_stream_t stream) {
   hipLaunchKernelGGL(select_concat_bwd_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, dout, mask, dx, dnull_row, dt, B, D);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_gru_recurrent_bwd(const float* dy, const float* gates, const float* hprev, const float* whh, float* dgi, float* dgh, int32_t B, int32_t L,
+                                     int32_t H, vmm_stream_t stream) {
+  if (!dy || !gates || !hprev || !whh || !dgi || !dgh || H < 1 || H > 4096 || L < 1) return -1;
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(gru_rec_bwd_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * 4 * H, (hipStream_t)stream, dy, gates, hprev, whh, dgi, dgh, L, H);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vmm_tokens_select_bwd(const float* dtokens, const uint8_t* mask, int32_t B, int32_t N, int32_t D, float* dg, float* dnull_token,
+                                     vmm_stream_t stream) {
+  if (!dtokens || !dg) return -1;
+  hipLaunchKernelGGL(tokens_select_bwd_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, (hipStream_t)stream, dtokens, mask, B, N, D, dg, dnull_token);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -1302,11 +1302,48 @@ class _Builder:
                 cur, cur_C, L = nxt, co, Lout
             if L != 1:
                 raise ValueError("sign_emb_CNN must reduce the conditioning signal to length 1 (cond length 32..63)")
-            if tokens is not None:
+            gru = []  # cond_att_GRU (vddp.py:546-549, 646-649, 769-770): the tokens are the states of a 3-layer GRU over the signal, one per sample of it
+            if tokens is not None and getattr(m, "cond_att_GRU", False):
+                Lg = self.cond_len
+                if Lg != ntok:
+                    raise ValueError(f"cond_att_GRU makes one token per sample of the conditioning signal: cond_attention_tokens ({ntok}) must equal its "
+                                     f"length ({Lg}) (the reference's torch.where against null_text_token, vddp.py:778)")
+                if D > 1024:
+                    raise NotImplementedError("cond_att_GRU with a hidden width above 1024")
+                xin, in_dim = self.ptr(cond_off), 1
+                for l in range(3):
+                    pf = "sign_emb_GRU.emb_model."
+                    wih, whh, bih, bhh = (pf + f"{n}_l{l}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                    gi, yl = self.alloc(B * Lg * 3 * D), self.alloc(B * Lg * D)
+                    hp, gates = (self.ptr(self.alloc(B * Lg * D)), self.ptr(self.alloc(B * Lg * 4 * D))) if tr else (0, 0)
+                    self.dense_level([dict(x=xin, w=self.wraw(wih), b=self.wraw(bih), y=self.ptr(gi), rows=B * Lg, K=in_dim, N=3 * D)],
+                                     f"sign_emb_GRU layer {l}: W_ih x + b_ih for every step")
+                    whh_t = self.pack(whh, 3 * D * D, want_grad=False, TH=1, TW=1, C=D, Cp=D, N=3 * D, sn=D, sc=1)[0]  # [H][3H]
+                    self.step(lib.vmm_gru_recurrent, (self.ptr(gi), whh_t, self.wraw(bhh), self.ptr(yl), hp or None, gates or None, B, Lg, D),
+                              f"sign_emb_GRU layer {l}: recurrence")
+                    for nm_ in (wih, whh, bih, bhh):
+                        self._touch(nm_)
+                    gru.append((xin, in_dim, wih, whh, bih, bhh, hp, gates))
+                    xin, in_dim = self.ptr(yl), D
+                self.step(lib.vmm_tokens_select, (xin, self.wraw("null_text_token"), self.ptr(mask_off), B, ntok, D, self.ptr(tokens)), "tokens (GRU states)")
+            elif tokens is not None:
                 self.step(lib.vmm_tokens_from_hidden, (self.ptr(hidden), self.wraw("null_text_token"), self.ptr(mask_off), B, ntok, D, self.ptr(tokens)), "tokens")
             if tr:
                 def cond_b():
-                    if tokens is not None:
+                    if gru:
+                        Lg = self.cond_len
+                        dy = self.ptr(self.alloc(B * Lg * D))
+                        self.step(lib.vmm_tokens_select_bwd, (self.dtokens_ptr, self.ptr(mask_off), B, ntok, D, dy, self.pg("null_text_token")), "tokens bwd")
+                        for l in (2, 1, 0):
+                            xin, in_dim, wih, whh, bih, bhh, hp, gates = gru[l]
+                            dgi, dgh = self.ptr(self.alloc(B * Lg * 3 * D)), self.ptr(self.alloc(B * Lg * 3 * D))
+                            self.step(lib.vmm_gru_recurrent_bwd, (dy, gates, hp, self.wraw(whh), dgi, dgh, B, Lg, D), f"sign_emb_GRU layer {l}: recurrence bwd")
+                            dx = self.scratch(B * Lg * in_dim) if l > 0 else 0  # (zeroed every backward: the dense backward accumulates into it)
+                            self.dense_bwd_level([dict(x=xin, w=self.wraw(wih), dy=dgi, dx=dx, dw=self.pg(wih), db=self.pg(bih), rows=B * Lg, K=in_dim, N=3 * D),
+                                                  dict(x=hp, w=self.wraw(whh), dy=dgh, dw=self.pg(whh), db=self.pg(bhh), rows=B * Lg, K=D, N=3 * D)],
+                                                 f"sign_emb_GRU layer {l}: weight / bias / input gradients")
+                            dy = dx
+                    elif tokens is not None:
                         self.step(lib.vmm_tokens_from_hidden_bwd, (self.dtokens_ptr, self.ptr(mask_off), B, ntok, D, ghidden, self.pg("null_text_token")),
                                   "tokens bwd")
                     rev = list(reversed(stages))

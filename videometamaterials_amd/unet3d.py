@@ -73,8 +73,6 @@ class Unet3D(nn.Module):
     ):
         super().__init__()
         assert init_kernel_size % 2 == 1  # vddp.py:621
-        if cond_att_GRU:
-            raise NotImplementedError("cond_att_GRU (ablation-only GRU embedding, vddp.py:546-549) is not built")
         if padding_mode not in ("zeros", "circular", "circular_1d"):
             raise ValueError(f"padding_mode {padding_mode!r}: 'zeros', 'circular' or 'circular_1d' (vddp.py:153-243)")
         if cond_to_time not in ("add", "concat"):
@@ -180,6 +178,10 @@ class Unet3D(nn.Module):
         for i, (ci, co) in enumerate(zip(chain[:-1], chain[1:])):
             _attach(self, f"sign_emb_CNN.emb_model.{2 * i}.weight", _uniform((co, ci, 4), ci * 4))
             _attach(self, f"sign_emb_CNN.emb_model.{2 * i}.bias", _uniform((co,), ci * 4))
+        if self.cond_att_GRU:  # SignalEmbedding('GRU') = nn.GRU(1, cond_dim, num_layers=3) (vddp.py:546-549, 646-649): uniform(+-1/sqrt(H)) like torch
+            for l in range(3):
+                for nm_, shp in (("weight_ih", (3 * cd, 1 if l == 0 else cd)), ("weight_hh", (3 * cd, cd)), ("bias_ih", (3 * cd,)), ("bias_hh", (3 * cd,))):
+                    _attach(self, f"sign_emb_GRU.emb_model.{nm_}_l{l}", _uniform(shp, cd))
         if self.per_frame_cond:
             self._linear("sign_emb", cd, 1)
             _attach(self, "cond_token_to_hidden.0.weight", torch.ones(cd))
