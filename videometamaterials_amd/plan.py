@@ -1638,12 +1638,22 @@ class _Builder:
             # token k/v, FiLM layers) were first used in the embedding stage, i.e. they sit in front of every block.
             self.in_bwd = True
             uj_hi = len(self.unpack_jobs)
-            for emit, pg_start, uj_start in reversed(self.tape):
+            # The packed weight gradients of a block are scattered into the flat torch-layout buffer -- and the buffer's tail marked final for the
+            # data-parallel reducer -- once at least `span` floats of it are pending: a scatter launch and a mark per block were 45 launches of
+            # ~15 us, most of them for the full-resolution blocks whose parameters are a few tens of thousands of floats (the reducer merges marks
+            # into >= 16 MB buckets anyway).
+            span = min(250_000, max(1, self.pgtop // 12)) if _enabled("scatter_merge") else 1
+            marked_pg, pend_lo = self.pgtop, uj_hi
+            rev = list(reversed(self.tape))
+            for idx, (emit, pg_start, uj_start) in enumerate(rev):
                 emit()
-                self.emit_unpack(self.unpack_jobs[uj_start:uj_hi], "scatter weight gradients")
-                uj_hi = min(uj_hi, uj_start)
-                if self.plan.bwd_steps:
-                    self.plan.bwd_marks.append((len(self.plan.bwd_steps) - 1, pg_start))
+                pend_lo = min(pend_lo, uj_start)
+                if marked_pg - pg_start >= span or idx == len(rev) - 1:
+                    self.emit_unpack(self.unpack_jobs[pend_lo:uj_hi], "scatter weight gradients")
+                    uj_hi = min(uj_hi, pend_lo)
+                    marked_pg = pg_start
+                    if self.plan.bwd_steps:
+                        self.plan.bwd_marks.append((len(self.plan.bwd_steps) - 1, pg_start))
             self.in_bwd = False
         return self.plan
 
