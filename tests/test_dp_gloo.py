@@ -61,6 +61,88 @@ def test_bucketed_allreduce_and_sharded_gather_world2():
         assert full == [float(i) for i in range(7)]
 
 
+class _GlooEngine:
+    """Stand-in with the surface of dp.RcclEngine (register / allreduce_bucket_async / wait_all / timing hooks) whose collectives go over gloo: the
+    native engine's N-rank CONTROL FLOW in BucketedAllReduce -- static bucket list from the plan's marks, buckets issued by index in mark order, one
+    wait before the optimiser -- on CPU, where RCCL itself cannot run."""
+
+    def __init__(self, world):
+        self.world, self.log, self.pending = world, [], []
+
+    def register(self, flat, slices):
+        self.flat, self.slices = flat, list(slices)
+        self.log.append(("register", len(slices)))
+
+    def allreduce_bucket_async(self, i):
+        lo, hi = self.slices[i]
+        self.pending.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+        self.log.append(("bucket", i))
+
+    def wait_all(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        self.log.append(("wait",))
+
+    def set_timing(self, on):
+        pass
+
+
+def _engine_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from videometamaterials_amd.dp import BucketedAllReduce, plan_buckets
+        n, marks = 10_000, [9000, 8800, 7000, 6999, 3000, 100, 0]
+        flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        eng = _GlooEngine(world)
+        red = BucketedAllReduce(flat, n, bucket_floats=1500, engine=eng, marks=marks)
+        want_slices = plan_buckets(n, marks, 1500)
+        for _ in range(2):  # two steps: the registered list is reused
+            flat.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+            red.start()
+            for x in marks:
+                red.mark(x)
+            red.finish()
+        want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok = torch.equal(flat, want)
+        issued = [e[1] for e in eng.log if e[0] == "bucket"]
+        q.put((rank, ok, red.launched == want_slices, issued, [e[0] for e in eng.log].count("register"), [e[0] for e in eng.log].count("wait")))
+        # a mark sequence the registered list does not cover is an error, not a silent skip
+        bad = BucketedAllReduce(flat, n, bucket_floats=1500, engine=_GlooEngine(world), marks=[5000, 0])
+        bad.start()
+        try:
+            bad.mark(7000)
+            q.put((rank, "no error"))
+        except RuntimeError:
+            q.put((rank, "raised"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_engine_control_flow_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 250
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        if len(r) == 2:
+            assert r[1] == "raised", r
+            continue
+        rank, ok, same_slices, issued, n_reg, n_wait = r
+        assert ok and same_slices, f"rank {rank}"
+        nb = len(issued) // 2
+        assert issued == list(range(nb)) * 2 and nb >= 3  # by index, in mark order, both steps
+        assert n_reg == 1 and n_wait == 2
+
+
 def _bcast_worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
