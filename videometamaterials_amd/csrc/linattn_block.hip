@@ -303,6 +303,81 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
       if (t < t_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
     }
   };
+#ifndef VMM_LA_PIPE
+#define VMM_LA_PIPE 1
+#endif
+  if constexpr (CC == 64 && VMM_LA_PIPE) {
+    // C = 64: ONE barrier per tile.  The head-sum buffer and the staged rows are double-buffered (2 x 64 KB + 2 x 8.5 KB of LDS; the
+    // workgroup is alone on its CU anyway): a tile's matrix phase writes red[buf], the NEXT tile's rows are normalised into ytile[buf ^ 1]
+    // behind it, one barrier publishes both, then the head sum of this tile runs straight into the next tile's matrix phase.
+    unsigned short* yt0 = reinterpret_cast<unsigned short*>(red + 2 * LH * 32 * 64);
+    auto red_of = [&](int b2) { return red + b2 * (LH * 32 * 64); };
+    auto yt_of = [&](int b2) { return yt0 + b2 * (32 * YP); };
+    f32x4 xa[NV], xb[NV];
+    load_x(t_begin, xa);
+    stage_norm_row<CC>(a, xa, gam, yt_of(0), tid);
+    load_x(t_begin + 1, xb);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int buf = (t - t_begin) & 1;
+      const long long row0 = (long long)frame * a.HW + t * 32;
+      f32x16 qt = zero16();
+      {
+        uint4 yh[4], yl[4];
+        read_row_frags<CC>(yt_of(buf), lrow, lk, 0, yh, yl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qt = mfma3<ONE>(wqh[i], wql[i], yh[i], yl[i], qt);
+      }
+      float mx = qt[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qt[r]);
+      mx = fmaxf(mx, lane_xor(mx, 5));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { qt[r] = __expf(qt[r] - mx); sum += qt[r]; }
+      sum += lane_xor(sum, 5);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qt[r] *= inv;
+      f32x16 ot = zero16();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint4 qh, ql;
+        split8(qt, s * 8, qh, ql);
+        ot = mfma3<ONE>(ch[s], cl[s], qh, ql, ot);
+      }
+      f32x16 pc[2] = {zero16(), zero16()};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint4 oh, ol;
+        split8(ot, s * 8, oh, ol);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) pc[ct] = mfma3<ONE>(oh, ol, woh[ct][s], wol[ct][s], pc[ct]);
+      }
+      float* rb = red_of(buf) + (h * 32) * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        rb[px * 64 + lrow] = pc[0][r];
+        rb[px * 64 + 32 + lrow] = pc[1][r];
+      }
+      stage_norm_row<CC>(a, xb, gam, yt_of(buf ^ 1), tid);  // the next tile's rows (zeros past the end)
+      f32x4 xc[NV];
+      load_x(t + 2, xc);
+      __syncthreads();
+      f32x4 acc = bias[0];
+#pragma unroll
+      for (int w = 0; w < LH; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red_of(buf) + (w * 32 + rp) * 64 + rc);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x += xa[0].x; acc.y += xa[0].y; acc.z += xa[0].z; acc.w += xa[0].w;  // residual: the element this thread normalised
+      *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + rc) = acc;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { xa[v] = xb[v]; xb[v] = xc[v]; }
+    }
+    return;
+  }
   f32x4 x_next[NV];
   load_x(t_begin, x_next);
   for (int t = t_begin; t < t_end; ++t) {
@@ -408,7 +483,7 @@ static int la_run(const LAArgs& a, unsigned blocks, int frames, hipStream_t s) {
   VMM_LAUNCH_CHECK();
   hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(frames * LH)), dim3(256), 0, s, a);
   VMM_LAUNCH_CHECK();
-  const size_t shm = sizeof(float) * LH * 32 * 64 + sizeof(unsigned short) * 32 * LAGeom<CC>::YPITCH;
+  const size_t shm = (CC == 64 && VMM_LA_PIPE ? 2 : 1) * (sizeof(float) * LH * 32 * 64 + sizeof(unsigned short) * 32 * LAGeom<CC>::YPITCH);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel<ONE, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
