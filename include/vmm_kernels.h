@@ -508,6 +508,39 @@ int vmm_linattn_bwd(const float* qkv, int32_t ldqkv, const float* ek, const floa
  * saved qkv, dout, the frame's ctx / dctx [frames*heads][32*32] and kstat */
 int vmm_linattn_bwd_rows_mfma(const float* qkv, int32_t ldqkv, const float* dout, int32_t lddo, const float* ctx, const float* dctx,
                               const float* kstat, float* dqkv, int32_t frames, int32_t HW, int32_t heads, float scale, vmm_stream_t stream);
+/* ---- backward of the FUSED attention blocks with recomputation (autograd of vddp.py:313-378 and 396-535 inside Residual(PreNorm(.))).
+ * The training forward is vmm_temporal_block_bf16x3 / vmm_linattn_block_bf16x3: no qkv rows, attention outputs or softmax statistics are
+ * stored.  The backward kernels re-form q, k, v and the probabilities from x on chip, take dO = dOut . W_out on chip, run the core's
+ * backward on the split-bf16 matrix cores and write
+ *   dqkv      rows x 768: gradient of the RAW to_qkv output (rotary and q-scale undone) -> vmm_qkv_bwd_bf16x3 (data + weight gradient)
+ *   ln_stats  rows x 2: (mean, rstd) of the PreNorm LayerNorm of x, for the same kernel
+ *   dwout_packed += [256][C] (packed-gradient layout [in][out] of to_out), dbias += [heads][T][T] (temporal), dek / dev += [B][ntok][256]
+ * The residual path (dx += dOut) and the LayerNorm backward stay with the caller. */
+typedef struct vmm_attn_block_bwd {
+  const float* x; int32_t ldx;            /* block input, rows x C */
+  const float* gamma;                     /* PreNorm LayerNorm weight [C] */
+  const float* wqkv_frag;                 /* vmm_pack_weights fmt 2 of to_qkv (768, C) */
+  const float* wout_t_frag;               /* fmt 2 of the (K = C, N = 256) operand: to_out (C, 256) read as [c][hd] (the data-gradient operand) */
+  const float* ek; const float* ev; int32_t ntok;  /* conditioning keys / values [B][ntok][256] or NULL */
+  const float* bias; int32_t bias_on_cond; /* temporal: relative-position bias [heads][T][T] */
+  const float* rot_tab;                   /* temporal: [T][16][2] */
+  const float* fwd_workspace;             /* linear: the workspace the forward vmm_linattn_block_bf16x3 call left (partials of the key softmax / context) */
+  const float* dout; int32_t lddo;        /* gradient of the block output, rows x C */
+  float* dqkv; int32_t lddqkv;
+  float* ln_stats;
+  float* dwout_packed;
+  float* dbout;                           /* linear: += [C] gradient of the to_out bias, or NULL */
+  float* dbias;
+  float* dek; float* dev;
+  float* workspace;                       /* vmm_*_block_bwd_workspace(...) floats */
+  int32_t B, T, HW, C, heads;
+  float q_scale, eps;
+} vmm_attn_block_bwd;
+/* floats of workspace; 0 outside the envelope (C == 64, heads == 8, dim_head == 32, T <= 16, ntok <= 16, even HW) */
+int64_t vmm_temporal_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok);
+/* returns 1 (nothing launched) outside the envelope */
+int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
 typedef struct vmm_dense_bwd_job {
   const float* x; const float* w; const float* b; float* dy; float* dx; float* dw; float* db;

@@ -1,0 +1,109 @@
+"""Backward of the fused attention blocks WITH RECOMPUTATION (temporal_block_bwd.hip, linattn_block_bwd.hip) against torch autograd of the same
+block in fp32 on the CPU (autograd of vddp.py:313-378, 396-535 inside Residual(PreNorm(.))).  The kernels see only x, dOut and the weights: the
+training forward (the fused block) stores no qkv rows, no attention output and no softmax statistics."""
+import ctypes as C
+
+import pytest
+import torch
+
+from test_gpu_kernels import _attn_ref, _lib, _pack_frag, _s, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack_frag_t(N, lib, gpu, w2d):
+    """(out, in) weight -> fmt-2 fragments of its TRANSPOSED use: K = out features, N = in features (the data-gradient operand, pack_linear_slice)."""
+    co, ci = w2d.shape
+    wg = w2d.contiguous().to(gpu)
+    packed = torch.zeros((co + 31) // 32 * 32 * ((ci + 31) // 32 * 32), device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 1, 1, co, co, ci
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = 1, ci, 0, 0, 0, 0, 0, 0, 0, 2
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, packed.numel(), 0, _s()), "pack")
+    torch.cuda.synchronize()
+    return packed
+
+
+@pytest.mark.parametrize("B,T,HW,ntok,bias_on_cond", [(2, 11, 36, 11, 1), (1, 16, 10, 0, 0), (3, 5, 130, 7, 0), (1, 11, 1152, 16, 0), (2, 1, 4, 3, 0),
+                                                      (1, 11, 2, 11, 1)])
+def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond):
+    """vmm_temporal_block_bwd_bf16x3: gradient of the raw to_qkv rows, LayerNorm statistics, dW_out, dbias, d(ek), d(ev) from x and dOut alone;
+    several tiles per workgroup, padded frame slots, with / without tokens and the bias on them."""
+    from videometamaterials_amd import hostmath
+    N, lib = _lib()
+    Cc, heads, hid = 64, 8, 256
+    ws_n = lib.vmm_temporal_block_bwd_workspace(B, T, HW, Cc, heads, ntok)
+    assert ws_n > 0
+    g = torch.Generator().manual_seed(101 + T + HW)
+    x = torch.randn(B, T, HW, Cc, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    wqkv = torch.randn(3 * hid, Cc, generator=g) / 8
+    wout = (torch.randn(Cc, hid, generator=g) / 16).requires_grad_()
+    bias = torch.randn(heads, T, T, generator=g).requires_grad_()
+    rot = hostmath.rotary_table(T, 32)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = 1 / (var + 1e-5).sqrt()
+    y = (x - mean) * rstd * gamma
+    qkv_raw = (y @ wqkv.t()).requires_grad_()
+    qkv = qkv_raw.reshape(B, T, HW, 3, heads, 32)
+    cos, sin = rot[:, :, 0].repeat_interleave(2, -1)[None, :, None, None], rot[:, :, 1].repeat_interleave(2, -1)[None, :, None, None]
+
+    def rotate(t):
+        pr = t.reshape(*t.shape[:-1], 16, 2)
+        return t * cos + torch.stack((-pr[..., 1], pr[..., 0]), -1).reshape(t.shape) * sin
+
+    q, k, v = rotate(qkv[:, :, :, 0] * 32 ** -0.5), rotate(qkv[:, :, :, 1]), qkv[:, :, :, 2]
+    q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))  # b hw h t d
+    bfull = bias[None, None]
+    ek = ev = None
+    if ntok:
+        ek = torch.randn(B, ntok, heads, 32, generator=g).requires_grad_()
+        ev = torch.randn(B, ntok, heads, 32, generator=g).requires_grad_()
+        k = torch.cat([ek.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), k], dim=-2)
+        v = torch.cat([ev.permute(0, 2, 1, 3)[:, None].expand(B, HW, heads, ntok, 32), v], dim=-2)
+        bfull = torch.cat([bias if bias_on_cond else torch.zeros(heads, T, ntok), bias], dim=-1)[None, None]
+    o = _attn_ref(q, k, v, bfull).permute(0, 3, 1, 2, 4).reshape(B * T * HW, hid)
+    branch = o @ wout.t()
+    dout = torch.randn(B * T * HW, Cc, generator=g)
+    branch.backward(dout)
+
+    wq, woT = _pack_frag(N, lib, gpu, wqkv, 2), _pack_frag_t(N, lib, gpu, wout.detach())
+    xg, gg, bg, rg = x.reshape(B * T * HW, Cc).to(gpu), gamma.to(gpu), bias.detach().to(gpu), rot.to(gpu)
+    ekg = ek.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
+    dg = dout.to(gpu)
+    rows = B * T * HW
+    dqkv = torch.full((rows, 3 * hid), 7.0, device=gpu)
+    stats = torch.full((rows, 2), 7.0, device=gpu)
+    dwo = torch.full((hid, Cc), 0.5, device=gpu)  # accumulated into (+=)
+    dbias = torch.full((heads, T, T), 0.25, device=gpu)
+    dek = torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    dev = torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    ws = torch.empty(ws_n, device=gpu)
+    d = N.AttnBlockBwd()
+    d.x, d.ldx, d.gamma = xg.data_ptr(), Cc, gg.data_ptr()
+    d.wqkv_frag, d.wout_t_frag = wq.data_ptr(), woT.data_ptr()
+    if ntok:
+        d.ek, d.ev, d.ntok = ekg.data_ptr(), evg.data_ptr(), ntok
+    d.bias, d.bias_on_cond, d.rot_tab = bg.data_ptr(), bias_on_cond, rg.data_ptr()
+    d.dout, d.lddo = dg.data_ptr(), Cc
+    d.dqkv, d.lddqkv, d.ln_stats = dqkv.data_ptr(), 3 * hid, stats.data_ptr()
+    d.dwout_packed, d.dbias, d.dek, d.dev = dwo.data_ptr(), dbias.data_ptr(), dek.data_ptr(), dev.data_ptr()
+    d.workspace = ws.data_ptr()
+    d.B, d.T, d.HW, d.C, d.heads = B, T, HW, Cc, heads
+    d.q_scale, d.eps = 32 ** -0.5, 1e-5
+    N.check(lib.vmm_temporal_block_bwd_bf16x3(C.byref(d), _s()), "temporal block backward")
+    torch.cuda.synchronize()
+    want = qkv_raw.grad.reshape(rows, 3 * hid)
+    got = dqkv.cpu()
+    for i, nm in enumerate("qkv"):
+        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < 1e-4, nm
+    assert relerr(stats.cpu()[:, 0], mean.reshape(-1)) < 1e-5 and relerr(stats.cpu()[:, 1], rstd.reshape(-1)) < 1e-5
+    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < 1e-4
+    assert relerr(dbias.cpu() - 0.25, bias.grad) < 1e-4
+    if ntok:
+        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
+        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4

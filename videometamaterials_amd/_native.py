@@ -67,6 +67,31 @@ class DenseBwdJob(C.Structure):
         "rows", "K", "N", "ldx", "lddy", "lddx", "act_in", "act_out", "accumulate")]
 
 
+class AttnBlockBwd(C.Structure):
+    """vmm_attn_block_bwd (include/vmm_kernels.h)."""
+
+    _fields_ = [
+        ("x", c_ptr), ("ldx", c_i32),
+        ("gamma", c_ptr),
+        ("wqkv_frag", c_ptr),
+        ("wout_t_frag", c_ptr),
+        ("ek", c_ptr), ("ev", c_ptr), ("ntok", c_i32),
+        ("bias", c_ptr), ("bias_on_cond", c_i32),
+        ("rot_tab", c_ptr),
+        ("fwd_workspace", c_ptr),
+        ("dout", c_ptr), ("lddo", c_i32),
+        ("dqkv", c_ptr), ("lddqkv", c_i32),
+        ("ln_stats", c_ptr),
+        ("dwout_packed", c_ptr),
+        ("dbout", c_ptr),
+        ("dbias", c_ptr),
+        ("dek", c_ptr), ("dev", c_ptr),
+        ("workspace", c_ptr),
+        ("B", c_i32), ("T", c_i32), ("HW", c_i32), ("C", c_i32), ("heads", c_i32),
+        ("q_scale", c_f32), ("eps", c_f32),
+    ]
+
+
 class OptimJob(C.Structure):
     """vmm_optim_job (include/vmm_kernels.h)."""
 
@@ -108,6 +133,8 @@ SIGNATURES = {
     "vmm_temporal_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
                                    c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
+    "vmm_temporal_block_bwd_workspace": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
+    "vmm_temporal_block_bwd_bf16x3": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_apply_mfma": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr],
     "vmm_linattn_bwd_rows_mfma": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr],
@@ -222,7 +249,7 @@ DP_SIGNATURES = {
     "vmm_dp_finalize": [c_ptr],
 }
 
-RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 
