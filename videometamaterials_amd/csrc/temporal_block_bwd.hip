@@ -25,7 +25,7 @@
 //   dv{key, d}    = p^T . dO                                                         -> dv rows
 //   d(ek){tok, d} += dSk^T . q       d(ev){tok, d} += pk^T . dO
 // 54 k16 steps (x 3 passes) per tile and head against the forward's 25.  Weight fragments are streamed from L2 (the registers hold the
-// accumulators of dW_out, d(ek), d(ev), dbias: 72 per lane).
+// accumulators of d(ek), d(ev), dbias; those of dW_out live in LDS, every lane adding to its own slots: 72 persistent registers spilled).
 #include "chain_mfma.h"
 #include "../../include/vmm_kernels.h"
 #include <math.h>
@@ -63,13 +63,13 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* ekA = reinterpret_cast<uint4*>(smem_raw);                      // [8 heads][2 steps][hi|lo][16 token rows x 2 halves]: A operand, rows = tokens
   uint4* evA = ekA + HEADS * 4 * 32;
-  uint4* ekB = evA + HEADS * 4 * 32;                                    // [8 heads][hi|lo][64 lanes]: contraction = tokens, lane = d
-  uint4* evB = ekB + HEADS * 2 * 64;
-  float* biasf = reinterpret_cast<float*>(evB + HEADS * 2 * 64);        // [8 heads][2 halves][16 frames][8]
+  f32x4* dwo = reinterpret_cast<f32x4*>(evA + HEADS * 4 * 32);          // [8 heads][2 channel tiles][4 register quads][64 lanes]: dW_out accumulators
+  float* biasf = reinterpret_cast<float*>(dwo + HEADS * 8 * 64);        // [8 heads][2 halves][16 frames][8]
   float* rotf = biasf + HEADS * 2 * 16 * 8;                             // [2 halves][16 frames][8 pairs][cos, sin]
-  unsigned short* ytile = reinterpret_cast<unsigned short*>(rotf + 2 * 16 * 8 * 2);  // [2][32 rows][YP]  LayerNorm(x)
-  unsigned short* gtile = ytile + 2 * 32 * YP;                          // [2][32 rows][YP]  dOut rows
-  unsigned short* gcol = gtile + 2 * 32 * YP;                           // [2][hi|lo][64 channels][GP]  dOut columns, positions in slot order
+  float* rotr = rotf + 2 * 16 * 8 * 2;                                  // [16 frames][16 pairs][cos, sin] (frames >= T: identity)
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(rotr + 16 * 16 * 2);  // [32 rows][YP]  LayerNorm(x)
+  unsigned short* gtile = ytile + 32 * YP;                              // [32 rows][YP]  dOut rows
+  unsigned short* gcol = gtile + 32 * YP;                               // [hi|lo][64 channels][GP]  dOut columns, positions in slot order
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,22 +102,10 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
         evA[((h * 2 + s) * 2 + 1) * 32 + lk * 16 + lrow] = lo;
       }
     }
-    float vk[8], vv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int tk = slot(0, lk, j);
-      const long long o = ((long long)b * ntok + tk) * HID + h * DHd + lrow;
-      vk[j] = tk < ntok ? a.ek[o] : 0.f;
-      vv[j] = tk < ntok ? a.ev[o] : 0.f;
-    }
-    uint4 hi, lo;
-    split8v(vk, hi, lo);
-    ekB[(h * 2 + 0) * 64 + lane] = hi;
-    ekB[(h * 2 + 1) * 64 + lane] = lo;
-    split8v(vv, hi, lo);
-    evB[(h * 2 + 0) * 64 + lane] = hi;
-    evB[(h * 2 + 1) * 64 + lane] = lo;
   }
+  f32x4* dwo_l = dwo + (h * 8) * 64 + lane;  // + (ct * 4 + quad) * 64: the lane's own accumulator registers 4 quad .. 4 quad + 3 of channel tile ct
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dwo_l[i * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
   // relative-position bias of query frame t against the 8 key frames a lane half holds: [h][lk][t][j]
   for (int i = tid; i < HEADS * 2 * 16 * 8; i += 512) {
     const int j = i & 7, t = (i >> 3) & 15, l2 = (i >> 7) & 1, hh = i >> 8;
@@ -131,6 +119,12 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
     const float2 cs = t < T ? *reinterpret_cast<const float2*>(a.rot + (t * 16 + (d >> 1)) * 2) : make_float2(1.f, 0.f);
     rotf[i * 2] = cs.x;
     rotf[i * 2 + 1] = cs.y;
+  }
+  for (int i = tid; i < 16 * 16; i += 512) {
+    const int t = i >> 4;
+    const float2 cs = t < T ? *reinterpret_cast<const float2*>(a.rot + i * 2) : make_float2(1.f, 0.f);
+    rotr[i * 2] = cs.x;
+    rotr[i * 2 + 1] = cs.y;
   }
   const float* rot_l = rotf + ((lk * 16 + ft) * 8) * 2;
   // u <- R u (sg = +1) or R^T u (sg = -1), rows = features in register pairs
@@ -151,53 +145,84 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   uint4 I[2];
   identity_frags(lane, I);
 
-  // streamed weight fragments: plane (step s, hi | lo) of the head's column tile
-  const uint4* wq_l = a.wqkv + ((long long)h * 4 * 2) * 64 + lane;
-  const uint4* wk_l = a.wqkv + ((long long)(HEADS + h) * 4 * 2) * 64 + lane;
-  const uint4* wv_l = a.wqkv + ((long long)(2 * HEADS + h) * 4 * 2) * 64 + lane;
-  const uint4* wo_l = a.woT + ((long long)h * 4 * 2) * 64 + lane;
+  // streamed weight fragments: plane (step s, hi | lo) of the head's column tile; a wave-uniform base + the lane's 16 bytes
+  const unsigned char* wq_b = reinterpret_cast<const unsigned char*>(a.wqkv + ((long long)h * 4 * 2) * 64);
+  const unsigned char* wk_b = reinterpret_cast<const unsigned char*>(a.wqkv + ((long long)(HEADS + h) * 4 * 2) * 64);
+  const unsigned char* wv_b = reinterpret_cast<const unsigned char*>(a.wqkv + ((long long)(2 * HEADS + h) * 4 * 2) * 64);
+  const unsigned char* wo_b = reinterpret_cast<const unsigned char*>(a.woT + ((long long)h * 4 * 2) * 64);
+  unsigned loff = (unsigned)lane * 16u;
+  // the 16 fragments (4 steps x {matrix 0 hi, lo, matrix 1 hi, lo}) of two matrices into the weight buffer: requested a phase ahead of their use
+  auto load_w2 = [&](const unsigned char* m0, const unsigned char* m1, uint4 (&wb)[16]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // (steps 2, 3 from a second uniform base: the instruction's immediate offset ends at 4095, and beyond it the compiler builds one 64-bit
+      // address per load in vector registers)
+      const unsigned char* b0 = s < 2 ? m0 : m0 + 4096;
+      const unsigned char* b1 = s < 2 ? m1 : m1 + 4096;
+      wb[4 * s + 0] = *reinterpret_cast<const uint4*>(b0 + ((s & 1) * 2) * 1024 + loff);
+      wb[4 * s + 1] = *reinterpret_cast<const uint4*>(b0 + ((s & 1) * 2 + 1) * 1024 + loff);
+      wb[4 * s + 2] = *reinterpret_cast<const uint4*>(b1 + ((s & 1) * 2) * 1024 + loff);
+      wb[4 * s + 3] = *reinterpret_cast<const uint4*>(b1 + ((s & 1) * 2 + 1) * 1024 + loff);
+    }
+  };
   const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
   const uint4* ekA_l = ekA + (h * 4) * 32 + lk * 16 + (lrow & 15);  // + (s * 2 + plane) * 32
   const uint4* evA_l = evA + (h * 4) * 32 + lk * 16 + (lrow & 15);
-  const uint4* ekB_l = ekB + (h * 2) * 64 + lane;                   // + plane * 64
-  const uint4* evB_l = evB + (h * 2) * 64 + lane;
+  // rotation of ROW-form matrices {m, d} (lane = feature): the pair partner is the neighbouring lane, the factors of register r are those of
+  // frame (r & 3) + 8 ((r >> 2) & 1) + 4 lk: rotr[frame][pair]
+  const float* rotr_l = rotr + (lrow >> 1) * 2;
+  const float rsgn = (lrow & 1) ? 1.f : -1.f;
+  auto rotate_rows2 = [&](f32x16& u, f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // (registers r and r + 8: the same frame of the two pixels)
+      const int t = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lk;
+      const float2 cs = *reinterpret_cast<const float2*>(rotr_l + t * 32);
+      const float sn = cs.y * rsgn;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int rr = r + 8 * q;
+        u[rr] = u[rr] * cs.x + lane_xor(u[rr], 0) * sn;
+        v[rr] = v[rr] * cs.x + lane_xor(v[rr], 0) * sn;
+      }
+    }
+  };
 
   // staging role: row rm of the tile, channels rcol .. rcol + 3
   const int rm = tid >> 4, rcol = (tid & 15) * 4;
   const int rpa = rm >> 4, rft = rm & 15;
   const int gpos = (rm >> 4) * 16 + ((rm >> 2) & 1) * 8 + (rm & 3) + 4 * ((rm >> 3) & 1);  // position of row rm in slot order: step | half | element
   const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + rcol);
+  unsigned x_loff = (unsigned)((rft * HW + rpa) * a.ldx + rcol), g_loff = (unsigned)((rft * HW + rpa) * a.ldg + rcol);
+  const unsigned st_loff = (unsigned)(rft * HW + rpa) * 2u;
   auto load_xg = [&](int pp, f32x4& xv, f32x4& gv) {
     xv = f32x4{0.f, 0.f, 0.f, 0.f};
     gv = xv;
-    if (rft < T && pp < p_end) {
-      const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
-      xv = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + rcol);
-      gv = *reinterpret_cast<const f32x4*>(a.gout + row * a.ldg + rcol);
+    if (rft < T && pp < p_end) {  // (wave-uniform base of the tile + the lane's 32-bit offset: no 64-bit address registers per load)
+      const long long row0 = (long long)b * T * HW + pp * 2;
+      xv = *reinterpret_cast<const f32x4*>(a.x + row0 * a.ldx + x_loff);
+      gv = *reinterpret_cast<const f32x4*>(a.gout + row0 * a.ldg + g_loff);
     }
   };
-  auto stage = [&](int buf, int pp, const f32x4& xv, const f32x4& gv) {
+  auto stage = [&](int pp, const f32x4& xv, const f32x4& gv) {
     float s = (xv.x + xv.y) + (xv.z + xv.w);
     const float mean = row_sum16(s) * (1.0f / TC);
     const f32x4 c = {xv.x - mean, xv.y - mean, xv.z - mean, xv.w - mean};
     const float q = (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
     const float rstd = 1.0f / sqrtf(row_sum16(q) * (1.0f / TC) + a.eps);
-    if ((tid & 15) == 0 && rft < T && pp < p_end) {
-      const long long row = ((long long)b * T + rft) * HW + pp * 2 + rpa;
-      *reinterpret_cast<float2*>(a.ln_stats + 2 * row) = make_float2(mean, rstd);
-    }
+    if ((tid & 15) == 0 && rft < T && pp < p_end)
+      *reinterpret_cast<float2*>(a.ln_stats + 2 * ((long long)b * T * HW + pp * 2) + st_loff) = make_float2(mean, rstd);
     unsigned l0, l1;
     unsigned h0 = split_bf16_pair(c.x * rstd * gam.x, c.y * rstd * gam.y, l0);
     unsigned h1 = split_bf16_pair(c.z * rstd * gam.z, c.w * rstd * gam.w, l1);
-    unsigned short* yt = ytile + buf * 32 * YP + rm * YP + rcol;
+    unsigned short* yt = ytile + rm * YP + rcol;
     *reinterpret_cast<uint2*>(yt) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(yt + TC) = make_uint2(l0, l1);
     h0 = split_bf16_pair(gv.x, gv.y, l0);
     h1 = split_bf16_pair(gv.z, gv.w, l1);
-    unsigned short* gt = gtile + buf * 32 * YP + rm * YP + rcol;
+    unsigned short* gt = gtile + rm * YP + rcol;
     *reinterpret_cast<uint2*>(gt) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(gt + TC) = make_uint2(l0, l1);
-    unsigned short* gc = gcol + buf * 2 * 64 * GP + rcol * GP + gpos;
+    unsigned short* gc = gcol + rcol * GP + gpos;
     gc[0] = (unsigned short)(h0 & 0xffffu);
     gc[GP] = (unsigned short)(h0 >> 16);
     gc[2 * GP] = (unsigned short)(h1 & 0xffffu);
@@ -210,46 +235,62 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   };
 
   // accumulators that live for the whole kernel
-  f32x16 dWo[2] = {zero16(), zero16()};   // {d, channel tile}
-  f32x16 dEk = zero16(), dEv = zero16();  // {tok, d}
-  float db[8];
+  float dEk[8], dEv[8], db[8];  // {tok, d} rows 0 .. 15 (registers 0 .. 7 of the product); dbias of (query frame, 8 key frames)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) db[j] = 0.f;
+  for (int j = 0; j < 8; ++j) dEk[j] = dEv[j] = db[j] = 0.f;
 
   // rows of the gradient of the raw qkv: X{m, d} -> gqkv[row(m)][col0 + d]
+  unsigned qr_loff = (unsigned)(4 * lk * HW * a.ldq + lrow);  // lane part of a row-form store: frame 4 lk of the register's frame group, feature lrow
   auto store_rows = [&](const f32x16& X, int pp, int col0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int tm = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lk, pm = r >> 3;  // frame slot, pixel of row row_of(r, lk)
-      if (tm < T) {
-        const long long row = ((long long)b * T + tm) * HW + pp * 2 + pm;
-        a.gqkv[row * a.ldq + col0 + h * DHd + lrow] = X[r];
+      const int t0 = (r & 3) + 8 * ((r >> 2) & 1), pm = r >> 3;  // frame slot (+ 4 lk), pixel of row row_of(r, lk)
+      if (t0 + 4 * lk < T) {
+        float* ub = a.gqkv + (((long long)b * T + t0) * HW + pp * 2 + pm) * a.ldq + col0 + h * DHd;  // wave-uniform
+        ub[qr_loff] = X[r];
       }
+    }
+  };
+
+  // columns of the gradient of the raw qkv from a T-form matrix X{d, m}: the lane's row m gets four 16-byte pieces (features 8 q + 4 lk .. + 3)
+  unsigned qc_loff = (unsigned)((ft * HW + pa) * a.ldq + 4 * lk);
+  auto store_cols = [&](const f32x16& X, int pp, int col0) {
+    if (ft < T) {
+      float* ub = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(ub + 8 * q4 + qc_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
     }
   };
 
   f32x4 xv, gv;
   load_xg(p_begin, xv, gv);
-  stage(0, p_begin, xv, gv);
-  __syncthreads();
+  uint4 wb[16];  // weight buffer: (W_q, W_k) from phase 3 of a tile to phase 1 of the next, (W_v, W_out^T) from phase 1 to phase 2
+  load_w2(wq_b, wk_b, wb);
   for (int pp = p_begin; pp < p_end; ++pp) {
-    const int buf = (pp - p_begin) & 1;
+    stage(pp, xv, gv);  // (one tile in LDS -- the dW_out accumulators take 64 KB of it --: a barrier on either side of the tile's products)
+    __syncthreads();
+    // The lanes' 32-bit offsets are made opaque once per iteration: as loop invariants the compiler adds them to every wave-uniform base OUTSIDE the
+    // loop -- one 64-bit vector-register address per load / store, ~60 registers that it then spills -- instead of using the
+    // scalar-base + vector-offset addressing mode of the instruction.
+    asm volatile("" : "+v"(loff), "+v"(x_loff), "+v"(g_loff), "+v"(qr_loff), "+v"(qc_loff));
     load_xg(pp + 1, xv, gv);  // a tile ahead: the HBM latency hides under this tile's products
-    const unsigned short* yt = ytile + buf * 32 * YP + lrow * YP + lk * 8;
-    const unsigned short* gt = gtile + buf * 32 * YP + lrow * YP + lk * 8;
+    const unsigned short* yt = ytile + lrow * YP + lk * 8;
+    const unsigned short* gt = gtile + lrow * YP + lk * 8;
 
-    // ---- q^T, k^T (rotated), scores, softmax
+    // ================= phase 1: q^T, k^T (rotated), scores, softmax
     f32x16 pT;       // {key, query}: probabilities, zero outside the query's own pixel / beyond T
     float pk[8];     // {token, query}: rows 0 .. 15 <-> registers 0 .. 7
-    F2 krf, qrf;     // k, q {m, d} as fragments
     {
       f32x16 qT = zero16(), kT = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
-        qT = mfma3(wq_l[(s * 2) * 64], wq_l[(s * 2 + 1) * 64], yh, yl, qT);
-        kT = mfma3(wk_l[(s * 2) * 64], wk_l[(s * 2 + 1) * 64], yh, yl, kT);
+        qT = mfma3(wb[4 * s], wb[4 * s + 1], yh, yl, qT);
+        kT = mfma3(wb[4 * s + 2], wb[4 * s + 3], yh, yl, kT);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w2(wv_b, wo_b, wb);  // for phase 2: a softmax ahead
+      __builtin_amdgcn_sched_barrier(0);
       rotate(qT, 1.f);
       rotate(kT, 1.f);
       const F2 qf = tofrag(qT), kf = tofrag(kT);
@@ -286,22 +327,22 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
       for (int r = 0; r < 16; ++r) pT[r] *= inv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pk[j] *= inv;
-      krf = tofrag(transp(kf, I));
-      qrf = tofrag(transp(qf, I));
     }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- v^T, dO^T, dP, dS
-    F2 vrf, dorf, dsf;   // v, dO {m, d}; dS^T {key, query}
-    uint4 dskh, dskl;    // dS_tok^T {tok, query} (one k16 step)
+    // ================= phase 2: v^T, dO^T, dP, dS; row forms of v and dO
+    F2 vrf, dorf, dsf, pf;   // v, dO {m, d}; dS^T, p^T {key, query}
+    uint4 dskh, dskl, pkh, pkl;  // dS_tok^T, p_tok^T {tok, query} (one k16 step each)
     {
       f32x16 vT = zero16(), doT = zero16();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
-        vT = mfma3(wv_l[(s * 2) * 64], wv_l[(s * 2 + 1) * 64], yh, yl, vT);
+        vT = mfma3(wb[4 * s], wb[4 * s + 1], yh, yl, vT);
         const uint4 gh = *reinterpret_cast<const uint4*>(gt + s * 16), gl = *reinterpret_cast<const uint4*>(gt + s * 16 + TC);
-        doT = mfma3(wo_l[(s * 2) * 64], wo_l[(s * 2 + 1) * 64], gh, gl, doT);
+        doT = mfma3(wb[4 * s + 2], wb[4 * s + 3], gh, gl, doT);
       }
+      __builtin_amdgcn_sched_barrier(0);
       const F2 vf = tofrag(vT), dof = tofrag(doT);
       f32x16 dPT = mmT(vf, dof, zero16()), dPk = zero16();
       if (ntok) {
@@ -324,60 +365,93 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
       }
       dsf = tofrag(dPT);
       split8v(dsk, dskh, dskl);
+      pf = tofrag(pT);
+      split8v(pk, pkh, pkl);
       vrf = tofrag(transp(vf, I));
       dorf = tofrag(transp(dof, I));
     }
-    const F2 pf = tofrag(pT);
-    uint4 pkh, pkl;
-    split8v(pk, pkh, pkl);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w2(wq_b, wk_b, wb);  // for phase 4 and the next tile's phase 1
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- o {m, d} and this head's rows of dW_out
+    // ================= phase 3: o and dW_out, dv, d(ev)
     {
       f32x16 o = mmT(pf, vrf, zero16());
-      if (ntok) o = mfma3(pkh, pkl, evB_l[0], evB_l[64], o);
+      if (ntok) {  // token values as a B operand {tok, d}: an A image times the identity is the image's matrix as an accumulator
+        F2 e;
+        e.h[0] = evA_l[0]; e.l[0] = evA_l[32]; e.h[1] = evA_l[64]; e.l[1] = evA_l[96];
+        uint4 eh, el;
+        split8(transp(e, I), 0, eh, el);
+        o = mfma3(pkh, pkl, eh, el, o);
+      }
       const F2 of = tofrag(o);
-      const unsigned short* gc = gcol + buf * 2 * 64 * GP + lrow * GP + lk * 8;
+      const unsigned short* gc = gcol + lrow * GP + lk * 8;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct) {  // (accumulators in LDS: each lane adds to its own registers' slots)
+        f32x16 acc;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 v = dwo_l[(ct * 4 + q4) * 64];
+          acc[4 * q4] = v.x; acc[4 * q4 + 1] = v.y; acc[4 * q4 + 2] = v.z; acc[4 * q4 + 3] = v.w;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const uint4 ch = *reinterpret_cast<const uint4*>(gc + ct * 32 * GP + s * 16);
           const uint4 cl = *reinterpret_cast<const uint4*>(gc + 64 * GP + ct * 32 * GP + s * 16);
-          dWo[ct] = mfma3(of.h[s], of.l[s], ch, cl, dWo[ct]);
+          acc = mfma3(of.h[s], of.l[s], ch, cl, acc);
         }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) dwo_l[(ct * 4 + q4) * 64] = f32x4{acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+      }
+      const F2 prf = tofrag(transp(pf, I));  // p {query, key}
+      store_rows(mmT(prf, dorf, zero16()), pp, 2 * HID);  // dv {key, d} = p^T . dO
+      if (ntok) {
+        const F2 pkr = tofrag(transp16(pkh, pkl, I));     // p_tok {query, tok}
+        const f32x16 tv_ = mmT(pkr, dorf, zero16());
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dEv[j] += tv_[j];
+      }
     }
-    // ---- dq: dq^T {d, query} = k^T . dS^T (+ tokens), scale, inverse rotary, rows
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ================= phase 4: q, k {m, d} re-projected (cheaper than carrying them through phases 2 and 3), dq, dk, d(ek)
     {
+      f32x16 qr = zero16(), kr = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
+        qr = mfma3(yh, yl, wb[4 * s], wb[4 * s + 1], qr);
+        kr = mfma3(yh, yl, wb[4 * s + 2], wb[4 * s + 3], kr);
+      }
+      rotate_rows2(qr, kr);
+      const F2 qrf = tofrag(qr), krf = tofrag(kr);
+      // dq^T {d, query} = k^T . dS^T (+ tokens), scale, inverse rotary
       f32x16 dqT = mmT(krf, dsf, zero16());
-      if (ntok) dqT = mfma3(ekB_l[0], ekB_l[64], dskh, dskl, dqT);
+      if (ntok) {  // token keys as an A operand [d][tok] = the fragments of {tok, d}
+        F2 e;
+        e.h[0] = ekA_l[0]; e.l[0] = ekA_l[32]; e.h[1] = ekA_l[64]; e.l[1] = ekA_l[96];
+        uint4 eh, el;
+        split8(transp(e, I), 0, eh, el);
+        dqT = mfma3(eh, el, dskh, dskl, dqT);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqT[r] *= a.q_scale;
       rotate(dqT, -1.f);
-      store_rows(transp(tofrag(dqT), I), pp, 0);
-    }
-    // ---- dk: dk^T {d, key} = q^T . dS
-    {
+      store_cols(dqT, pp, 0);
+      // dk^T {d, key} = q^T . dS
       const F2 dsrf = tofrag(transp(dsf, I));
       f32x16 dkT = mmT(qrf, dsrf, zero16());
 #pragma unroll
       for (int r = 0; r < 16; ++r) dkT[r] *= a.q_scale;
       rotate(dkT, -1.f);
-      store_rows(transp(tofrag(dkT), I), pp, HID);
+      store_cols(dkT, pp, HID);
+      if (ntok) {
+        const F2 dskr = tofrag(transp16(dskh, dskl, I));  // dS_tok {query, tok}
+        const f32x16 tk_ = mmT(dskr, qrf, zero16());
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dEk[j] += tk_[j];
+      }
     }
-    // ---- dv {key, d} = p^T . dO
-    {
-      const F2 prf = tofrag(transp(pf, I));
-      store_rows(mmT(prf, dorf, zero16()), pp, 2 * HID);
-    }
-    // ---- token keys / values
-    if (ntok) {
-      const F2 dskr = tofrag(transp16(dskh, dskl, I));  // dS_tok {query, tok}
-      dEk = mmT(dskr, qrf, dEk);
-      const F2 pkr = tofrag(transp16(pkh, pkl, I));     // p_tok {query, tok}
-      dEv = mmT(pkr, dorf, dEv);
-    }
-    // ---- the next tile's rows into the other buffer (everyone finished reading it before the previous barrier)
-    if (pp + 1 < p_end) stage(buf ^ 1, pp + 1, xv, gv);
     __syncthreads();
   }
 
@@ -387,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pw[(h * DHd + row_of(r, lk)) * TC + ct * 32 + lrow] = dWo[ct][r];
+      for (int r = 0; r < 16; ++r) pw[(h * DHd + row_of(r, lk)) * TC + ct * 32 + lrow] = reinterpret_cast<const float*>(dwo_l + (ct * 4 + (r >> 2)) * 64)[r & 3];
     float* pd = a.part_db + (long long)blockIdx.x * (HEADS * T * T);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -456,8 +530,8 @@ extern "C" int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_st
   a.part_ev = a.part_ek + (long long)sp.nsplit * d->B * ntok * HID;
   a.B = d->B; a.T = d->T; a.HW = d->HW; a.nsplit = sp.nsplit; a.tps = sp.tps;
   a.q_scale = d->q_scale; a.eps = d->eps;
-  const size_t shm = sizeof(uint4) * (2 * HEADS * 4 * 32 + 2 * HEADS * 2 * 64) + sizeof(float) * (HEADS * 2 * 16 * 8 + 2 * 16 * 8 * 2) +
-                     sizeof(unsigned short) * (4 * 32 * YP + 2 * 2 * 64 * GP);
+  const size_t shm = sizeof(uint4) * (2 * HEADS * 4 * 32 + HEADS * 8 * 64) + sizeof(float) * (HEADS * 2 * 16 * 8 + 2 * 16 * 8 * 2 + 16 * 16 * 2) +
+                     sizeof(unsigned short) * (2 * 32 * YP + 2 * 64 * GP);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

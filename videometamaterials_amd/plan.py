@@ -972,19 +972,57 @@ class _Builder:
                              "cond_attention='none' accept one")
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, p, linear=False, temporal=temporal)
-        if (temporal and not focus and self.x3 and not self.training and getattr(self.m, "use_fused_temporal", True)
-                and (x.C != 128 or _enabled("tb_c128")) and self.lib.vmm_temporal_block_supported(T, self.ntok if site else 0, HW, x.C, heads) > 0):
+        ntok_s = self.ntok if site else 0
+        fused_fwd = bool(temporal and not focus and self.x3 and getattr(self.m, "use_fused_temporal", True) and (x.C != 128 or _enabled("tb_c128"))
+                         and self.lib.vmm_temporal_block_supported(T, ntok_s, HW, x.C, heads) > 0)
+        # training: the fused block stores nothing but its output; the backward re-forms q, k, v and the probabilities on chip (temporal_block_bwd.hip)
+        bwd_ws_n = int(self.lib.vmm_temporal_block_bwd_workspace(B, T, HW, x.C, heads, ntok_s)) if (
+            fused_fwd and self.training and getattr(self.m, "use_x3_wgrad", True) and _enabled("fused_attn_train")) else 0
+        if fused_fwd and (not self.training or bwd_ws_n):
             # the two upper levels (C = 64, 128): the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
-            wq, _ = self.pack_linear(p + ".to_qkv.weight", frag=2)
-            wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
+            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2)
+            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             out = self.act(x.C, x.H, x.W)
-            flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + (self.ntok if site else 0))
+            flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok_s)
+            pfc_ = 1 if self.m.per_frame_cond else 0
             self.step(self.lib.vmm_temporal_block_bf16 if self.one else self.lib.vmm_temporal_block_bf16x3,
-                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, self.ntok if site else 0, self.bias_ptr,
-                       1 if self.m.per_frame_cond else 0, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
+                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, ntok_s, self.bias_ptr,
+                       pfc_, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=8.0 * x.n)
             self.plan.named[name] = out
+            if self.training:
+                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True)
+                gamma_ptr = self.wraw(name + ".fn.norm.gamma")
+                dq = self.conv_desc(a1=x, w=wq, Cout=3 * hid, out_ptr=out.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W)  # (descriptor of to_qkv for its backward; never launched)
+
+                def bwd_fused():
+                    gout, _ = self.grad_of(out)
+                    self.add_into(x, gout.ptr, gout)  # residual
+                    gqkv = self.act(3 * hid, x.H, x.W)
+                    stats, ws = self.alloc(2 * rows), self.alloc(bwd_ws_n)
+                    geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
+                    d = N.AttnBlockBwd()
+                    d.x, d.ldx, d.gamma, d.wqkv_frag, d.wout_t_frag = x.ptr, x.ld, gamma_ptr, wq, wo_t
+                    d.ek, d.ev, d.ntok = ek or None, ev or None, ntok_s
+                    d.bias, d.bias_on_cond, d.rot_tab = self.bias_ptr, pfc_, self.rot_ptr
+                    d.dout, d.lddo, d.dqkv, d.lddqkv, d.ln_stats = gout.ptr, x.C, gqkv.ptr, 3 * hid, self.ptr(stats)
+                    d.dwout_packed, d.dbias, d.dek, d.dev = gwo or self.scratch(hid * x.C), self.dbias_ptr, geo or None, gvo or None
+                    d.workspace = self.ptr(ws)
+                    d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
+                    self.plan.keepalive.append(d)
+                    self.step(self.lib.vmm_temporal_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
+                              nbytes=4.0 * rows * (2 * x.C + 3 * hid))
+                    self.tmp_free((ws, bwd_ws_n))
+                    dq._ln = (self.ptr(stats), gamma_ptr)
+                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
+                    self.tmp_free(gqkv)
+                    self.tmp_free((stats, 2 * rows))
+                    self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+                    self.tmp_free(gy)
+                    if site:
+                        self.token_kv_bwd(site)
+                self.on_backward(bwd_fused, pg_start, uj_start)
             return out
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
