@@ -41,6 +41,10 @@ constexpr int HID = HEADS * DHd;
 constexpr int YP = 2 * TC + 8;  // bf16 per row of a row image: hi 64 | lo 64 | pad 8 (272 bytes = 17 x 16: conflict-free ds_read_b128)
 constexpr int GP = 40;          // bf16 per channel of the column image: 32 positions + pad (80 bytes = 5 x 16)
 
+#ifndef VMM_TBB_SKIP
+#define VMM_TBB_SKIP 0  // measurement builds only (tools/build_ab.py -DVMM_TBB_SKIP=n): bit 0 drops phase 3, bit 1 phase 4 of the tile loop
+#endif
+
 struct TBBArgs {
   const float* x; int ldx;
   const float* gamma;
@@ -66,8 +70,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   f32x4* dwo = reinterpret_cast<f32x4*>(evA + HEADS * 4 * 32);          // [8 heads][2 channel tiles][4 register quads][64 lanes]: dW_out accumulators
   float* biasf = reinterpret_cast<float*>(dwo + HEADS * 8 * 64);        // [8 heads][2 halves][16 frames][8]
   float* rotf = biasf + HEADS * 2 * 16 * 8;                             // [2 halves][16 frames][8 pairs][cos, sin]
-  float* rotr = rotf + 2 * 16 * 8 * 2;                                  // [16 frames][16 pairs][cos, sin] (frames >= T: identity)
-  unsigned short* ytile = reinterpret_cast<unsigned short*>(rotr + 16 * 16 * 2);  // [32 rows][YP]  LayerNorm(x)
+  unsigned short* ytile = reinterpret_cast<unsigned short*>(rotf + 2 * 16 * 8 * 2);  // [32 rows][YP]  LayerNorm(x)
   unsigned short* gtile = ytile + 32 * YP;                              // [32 rows][YP]  dOut rows
   unsigned short* gcol = gtile + 32 * YP;                               // [hi|lo][64 channels][GP]  dOut columns, positions in slot order
 
@@ -120,12 +123,6 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
     rotf[i * 2] = cs.x;
     rotf[i * 2 + 1] = cs.y;
   }
-  for (int i = tid; i < 16 * 16; i += 512) {
-    const int t = i >> 4;
-    const float2 cs = t < T ? *reinterpret_cast<const float2*>(a.rot + i * 2) : make_float2(1.f, 0.f);
-    rotr[i * 2] = cs.x;
-    rotr[i * 2 + 1] = cs.y;
-  }
   const float* rot_l = rotf + ((lk * 16 + ft) * 8) * 2;
   // u <- R u (sg = +1) or R^T u (sg = -1), rows = features in register pairs
   auto rotate = [&](f32x16& u, float sg) {
@@ -168,25 +165,6 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   const float* bias_l = biasf + ((h * 2 + lk) * 16 + ft) * 8;
   const uint4* ekA_l = ekA + (h * 4) * 32 + lk * 16 + (lrow & 15);  // + (s * 2 + plane) * 32
   const uint4* evA_l = evA + (h * 4) * 32 + lk * 16 + (lrow & 15);
-  // rotation of ROW-form matrices {m, d} (lane = feature): the pair partner is the neighbouring lane, the factors of register r are those of
-  // frame (r & 3) + 8 ((r >> 2) & 1) + 4 lk: rotr[frame][pair]
-  const float* rotr_l = rotr + (lrow >> 1) * 2;
-  const float rsgn = (lrow & 1) ? 1.f : -1.f;
-  auto rotate_rows2 = [&](f32x16& u, f32x16& v) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {  // (registers r and r + 8: the same frame of the two pixels)
-      const int t = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lk;
-      const float2 cs = *reinterpret_cast<const float2*>(rotr_l + t * 32);
-      const float sn = cs.y * rsgn;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int rr = r + 8 * q;
-        u[rr] = u[rr] * cs.x + lane_xor(u[rr], 0) * sn;
-        v[rr] = v[rr] * cs.x + lane_xor(v[rr], 0) * sn;
-      }
-    }
-  };
-
   // staging role: row rm of the tile, channels rcol .. rcol + 3
   const int rm = tid >> 4, rcol = (tid & 15) * 4;
   const int rpa = rm >> 4, rft = rm & 15;
@@ -240,31 +218,31 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   for (int j = 0; j < 8; ++j) dEk[j] = dEv[j] = db[j] = 0.f;
 
   // rows of the gradient of the raw qkv: X{m, d} -> gqkv[row(m)][col0 + d]
+  // Stores of the gradient rows: ONE wave-uniform pointer per tile (scalar registers) + a 32-bit offset per lane and register.  (A uniform pointer
+  // per register row instead became sixteen loop-carried 64-bit induction variables, spilled and reloaded every tile.)
   unsigned qr_loff = (unsigned)(4 * lk * HW * a.ldq + lrow);  // lane part of a row-form store: frame 4 lk of the register's frame group, feature lrow
+  const unsigned hwq = (unsigned)(HW * a.ldq);
   auto store_rows = [&](const f32x16& X, int pp, int col0) {
+    float* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t0 = (r & 3) + 8 * ((r >> 2) & 1), pm = r >> 3;  // frame slot (+ 4 lk), pixel of row row_of(r, lk)
-      if (t0 + 4 * lk < T) {
-        float* ub = a.gqkv + (((long long)b * T + t0) * HW + pp * 2 + pm) * a.ldq + col0 + h * DHd;  // wave-uniform
-        ub[qr_loff] = X[r];
-      }
+      if (t0 + 4 * lk < T) gq[qr_loff + (unsigned)t0 * hwq + (unsigned)(pm * a.ldq)] = X[r];
     }
   };
-
   // columns of the gradient of the raw qkv from a T-form matrix X{d, m}: the lane's row m gets four 16-byte pieces (features 8 q + 4 lk .. + 3)
   unsigned qc_loff = (unsigned)((ft * HW + pa) * a.ldq + 4 * lk);
   auto store_cols = [&](const f32x16& X, int pp, int col0) {
     if (ft < T) {
-      float* ub = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
+      float* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(ub + 8 * q4 + qc_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
+      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(gq + 8 * q4 + qc_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
     }
   };
 
   f32x4 xv, gv;
   load_xg(p_begin, xv, gv);
-  uint4 wb[16];  // weight buffer: (W_q, W_k) from phase 3 of a tile to phase 1 of the next, (W_v, W_out^T) from phase 1 to phase 2
+  uint4 wb[16];  // weight buffer: (W_q, W_k) from phase 4 of a tile to phase 1 of the next, (W_v, W_out^T) from phase 1 to phase 2
   load_w2(wq_b, wk_b, wb);
   for (int pp = p_begin; pp < p_end; ++pp) {
     stage(pp, xv, gv);  // (one tile in LDS -- the dW_out accumulators take 64 KB of it --: a barrier on either side of the tile's products)
@@ -280,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
     // ================= phase 1: q^T, k^T (rotated), scores, softmax
     f32x16 pT;       // {key, query}: probabilities, zero outside the query's own pixel / beyond T
     float pk[8];     // {token, query}: rows 0 .. 15 <-> registers 0 .. 7
+    F2 krf, qrf;     // k, q {m, d} (rotated) as fragments: carried to phase 4 (32 registers; the weight buffer idle over phases 3 and 4 was 64)
     {
       f32x16 qT = zero16(), kT = zero16();
 #pragma unroll
@@ -327,6 +306,8 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
       for (int r = 0; r < 16; ++r) pT[r] *= inv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pk[j] *= inv;
+      krf = tofrag(transp(kf, I));
+      qrf = tofrag(transp(qf, I));
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -371,11 +352,9 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
       dorf = tofrag(transp(dof, I));
     }
     __builtin_amdgcn_sched_barrier(0);
-    load_w2(wq_b, wk_b, wb);  // for phase 4 and the next tile's phase 1
-    __builtin_amdgcn_sched_barrier(0);
 
     // ================= phase 3: o and dW_out, dv, d(ev)
-    {
+    if constexpr (!(VMM_TBB_SKIP & 1)) {
       f32x16 o = mmT(pf, vrf, zero16());
       if (ntok) {  // token values as a B operand {tok, d}: an A image times the identity is the image's matrix as an accumulator
         F2 e;
@@ -414,17 +393,10 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ================= phase 4: q, k {m, d} re-projected (cheaper than carrying them through phases 2 and 3), dq, dk, d(ek)
-    {
-      f32x16 qr = zero16(), kr = zero16();
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const uint4 yh = *reinterpret_cast<const uint4*>(yt + s * 16), yl = *reinterpret_cast<const uint4*>(yt + s * 16 + TC);
-        qr = mfma3(yh, yl, wb[4 * s], wb[4 * s + 1], qr);
-        kr = mfma3(yh, yl, wb[4 * s + 2], wb[4 * s + 3], kr);
-      }
-      rotate_rows2(qr, kr);
-      const F2 qrf = tofrag(qr), krf = tofrag(kr);
+    // ================= phase 4: dq, dk, d(ek); (W_q, W_k) of the next tile requested at its start (phases 2 and 3 need the registers)
+    load_w2(wq_b, wk_b, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(VMM_TBB_SKIP & 2)) {
       // dq^T {d, query} = k^T . dS^T (+ tokens), scale, inverse rotary
       f32x16 dqT = mmT(krf, dsf, zero16());
       if (ntok) {  // token keys as an A operand [d][tok] = the fragments of {tok, d}
@@ -530,7 +502,7 @@ extern "C" int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_st
   a.part_ev = a.part_ek + (long long)sp.nsplit * d->B * ntok * HID;
   a.B = d->B; a.T = d->T; a.HW = d->HW; a.nsplit = sp.nsplit; a.tps = sp.tps;
   a.q_scale = d->q_scale; a.eps = d->eps;
-  const size_t shm = sizeof(uint4) * (2 * HEADS * 4 * 32 + HEADS * 8 * 64) + sizeof(float) * (HEADS * 2 * 16 * 8 + 2 * 16 * 8 * 2 + 16 * 16 * 2) +
+  const size_t shm = sizeof(uint4) * (2 * HEADS * 4 * 32 + HEADS * 8 * 64) + sizeof(float) * (HEADS * 2 * 16 * 8 + 2 * 16 * 8 * 2) +
                      sizeof(unsigned short) * (2 * 32 * YP + 2 * 64 * GP);
   static bool attr_set = false;
   if (!attr_set) {
