@@ -540,6 +540,11 @@ typedef struct vmm_attn_block_bwd {
 int64_t vmm_temporal_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok);
 /* returns 1 (nothing launched) outside the envelope */
 int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+/* the linear-attention block (vddp.py:313-378): d->fwd_workspace = the workspace of the forward vmm_linattn_block_bf16x3 call on the same x
+ * (its key-softmax partials and context fragments are read, not modified); envelope C == 64, heads == 8, dim_head == 32, HW % 32 == 0;
+ * bias / bias_on_cond / rot_tab / dbias are ignored, dbout (+= [C]) receives the to_out bias gradient */
+int64_t vmm_linattn_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok);
+int vmm_linattn_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
 typedef struct vmm_dense_bwd_job {

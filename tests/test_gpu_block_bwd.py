@@ -107,3 +107,85 @@ def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond):
     if ntok:
         assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
         assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 8, 8, 5), (1, 2, 16, 24, 0), (2, 11, 32, 32, 11), (1, 1, 4, 8, 16), (1, 3, 48, 48, 11)])
+def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok):
+    """vmm_linattn_block_bwd_bf16x3 after the fused forward (whose workspace it reads): gradient of the raw to_qkv rows, LayerNorm statistics,
+    dW_out, the to_out bias gradient, d(ek), d(ev) -- against torch autograd of SpatialLinearAttention's arithmetic (vddp.py:313-378)."""
+    N, lib = _lib()
+    Cc, heads, hid = 64, 8, 256
+    HW = H * W
+    ws_n = lib.vmm_linattn_block_bwd_workspace(B, T, HW, Cc, heads, ntok)
+    assert ws_n > 0
+    g = torch.Generator().manual_seed(7 + HW + ntok)
+    x = torch.randn(B * T, HW, Cc, generator=g) * 1.5 + 0.2
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    wqkv = torch.randn(3 * hid, Cc, generator=g) / 8
+    wout = (torch.randn(Cc, hid, generator=g) / 16).requires_grad_()
+    bout = torch.randn(Cc, generator=g).requires_grad_()
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = 1 / (var + 1e-5).sqrt()
+    y = (x - mean) * rstd * gamma
+    qkv_raw = (y @ wqkv.t()).requires_grad_()                       # (BT, HW, 768)
+    q, k, v = (qkv_raw[..., i * hid:(i + 1) * hid].reshape(B * T, HW, heads, 32).permute(0, 2, 3, 1) for i in range(3))  # bt h d n
+    ek = ev = None
+    if ntok:
+        ek = torch.randn(B, ntok, heads, 32, generator=g).requires_grad_()
+        ev = torch.randn(B, ntok, heads, 32, generator=g).requires_grad_()
+        ekf = ek.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        evf = ev.permute(0, 2, 3, 1)[:, None].expand(B, T, heads, 32, ntok).reshape(B * T, heads, 32, ntok)
+        k, v = torch.cat([ekf, k], -1), torch.cat([evf, v], -1)
+    qs = q.softmax(dim=-2) * 32 ** -0.5
+    ks = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks, v / HW)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, qs)                  # bt h e n
+    o = out.permute(0, 3, 1, 2).reshape(B * T * HW, hid)
+    branch = o @ wout.t() + bout
+    dout = torch.randn(B * T * HW, Cc, generator=g)
+    branch.backward(dout)
+
+    rows = B * T * HW
+    wq, wo3, woT = _pack_frag(N, lib, gpu, wqkv, 2), _pack_frag(N, lib, gpu, wout.detach(), 3), _pack_frag_t(N, lib, gpu, wout.detach())
+    xg, gg, bg = x.reshape(rows, Cc).to(gpu), gamma.to(gpu), bout.detach().to(gpu)
+    ekg = ek.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
+    evg = ev.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
+    fws = torch.empty(lib.vmm_linattn_block_workspace(B, T, HW), device=gpu)
+    fout = torch.empty_like(xg)
+    N.check(lib.vmm_linattn_block_bf16x3(xg.data_ptr(), Cc, gg.data_ptr(), wq.data_ptr(), wo3.data_ptr(), bg.data_ptr(), ekg.data_ptr() if ntok else None,
+                                         evg.data_ptr() if ntok else None, ntok, fws.data_ptr(), fout.data_ptr(), Cc, B, T, HW, Cc, heads,
+                                         C.c_float(1e-5), _s()), "linear attention block")
+    torch.cuda.synchronize()
+    assert relerr(fout.cpu() - x.reshape(rows, Cc), branch.detach()) < 5e-5
+    dg = dout.to(gpu)
+    dqkv = torch.full((rows, 3 * hid), 7.0, device=gpu)
+    stats = torch.full((rows, 2), 7.0, device=gpu)
+    dwo = torch.full((hid, Cc), 0.5, device=gpu)
+    dbo = torch.full((Cc,), 0.25, device=gpu)
+    dek = torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    dev = torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    ws = torch.empty(ws_n, device=gpu)
+    d = N.AttnBlockBwd()
+    d.x, d.ldx, d.gamma = xg.data_ptr(), Cc, gg.data_ptr()
+    d.wqkv_frag, d.wout_t_frag = wq.data_ptr(), woT.data_ptr()
+    if ntok:
+        d.ek, d.ev, d.ntok = ekg.data_ptr(), evg.data_ptr(), ntok
+    d.fwd_workspace = fws.data_ptr()
+    d.dout, d.lddo = dg.data_ptr(), Cc
+    d.dqkv, d.lddqkv, d.ln_stats = dqkv.data_ptr(), 3 * hid, stats.data_ptr()
+    d.dwout_packed, d.dbout, d.dek, d.dev = dwo.data_ptr(), dbo.data_ptr(), dek.data_ptr(), dev.data_ptr()
+    d.workspace = ws.data_ptr()
+    d.B, d.T, d.HW, d.C, d.heads = B, T, HW, Cc, heads
+    d.q_scale, d.eps = 32 ** -0.5, 1e-5
+    N.check(lib.vmm_linattn_block_bwd_bf16x3(C.byref(d), _s()), "linear attention block backward")
+    torch.cuda.synchronize()
+    want = qkv_raw.grad.reshape(rows, 3 * hid)
+    got = dqkv.cpu()
+    for i, nm in enumerate("qkv"):
+        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < 1e-4, nm
+    assert relerr(stats.cpu()[:, 0], mean.reshape(-1)) < 1e-5 and relerr(stats.cpu()[:, 1], rstd.reshape(-1)) < 1e-5
+    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < 1e-4
+    assert relerr(dbo.cpu() - 0.25, bout.grad) < 1e-5
+    if ntok:
+        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
+        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4

@@ -135,6 +135,8 @@ SIGNATURES = {
     "vmm_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bwd_workspace": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bwd_bf16x3": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_linattn_block_bwd_workspace": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
+    "vmm_linattn_block_bwd_bf16x3": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_apply_mfma": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr],
     "vmm_linattn_bwd_rows_mfma": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr],
@@ -249,7 +251,7 @@ DP_SIGNATURES = {
     "vmm_dp_finalize": [c_ptr],
 }
 
-RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64, "vmm_linattn_block_bwd_workspace": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

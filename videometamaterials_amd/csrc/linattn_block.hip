@@ -21,6 +21,7 @@
 // Operands produced in-kernel (p, v, q, o) have that order by construction; the static ones that meet them (ctx^T fragments,
 // to_out weights) are written in that order by the combine kernel / vmm_pack_weights fmt 3.
 #include "igemm_common.h"
+#include "linattn_split.h"
 
 namespace {
 
@@ -461,12 +462,7 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
   }
 }
 
-int choose_split(int frames, int HW, int* sps) {
-  const int tiles = HW / 32;
-  int ns = max(1, min(tiles / 4, 768 / max(frames, 1)));
-  *sps = (tiles + ns - 1) / ns;
-  return (tiles + *sps - 1) / *sps;
-}
+int choose_split(int frames, int HW, int* sps) { return vmm_linattn_block_split(frames, HW, sps); }
 
 }  // namespace
 

@@ -877,22 +877,61 @@ class _Builder:
         rows = B * T * HW
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, name + ".fn.fn", linear=True)
-        if (self.x3 and not self.training and (x.C == 64 or (x.C == 128 and _enabled("la_c128"))) and heads == 8 and HW % 32 == 0
-                and getattr(self.m, "use_fused_linattn", True)):
+        ntok_s = self.ntok if site else 0
+        fused_fwd = bool(self.x3 and (x.C == 64 or (x.C == 128 and _enabled("la_c128"))) and heads == 8 and HW % 32 == 0
+                         and getattr(self.m, "use_fused_linattn", True))
+        # training: the fused block keeps its small workspace; the backward re-forms q, k, v on chip (linattn_block_bwd.hip)
+        bwd_ws_n = int(self.lib.vmm_linattn_block_bwd_workspace(B, T, HW, x.C, heads, ntok_s)) if (
+            fused_fwd and self.training and getattr(self.m, "use_x3_wgrad", True) and _enabled("fused_attn_train")) else 0
+        if fused_fwd and (not self.training or bwd_ws_n):
             # the two upper levels (C = 64, 128): q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
-            wq, _ = self.pack_linear(name + ".fn.fn.to_qkv.weight", frag=2)
-            wo, _ = self.pack_linear(name + ".fn.fn.to_out.weight", frag=3)
+            p = name + ".fn.fn"
+            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2)
+            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3)
             ws_n = int(self.lib.vmm_linattn_block_workspace(B, T, HW))
             ws = self.alloc(ws_n)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             out = self.act(x.C, x.H, x.W)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * hid * 32
             self.step(self.lib.vmm_linattn_block_bf16 if self.one else self.lib.vmm_linattn_block_bf16x3,
-                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(name + ".fn.fn.to_out.bias"), ek or None, ev or None,
-                       self.ntok if site else 0, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
+                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(p + ".to_out.bias"), ek or None, ev or None,
+                       ntok_s, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=12.0 * x.n)
-            self.free(ws, ws_n)
+            self.free(ws, ws_n)  # (a no-op in training plans: the backward reads the key-softmax partials and context fragments it holds)
             self.plan.named[name] = out
+            if self.training:
+                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True)
+                gamma_ptr = self.wraw(name + ".fn.norm.gamma")
+                dq = self.conv_desc(a1=x, w=wq, Cout=3 * hid, out_ptr=out.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W)  # (descriptor of to_qkv for its backward; never launched)
+
+                def bwd_fused():
+                    gout, _ = self.grad_of(out)
+                    self.add_into(x, gout.ptr, gout)  # residual
+                    gqkv = self.act(3 * hid, x.H, x.W)
+                    stats, bws = self.alloc(2 * rows), self.alloc(bwd_ws_n)
+                    geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
+                    d = N.AttnBlockBwd()
+                    d.x, d.ldx, d.gamma, d.wqkv_frag, d.wout_t_frag = x.ptr, x.ld, gamma_ptr, wq, wo_t
+                    d.ek, d.ev, d.ntok = ek or None, ev or None, ntok_s
+                    d.fwd_workspace = self.ptr(ws)
+                    d.dout, d.lddo, d.dqkv, d.lddqkv, d.ln_stats = gout.ptr, x.C, gqkv.ptr, 3 * hid, self.ptr(stats)
+                    d.dwout_packed, d.dbout = gwo or self.scratch(hid * x.C), self.pg(p + ".to_out.bias") or None
+                    d.dek, d.dev = geo or None, gvo or None
+                    d.workspace = self.ptr(bws)
+                    d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
+                    self.plan.keepalive.append(d)
+                    self.step(self.lib.vmm_linattn_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
+                              nbytes=4.0 * rows * (4 * x.C + 3 * hid))
+                    self.tmp_free((bws, bwd_ws_n))
+                    dq._ln = (self.ptr(stats), gamma_ptr)
+                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
+                    self.tmp_free(gqkv)
+                    self.tmp_free((stats, 2 * rows))
+                    self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+                    self.tmp_free(gy)
+                    if site:
+                        self.token_kv_bwd(site)
+                self.on_backward(bwd_fused, pg_start, uj_start)
             return out
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
