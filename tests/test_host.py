@@ -240,3 +240,52 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for fname, _ in N.ConvDesc._fields_:
         assert re.search(r'\("%s"' % fname, doc), f"INTEGRATION.md's vmm_conv_desc listing lacks {fname}"
+
+
+@pytest.mark.parametrize("cfg_name", sorted(helpers.CONFIGS))
+def test_optimizer_state_indices_follow_the_reference_parameter_order(cfg_name):
+    """torch.optim.Adam's state_dict is indexed by position in GaussianDiffusion.parameters() (vddp.py:1455, Trainer.save / load 1548-1585).
+    The key lists tests/golden/shapes_*.json were dumped from the real reference's state_dict (module registration order, the shared rotary table
+    repeated under every temporal attention): parameters() = that order with the repeats dropped.  The checkpoint index list of the trainer must
+    be exactly that -- PreNorm's fn before its norm, `ups` registered before the middle blocks, one slot for the frozen rotary table."""
+    import videometamaterials_amd as vm
+    from videometamaterials_amd.dp import DataParallelTrainer
+    kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    ref, seen = [], False
+    for k in helpers.load_shapes(cfg_name):
+        if k.endswith("rotary_emb.freqs"):
+            if seen:
+                continue
+            seen = True
+        ref.append(k)
+    model = vm.Unet3D(**kw)
+    diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=8, sampling_timesteps=8)
+    tr = DataParallelTrainer(diff)
+    names = tr._optimizer_param_names()
+    assert [model._ref_key(n) if n is not None else "init_temporal_attn.fn.fn.fn.rotary_emb.freqs" for n in names] == ref
+    assert [model._ref_key(n) for n, _ in model.named_parameters()] == [k for k in ref if not k.endswith("rotary_emb.freqs")]
+    sd = tr.state_dict()
+    assert sd["optimizer"]["param_groups"][0]["params"] == list(range(len(ref)))
+
+
+def test_optimizer_state_of_the_wrong_size_is_rejected():
+    import videometamaterials_amd as vm
+    from videometamaterials_amd.dp import DataParallelTrainer
+    kw, (B, T, H, W), _ = helpers.CONFIGS["plumb16"]
+    model = vm.Unet3D(**kw)
+    diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=8, sampling_timesteps=8)
+    tr = DataParallelTrainer(diff)
+    names = tr._optimizer_param_names()
+    params = dict(model.named_parameters())
+    obj = tr.state_dict()
+    i = names.index("init_conv.weight")
+    good = {"step": torch.tensor(3.0), "exp_avg": torch.ones_like(params["init_conv.weight"]).cpu(), "exp_avg_sq": torch.ones_like(params["init_conv.weight"]).cpu()}
+    obj["optimizer"]["state"] = {i: good}
+    tr.load_state_dict(obj)  # fits
+    assert float(tr._moments["init_conv.weight"][0].sum()) == params["init_conv.weight"].numel()
+    obj["optimizer"]["state"] = {i + 1: good}  # the same moments one index off (init_conv.bias): must raise, not bind 3 k floats to a 16-float parameter
+    with pytest.raises(ValueError, match="does not fit"):
+        tr.load_state_dict(obj)
+    obj["optimizer"]["param_groups"][0]["params"] = list(range(len(names) - 1))  # a checkpoint of this repo's earlier layout (no rotary slot)
+    with pytest.raises(ValueError, match="optimizer state covers"):
+        tr.load_state_dict(obj)

@@ -6,7 +6,7 @@
 // has no link-time dependency on it (single-GPU users never load it, and a host that ships its own RCCL keeps one copy per process).
 //
 // xGMI is point to point (7 links per GPU): RCCL's ring / tree kernels for a 150 MB gradient buffer are link-bound, so the buckets are few
-// and large (>= 25 MB, chosen by the host from the plan's "tail is final" marks) and every one is reduced in place, fp32, sum; the mean's
+// and large (>= 16 MB by default: DataParallelTrainer.bucket_floats = 4 M floats; chosen by the host from the plan's "tail is final" marks) and every one is reduced in place, fp32, sum; the mean's
 // 1 / world rides in the optimiser launch.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>

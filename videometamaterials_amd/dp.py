@@ -396,17 +396,28 @@ class DataParallelTrainer:
         return {"sum_of_rank_ids": got, "expected": want, "ok": got == want, "backend": dist.get_backend(self.group) if through else None}
 
     # ------------------------------------------------------------------ checkpoints in the reference's layout (vddp.py:1548-1585)
+    def _optimizer_param_names(self) -> list:
+        """Names of GaussianDiffusion.parameters() in the REFERENCE's order (= torch.optim.Adam's state index): this tree registers its
+        parameters in the reference's order (unet3d.py), and the reference additionally carries the shared rotary table
+        `init_temporal_attn.fn.fn.fn.rotary_emb.freqs` as a frozen nn.Parameter (a buffer here) in front of that attention's projections --
+        it is inside Adam(model.parameters()) (vddp.py:1455) without ever receiving state.  None marks its slot."""
+        names = [n for n, _ in self.unet.named_parameters()]
+        first = next((i for i, n in enumerate(names) if n.startswith("init_temporal_attn.fn.fn.fn.")), None)
+        if first is not None:
+            names.insert(first, None)
+        return names
+
     def state_dict(self) -> dict:
         """{model, optimizer, steps, ema} as Trainer.save writes it: `optimizer` in torch.optim.Adam's format over
-        GaussianDiffusion.parameters() (index = position in that list; parameters that never received a gradient have no state)."""
-        named = list(self.unet.named_parameters())
-        names = [n for n, _ in named]
+        GaussianDiffusion.parameters() (index = position in the reference's list; parameters that never received a gradient have no state)."""
+        names = self._optimizer_param_names()
+        params = dict(self.unet.named_parameters())
         moments = getattr(self, "_moments", {})
         state = {}
-        for i, (n, prm) in enumerate(named):
-            if n in moments:
+        for i, n in enumerate(names):
+            if n is not None and n in moments:
                 m, v = moments[n]
-                shape = prm.shape
+                shape = params[n].shape
                 state[i] = {"step": torch.tensor(float(self.step)), "exp_avg": m.detach().clone().view(shape).cpu(),
                             "exp_avg_sq": v.detach().clone().view(shape).cpu()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
@@ -421,12 +432,21 @@ class DataParallelTrainer:
         self.step = int(obj.get("steps", 0))
         opt = obj.get("optimizer")
         if opt:
-            names = [n for n, _ in self.unet.named_parameters()]
+            names = self._optimizer_param_names()
+            params = dict(self.unet.named_parameters())
+            n_ckpt = sum(len(g["params"]) for g in opt["param_groups"])
+            if n_ckpt != len(names):
+                raise ValueError(f"optimizer state covers {n_ckpt} parameters, this model has {len(names)} (reference order, frozen rotary table included)")
             dev = next(self.unet.parameters()).device
             if not hasattr(self, "_moments"):
                 self._moments = {}
             for i, st in opt["state"].items():
                 n = names[int(i)]
+                if n is None:
+                    continue  # (the frozen rotary table: torch never creates state for it)
+                for key in ("exp_avg", "exp_avg_sq"):  # a moment bound to a parameter of another size would be read out of bounds by vmm_adam_step
+                    if st[key].numel() != params[n].numel():
+                        raise ValueError(f"optimizer state {i} ({key}: {st[key].numel()} elements) does not fit parameter {n} ({params[n].numel()})")
                 if n in self._moments:  # keep the storage the device job tables point at
                     self._moments[n][0].copy_(st["exp_avg"].reshape(-1))
                     self._moments[n][1].copy_(st["exp_avg_sq"].reshape(-1))
@@ -487,9 +507,9 @@ class DataParallelTrainer:
         self._ema_table = (torch.frombuffer(bytearray(bytes(ejobs)), dtype=torch.uint8).to(dev), len(ejobs))
         self._ptr_sig = self._pointer_signature()
 
-    def _prepare(self, x, cond):
+    def _prepare(self, x, cond, focus: bool = False):
         B, _, T, H, W = x.shape
-        pl = self.unet.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True)
+        pl = self.unet.get_plan(B, T, H, W, cond.shape[-1], x.device, training=True, focus=focus)
         dev = x.device
         if pl is not self._plan:
             self._plan = pl
@@ -508,12 +528,15 @@ class DataParallelTrainer:
 
     # ------------------------------------------------------------------ one optimisation step
     def train_step(self, x: torch.Tensor, cond: torch.Tensor, *, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                   mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x in [0,1] (B,C,T,H,W), cond (B,F).  Returns the (device) loss of this rank.  t / noise / mask may be injected."""
+                   mask: Optional[torch.Tensor] = None, prob_focus_present: float = 0.0, focus_present_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x in [0,1] (B,C,T,H,W), cond (B,F).  Returns the (device) loss of this rank.  t / noise / mask may be injected.
+        prob_focus_present / focus_present_mask: forwarded like Trainer.train does (vddp.py:1626-1627); the mask is drawn before the
+        classifier-free-guidance mask, as in the reference's forward (vddp.py:740, 749)."""
         d, lib = self.model, N.lib()
         B = x.shape[0]
         dev = x.device
-        pl = self._prepare(x, cond)
+        focus = self.unet._focus(B, focus_present_mask, prob_focus_present, dev)
+        pl = self._prepare(x, cond, focus=focus is not None)
         self.step += 1
         t = torch.randint(0, d.num_timesteps, (B,), device=dev).long() if t is None else t  # vddp.py:1065
         noise = torch.randn_like(x) if noise is None else noise  # vddp.py:1047
@@ -525,6 +548,8 @@ class DataParallelTrainer:
         pl.time_in.copy_(t)
         pl.cond_in.copy_(cond)
         pl.mask_in.copy_(mask)
+        if focus is not None:
+            pl.focus_in.copy_(focus)
         # (_prepare -> get_plan re-packed the operand layouts from the live parameters, one launch: the last optimiser step bumped the
         # model's generation)
         pl.launch()

@@ -112,8 +112,10 @@ class Unet3D(nn.Module):
         self.static_weights = False  # set True to skip the per-call parameter-version scan (sampling loops)
         # matrix-core arithmetic of the contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative, 5x the MFMA
         # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
-        # (forward + data gradients; weight gradients are always exact fp32).  Training defaults to fp32: with the reference's l1 loss
-        # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3.
+        # (forward, data gradients and -- with use_x3_wgrad, the default -- the 3 x 3 / 1 x 1 weight gradients on the split-bf16 kernels, ~1e-5
+        # relative per contraction; the remaining layers' weight gradients are exact fp32).  Training defaults to fp32: with the reference's l1 loss
+        # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3
+        # (an order of magnitude inside the reference's own fp16-autocast deviation, tests/test_gpu_train.py).
         # "bf16" (sampling only) = the throughput mode of BASELINE.json configs[3]: one matrix pass on bf16-rounded operands in the 3 x 3 convolutions
         # and the fused attention blocks (~1e-2 relative on the denoiser output; tests/test_gpu_hires.py states and checks the tolerance).
         self.precision = "bf16x3"
@@ -142,7 +144,8 @@ class Unet3D(nn.Module):
 
     def _softmax_attn(self, name, dim, rotary: bool, dim_head: int):
         hid = dim_head * self.attn_heads
-        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
+        # (registration order = the reference's: PreNorm registers `fn` before `norm` (vddp.py:256-263) -- torch.optim.Adam's state is indexed by
+        # position in parameters(), so the order is part of the checkpoint format)
         p = name + ".fn.fn"
         if rotary:
             rot = min(32, dim_head)
@@ -153,10 +156,10 @@ class Unet3D(nn.Module):
         self._linear(p + ".to_k", hid, self.cond_dim, bias=False)
         self._linear(p + ".to_v", hid, self.cond_dim, bias=False)
         self._linear(p + ".to_out", dim, hid, bias=False)
+        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
 
     def _linear_attn(self, name, dim):
         hid = 32 * self.attn_heads  # dim_head default (vddp.py:314, not forwarded at 679/700)
-        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
         p = name + ".fn"
         _attach(self, p + ".to_qkv.weight", _uniform((hid * 3, dim, 1, 1), dim))
         _attach(self, p + ".to_q.weight", _uniform((hid, dim, 1, 1), dim))
@@ -164,6 +167,7 @@ class Unet3D(nn.Module):
         self._linear(p + ".to_v", hid, self.cond_dim, bias=False)
         _attach(self, p + ".to_out.weight", _uniform((dim, hid, 1, 1), hid))
         _attach(self, p + ".to_out.bias", _uniform((dim,), hid))
+        _attach(self, name + ".norm.gamma", torch.ones(1, dim, 1, 1, 1))
 
     def _build_parameters(self):
         heads, td, cd = self.attn_heads, self.time_dim, self.cond_dim
@@ -197,6 +201,7 @@ class Unet3D(nn.Module):
             self._softmax_attn(f"downs.{i}.3.fn", co, True, self.attn_dim_head)
             if i < n_lvl - 1:
                 self._conv(f"downs.{i}.4", co, co, 4)
+        self.add_module("ups", _Node())  # (the reference creates both ModuleLists before the middle blocks, vddp.py:653-654: parameters() order)
         mid = self.in_out[-1][1]
         self._resnet("mid_block1", mid, mid, te)
         self._softmax_attn("mid_spatial_attn.fn", mid, False, 32)
