@@ -237,6 +237,9 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
            "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
            "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32",
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
+           "arena_GB": round(pl.arena_floats * 4 / 1e9, 2), "launches_per_step": len(pl.steps) + len(pl.bwd_steps),
+           "attention": ("fused blocks forward (no qkv rows / attention outputs / softmax statistics stored), recomputing backward kernels at the C = 64 sites"
+                         if any(fn.__name__.endswith("block_bwd_bf16x3") for fn, _, _ in pl.bwd_steps) else "unfused (qkv rows through HBM)"),
            "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if (world > 1 or rehearse) else 0,
            "dp_engine": (f"native: vmm_dp C ABI over RCCL {tr.engine.rccl_version} (include/vmm_dp.h)" if tr.engine is not None
                          else f"torch.distributed/{dist.get_backend()}" if dist is not None else "none (single rank)")}
@@ -262,7 +265,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
                        "launches_per_step": n, "ms_per_step": round(t_ms, 3), "avg_launch_ms": round(t_ms / n, 4), "algorithmic_GFLOP_per_step": round(flops / 1e9, 1),
                        "algorithmic_GB_per_step": round(nbytes / 1e9, 2)}
         out["roofline_training"] = {"dominant": dom, "kernels": objs, "event_ms_forward": round(sum(fwd_ms), 2), "event_ms_backward": round(sum(bwd_ms), 2),
-                                    "ms_by_kernel_family": {k: round(v[0], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]},
+                                    "ms_by_kernel_family": {k: round(v[0], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:20]},
                                     "peak_note": "fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32); split-bf16 kernels: 2500 / 3"}
     if tr.engine is not None:
         tr.engine.close()  # the next leg builds its own communicator

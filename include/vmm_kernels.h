@@ -456,10 +456,17 @@ int vmm_posterior_step(const float* x0, const float* x, const float* noise, cons
 int vmm_posterior_step_rng(const float* x0, const float* x, const int64_t* rng_seed, const float* s, const int64_t* t, const float* coef1,
                            const float* coef2, const float* logvar, int32_t clip_mode, float* out, int32_t B, int64_t per_sample,
                            int64_t* t_next, vmm_stream_t stream);
-/* inputs of a captured guided step in one launch: t[b] = time_in[b] = time_in[B + b] = t_src[b]; x_in[0 .. n) = img (n floats, a multiple
- * of 4), and x_in[n .. 2n) = img too when copy_second_half (plans that are not mirrored) */
+/* inputs of a captured sampling step in one launch: t[b] = time_in[b] = time_in[B + b] = t_src[b]; x_in[0 .. n) = img (n floats, a multiple
+ * of 4).  copy_second_half bit 0: x_in[n .. 2n) = img too (guided plans of 2B rows that are not mirrored); bit 1: the plan has B rows (the
+ * unguided step, guidance_scale == 1): time_in[B + b] is not written */
 int vmm_step_inputs(const float* img, const int64_t* t_src, float* x_in, int32_t copy_second_half, int64_t* t, int64_t* time_in, int32_t B,
                     int64_t n, vmm_stream_t stream);
+/* one DDIM step (vddp.py:986-1018) for the captured sampler: eps = null + (cond - null) w (eps_null may be NULL), x0 = c_recip[t] x - c_recipm1[t] eps,
+ * out = coef[t][0] x0 + coef[t][1] eps + coef[t][2] noise (coef [T][4] made on the host: sqrt(alpha_next), c, sigma, last-step flag -> out = x0);
+ * noise from the in-kernel Philox generator (only when sigma != 0); t_next[b] = next_of[t[b]].  per_sample % 4 == 0, 16-byte aligned pointers. */
+int vmm_ddim_step_rng(const float* x, const float* eps_cond, const float* eps_null, float w, const int64_t* t, const float* c_recip,
+                      const float* c_recipm1, const float* coef, const int64_t* next_of, const int64_t* rng_seed, float* out, int32_t B,
+                      int64_t per_sample, int64_t* t_next, vmm_stream_t stream);
 /* sum |a-b| or (a-b)^2 -> out[0] (fp64 accumulate, zeroed by the call); sign/diff for backward (vddp.py:1053-1056) */
 int vmm_loss_reduce(const float* a, const float* b, int64_t n, int32_t squared, double* acc, float* out_mean,
                     vmm_stream_t stream);

@@ -224,6 +224,7 @@ SIGNATURES = {
     "vmm_quantile_rows": [c_ptr, c_i32, c_i64, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
     "vmm_posterior_step": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr],
     "vmm_posterior_step_rng": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr, c_ptr],
+    "vmm_ddim_step_rng": [c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_ptr, c_ptr],
     "vmm_step_inputs": [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_ptr],
     "vmm_loss_reduce": [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_cfg_combine": [c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr],

@@ -136,13 +136,57 @@ __global__ __launch_bounds__(256) void step_inputs_kernel(const float* __restric
     const int64_t v = t_src[i0];
     t[i0] = v;
     time_in[i0] = v;
-    time_in[B + i0] = v;
+    if (!(copy_second & 2)) time_in[B + i0] = v;  // (bit 1: a plan of B rows -- the unguided step --, no second half anywhere)
   }
   for (long long i = i0; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(img)[i];
     reinterpret_cast<f32x4*>(x_in)[i] = v;
-    if (copy_second) reinterpret_cast<f32x4*>(x_in)[n4 + i] = v;
+    if (copy_second & 1) reinterpret_cast<f32x4*>(x_in)[n4 + i] = v;
   }
+}
+
+// One DDIM step (vddp.py:986-1018) in one launch, for the captured sampler: eps = null + (cond - null) w, x0 = sqrt_recip[t] x - sqrt_recipm1[t] eps,
+// x <- sqrt(a_next) x0 + c eps + sigma noise with the step's three coefficients from a host-made table indexed by t (coef[t] = {sqrt(a_next), c,
+// sigma, last}: evaluated on the host exactly as the eager path does, fp32 0-d tensors; last != 0: x <- x0), the noise (sigma != 0 only) from the
+// in-kernel Philox generator of the ancestral step; block (0, b) leaves the list's next timestep in t_next[b].
+__global__ __launch_bounds__(256) void ddim_step_rng_kernel(const float* __restrict__ x, const float* __restrict__ ec, const float* __restrict__ en, float w,
+                                                            const int64_t* __restrict__ t, const float* __restrict__ c_recip,
+                                                            const float* __restrict__ c_recipm1, const float* __restrict__ coef,
+                                                            const int64_t* __restrict__ next_of, const int64_t* __restrict__ rng, float* __restrict__ out,
+                                                            long long per_sample, int64_t* __restrict__ t_next) {
+  const int64_t tb = t[blockIdx.y];
+  const float cr = c_recip[tb], cm = c_recipm1[tb];
+  const float sa = coef[4 * tb], cc = coef[4 * tb + 1], sig = coef[4 * tb + 2];
+  const bool last = coef[4 * tb + 3] != 0.f;
+  const unsigned long long seed = (unsigned long long)rng[0];
+  const long long base = (long long)blockIdx.y * per_sample, n4 = per_sample >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + 4 * i);
+    f32x4 e = *reinterpret_cast<const f32x4*>(ec + base + 4 * i);
+    if (en) {
+      const f32x4 nn = *reinterpret_cast<const f32x4*>(en + base + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = nn[j] + (e[j] - nn[j]) * w;
+    }
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sig != 0.f && !last) {
+      unsigned r[4];
+      philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)tb, blockIdx.y, (unsigned)seed, (unsigned)(seed >> 32), r);
+      box_muller(r[0], r[1], z[0], z[1]);
+      box_muller(r[2], r[3], z[2], z[3]);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = cr * xv[j] - cm * e[j];
+      float v = sa * x0;
+      v += cc * e[j];
+      if (sig != 0.f) v += sig * z[j];
+      o[j] = last ? x0 : v;
+    }
+    *reinterpret_cast<f32x4*>(out + base + 4 * i) = o;
+  }
+  if (t_next && blockIdx.x == 0 && threadIdx.x == 0) t_next[blockIdx.y] = next_of[tb];
 }
 
 __global__ void lincomb_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, float a, float b,
@@ -326,6 +370,18 @@ extern "C" int vmm_step_inputs(const float* img, const int64_t* t_src, float* x_
   const int blocks = (int)min((long long)cdiv(n / 4, 256), 4096LL);
   hipLaunchKernelGGL(step_inputs_kernel, dim3(max(blocks, cdiv(B, 256))), dim3(256), 0, (hipStream_t)stream, img, t_src, x_in, copy_second_half, t, time_in, B,
                      (long long)(n / 4));
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmm_ddim_step_rng(const float* x, const float* eps_cond, const float* eps_null, float w, const int64_t* t, const float* c_recip,
+                                 const float* c_recipm1, const float* coef, const int64_t* next_of, const int64_t* rng_seed, float* out, int32_t B,
+                                 int64_t per_sample, int64_t* t_next, vmm_stream_t stream) {
+  if (B <= 0 || per_sample <= 0) return 0;
+  if ((per_sample & 3) || (((uintptr_t)x | (uintptr_t)eps_cond | (uintptr_t)eps_null | (uintptr_t)out) & 15)) return -1;
+  const int blocks = (int)max(1LL, min((long long)2048, (per_sample / 4 + 255) / 256));
+  hipLaunchKernelGGL(ddim_step_rng_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, x, eps_cond, eps_null, w, t, c_recip, c_recipm1, coef, next_of,
+                     rng_seed, out, (long long)per_sample, t_next);
   VMM_LAUNCH_CHECK();
   return 0;
 }

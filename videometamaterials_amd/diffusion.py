@@ -175,13 +175,21 @@ class GaussianDiffusion(nn.Module):
         self.denoise_fn.refresh_plans()
         self.denoise_fn.static_weights = True  # weights cannot change inside the sampling loop
         try:
-            if self.use_graph and noises is None and cond is not None and guidance_scale != 1:
-                stepper = self._graphed_step(tuple(shape), cond, float(guidance_scale))
+            per_sample = 1
+            for v in shape[1:]:
+                per_sample *= int(v)
+            # (the captured step's elementwise kernels move 16 bytes per thread: samples of a multiple of four elements; others take the eager step)
+            if self.use_graph and cond is not None and per_sample % 4 == 0 and (noises is None or self.use_graph == "inject"):
+                # (guidance_scale == 1: a B-row plan, the conditional branch alone -- vddp.py:715-728; use_graph = "inject": the captured step with
+                # the caller's noise tensors instead of the in-kernel generator, for parity tests against golden loops)
+                stepper = self._graphed_step(tuple(shape), cond, float(guidance_scale), inject=noises is not None)
                 if self.use_graph == "eager" and not stepper.captured:
                     stepper.captured = True  # the step's launch list without the capture (same kernels, same in-kernel noise)
                 stepper.reseed()
             for j, i in enumerate(reversed(range(0, self.num_timesteps))):
                 if stepper is not None:
+                    if noises is not None:
+                        stepper.set_noise(noises[j])
                     img = stepper(img, i)
                 else:
                     t = torch.full((b,), i, device=device, dtype=torch.long)
@@ -203,6 +211,23 @@ class GaussianDiffusion(nn.Module):
         pairs = hostmath.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).clone()
         from .plan import cfg_combine
+        if self.use_graph and noises is None and cond is not None and self.use_graph != "inject" and (img.numel() // batch) % 4 == 0:
+            # the captured DDIM step: denoiser + vmm_ddim_step_rng (coefficients of the whole time list in a device table, the next timestep left
+            # on the device by the step itself): one hipGraph replay per step, no host arithmetic in the loop
+            cond = cond.to(device).contiguous()
+            was_static = getattr(self.denoise_fn, "static_weights", False)
+            self.denoise_fn.refresh_plans()
+            self.denoise_fn.static_weights = True
+            try:
+                stepper = self._graphed_step(tuple(shape), cond, float(guidance_scale), ddim=True)
+                if self.use_graph == "eager" and not stepper.captured:
+                    stepper.captured = True
+                stepper.reseed()
+                for time, time_next in pairs:
+                    img = stepper(img, time, nxt=time_next)
+            finally:
+                self.denoise_fn.static_weights = was_static
+            return unnormalize_img(img)
         acp = self.alphas_cumprod.cpu()  # one transfer; the per-step scalars below are evaluated on 0-d fp32 host tensors
         for j, (time, time_next) in enumerate(pairs):
             tt = torch.full((batch,), time, device=device, dtype=torch.long)
@@ -225,13 +250,13 @@ class GaussianDiffusion(nn.Module):
         raise NotImplementedError("interpolate() crashes in the reference for conditional models (SURVEY quirk 9) and is not built")
 
     # ------------------------------------------------------------------ hipGraph-captured guided sampling step
-    def _graphed_step(self, shape, cond, w):
-        # everything the captured launch list bakes in: shapes, guidance weight, thresholding mode / rank, the denoiser's arithmetic
+    def _graphed_step(self, shape, cond, w, inject: bool = False, ddim: bool = False):
+        # everything the captured launch list bakes in: shapes, guidance weight, thresholding mode / rank, the denoiser's arithmetic, the sampler
         key = (shape, w, cond.shape[-1], str(cond.device), bool(self.use_dynamic_thres), float(self.dynamic_thres_percentile),
-               self.denoise_fn.precision)
+               self.denoise_fn.precision, bool(inject), (self.sampling_timesteps, float(self.ddim_sampling_eta)) if ddim else None)
         st = self._graph_cache.get(key)
         if st is None:
-            st = _GraphedStep(self, shape, cond.shape[-1], w)
+            st = _GraphedStep(self, shape, cond.shape[-1], w, inject=inject, ddim=ddim)
             self._graph_cache[key] = st
         st.refresh_weights()
         st.set_cond(cond)
@@ -258,10 +283,14 @@ class GaussianDiffusion(nn.Module):
 
 
 class _GraphedStep:
-    """One guided ancestral step captured as a hipGraph: img <- p_sample(img, t) entirely on device."""
+    """One sampling step captured as a hipGraph: img <- p_sample(img, t) (or the DDIM update) entirely on device.
+    guidance_scale != 1: both guidance branches as ONE batch of 2B rows (mirrored plan); == 1: the conditional branch alone, B rows.
+    inject: the step noise comes from a static buffer the caller fills before every replay (parity tests) instead of the in-kernel generator."""
 
-    def __init__(self, diff: GaussianDiffusion, shape, cond_len: int, w: float):
+    def __init__(self, diff: GaussianDiffusion, shape, cond_len: int, w: float, inject: bool = False, ddim: bool = False):
         self.diff, self.shape, self.w = diff, shape, w
+        self.guided = w != 1
+        self.inject, self.ddim = bool(inject), bool(ddim)
         with torch.inference_mode(False):
             self._alloc(diff, shape, cond_len)
 
@@ -269,21 +298,42 @@ class _GraphedStep:
         dev = diff.betas.device
         B = shape[0]
         self.B = B
+        self.nb = 2 * B if self.guided else B
         self.img = torch.zeros(shape, device=dev)
         self.t = torch.zeros(B, dtype=torch.long, device=dev)       # the step's timestep (every kernel of the step reads it)
-        self.t_src = torch.zeros(B, dtype=torch.long, device=dev)   # where the step takes it from: the previous step left t - 1 here
+        self.t_src = torch.zeros(B, dtype=torch.long, device=dev)   # where the step takes it from: the previous step left the next one here
         self.t_expect = None                                        # host mirror of t_src (None = unknown)
         self.rng = torch.zeros(2, dtype=torch.long, device=dev)     # [0] = Philox key of the step noise (vmm_posterior_step_rng)
-        self.cond2 = torch.zeros(2 * B, cond_len, device=dev)
-        self.mask2 = torch.cat([torch.zeros(B, dtype=torch.uint8, device=dev), torch.ones(B, dtype=torch.uint8, device=dev)])
+        self.cond2 = torch.zeros(self.nb, cond_len, device=dev)
+        self.mask2 = torch.cat([torch.zeros(B, dtype=torch.uint8, device=dev), torch.ones(B, dtype=torch.uint8, device=dev)])[: self.nb]
         self.x0 = torch.empty(shape, device=dev)
         self.ax0 = torch.empty(shape, device=dev)
         self.s = torch.empty(B, device=dev)
+        self.noise = torch.zeros(shape, device=dev) if self.inject else None
         self.scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=dev)
         n = self.img.numel() // B
+        if n % 4:
+            raise NotImplementedError("the captured sampling step takes samples of a multiple of four elements (use_graph = False samples any shape)")
         self.k_lo, self.frac = hostmath.quantile_rank(n, diff.dynamic_thres_percentile)
-        _, C_, T, H, W = shape
-        self.plan = diff.denoise_fn.get_plan(2 * B, T, H, W, cond_len, dev, mirrored=True)
+        if self.ddim:
+            # coefficients of every step of the time list, evaluated like the eager path (fp32 0-d tensors, vddp.py:1006-1010), indexed by timestep
+            T_ = diff.num_timesteps
+            acp = diff.alphas_cumprod.cpu()
+            coef = torch.zeros(T_, 4)
+            nxt = torch.zeros(T_, dtype=torch.long)
+            eta = diff.ddim_sampling_eta
+            for time, time_next in hostmath.ddim_time_pairs(T_, diff.sampling_timesteps):
+                nxt[time] = time_next
+                if time_next < 0:
+                    coef[time, 3] = 1.0
+                    continue
+                a, an = acp[time], acp[time_next]
+                sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                c = (1 - an - sigma ** 2).sqrt()
+                coef[time, 0], coef[time, 1], coef[time, 2] = float(an.sqrt()), float(c), float(sigma)
+            self.coef, self.next_of = coef.to(dev), nxt.to(dev)
+        self.plan = None
+        self.refresh_weights()
         self.graph = None
         self.captured = False
 
@@ -291,13 +341,17 @@ class _GraphedStep:
         """Re-pack the plan's operand layouts if the parameters changed since they were packed (the packed buffers have static
         addresses, so a captured graph stays valid)."""
         _, _, T, H, W = self.shape
-        self.plan = self.diff.denoise_fn.get_plan(2 * self.B, T, H, W, self.cond2.shape[1], self.img.device, mirrored=True)
+        self.plan = self.diff.denoise_fn.get_plan(self.nb, T, H, W, self.cond2.shape[1], self.img.device, mirrored=self.guided)
 
     def set_cond(self, cond):
         self.cond2[: self.B].copy_(cond)
-        self.cond2[self.B:].copy_(cond)
+        if self.guided:
+            self.cond2[self.B:].copy_(cond)
         self.plan.cond_in.copy_(self.cond2)
         self.plan.mask_in.copy_(self.mask2)
+
+    def set_noise(self, noise):
+        self.noise.copy_(noise)
 
     def reseed(self):
         """A new Philox key for the step noise, drawn from torch's device generator (so torch.manual_seed governs it, and no host
@@ -309,15 +363,27 @@ class _GraphedStep:
         pl = self.plan
         # kernel nodes only (a same-dtype contiguous copy_ would be a memcpy NODE once captured, and a memset node of this graph was
         # observed to run unordered with its neighbouring kernels); no torch kernels either: inputs in one launch
-        N.check(lib.vmm_step_inputs(_ptr(self.img), _ptr(self.t_src), _ptr(pl.x_in), 0 if pl.mirrored else 1, _ptr(self.t), _ptr(pl.time_in), B,
+        flags = (0 if pl.mirrored else 1) if self.guided else 2
+        N.check(lib.vmm_step_inputs(_ptr(self.img), _ptr(self.t_src), _ptr(pl.x_in), flags, _ptr(self.t), _ptr(pl.time_in), B,
                                     self.img.numel(), _stream()), "vmm_step_inputs")
         pl.launch()
         n = self.img.numel() // B
+        eps_c, eps_n = pl.out[:B], (pl.out[B:] if self.guided else None)
+        if self.ddim:
+            N.check(lib.vmm_ddim_step_rng(_ptr(self.img), _ptr(eps_c), _ptr(eps_n), self.w, _ptr(self.t), _ptr(d.sqrt_recip_alphas_cumprod),
+                                          _ptr(d.sqrt_recipm1_alphas_cumprod), _ptr(self.coef), _ptr(self.next_of), _ptr(self.rng), _ptr(self.img), B, n,
+                                          _ptr(self.t_src), _stream()), "vmm_ddim_step_rng")
+            return
         dyn = d.use_dynamic_thres
-        N.check(lib.vmm_predict_x0(_ptr(self.img), _ptr(pl.out[:B]), _ptr(pl.out[B:]), self.w, _ptr(self.t), _ptr(d.sqrt_recip_alphas_cumprod),
+        N.check(lib.vmm_predict_x0(_ptr(self.img), _ptr(eps_c), _ptr(eps_n), self.w, _ptr(self.t), _ptr(d.sqrt_recip_alphas_cumprod),
                                    _ptr(d.sqrt_recipm1_alphas_cumprod), _ptr(self.x0), _ptr(self.ax0) if dyn else None, B, n, _stream()), "vmm_predict_x0")
         if dyn:
             N.check(lib.vmm_quantile_rows(_ptr(self.ax0), B, n, self.k_lo, self.frac, 1.0, _ptr(self.s), _ptr(self.scratch), _stream()), "vmm_quantile_rows")
+        if self.inject:  # the caller's noise (the same kernel the eager p_sample runs)
+            N.check(lib.vmm_posterior_step(_ptr(self.x0), _ptr(self.img), _ptr(self.noise), _ptr(self.s), _ptr(self.t), _ptr(d.posterior_mean_coef1),
+                                           _ptr(d.posterior_mean_coef2), _ptr(d.posterior_log_variance_clipped), 2 if dyn else 1, _ptr(self.img), B, n,
+                                           _stream()), "vmm_posterior_step")
+            return
         # posterior mean + sigma * noise with the noise generated in the kernel (Philox keyed by self.rng); leaves t - 1 in t_src
         N.check(lib.vmm_posterior_step_rng(_ptr(self.x0), _ptr(self.img), _ptr(self.rng), _ptr(self.s), _ptr(self.t), _ptr(d.posterior_mean_coef1),
                                            _ptr(d.posterior_mean_coef2), _ptr(d.posterior_log_variance_clipped), 2 if dyn else 1, _ptr(self.img), B, n,
@@ -334,7 +400,7 @@ class _GraphedStep:
             self._body()
         self.graph = g
 
-    def __call__(self, img, i: int):
+    def __call__(self, img, i: int, nxt: Optional[int] = None):
         if self.img.data_ptr() != img.data_ptr():
             self.img.copy_(img)
         if not self.captured:
@@ -350,5 +416,8 @@ class _GraphedStep:
             self.graph.replay()
         else:
             self._body()
-        self.t_expect = i - 1
+        # what the step left in t_src: t - 1 (ancestral, in-kernel noise), the time list's next entry (DDIM); nothing with injected noise
+        self.t_expect = None if self.inject else (nxt if self.ddim else i - 1)
+        if self.t_expect is not None and self.t_expect < 0:
+            self.t_expect = None
         return self.img
