@@ -314,6 +314,85 @@ def bench_config4(vm, dev, timed_region, world, B: int = 8, frames: int = 22, si
     return out
 
 
+def preflight(vm, dev, dist, world, rank, local_rank, backend) -> dict:
+    """`bench.py --gpus N --preflight`: everything the N-rank run touches before its first timed step, on a small model, with a verdict per item --
+    so that a first contact with a multi-GPU node that goes wrong says WHERE (launcher / binding / rendezvous / collective / engine / step).
+    Under VMM_DIST_BACKEND=gloo several ranks may share one GPU (RCCL refuses duplicate devices): the native engine's communicator is then
+    skipped, its rendezvous-id exchange is not."""
+    from videometamaterials_amd import dp as _dp
+    checks = {"launcher": {"RANK": rank, "LOCAL_RANK": local_rank, "WORLD_SIZE": world, "MASTER_ADDR": os.environ.get("MASTER_ADDR"),
+                           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "backend": backend if world > 1 else None}}
+    ok = True
+    ndev = torch.cuda.device_count()
+    checks["device_binding"] = {"visible_gpus": ndev, "this_rank": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
+                                "one_gpu_per_rank": backend != "nccl" or ndev >= world}
+    ok &= checks["device_binding"]["one_gpu_per_rank"]
+    if dist is not None:
+        # every rank's (rank, device) through the backend: the all-gathered table must list each rank once
+        t = torch.tensor([rank, torch.cuda.current_device()], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        table = [tuple(int(v) for v in g.tolist()) for g in got]
+        checks["all_gather"] = {"rank_device_table": table, "ok": [r for r, _ in table] == list(range(world))}
+        ok &= checks["all_gather"]["ok"]
+        # the native engine's rendezvous: rank 0 asks RCCL for a unique id (if RCCL loads), every rank receives the same 128 bytes
+        try:
+            box = [_dp.RcclEngine.new_unique_id() if rank == 0 else None]
+            err = None
+        except Exception as e:  # noqa: BLE001 -- the report carries the reason
+            box, err = [None], repr(e)
+        dist.broadcast_object_list(box, src=0)
+        same = None
+        if box[0] is not None:
+            import hashlib
+            digest = hashlib.sha256(box[0]).hexdigest()[:16]
+            all_d = [None] * world
+            dist.all_gather_object(all_d, digest)
+            same = len(set(all_d)) == 1
+            ok &= same
+        checks["rccl_unique_id"] = {"obtained_on_rank0": box[0] is not None, "error": err, "same_on_every_rank": same}
+    # a small data-parallel step through the trainer (torch.distributed collectives; the native engine when every rank owns a GPU)
+    torch.manual_seed(0)
+    small = vm.Unet3D(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True, per_frame_cond=True,
+                      cond_bias=True).to(dev)
+    small.train_precision = "bf16x3"
+    d_small = vm.GaussianDiffusion(small, image_size=32, num_frames=T, channels=3, timesteps=TIMESTEPS, loss_type="l1", sampling_timesteps=TIMESTEPS).to(dev)
+    engines = ["torch"] + (["native"] if (dist is None or backend == "nccl") else [])
+    checks["train_step"] = {}
+    for eng in engines:
+        try:
+            tr = _dp.DataParallelTrainer(d_small, train_lr=1e-4, engine=eng)
+            g = torch.Generator().manual_seed(10 + rank)
+            x = torch.rand(2, 3, T, 32, 32, generator=g).to(dev)
+            c = (torch.rand(2, 11, generator=g) * 2 - 1).to(dev)
+            sc = tr.rccl_selfcheck() if (world > 1 or tr.engine is not None) else None
+            l0 = float(tr.train_step(x, c))
+            tr._reducer.timing = world > 1 or tr.engine is not None
+            l1 = float(tr.train_step(x, c))
+            torch.cuda.synchronize()
+            comm = tr._reducer.last_step_timing() if tr._reducer.timing else None
+            # the replicas must still agree after two steps: checksum of the parameters, max - min over ranks
+            cs = torch.stack([p.detach().double().sum() for p in small.parameters()]).sum().reshape(1)
+            spread = 0.0
+            if dist is not None:
+                lo, hi = cs.clone(), cs.clone()
+                if backend != "nccl":
+                    lo, hi = lo.cpu(), hi.cpu()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                spread = float((hi - lo).abs().item())
+            good = l0 == l0 and l1 == l1 and spread == 0.0 and (sc is None or sc["ok"])
+            checks["train_step"][eng] = {"loss": [round(l0, 5), round(l1, 5)], "selfcheck": sc, "replica_checksum_spread": spread,
+                                         "buckets": len(tr._reducer.launched) if comm else 0,
+                                         "bucket_spans_ms": comm.get("bucket_spans_ms") if comm else None, "overlap_frac": comm.get("overlap_frac") if comm else None, "ok": bool(good)}
+            ok &= bool(good)
+            del tr
+        except Exception as e:  # noqa: BLE001
+            checks["train_step"][eng] = {"ok": False, "error": repr(e)}
+            ok = False
+    return {"preflight": True, "n_gpus": world, "ok": bool(ok), "checks": checks}
+
+
 def _respawn_under_torchrun(n: int) -> None:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
     import socket
@@ -338,6 +417,8 @@ def main():
     ap.add_argument("--detail", action="store_true", help="per-launch timing table on stderr")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the sample() call and the exact-fp32 sampler (profiling passes)")
+    ap.add_argument("--preflight", action="store_true", help="multi-rank contact check: respawn, device binding, rendezvous-id exchange, one all-reduce, "
+                                                             "one small data-parallel training step; prints a JSON report and exits before any timing")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -382,6 +463,16 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     import videometamaterials_amd as vm
+    if args.preflight:
+        report = preflight(vm, dev, dist, world, rank, local_rank, backend)
+        if rank == 0:
+            os.write(json_fd, (json.dumps(report) + "\n").encode())
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if not report["ok"]:
+            raise SystemExit(1)
+        return
     torch.manual_seed(0)  # identical random-init weights on every rank
     model = vm.Unet3D(**LAGRANGIAN).to(dev).eval()
     diff = vm.GaussianDiffusion(model, image_size=HW, num_frames=T, channels=3, timesteps=TIMESTEPS, loss_type="l1", use_dynamic_thres=True,
@@ -411,20 +502,29 @@ def main():
             el = float(et.item())
         return el
 
-    def sampler_leg(steps, warmup):
+    def sampler_leg(steps, warmup, w=W_GUIDE, ddim=False, d_=None):
         """K guided p_sample steps t = 255, 254, ... on the sampler's own captured step (GaussianDiffusion._graphed_step)."""
+        d_ = diff if d_ is None else d_
         model.refresh_plans()
         model.static_weights = True
-        diff.use_graph = not args.no_graph
-        stepper = diff._graphed_step(shape, cond, W_GUIDE)
+        d_.use_graph = not args.no_graph
+        stepper = d_._graphed_step(shape, cond, float(w), ddim=ddim)
         if args.no_graph:
             stepper.captured = True  # stay eager
         ts = list(reversed(range(TIMESTEPS)))
         state = {"img": x_T.clone()}
 
+        if ddim:  # the sampler's own time list (vddp.py:990-991), cycled
+            from videometamaterials_amd import hostmath
+            pairs = hostmath.ddim_time_pairs(d_.num_timesteps, d_.sampling_timesteps)
+
         def run(n, offset):
             for j in range(n):
-                state["img"] = stepper(state["img"], ts[(offset + j) % TIMESTEPS])
+                if ddim:
+                    tm, tn = pairs[(offset + j) % len(pairs)]
+                    state["img"] = stepper(state["img"], tm, nxt=tn)
+                else:
+                    state["img"] = stepper(state["img"], ts[(offset + j) % TIMESTEPS])
         with torch.inference_mode():
             run(warmup, 0)
             state["img"] = x_T.clone()  # the timed steps start from pure noise at t = 255, like sample()
@@ -467,6 +567,25 @@ def main():
                          "arithmetic": "one MFMA pass on bf16-rounded operands in the 3x3 / stride-2 convolutions, projections and fused attention blocks; "
                                        "fp32 activations and accumulation (2e-2 relative on the denoiser output)",
                          "hipgraph": st16.graph is not None, "output_finite": bool(torch.isfinite(img16).all().item())}
+
+    # ---- BASELINE.json configs[4]: the guidance sweep w in {0, 1, 3, 5} (vddp.py:715-728: w == 1 runs the conditional branch alone -- a B-row
+    # captured step --, every other w both branches as one 2B-row batch), and the DDIM sampler's captured step (vddp.py:986-1018)
+    guidance_sweep = None
+    if not args.no_extras:
+        guidance_sweep = {}
+        nsw = max(2, min(args.steps, 16))
+        for w_ in (0.0, 1.0, 3.0, 5.0):
+            el_, st_, img_ = sampler_leg(nsw, 2, w=w_)
+            guidance_sweep[f"w={w_:g}"] = {"ms_per_step": round(el_ / nsw * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (TIMESTEPS * el_ / nsw), 4),
+                                          "denoiser_rows": st_.plan.shape[0], "launches_per_step": len(st_.plan.steps) + 4, "hipgraph": st_.graph is not None,
+                                          "output_finite": bool(torch.isfinite(img_).all().item())}
+        guidance_sweep["w1_over_w5"] = round(guidance_sweep["w=1"]["ms_per_step"] / guidance_sweep["w=5"]["ms_per_step"], 3)
+        diff_ddim = vm.GaussianDiffusion(model, image_size=HW, num_frames=T, channels=3, timesteps=TIMESTEPS, loss_type="l1", use_dynamic_thres=True,
+                                         sampling_timesteps=50).to(dev)
+        el_, st_, img_ = sampler_leg(nsw, 2, ddim=True, d_=diff_ddim)
+        guidance_sweep["ddim50_w=5"] = {"ms_per_step": round(el_ / nsw * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (50 * el_ / nsw), 4),
+                                        "hipgraph": st_.graph is not None, "output_finite": bool(torch.isfinite(img_).all().item())}
+        del diff_ddim
 
     # ---- second half of BASELINE.json's metric: training denoising steps/s (configs[2]: per-GPU batch 4, fp32, Adam, RCCL all-reduce)
     train = None
@@ -545,7 +664,7 @@ def main():
             "full_sample": full_sample, "fp32_exact": fp32_exact, "bf16_throughput_mode": bf16_mode,
             "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
             "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
-            "training": train, "config4": config4, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
+            "training": train, "config4": config4, "guidance_sweep": guidance_sweep, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -52,6 +52,10 @@ int vmm_dp_wait_all(vmm_dp_engine* e, vmm_dp_stream_t compute_stream);
 int vmm_dp_set_timing(vmm_dp_engine* e, int32_t on);
 int vmm_dp_window_mark(vmm_dp_engine* e, int32_t which, vmm_dp_stream_t compute_stream);
 int vmm_dp_timing(vmm_dp_engine* e, float* out3);
+/* per registered bucket i < n: out[2 i] = ms from the opening window mark to the START of its reduction on the side stream, out[2 i + 1] = to its
+ * completion (-1, -1: not reduced since the window opened).  A scaling result below expectation is read from these: late starts = the
+ * backward produced the slice late or the side stream was busy, long spans = the collective itself (link bandwidth, contention). */
+int vmm_dp_bucket_timing(vmm_dp_engine* e, float* out, int32_t n);
 
 /* Plain collectives ON `stream` (ordered with the caller's work, no side stream):
  *   all-reduce in place; dtype 0 = fp32, 1 = fp64, 2 = int32, 3 = int64; op 0 = sum, 1 = max, 2 = min;

@@ -178,12 +178,19 @@ def test_trainer_checkpoint_round_trip_in_the_reference_layout(gpu, tmp_path):
     tr.save(path)
     obj = torch.load(path, map_location="cpu")
     assert set(obj) == {"model", "optimizer", "steps", "ema"} and obj["steps"] == 2
-    names = [n for n, _ in tr.unet.named_parameters()]
+    # the index list is the REFERENCE's parameters(): this tree's parameters in the reference's registration order plus one slot for the shared
+    # rotary table, a frozen nn.Parameter there (tests/test_host.py checks the order against the key lists dumped from the real reference)
+    names = tr._optimizer_param_names()
+    params = dict(tr.unet.named_parameters())
+    assert len(names) == len(params) + 1 and names.count(None) == 1
     assert obj["optimizer"]["param_groups"][0]["params"] == list(range(len(names)))
     some = next(iter(obj["optimizer"]["state"].values()))
     assert set(some) == {"step", "exp_avg", "exp_avg_sq"} and float(some["step"]) == 2.0
-    # torch's own Adam takes it (what Trainer.load does with the entry)
-    probe = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for p in tr.unet.parameters()], lr=1e-3)
+    for i, st in obj["optimizer"]["state"].items():
+        assert names[i] is not None and tuple(st["exp_avg"].shape) == tuple(params[names[i]].shape), (i, names[i])
+    # torch's own Adam over the reference's parameter list takes it (what Trainer.load does with the entry)
+    probe = torch.optim.Adam([torch.nn.Parameter(torch.zeros(16) if n is None else torch.zeros_like(params[n]), requires_grad=n is not None) for n in names],
+                             lr=1e-3)
     probe.load_state_dict(obj["optimizer"])
     x, cond, t, noise, mask = (a[:2].to(gpu) for a in _inputs(2))
     tr.train_step(x, cond, t=t, noise=noise, mask=mask)

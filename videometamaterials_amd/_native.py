@@ -242,6 +242,7 @@ DP_SIGNATURES = {
     "vmm_dp_set_timing": [c_ptr, c_i32],
     "vmm_dp_window_mark": [c_ptr, c_i32, c_ptr],
     "vmm_dp_timing": [c_ptr, C.POINTER(c_f32)],
+    "vmm_dp_bucket_timing": [c_ptr, C.POINTER(c_f32), c_i32],
     "vmm_dp_allreduce": [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_dp_broadcast": [c_ptr, c_ptr, c_i64, c_i32, c_ptr],
     "vmm_dp_all_gather": [c_ptr, c_ptr, c_ptr, c_i64, c_ptr],

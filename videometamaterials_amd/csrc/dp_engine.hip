@@ -267,6 +267,23 @@ extern "C" int vmm_dp_timing(vmm_dp_engine* e, float* out3) {
   return 0;
 }
 
+// per bucket of the registered list: out[2 i] = ms from the window's opening mark to the start of bucket i's reduction on the side stream (its slice
+// was final and the stream free), out[2 i + 1] = ms to its completion; -1 for buckets not reduced since the window opened.  After a synchronize.
+extern "C" int vmm_dp_bucket_timing(vmm_dp_engine* e, float* out, int32_t n) {
+  if (!e || !out || n < 0) return -1;
+  if (!e->win_set[0]) {
+    snprintf(e->err, sizeof e->err, "vmm_dp_bucket_timing without the opening window mark");
+    return -1;
+  }
+  for (int i = 0; i < n; ++i) {
+    out[2 * i] = out[2 * i + 1] = -1.f;
+    if (i >= (int)e->buckets.size() || !e->buckets[i].stamped) continue;
+    DP_HIP(hipEventElapsedTime(&out[2 * i], e->win[0], e->buckets[i].t0));
+    DP_HIP(hipEventElapsedTime(&out[2 * i + 1], e->win[0], e->buckets[i].done));
+  }
+  return 0;
+}
+
 extern "C" int vmm_dp_allreduce(vmm_dp_engine* e, void* buf, int64_t count, int32_t dtype, int32_t op, vmm_dp_stream_t stream) {
   ncclDataType_t t;
   if (!e || !buf || count <= 0 || !dtype_of(dtype, t) || op < 0 || op > 2) return -1;

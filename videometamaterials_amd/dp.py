@@ -103,6 +103,12 @@ class RcclEngine:
         self._check(self.lib.vmm_dp_timing(self._h, out), "vmm_dp_timing")
         return float(out[0]), float(out[1]), float(out[2])
 
+    def bucket_timing(self, n: int) -> List[Tuple[float, float]]:
+        """(start, done) of every registered bucket's reduction in ms after the backward window opened (after a synchronize)."""
+        out = (C.c_float * max(2 * n, 2))()
+        self._check(self.lib.vmm_dp_bucket_timing(self._h, out, n), "vmm_dp_bucket_timing")
+        return [(round(float(out[2 * i]), 3), round(float(out[2 * i + 1]), 3)) for i in range(n)]
+
     _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
 
     def all_reduce(self, t: torch.Tensor, op: str = "sum") -> None:
@@ -246,8 +252,11 @@ class BucketedAllReduce:
             if not self.timing or not self.launched:
                 return None
             busy, inside, win = self.engine.timing()
+            spans = self.engine.bucket_timing(len(self._index))
+            by_slice = {v: k for k, v in self._index.items()}
             return {"allreduce_ms": round(busy, 3), "overlap_frac": round(inside / busy, 4) if busy > 0 else None, "backward_ms": round(win, 3),
-                    "buckets_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.launched]}
+                    "bucket_spans_ms": [spans[self._index[sl]] for sl in self.launched if sl in self._index],
+                    "buckets_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.launched], "registered_buckets": len(by_slice)}
         if len(self._ev_window) < 2 or not self._ev_buckets:
             return None
         w0, w1 = self._ev_window
