@@ -1719,7 +1719,9 @@ class _Builder:
             # data-parallel reducer -- once at least `span` floats of it are pending: a scatter launch and a mark per block were 45 launches of
             # ~15 us, most of them for the full-resolution blocks whose parameters are a few tens of thousands of floats (the reducer merges marks
             # into >= 16 MB buckets anyway).
-            span = min(250_000, max(1, self.pgtop // 12)) if _enabled("scatter_merge") else 1
+            # (round 4: 250 k -> 2 M floats.  The reducer's buckets are >= 4 M floats, so marks finer than that bought nothing, and every scatter launch
+            # is ~19 us: 31 -> ~19 launches per step)
+            span = min(2_000_000, max(1, self.pgtop // 12)) if _enabled("scatter_merge") else 1
             marked_pg, pend_lo = self.pgtop, uj_hi
             rev = list(reversed(self.tape))
             for idx, (emit, pg_start, uj_start) in enumerate(rev):
