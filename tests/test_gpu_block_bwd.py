@@ -189,3 +189,45 @@ def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok):
     if ntok:
         assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
         assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4
+
+
+def test_training_plan_uses_the_fused_blocks_and_agrees_with_the_unfused_path(gpu, monkeypatch):
+    """The split-bf16 training plan of the Lagrangian wiring at the real widths: the C = 64 attention sites run the fused forward blocks and the
+    recomputing backward kernels (no launch of the unfused to_qkv / core / to_out chain there), the arena shrinks accordingly, and every
+    parameter gradient equals the one of the UNFUSED training path (VMM_DISABLE=fused_attn_train: qkv rows through HBM) on the same inputs --
+    two independent implementations of the same backward."""
+    import helpers
+    import videometamaterials_amd as vm
+    kw, (B, T, H, W), _ = helpers.CONFIGS["lagr64"]
+    sd = helpers.synth_state_dict(helpers.load_shapes("lagr64"))
+    x, t, cond = (v.to(gpu) for v in helpers.synth_inputs("lagr64"))
+    g = torch.Generator().manual_seed(3)
+    dout = torch.randn(B, 3, T, H, W, generator=g).to(gpu)
+    grads, arenas = {}, {}
+    for mode in ("fused", "unfused"):
+        monkeypatch.setenv("VMM_DISABLE", "" if mode == "fused" else "fused_attn_train")
+        m = vm.Unet3D(**kw)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(gpu)
+        m.train_precision = "bf16x3"
+        pl = m.get_plan(B, T, H, W, cond.shape[-1], gpu, training=True)
+        fwd, bwd = [fn.__name__ for fn, _, _ in pl.steps], [fn.__name__ for fn, _, _ in pl.bwd_steps]
+        if mode == "fused":
+            # lagr64 at 32 x 32: C = 64 sites = init_temporal_attn, downs.0.{2,3}, ups.2.{2,3}, ups.3.{2,3}
+            assert fwd.count("vmm_temporal_block_bf16x3") == 4 and bwd.count("vmm_temporal_block_bwd_bf16x3") == 4
+            assert fwd.count("vmm_linattn_block_bf16x3") == 3 and bwd.count("vmm_linattn_block_bwd_bf16x3") == 3
+        else:
+            assert "vmm_temporal_block_bwd_bf16x3" not in bwd and "vmm_linattn_block_bwd_bf16x3" not in bwd
+        pl.run(x, t, cond, torch.zeros(B, dtype=torch.uint8, device=gpu))
+        pl.backward(dout)
+        torch.cuda.synchronize()
+        grads[mode] = {k: v.clone().cpu() for k, v in pl.grad_views(dict(m.named_parameters())).items()}
+        arenas[mode] = pl.arena_floats
+        del pl, m
+    assert arenas["fused"] < 0.75 * arenas["unfused"]
+    assert set(grads["fused"]) == set(grads["unfused"])
+    typical = max(float(v.double().norm()) for v in grads["unfused"].values())
+    for k, w in grads["unfused"].items():
+        if float(w.double().norm()) < 1e-9 * typical:
+            continue
+        assert relerr(grads["fused"][k], w) < 2e-4, (k, relerr(grads["fused"][k], w))

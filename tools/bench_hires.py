@@ -50,7 +50,7 @@ def main():
     out = {"workload": f"configs[3]: 22x192x192, batch {B}, dim 64, random init", "precision": m.precision, "denoiser_forward_ms": round(fwd, 2),
            "guided_step_ms": round(step, 2), "sampled_frames_per_sec": round(B * T / (step * 256 / 1000.0), 3),
            "launches_per_forward": len(plan.meta), "plan_GB": round(plan.arena_floats * 4 / 1e9, 1),
-           "ms_by_family": {k: [round(v[0], 2), v[2], round(v[1] / v[0] / 1e9, 1) if v[0] and v[1] else None] for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]}}
+           "ms_by_family": {k: [round(v[0], 2), v[2], round(v[1] / v[0] / 1e9, 1) if v[0] and v[1] else None] for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:24]}}
     print(json.dumps(out))
 
 
