@@ -63,6 +63,10 @@ typedef struct vmm_conv_desc {
    * halves of a guidance batch sharing ONE pre-norm tensor that the first convolution computed for half the batch (plan.py, mirrored
    * plans).  Honoured by the 2-D-tiled unsplit instances of the 3 x 3 halo kernels; every other kernel returns 1 / -1 for it. */
   int32_t a_img_mod;
+  /* storage of the feature maps (the "bf16" throughput mode keeps the two upper levels' maps as bf16 in HBM): bit 0 = a1 / a2 point at bf16,
+   * bit 1 = out (and res) point at bf16; 0 = fp32 everywhere.  Honoured by the single-pass entry points (vmm_conv3x3_bf16, vmm_conv_s2_acc_bf16,
+   * vmm_proj_bf16, vmm_proj_bf16_res_silu); every other kernel returns -1 for a non-zero value.  ld* stay in ELEMENTS. */
+  int32_t act_bf16;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
@@ -226,6 +230,11 @@ int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_packed, c
 int vmm_conv_s2_acc_bf16(const float* x, int32_t ldx, const float* w_packed, const float* bias, const float* res, int32_t ldres, float* out,
                            int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
                            int32_t n_tickets, vmm_stream_t stream);
+/* ... over bf16-STORED feature maps: a16 = 1: x, res, out bf16; 2: x bf16, out (res) fp32 (the Downsample leaving the bf16 levels); 3: x fp32, out
+ * (res) bf16 (the Upsample entering them).  Unsplit instances (the upper levels have tiles to spare); ld in elements. */
+int vmm_conv_s2_acc_bf16_a16(const void* x, int32_t ldx, const float* w_packed, const float* bias, const void* res, int32_t ldres, void* out,
+                             int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t a16,
+                             vmm_stream_t stream);
 
 /* ---- K6: GroupNorm(groups, C) statistics + fused affine/FiLM/SiLU (vddp.py:274-285) ---- */
 /* sums[b, g] = (sum x, sum x^2) over (C/G channels, all rows of sample b), accumulated in fp64. */
@@ -248,6 +257,26 @@ int vmm_groupnorm_coef(const double* sums, int64_t count_per_group, float eps, c
 /* y = silu(x*a + b') (+ res) ; in place allowed (vddp.py:285,311). */
 int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, const float* res, int32_t ldres, float* y, int32_t ldy,
                     int64_t rows, int32_t rows_per_sample, int32_t C, vmm_stream_t stream);
+/* the same pass over bf16-STORED feature maps (x, res, y = bf16 bits, ld in elements; coefficients fp32): the "bf16" throughput mode */
+int vmm_affine_silu_a16(const void* x, int32_t ldx, const float* coef, const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows,
+                        int32_t rows_per_sample, int32_t C, vmm_stream_t stream);
+/* ---- entry points over bf16-STORED feature maps (the "bf16" throughput mode keeps the two upper levels' maps as bf16 in HBM; same arguments as the
+ * functions they are named after, activation pointers = bf16 bits, ld in elements, everything else fp32) */
+int vmm_affine_silu_pointwise_to_ncthw_a16(const void* x, int32_t ldx, const float* coef, const void* res, int32_t ldres, int32_t C, const float* w,
+                                           const float* bias, int32_t B, int32_t Cout, int32_t T, int32_t HW, float* out, vmm_stream_t stream);
+int vmm_stem_conv_bf16x3_a16(const float* x, const float* w_frag, const float* bias, void* out, int32_t ldo, int32_t nimg, int32_t H, int32_t W,
+                             int32_t Cout, int32_t k, vmm_stream_t stream);
+int vmm_temporal_attention_a16(const void* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,
+                               int32_t bias_on_cond, void* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, float* lse,
+                               vmm_stream_t stream);
+int vmm_temporal_block_bf16_a16(const void* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed, const float* ek,
+                                const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond, const float* rot_tab, void* out, int32_t ldo,
+                                int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float q_scale, float eps, vmm_stream_t stream);
+int vmm_linattn_block_bf16_a16(const void* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* bias_out,
+                               const float* ek, const float* ev, int32_t ntok, float* workspace, void* out, int32_t ldo, int32_t B, int32_t T,
+                               int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
+/* storage conversion of a dense feature map, n elements (a multiple of 4): src_bf16 / dst_bf16 = 0 fp32, 1 bf16 (round to nearest even) */
+int vmm_convert_act(const void* src, int32_t src_bf16, void* dst, int32_t dst_bf16, int64_t n, vmm_stream_t stream);
 
 /* the last ResnetBlock's output pass and final_conv.1 (vddp.py:311,729) in one kernel: out (B, Cout, T, HW) = bias + w (Cout, 64) .
  * (silu(x*a + b') + res) per row; the block's output is never stored.  Returns 1 (nothing launched) unless C == 64 and Cout <= 4. */

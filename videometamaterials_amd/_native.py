@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("split_tickets", c_ptr), ("n_tickets", c_i32),
         ("gn_part", c_ptr), ("gn_groups", c_i32),
         ("wrap_h", c_i32), ("wrap_w", c_i32), ("a_img_mod", c_i32),
+        ("act_bf16", c_i32),
     ]
 
 
@@ -157,6 +158,15 @@ SIGNATURES = {
     "vmm_groupnorm_stats_slots": [c_i32, c_i32, c_i32],
     "vmm_groupnorm_stats_partials": [c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_groupnorm_coef": [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_affine_silu_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_affine_silu_pointwise_to_ncthw_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_stem_conv_bf16x3_a16": [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_temporal_attention_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_temporal_block_bf16_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  c_i32, c_f32, c_f32, c_ptr],
+    "vmm_linattn_block_bf16_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_f32, c_ptr],
+    "vmm_convert_act": [c_ptr, c_i32, c_ptr, c_i32, c_i64, c_ptr],
     "vmm_affine_silu": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr],
     "vmm_affine_silu_pointwise_to_ncthw": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_channel_layernorm": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f32, c_ptr],
@@ -167,6 +177,7 @@ SIGNATURES = {
     "vmm_conv_s2_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_conv_s2_acc_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
     "vmm_conv_s2_acc_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_conv_s2_acc_bf16_a16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_temporal_block_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
                                   c_i32, c_f32, c_f32, c_ptr],

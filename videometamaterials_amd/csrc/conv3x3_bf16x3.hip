@@ -71,9 +71,14 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
 // Eight k16 steps per chunk instead of eighteen; every input element is still staged once (the generic kernel gathers it four times).
 // ONE: the "bf16" throughput mode (BASELINE.json configs[3]): the operands' hi planes only, ONE MFMA pass per product (the lo planes of the patch and of
 // the fmt-2 weights are neither read nor multiplied): bf16-rounded operands, fp32 accumulation.
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false>
+// A16 (single-pass mode only): storage of the feature maps -- 0: fp32 in, fp32 out; 1: bf16 in, bf16 out; 2: bf16 in, fp32 out; 3: fp32 in, bf16 out
+// (the level boundaries of the resampling layers).  bf16 in: a patch item is 8 bytes, and without the fused transform the stored bits ARE the hi
+// plane (no conversion at all between HBM and the LDS patch); bf16 out: the epilogue rounds once, the GroupNorm sums come from the fp32 accumulators.
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0>
 __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   static_assert(!ONE || !F32, "single pass: bf16 operands");
+  static_assert(A16 == 0 || (ONE && !SPLIT), "bf16-stored maps: the unsplit single-pass instances");
+  constexpr bool IN16 = A16 == 1 || A16 == 2, OUT16 = A16 == 1 || A16 == 3;
   constexpr int BM = WM * 64;
   constexpr int NQ = TS ? 8 : 18;  // k16 steps per chunk
   static_assert(!TS || !F32, "tap-subset layers: split-bf16 only");
@@ -243,7 +248,12 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       const int sr = max(src_row(ps, sub_of(cc)), 0);
-      preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
+      if constexpr (IN16) {  // four bf16 = 8 bytes, carried as bits in the item's first two registers
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16s*>(src) + (long long)sr * ld + cb);
+        preg[ps] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+      } else {
+        preg[ps] = *reinterpret_cast<const f32x4*>(src + (long long)sr * ld + cb);
+      }
     }
   };
   // One item of the next chunk's patch.  vmcnt retires in order, so an HBM-latency load blocks every younger weight-fragment wait
@@ -252,7 +262,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   // `last` (wave-uniform; unsplit 3 x 3 layers): the tile's last chunk has nothing to prefetch, and the request cannot be skipped without a
   // branch in the step -- it used to re-read its own patch (41 KB per workgroup for nothing).  It fetches the epilogue's bias pieces instead:
   // item ps < 8 = the 16 bytes that bias piece (j, g) = (ps >> 2, ps & 3) of this lane needs, so the epilogue finds them in registers.
-  constexpr int NBIAS = (!SPLIT && !TS) ? (MAXP < 8 ? MAXP : 8) : 0;  // bias pieces that ride in the prefetch registers
+  constexpr int NBIAS = (!SPLIT && !TS && !IN16) ? (MAXP < 8 ? MAXP : 8) : 0;  // bias pieces that ride in the prefetch registers
   auto load_patch_item = [&](int cc, int ps, bool last) {
     const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
@@ -260,6 +270,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     const int ld = src1 ? p.lda1 : p.lda2;
     const int cb = (src1 ? c0 : c0 - p.C1) + k4 * 4;
     const int sr = max(src_row(ps, sub_of(cc)), 0);
+    if constexpr (IN16) {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16s*>(src) + (long long)sr * ld + cb);
+      preg[ps] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+      return;
+    }
     const float* q = src + (long long)sr * ld + cb;
     if (NBIAS) {
       // (lane offset recomputed here, two instructions: as a loop-invariant 64-bit pointer it cost the 256 x 64 kernel a spill whose reload in
@@ -284,6 +299,14 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       const int r = (tid >> 3) + ps * 32;
       f32x4 v = preg[ps];
       const bool real = (vmask >> ps) & 1u;
+      if constexpr (IN16) {
+        unsigned b0 = __float_as_uint(v.x), b1 = __float_as_uint(v.y);
+        if (!xform) {  // (wave-uniform) the stored bits are the operand
+          if ((ps + 1) * 32 <= PRc || r < PRc) *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(real ? b0 : 0u, real ? b1 : 0u);
+          continue;
+        }
+        v = f32x4{__uint_as_float(b0 << 16), __uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 << 16), __uint_as_float(b1 & 0xffff0000u)};
+      }
       if (!MODE && xform) {  // flat row tiles run across samples (wave-uniform condition; padding items read sample 0's coefficients, unused)
         const int sr = max(src_row(ps, 0), 0);
         const float* cf = p.a_coef + ((long long)(sr / rows_per_sample) * p.C1 + c0 + k4 * 4) * 2;
@@ -624,7 +647,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          rv[j][g] = p.res ? *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + c0 + j * 32 + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+          rv[j][g] = !p.res ? f32x4{0.f, 0.f, 0.f, 0.f}
+                     : OUT16 ? ld4(reinterpret_cast<const bf16s*>(p.res) + orow * p.ldres + c0 + j * 32 + 8 * g)
+                             : *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + c0 + j * 32 + 8 * g);
       float* orp = p.out + orow * p.ldo + c0;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -632,7 +657,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = {acc[i][j][4 * g] + rv[j][g].x, acc[i][j][4 * g + 1] + rv[j][g].y, acc[i][j][4 * g + 2] + rv[j][g].z,
                            acc[i][j][4 * g + 3] + rv[j][g].w};
-          *reinterpret_cast<f32x4*>(orp + j * 32 + 8 * g) = v;
+          if constexpr (OUT16) st4(reinterpret_cast<bf16s*>(p.out) + orow * p.ldo + c0 + j * 32 + 8 * g, v);
+          else *reinterpret_cast<f32x4*>(orp + j * 32 + 8 * g) = v;
         }
     }
     stamp(12);
@@ -731,18 +757,18 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   }
 }
 
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false>
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false, int A16 = 0>
 #ifndef VMM_C3_WGS
 #define VMM_C3_WGS 2
 #endif
 __global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Args a) {
-  conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0, ONE>(a);
+  conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0, ONE, A16>(a);
 }
 
 // the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
-template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false>
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false, int A16 = 0>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(const C3Args a) {
-  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS, ONE>(a);
+  conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS, ONE, A16>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1452,15 +1478,30 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
-template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false>
+template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false, int A16 = 0>
 int launch_s2(const C3Args& a, int mtiles, hipStream_t s, int ksplit = 1) {
   const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;  // (+ three rows of zeros for the masked taps of flat row tiles)
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE, A16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE>), dim3((unsigned)(mtiles * a.n_tiles), (unsigned)ksplit), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((conv_s2_kernel<WM, WN, MAXP, MODE, TS, SPLIT, ONE, A16>), dim3((unsigned)(mtiles * a.n_tiles), (unsigned)ksplit), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// the single-pass 3 x 3 instances over bf16-stored maps (A16 = 1: in and out)
+template <int WM, int WN, int MAXP, int MODE, int PFB>
+int launch_c3_a16(const C3Args& a, int mtiles, hipStream_t s) {
+  const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_x3_kernel<WM, WN, MAXP, MODE, PFB, false, false, true, 1>), dim3((unsigned)(mtiles * a.n_tiles), 1), dim3(256), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -1617,6 +1658,7 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   C3Args a;
   int mtiles, ksplit;
   bool gn = false;
+  if (d.act_bf16) return -1;  // (bf16-stored maps: the single-pass entry point only)
   const int rc = plan_c3(d, a, mtiles, ksplit, gn);
   if (rc != 0) return rc;
   if (a.total_rows <= 0) return 0;
@@ -1635,6 +1677,12 @@ extern "C" int vmm_conv3x3_bf16(const vmm_conv_desc* dp, vmm_stream_t stream) {
   const int rc = plan_c3(d, a, mtiles, ksplit, gn);
   if (rc != 0) return rc;
   if (a.total_rows <= 0) return 0;
+  if (d.act_bf16) {  // bf16-stored maps: input(s), residual and output alike; the unsplit instances (the upper levels have tiles to spare)
+    if (d.act_bf16 != 3 || ksplit != 1) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (d.Cout >= 128) return a.mode ? launch_c3_a16<2, 2, 6, 1, 2>(a, mtiles, s) : launch_c3_a16<2, 2, 6, 0, 2>(a, mtiles, s);
+    return a.mode ? launch_c3_a16<4, 1, 11, 1, 2>(a, mtiles, s) : launch_c3_a16<4, 1, 11, 0, 2>(a, mtiles, s);
+  }
   return dispatch_c3<false, true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
 }
 
@@ -1738,6 +1786,35 @@ extern "C" int vmm_conv_s2_acc_bf16(const float* x, int32_t ldx, const float* w_
                                     int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
                                     int32_t n_tickets, vmm_stream_t stream) {
   return s2_run<true>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, split_tickets, n_tickets, stream);
+}
+
+// The single-pass resampling layers over bf16-STORED maps: a16 = 1: input, residual and output bf16; 2: bf16 in, fp32 out (the Downsample that leaves the
+// bf16 levels); 3: fp32 in, bf16 out (the Upsample that enters them).  Unsplit instances only (returns -1 if the shape would need the channel split).
+template <int A16>
+static int s2_run_a16(const void* x, int32_t ldx, const float* w_frag, const float* bias, const void* res, int32_t ldres, void* out, int32_t ldo, int32_t nimg,
+                      int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, hipStream_t s) {
+  C3Args a;
+  int mtiles;
+  bool wide;
+  const int rc = s2_plan(static_cast<const float*>(x), ldx, w_frag, bias, static_cast<float*>(out), ldo, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide);
+  if (rc) return rc;
+  if (res && (ldres & 3)) return 1;
+  a.p.res = static_cast<const float*>(res);
+  a.p.ldres = ldres;
+  if (up) return a.mode ? launch_s2<2, 2, 6, 1, 1, false, true, A16>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 1, false, true, A16>(a, mtiles, s);
+  if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, false, true, A16>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2, false, true, A16>(a, mtiles, s);
+  return a.mode ? launch_s2<4, 1, 11, 1, 2, false, true, A16>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2, false, true, A16>(a, mtiles, s);
+}
+extern "C" int vmm_conv_s2_acc_bf16_a16(const void* x, int32_t ldx, const float* w_frag, const float* bias, const void* res, int32_t ldres, void* out,
+                                        int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t a16,
+                                        vmm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (a16) {
+    case 1: return s2_run_a16<1>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, s);
+    case 2: return s2_run_a16<2>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, s);
+    case 3: return s2_run_a16<3>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, s);
+    default: return -1;
+  }
 }
 extern "C" int vmm_conv_s2_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg,
                                   int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, vmm_stream_t stream) {

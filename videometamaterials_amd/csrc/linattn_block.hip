@@ -37,7 +37,7 @@ constexpr int LD = 32;            // dim_head
 constexpr int PART = 64 + LD * LD;  // floats per partial: max[32] | sum[32] | ctx^T[e][d]
 
 struct LAArgs {
-  const float* x; int ldx;
+  const void* x; int ldx;   // rows of ST: float, or bf16s when the maps are bf16-stored (the "bf16" mode; A16 instances of the two passes)
   const float* gamma; float eps;
   const uint4* wqkv;   // fmt 2 fragments, N = 768 (q | k | v), K = 64 (4 k16 steps)
   const uint4* wout;   // fmt 3 fragments, N = 64, K = 256 (16 k16 steps)
@@ -45,7 +45,7 @@ struct LAArgs {
   const float* ek; const float* ev; int ntok;
   float* part;         // [frame][split][head][PART]
   uint4* ctxfrag;      // [frame][head][2 steps][hi|lo][64 lanes]
-  float* out; int ldo;
+  void* out; int ldo;
   int T, HW, nsplit, sps;  // sps: 32-pixel tiles per split
   float q_scale;
 };
@@ -128,9 +128,10 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- pass A
-template <bool ONE, int CC>
+template <bool ONE, int CC, typename ST = float>
 __global__ __launch_bounds__(512) void linattn_ctx_kernel(const LAArgs a) {
   constexpr int NV = CC / 64, NS = CC / 16, YP = LAGeom<CC>::YPITCH;
+  const ST* const xin = static_cast<const ST*>(a.x);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
   const int frame = blockIdx.x / a.nsplit, split = blockIdx.x - frame * a.nsplit;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512) void linattn_ctx_kernel(const LAArgs a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < t_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + v * 64 + (tid & 15) * 4);
+      if (t < t_end) d[v] = ld4(xin + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + v * 64 + (tid & 15) * 4);
     }
   };
   float m = -INFINITY, ssum = 0.f;
@@ -256,9 +257,11 @@ __global__ __launch_bounds__(256) void linattn_combine_kernel(const LAArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- pass B
-template <bool ONE, int CC>
+template <bool ONE, int CC, typename ST = float>
 __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
   constexpr int NV = CC / 64, NS = CC / 16, NCT = CC / 32, YP = LAGeom<CC>::YPITCH;
+  const ST* const xin = static_cast<const ST*>(a.x);
+  ST* const outp = static_cast<ST*>(a.out);
   constexpr bool HOLD_WO = CC == 64;  // the to_out fragments of the head stay in registers (C = 64) or are streamed per tile (C = 128)
   extern __shared__ __attribute__((aligned(16))) float red[];  // [8 heads][32 pixels][64 channels] (one 64-channel half at a time), then the staged input tile
   unsigned short* ytile = reinterpret_cast<unsigned short*>(red + LH * 32 * 64);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < t_end) d[v] = *reinterpret_cast<const f32x4*>(a.x + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
+      if (t < t_end) d[v] = ld4(xin + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
     }
   };
 #ifndef VMM_LA_PIPE
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       acc.x += xa[0].x; acc.y += xa[0].y; acc.z += xa[0].z; acc.w += xa[0].w;  // residual: the element this thread normalised
-      *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + rc) = acc;
+      st4(outp + (row0 + rp) * a.ldo + rc, acc);
 #pragma unroll
       for (int v = 0; v < NV; ++v) { xa[v] = xb[v]; xb[v] = xc[v]; }
     }
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       acc.x += x_cur[half].x; acc.y += x_cur[half].y; acc.z += x_cur[half].z; acc.w += x_cur[half].w;  // residual: the element this thread normalised
-      *reinterpret_cast<f32x4*>(a.out + (row0 + rp) * a.ldo + half * 64 + rc) = acc;
+      st4(outp + (row0 + rp) * a.ldo + half * 64 + rc, acc);
     }
   }
 }
@@ -473,27 +476,27 @@ extern "C" int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW)
   return (int64_t)B * T * ns * LH * PART + (int64_t)B * T * LH * 1024;
 }
 
-template <bool ONE, int CC>
+template <bool ONE, int CC, typename ST = float>
 static int la_run(const LAArgs& a, unsigned blocks, int frames, hipStream_t s) {
-  hipLaunchKernelGGL((linattn_ctx_kernel<ONE, CC>), dim3(blocks), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((linattn_ctx_kernel<ONE, CC, ST>), dim3(blocks), dim3(512), 0, s, a);
   VMM_LAUNCH_CHECK();
   hipLaunchKernelGGL(linattn_combine_kernel, dim3((unsigned)(frames * LH)), dim3(256), 0, s, a);
   VMM_LAUNCH_CHECK();
   const size_t shm = (CC == 64 && VMM_LA_PIPE ? 2 : 1) * (sizeof(float) * LH * 32 * 64 + sizeof(unsigned short) * 32 * LAGeom<CC>::YPITCH);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel<ONE, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel<ONE, CC, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((linattn_apply_kernel<ONE, CC>), dim3(blocks), dim3(512), shm, s, a);
+  hipLaunchKernelGGL((linattn_apply_kernel<ONE, CC, ST>), dim3(blocks), dim3(512), shm, s, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }
 
 // Returns 1 (nothing launched) outside the envelope: C == 64 or 128, heads == 8, dim_head == 32, HW % 32 == 0.
-template <bool ONE>
-static int la_launch(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* bias_out, const float* ek,
-                     const float* ev, int32_t ntok, float* workspace, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
+template <bool ONE, typename ST = float>
+static int la_launch(const void* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* bias_out, const float* ek,
+                     const float* ev, int32_t ntok, float* workspace, void* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
                      float eps, vmm_stream_t stream) {
   if ((C != 64 && C != 128) || heads != LH || (HW % 32) || (ldx & 3) || (ldo & 3)) return 1;
   if (B * T <= 0) return 0;
@@ -511,7 +514,7 @@ static int la_launch(const float* x, int32_t ldx, const float* gamma, const floa
   a.out = out; a.ldo = ldo;
   a.q_scale = 1.0f / sqrtf((float)LD);
   const unsigned blocks = (unsigned)(B * T * a.nsplit);
-  return C == 64 ? la_run<ONE, 64>(a, blocks, B * T, s) : la_run<ONE, 128>(a, blocks, B * T, s);
+  return C == 64 ? la_run<ONE, 64, ST>(a, blocks, B * T, s) : la_run<ONE, 128, ST>(a, blocks, B * T, s);
 }
 
 extern "C" int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
@@ -524,4 +527,10 @@ extern "C" int vmm_linattn_block_bf16(const float* x, int32_t ldx, const float* 
                                       const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
                                       int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
   return la_launch<true>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
+}
+// ... over bf16-STORED feature maps (x, out = bf16 bits; ld in elements): the "bf16" mode's two upper levels
+extern "C" int vmm_linattn_block_bf16_a16(const void* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                          const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, void* out,
+                                          int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
+  return la_launch<true, bf16s>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
 }

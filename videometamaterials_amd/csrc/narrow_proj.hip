@@ -29,6 +29,9 @@ struct NPArgs {
   int rows_per_sample;
 };
 
+// A16: the rows, the residual and the output are bf16-STORED maps (the "bf16" throughput mode): a lane's fragment is 16 contiguous bytes of its
+// row and IS the matrix operand (no split); one pass on the weights' hi planes, like the mode's other kernels.
+template <bool A16>
 __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) {
   const vmm_conv_desc& p = a.p;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,12 +50,21 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
 
   // A request covers TWO k16 steps: the four 16-byte loads of a row fragment then touch one whole 128-byte line of every row back to back
   // (requested one step at a time the second half of a line came ~300 cycles later, after the CU's other waves had pushed it out of the L1)
-  f32x4 xa[DEPTH][2][2][2];   // [stage][step of the pair][row fragment][first / second four floats]
+  auto src16 = [&](long long r, int ks) -> const bf16s* {
+    return ks < KS1 ? reinterpret_cast<const bf16s*>(p.a1) + r * p.lda1 + ks * 16 + half * 8
+                    : reinterpret_cast<const bf16s*>(p.a2) + r * p.lda2 + (ks - KS1) * 16 + half * 8;
+  };
+  f32x4 xa[DEPTH][2][2][2];   // [stage][step of the pair][row fragment][first / second four floats]  (A16: [..][0] carries the fragment's 16 bytes as bits)
   uint4 wv[DEPTH][2][2][2];   // [stage][step of the pair][column tile][hi | lo]
   auto request = [&](int st, int kd) {
     const int k = min(2 * kd, KS - 2);  // (the tail re-requests the last pair: unconditional loads, no branch in the step)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      if constexpr (A16) {
+        xa[st][u][0][0] = __builtin_bit_cast(f32x4, *reinterpret_cast<const uint4*>(src16(r0, k + u)));
+        xa[st][u][1][0] = __builtin_bit_cast(f32x4, *reinterpret_cast<const uint4*>(src16(r1, k + u)));
+        continue;
+      }
       const float* s0 = src(r0, k + u);
       const float* s1 = src(r1, k + u);
       xa[st][u][0][0] = *reinterpret_cast<const f32x4*>(s0);
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         wv[st][u][nt][0] = *wplane(nt, k + u, 0);
-        wv[st][u][nt][1] = *wplane(nt, k + u, 1);
+        if constexpr (!A16) wv[st][u][nt][1] = *wplane(nt, k + u, 1);
       }
   };
   f32x16 acc[2][2];  // [column tile][row fragment]
@@ -87,6 +99,10 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
           for (int rf = 0; rf < 2; ++rf) {
+            if constexpr (A16) {
+              bh[u][rf] = __builtin_bit_cast(bf16x8, xa[s][u][rf][0]);
+              continue;
+            }
             uint4 h, l;
             h.x = split_bf16_pair(xa[s][u][rf][0].x, xa[s][u][rf][0].y, l.x);
             h.y = split_bf16_pair(xa[s][u][rf][0].z, xa[s][u][rf][0].w, l.y);
@@ -98,21 +114,23 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             ah[u][nt] = __builtin_bit_cast(bf16x8, wv[s][u][nt][0]);
-            al[u][nt] = __builtin_bit_cast(bf16x8, wv[s][u][nt][1]);
+            if constexpr (!A16) al[u][nt] = __builtin_bit_cast(bf16x8, wv[s][u][nt][1]);
           }
         }
         request(s, kd0 + s + DEPTH);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           // pass-major, lo products first
+          if constexpr (!A16) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][nt], bl[u][rf], acc[nt][rf], 0, 0, 0);
+              for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][nt], bl[u][rf], acc[nt][rf], 0, 0, 0);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u][nt], bh[u][rf], acc[nt][rf], 0, 0, 0);
+              for (int rf = 0; rf < 2; ++rf) acc[nt][rf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u][nt], bh[u][rf], acc[nt][rf], 0, 0, 0);
+          }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
         f32x4 v = {acc[nt][rf][4 * q], acc[nt][rf][4 * q + 1], acc[nt][rf][4 * q + 2], acc[nt][rf][4 * q + 3]};
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c);
         if (p.res) {
-          f32x4 r = *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + c);
+          f32x4 r = A16 ? ld4(reinterpret_cast<const bf16s*>(p.res) + row * p.ldres + c) : *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + c);
           if (a.res_coef) {
             const float* cf = a.res_coef + ((row / a.rows_per_sample) * 64 + c) * 2;
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf), c1 = *reinterpret_cast<const f32x4*>(cf + 4);
@@ -142,7 +160,8 @@ __global__ __launch_bounds__(256, 2) void narrow_proj_x3_kernel(const NPArgs a) 
           }
           v += r;
         }
-        *reinterpret_cast<f32x4*>(p.out + row * p.ldo + c) = v;
+        if constexpr (A16) st4(reinterpret_cast<bf16s*>(p.out) + row * p.ldo + c, v);
+        else *reinterpret_cast<f32x4*>(p.out + row * p.ldo + c) = v;
       }
   }
 }
@@ -159,6 +178,7 @@ static int np_launch(const vmm_conv_desc& d, const float* res_coef, int rows_per
   const bool chan_ok = d.Cout == 64 && d.C1 > 0 && d.C1 % 16 == 0 && d.C2 % 16 == 0 && K >= 64 && K % 32 == 0 && (d.lda1 & 3) == 0 && (!d.C2 || (d.lda2 & 3) == 0) &&
                        (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
   if (!shape_ok || !chan_ok) return 1;
+  if (d.act_bf16 && (d.act_bf16 != 3 || (d.lda1 & 7) || (d.C2 && (d.lda2 & 7)))) return -1;  // bf16-stored rows, residual and output alike
   NPArgs a;
   a.p = d;
   a.rows = (long long)d.nimg * d.Hv * d.Wv;
@@ -166,7 +186,8 @@ static int np_launch(const vmm_conv_desc& d, const float* res_coef, int rows_per
   a.res_coef = res_coef;
   a.rows_per_sample = rows_per_sample;
   if (a.rows <= 0) return 0;
-  hipLaunchKernelGGL(narrow_proj_x3_kernel, dim3((unsigned)cdiv(a.rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (d.act_bf16) hipLaunchKernelGGL(narrow_proj_x3_kernel<true>, dim3((unsigned)cdiv(a.rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(narrow_proj_x3_kernel<false>, dim3((unsigned)cdiv(a.rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coef,
-                                                          const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy,
+template <typename ST>
+__global__ __launch_bounds__(256) void affine_silu_kernel(const ST* __restrict__ x, int ldx, const float* __restrict__ coef,
+                                                          const ST* __restrict__ res, int ldres, ST* __restrict__ y, int ldy,
                                                           long long rows, int rows_per_sample, int C) {
   const int c4n = C >> 2;
   const long long total = rows * c4n;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restric
     const long long r = i / c4n;
     const int c = (int)(i - r * c4n) * 4;
     const int b = (int)(r / rows_per_sample);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    const f32x4 v = ld4(x + r * ldx + c);
     const float* cf = coef + ((long long)b * C + c) * 2;
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf);
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + 4);
@@ -141,11 +142,17 @@ __global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restric
     o.z = silu_f(v.z * c1.x + c1.y);
     o.w = silu_f(v.w * c1.z + c1.w);
     if (res) {
-      const f32x4 rr = *reinterpret_cast<const f32x4*>(res + r * ldres + c);
+      const f32x4 rr = ld4(res + r * ldres + c);
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
     }
-    *reinterpret_cast<f32x4*>(y + r * ldy + c) = o;
+    st4(y + r * ldy + c, o);
   }
+}
+
+// storage conversion of a dense activation (fp32 <-> bf16): only where a kernel without a bf16-storage instance meets one with
+template <typename SS, typename DS>
+__global__ __launch_bounds__(256) void convert_act_kernel(const SS* __restrict__ src, DS* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) st4(dst + 4 * i, ld4(src + 4 * i));
 }
 
 // ---------------------------------------------------------------- last block's output pass + final 1x1 convolution
@@ -153,8 +160,9 @@ __global__ __launch_bounds__(256) void affine_silu_kernel(const float* __restric
 // vddp.py:729): the block's output never goes to memory.  16 lanes per row (one float4 each, 256-byte row reads), a wave walks 64
 // consecutive rows, the per-row dot products are reduced inside the DPP row and leave through LDS so that lane r writes row r (256-byte
 // runs of every output plane).
-__global__ __launch_bounds__(256) void affine_silu_pointwise_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coef,
-                                                                    const float* __restrict__ res, int ldres, int rows_per_sample,
+template <typename ST>
+__global__ __launch_bounds__(256) void affine_silu_pointwise_kernel(const ST* __restrict__ x, int ldx, const float* __restrict__ coef,
+                                                                    const ST* __restrict__ res, int ldres, int rows_per_sample,
                                                                     const float* __restrict__ w, const float* __restrict__ bias, int Cout,
                                                                     int T, int HW, float* __restrict__ out, long long nrows) {
   __shared__ float sm[4][64][4];
@@ -172,12 +180,12 @@ __global__ __launch_bounds__(256) void affine_silu_pointwise_kernel(const float*
     float d[4] = {0.f, 0.f, 0.f, 0.f};
     if (r < nrows) {
       const int b = (int)(r / rows_per_sample);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+      const f32x4 v = ld4(x + r * ldx + c);
       const float* cf = coef + ((long long)b * 64 + c) * 2;
       const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf), c1 = *reinterpret_cast<const f32x4*>(cf + 4);
       f32x4 o = {silu_f(v.x * c0.x + c0.y), silu_f(v.y * c0.z + c0.w), silu_f(v.z * c1.x + c1.y), silu_f(v.w * c1.z + c1.w)};
       if (res) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(res + r * ldres + c);
+        const f32x4 rr = ld4(res + r * ldres + c);
         o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       }
 #pragma unroll
@@ -313,8 +321,36 @@ extern "C" int vmm_affine_silu(const float* x, int32_t ldx, const float* coef, c
   if ((C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldres & 3))) return -1;
   const long long total = rows * (C >> 2);
   const int blocks = (int)min((long long)cdiv(total, 256), 8192LL);
-  hipLaunchKernelGGL(affine_silu_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, coef, res, ldres, y, ldy, (long long)rows,
+  hipLaunchKernelGGL(affine_silu_kernel<float>, dim3(blocks), dim3(256), 0, s, x, ldx, coef, res, ldres, y, ldy, (long long)rows,
                      rows_per_sample, C);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same pass over bf16-stored feature maps (x, res, y: bf16 bits; the coefficients stay fp32)
+extern "C" int vmm_affine_silu_a16(const void* x, int32_t ldx, const float* coef, const void* res, int32_t ldres, void* y, int32_t ldy, int64_t rows,
+                                   int32_t rows_per_sample, int32_t C, vmm_stream_t stream) {
+  if (rows <= 0) return 0;
+  if ((C & 3) || (ldx & 3) || (ldy & 3) || (res && (ldres & 3))) return -1;
+  const long long total = rows * (C >> 2);
+  const int blocks = (int)min((long long)cdiv(total, 256), 8192LL);
+  hipLaunchKernelGGL(affine_silu_kernel<bf16s>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16s*>(x), ldx, coef,
+                     static_cast<const bf16s*>(res), ldres, static_cast<bf16s*>(y), ldy, (long long)rows, rows_per_sample, C);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// dst = src with the storage type changed (n elements, a multiple of 4; 16-byte / 8-byte aligned): src_bf16 / dst_bf16 = 0 fp32, 1 bf16
+extern "C" int vmm_convert_act(const void* src, int32_t src_bf16, void* dst, int32_t dst_bf16, int64_t n, vmm_stream_t stream) {
+  if (n <= 0) return 0;
+  if ((n & 3) || src_bf16 == dst_bf16) return -1;
+  const int blocks = (int)min((long long)cdiv(n / 4, 256), 8192LL);
+  if (src_bf16)
+    hipLaunchKernelGGL((convert_act_kernel<bf16s, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16s*>(src),
+                       static_cast<float*>(dst), (long long)(n / 4));
+  else
+    hipLaunchKernelGGL((convert_act_kernel<float, bf16s>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(src),
+                       static_cast<bf16s*>(dst), (long long)(n / 4));
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -327,8 +363,20 @@ extern "C" int vmm_affine_silu_pointwise_to_ncthw(const float* x, int32_t ldx, c
   if (C != 64 || Cout < 1 || Cout > 4 || (ldx & 3) || (res && (ldres & 3))) return 1;
   const long long nrows = (long long)B * T * HW;
   if (nrows <= 0) return 0;
-  hipLaunchKernelGGL(affine_silu_pointwise_kernel, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, coef, res, ldres,
+  hipLaunchKernelGGL(affine_silu_pointwise_kernel<float>, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, coef, res, ldres,
                      T * HW, w, bias, Cout, T, HW, out, nrows);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+// ... over bf16-STORED maps (x, res = bf16 bits); the (B, Cout, T, HW) output stays fp32 (the API edge)
+extern "C" int vmm_affine_silu_pointwise_to_ncthw_a16(const void* x, int32_t ldx, const float* coef, const void* res, int32_t ldres, int32_t C,
+                                                      const float* w, const float* bias, int32_t B, int32_t Cout, int32_t T, int32_t HW, float* out,
+                                                      vmm_stream_t stream) {
+  if (C != 64 || Cout < 1 || Cout > 4 || (ldx & 3) || (res && (ldres & 3))) return 1;
+  const long long nrows = (long long)B * T * HW;
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(affine_silu_pointwise_kernel<bf16s>, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const bf16s*>(x), ldx, coef, static_cast<const bf16s*>(res), ldres, T * HW, w, bias, Cout, T, HW, out, nrows);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -46,9 +46,12 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { r
 #define VMM_PJ_DBG 0
 #endif
 // ONE: the "bf16" throughput mode (BASELINE.json configs[3]): hi planes only, one matrix pass per product
-template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false>
+// A16 (single-pass instances): the rows, the residual and the output are bf16-STORED feature maps (the "bf16" mode's two upper levels): half-width
+// staging loads, one rounding per stored output element; LayerNorm, q-scale, rotary, bias and the residual sum stay fp32.
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   static_assert(!ONE || !F32, "single pass: bf16 operands");
+  static_assert(!A16 || (ONE && !KSPLIT4), "bf16-stored maps: the single-pass instances without the k split");
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int KP = KS * 16;         // padded K
   constexpr int PITCH = 2 * KP + 8;   // bf16 per LDS row: hi[KP] | lo[KP] | pad  ((4 KP + 16) / 16 is odd: conflict-free ds_read_b128)
@@ -92,13 +95,24 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
         const int c = (l16 + 16 * i) * 4;
         const bool okc = c < K;
         const int cc = okc ? c : 0;
-        const float* q1 = p.a1 + mc * p.lda1 + min(cc, p.C1 - 4);
-        const float* src = q1;
-        if (two) {  // (uniform branch; the select inside is per lane)
-          const float* q2 = p.a2 + mc * p.lda2 + max(cc - p.C1, 0);
-          src = cc < p.C1 ? q1 : q2;
+        f32x4 t;
+        if constexpr (A16) {
+          const bf16s* q1 = reinterpret_cast<const bf16s*>(p.a1) + mc * p.lda1 + min(cc, p.C1 - 4);
+          const bf16s* src = q1;
+          if (two) {
+            const bf16s* q2 = reinterpret_cast<const bf16s*>(p.a2) + mc * p.lda2 + max(cc - p.C1, 0);
+            src = cc < p.C1 ? q1 : q2;
+          }
+          t = ld4(src);
+        } else {
+          const float* q1 = p.a1 + mc * p.lda1 + min(cc, p.C1 - 4);
+          const float* src = q1;
+          if (two) {  // (uniform branch; the select inside is per lane)
+            const float* q2 = p.a2 + mc * p.lda2 + max(cc - p.C1, 0);
+            src = cc < p.C1 ? q1 : q2;
+          }
+          t = *reinterpret_cast<const f32x4*>(src);
         }
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
         const bool ok = okc & (m < a.M);
         v[ps][i] = f32x4{ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f};
       }
@@ -283,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
           }
           if (resrow) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const f32x4*>(resrow + c0 + 8 * g);
+            for (int g = 0; g < 4; ++g)
+              rv[g] = A16 ? ld4(reinterpret_cast<const bf16s*>(p.res) + (long long)m * p.ldres + c0 + 8 * g) : *reinterpret_cast<const f32x4*>(resrow + c0 + 8 * g);
             if (a.res_coef) {  // the ResnetBlock's main branch arrives pre-norm: GroupNorm * SiLU on the way in (vddp.py:311)
               const float* cf = a.res_coef + ((long long)(m / a.res_rps) * p.Cout + c0) * 2;
 #pragma unroll
@@ -309,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
 #if VMM_PJ_DBG == 1   // measurement aid (tools/build_ab.py proj_bf16x3 -DVMM_PJ_DBG=1): no output stores unless a value is NaN
             if (v.x != v.x) *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
 #else
-            *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
+            if constexpr (A16) st4(reinterpret_cast<bf16s*>(p.out) + (long long)m * p.ldo + c0 + 8 * g, v);
+            else *reinterpret_cast<f32x4*>(outrow + c0 + 8 * g) = v;
 #endif
           }
         }
@@ -444,6 +460,20 @@ int launch_pj(const PJArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <int WM, int WN, int KS>
+int launch_pj_a16(const PJArgs& a, hipStream_t s) {
+  constexpr int BM = WM * 64;
+  const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, false, false, true, true>), dim3((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.n_chunks, a.chunks_per_y)), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 // 1x1 / Linear projection.  d->w = vmm_pack_weights fmt 2 of the (Cout, K) weight.  ln_gamma != NULL: the rows pass through the
@@ -481,6 +511,14 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   int ny = (int)max(1LL, min((long long)a.n_chunks, 1024 / max(mt, 1LL)));
   a.chunks_per_y = (int)cdiv(a.n_chunks, ny);
   hipStream_t s = (hipStream_t)stream;
+  if (d.act_bf16) {  // bf16-stored rows, residual and output (all three; the single-pass mode only)
+    if (!ONE || d.act_bf16 != 3) return -1;
+    if (KP == 32) return launch_pj_a16<4, 1, 2>(a, s);
+    if (KP == 64) return launch_pj_a16<4, 1, 4>(a, s);
+    if (KP == 128) return launch_pj_a16<2, 2, 8>(a, s);
+    if (KP == 256 && d.Cout > 64) return launch_pj_a16<1, 4, 16>(a, s);
+    return 1;
+  }
   if (KP == 32) return launch_pj<4, 1, 2, F32, false, ONE>(a, s);
   if (KP == 64) return launch_pj<4, 1, 4, F32, false, ONE>(a, s);
   if (KP <= 128) {

@@ -29,6 +29,7 @@ struct StemArgs {
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) { hi = split_bf16_pair(x0, x1, lo); }
 
+template <typename ST>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f32x4* patch = reinterpret_cast<f32x4*>(smem);                 // [23][SP] pixels
@@ -115,14 +116,14 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int h = ty0 + 4 * wave + 2 * i + (lrow >> 4), w = tx0 + (lrow & 15);
       if (h < H && w < W) {
-        float* o = a.out + ((long long)(img * H + h) * W + w) * a.ldo + 4 * lk;
+        ST* o = reinterpret_cast<ST*>(a.out) + ((long long)(img * H + h) * W + w) * a.ldo + 4 * lk;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 v = {acc[i][j][4 * g] + bv[j][g].x, acc[i][j][4 * g + 1] + bv[j][g].y, acc[i][j][4 * g + 2] + bv[j][g].z,
                              acc[i][j][4 * g + 3] + bv[j][g].w};
-            *reinterpret_cast<f32x4*>(o + j * 32 + 8 * g) = v;
+            st4(o + j * 32 + 8 * g, v);
           }
       }
     }
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemArgs a) {
 
 // x rows [nimg * H * W][4] (channels >= C are zero or carry zero weights), w = vmm_pack_weights fmt 7 of the (64, C, 1, k, k) tensor, out rows x 64.
 // Returns 1 (nothing launched) unless Cout == 64, 1 <= k <= 8, k odd.
-extern "C" int vmm_stem_conv_bf16x3(const float* x, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg, int32_t H,
-                                    int32_t W, int32_t Cout, int32_t k, vmm_stream_t stream) {
+template <typename ST>
+static int stem_run(const float* x, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg, int32_t H,
+                    int32_t W, int32_t Cout, int32_t k, vmm_stream_t stream) {
   if (Cout != 64 || k < 1 || k > 8 || !(k & 1) || (ldo & 3)) return 1;
   if (nimg <= 0 || H <= 0 || W <= 0) return 0;
   if ((long long)nimg * H * W * 64 >= (1LL << 31)) return 1;
@@ -146,11 +148,21 @@ extern "C" int vmm_stem_conv_bf16x3(const float* x, const float* w_frag, const f
   const size_t shm = 23 * SP * 16 + (size_t)2 * 2 * k * 2 * 64 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel<ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), shm, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(stem_conv_kernel<ST>, dim3(grid), dim3(256), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vmm_stem_conv_bf16x3(const float* x, const float* w_frag, const float* bias, float* out, int32_t ldo, int32_t nimg, int32_t H,
+                                    int32_t W, int32_t Cout, int32_t k, vmm_stream_t stream) {
+  return stem_run<float>(x, w_frag, bias, out, ldo, nimg, H, W, Cout, k, stream);
+}
+// the same with a bf16-STORED output map (the "bf16" mode; the 4-channel input rows stay fp32)
+extern "C" int vmm_stem_conv_bf16x3_a16(const float* x, const float* w_frag, const float* bias, void* out, int32_t ldo, int32_t nimg, int32_t H,
+                                        int32_t W, int32_t Cout, int32_t k, vmm_stream_t stream) {
+  return stem_run<bf16s>(x, w_frag, bias, static_cast<float*>(out), ldo, nimg, H, W, Cout, k, stream);
 }

@@ -16,13 +16,23 @@ namespace {
 constexpr int DH = 32, HEADS = 8, HID = HEADS * DH;
 
 struct TFMArgs {
-  const float *qkv, *ek, *ev, *bias;
-  float *out, *lse;
+  const void* qkv;  // rows of ST: float, or bf16s when the feature maps are bf16-stored (the "bf16" mode's upper levels)
+  const float *ek, *ev, *bias;
+  void* out;
+  float* lse;
   int ldqkv, ldo, B, T, HW, ntok, bias_on_cond, blocks_per_sample;
 };
 
 __device__ __forceinline__ f32x4 mm(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+__device__ __forceinline__ void load_row8(float (&dst)[8], const bf16s* p, bool ok) {
+  uint4 u = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) u = *reinterpret_cast<const uint4*>(p);
+  dst[0] = __uint_as_float(u.x << 16); dst[1] = __uint_as_float(u.x & 0xffff0000u);
+  dst[2] = __uint_as_float(u.y << 16); dst[3] = __uint_as_float(u.y & 0xffff0000u);
+  dst[4] = __uint_as_float(u.z << 16); dst[5] = __uint_as_float(u.z & 0xffff0000u);
+  dst[6] = __uint_as_float(u.w << 16); dst[7] = __uint_as_float(u.w & 0xffff0000u);
+}
 __device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool ok) {
   f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = u;
   if (ok) {
@@ -34,8 +44,10 @@ __device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool 
 }
 
 // NT = frame tiles of 16 (T <= 16 NT): queries and frame keys are walked tile by tile, the conditioning tokens are one more key tile
-template <int NT>
+template <int NT, typename ST = float>
 __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMArgs a) {
+  const ST* const qkv = static_cast<const ST*>(a.qkv);
+  ST* const outp = static_cast<ST*>(a.out);
   const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, c = lane & 15, g = lane >> 4;
   const int T = a.T, ntok = a.ntok;
   const int b = blockIdx.x / a.blocks_per_sample, blk = blockIdx.x % a.blocks_per_sample;
@@ -65,15 +77,15 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
   auto request = [&](int pn) {
     const bool okp = pn < a.HW;
     const long long r0 = (long long)b * T * a.HW + min(pn, a.HW - 1);
-    load_row8(nk, a.qkv + (r0 + (long long)c * a.HW) * a.ldqkv + HID + head * DH + 8 * g, okp && c < T);
-    load_row8(nqr, a.qkv + (r0 + (long long)c * a.HW) * a.ldqkv + head * DH + 8 * g, okp && c < T);
+    load_row8(nk, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + HID + head * DH + 8 * g, okp && c < T);
+    load_row8(nqr, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + head * DH + 8 * g, okp && c < T);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int tv = 4 * g + r;
       const bool ok = okp && tv < T;
-      const float* vrow = a.qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
-      nvc[0][r] = ok ? vrow[0] : 0.f;
-      nvc[1][r] = ok ? vrow[16] : 0.f;
+      const ST* vrow = qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
+      nvc[0][r] = ok ? ld1(vrow) : 0.f;
+      nvc[1][r] = ok ? ld1(vrow + 16) : 0.f;
     }
   };
   if constexpr (NT == 1) request(blk);
@@ -95,14 +107,14 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
 #pragma unroll
     for (int jk = 0; jk < (NT == 1 ? 0 : NT); ++jk) {
       const int tk = 16 * jk + c;
-      load_row8(kr[jk], a.qkv + (row0 + (long long)tk * a.HW) * a.ldqkv + HID + head * DH + 8 * g, tk < T);
+      load_row8(kr[jk], qkv + (row0 + (long long)tk * a.HW) * a.ldqkv + HID + head * DH + 8 * g, tk < T);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tv = 16 * jk + 4 * g + r;
         const bool ok = tv < T;
-        const float* vrow = a.qkv + (row0 + (long long)tv * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
-        vc[jk][0][r] = ok ? vrow[0] : 0.f;
-        vc[jk][1][r] = ok ? vrow[16] : 0.f;
+        const ST* vrow = qkv + (row0 + (long long)(ok ? tv : 0) * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
+        vc[jk][0][r] = ok ? ld1(vrow) : 0.f;
+        vc[jk][1][r] = ok ? ld1(vrow + 16) : 0.f;
       }
     }
 #pragma unroll
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
 #pragma unroll
         for (int j = 0; j < 8; ++j) qr[j] = qpre[j];
       } else {
-        load_row8(qr, a.qkv + rq * a.ldqkv + head * DH + 8 * g, qok);
+        load_row8(qr, qkv + rq * a.ldqkv + head * DH + 8 * g, qok);
       }
       f32x4 S[NT], St = zero4;
 #pragma unroll
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int to = 16 * iq + 4 * g + r;
-          if (to < T) a.out[(row0 + (long long)to * a.HW) * a.ldo + head * DH + c + 16 * h] = O[h][r];
+          if (to < T) st1(outp + (row0 + (long long)to * a.HW) * a.ldo + head * DH + c + 16 * h, O[h][r]);
         }
     }
   }
@@ -190,6 +202,24 @@ extern "C" int vmm_temporal_attention_staged(const float* qkv, int32_t ldqkv, co
   a.blocks_per_sample = (int)max(1LL, min((long long)HW, cdiv(1024, B)));
   if (T <= 16) hipLaunchKernelGGL(temporal_attn_fwd_mfma_kernel<1>, dim3((unsigned)(B * a.blocks_per_sample)), dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(temporal_attn_fwd_mfma_kernel<2>, dim3((unsigned)(B * a.blocks_per_sample)), dim3(512), 0, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same core over bf16-STORED qkv rows and output (the "bf16" mode's C = 128 level with more than 16 frames): fp32 arithmetic, half the bytes.
+// Envelope of the fast path above (returns 1 outside it; no thread-per-query fallback for this storage).
+extern "C" int vmm_temporal_attention_a16(const void* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok, const float* bias,
+                                          int32_t bias_on_cond, void* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh,
+                                          float* lse, vmm_stream_t stream) {
+  if (!ek) ntok = 0;
+  if (heads != HEADS || dh != DH || T > 32 || T < 1 || ntok > 16 || (ldqkv & 7) || (ldo & 3)) return 1;
+  if (bias && bias_on_cond && ntok > T) return 1;
+  if (bias_on_cond && ek && ntok != T) return -2;
+  if (B <= 0 || HW <= 0) return 0;
+  TFMArgs a{qkv, ek, ev, bias, out, lse, ldqkv, ldo, B, T, HW, ntok, bias_on_cond, 0};
+  a.blocks_per_sample = (int)max(1LL, min((long long)HW, cdiv(1024, B)));
+  if (T <= 16) hipLaunchKernelGGL((temporal_attn_fwd_mfma_kernel<1, bf16s>), dim3((unsigned)(B * a.blocks_per_sample)), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((temporal_attn_fwd_mfma_kernel<2, bf16s>), dim3((unsigned)(B * a.blocks_per_sample)), dim3(512), 0, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   return 0;
 }

@@ -39,7 +39,7 @@ constexpr int HID = HEADS * DHd;
 constexpr int TB_TRACE_N = 40;  // intervals recorded by VMM_TB_TRACE
 
 struct TBArgs {
-  const float* x; int ldx;
+  const float* x; int ldx;   // (the A16 instance of the second kernel reads / writes these as bf16s: bf16-stored maps of the "bf16" mode)
   const float* gamma;
   const uint4* wqkv;  // fmt 2 fragments of to_qkv (768, 64)
   const uint4* wout;  // fmt 3 fragments of to_out (64, 256)
@@ -698,8 +698,10 @@ __global__ __launch_bounds__(512) void temporal_block128_kernel(const TBArgs a) 
 //              2j + 2   A: F(j)     2j + 3  A: S(j) -> redA[j & 1]   B: F(j)
 //              2j + 4   B: S(j) -> redB                              2j + 5  head sum(j) + residual -> out    (group A's threads, next to S)
 // Frame slots: SLOTS = 16 (two pixels per 32-row tile, T <= 16) or 32 (one pixel, T <= 32: the 22-frame configuration).
-template <int SLOTS, int PARK, bool ONE>
+template <int SLOTS, int PARK, bool ONE, typename ST = float>
 __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a) {
+  const ST* const xin = reinterpret_cast<const ST*>(a.x);
+  ST* const outp = reinterpret_cast<ST*>(a.out);
   constexpr int NP = 32 / SLOTS;  // pixels per tile
   constexpr int NK = SLOTS / 2;   // frame keys per lane
   constexpr int YPITCH = 2 * TC + 8;
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
     const int jc = min(max(j, 0), nt - 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      v[i] = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * T + rfc[i]) * HW + (long long)(p_begin + jc) * NP + rpx[i]) * a.ldx + rcol);
+      v[i] = ld4(xin + (((long long)b * T + rfc[i]) * HW + (long long)(p_begin + jc) * NP + rpx[i]) * a.ldx + rcol);
   };
   // sum over the 16 lanes of a row, every lane gets it: four rotate-and-add steps inside the DPP row (no LDS permutes, no waits)
   auto row_sum16 = [](float v) {
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
               acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             acc.x += xv[i].x; acc.y += xv[i].y; acc.z += xv[i].z; acc.w += xv[i].w;
-            *reinterpret_cast<f32x4*>(a.out + x_row(j, i) * a.ldo + rcol) = acc;
+            st4(outp + x_row(j, i) * a.ldo + rcol, acc);
           }
         }
       }
@@ -1076,13 +1078,14 @@ extern "C" int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW,
   return T <= 16 ? 1 : 0;
 }
 
-template <bool ONE>
+template <bool ONE, typename ST = float>
 static int tb_launch(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag, const float* ek, const float* ev,
                      int32_t ntok, const float* bias, int32_t bias_on_cond, const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW,
                      int32_t C, int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
   if ((ldx & 3) || (ldo & 3)) return 1;
   const int kind = vmm_temporal_block_supported(T, ek ? ntok : 0, HW, C, heads);
   if (kind == 0) return 1;
+  if (!std::is_same<ST, float>::value && kind != 2) return 1;  // bf16-stored maps: the two-tiles-in-flight kernel (C = 64)
   if (bias_on_cond && ek && ntok != T) return -2;
   if (B <= 0) return 0;
   TBArgs a;
@@ -1123,20 +1126,20 @@ static int tb_launch(const float* x, int32_t ldx, const float* gamma, const floa
   static bool attr_set = false;  // (one flag per instantiation of this launcher)
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block_kernel<ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 1, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 1, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 3, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 3, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 1, ONE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 1, ONE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<16, 3, ONE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_block2_kernel<32, 3, ONE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const dim3 grid((unsigned)(B * a.nsplit));
   if (kind == 2) {
     const int park = tb2_lds_bytes(slots, T, a.ntok, 3) <= 160 * 1024 ? 3 : 1;
     const size_t shm = tb2_lds_bytes(slots, T, a.ntok, park);
-    if (slots == 16 && park == 3) hipLaunchKernelGGL((temporal_block2_kernel<16, 3, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else if (slots == 16) hipLaunchKernelGGL((temporal_block2_kernel<16, 1, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else if (park == 3) hipLaunchKernelGGL((temporal_block2_kernel<32, 3, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((temporal_block2_kernel<32, 1, ONE>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    if (slots == 16 && park == 3) hipLaunchKernelGGL((temporal_block2_kernel<16, 3, ONE, ST>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (slots == 16) hipLaunchKernelGGL((temporal_block2_kernel<16, 1, ONE, ST>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else if (park == 3) hipLaunchKernelGGL((temporal_block2_kernel<32, 3, ONE, ST>), grid, dim3(512), shm, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((temporal_block2_kernel<32, 1, ONE, ST>), grid, dim3(512), shm, (hipStream_t)stream, a);
   } else {
     const size_t shm = sizeof(float) * HEADS * 32 * TC + sizeof(uint4) * HEADS * 6 * 64 + sizeof(float) * HEADS * 2 * 16 * 8 +
                        sizeof(unsigned short) * 32 * (2 * TC + 8) + sizeof(float) * 2 * 16 * 8 * 2;
@@ -1177,4 +1180,12 @@ extern "C" int vmm_temporal_block_bf16(const float* x, int32_t ldx, const float*
                                        const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
                                        int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
   return tb_launch<true>(x, ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, out, ldo, B, T, HW, C, heads, q_scale, eps, stream);
+}
+// ... over bf16-STORED feature maps (x, out = bf16 bits; ld in elements): the "bf16" mode's C = 64 level (the two-tiles-in-flight kernel)
+extern "C" int vmm_temporal_block_bf16_a16(const void* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                           const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                           const float* rot_tab, void* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
+                                           int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+  return tb_launch<true, bf16s>(static_cast<const float*>(x), ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, static_cast<float*>(out), ldo,
+                                B, T, HW, C, heads, q_scale, eps, stream);
 }

@@ -86,6 +86,30 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
+// ---- activation storage of the "bf16" throughput mode (BASELINE.json configs[3]): feature maps of the two upper levels live in HBM as bf16
+// (round-to-nearest-even once, when a kernel stores them; every kernel computes in fp32 / on the matrix cores as before).  Kernels are templated
+// on the element type of their activation pointers: float, or bf16s = the 16 stored bits.
+typedef unsigned short bf16s;
+__device__ __forceinline__ unsigned pack_bf16_pair(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16s* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16s* p, const f32x4& v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16_pair(v.x, v.y), pack_bf16_pair(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16s* p, float v) { *p = (bf16s)(pack_bf16_pair(v, 0.f) & 0xffffu); }
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Zero-fill on a stream as a KERNEL.  The library never uses hipMemsetAsync: captured into a hipGraph its memset node was observed

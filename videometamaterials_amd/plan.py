@@ -38,6 +38,10 @@ LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 GN_DIRECT_MAX = 1 << 14
 N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
+# op classes whose kernels have an instance over bf16-STORED feature maps ("bf16" mode; _Builder.nat16): 3 x 3 convolutions, the stride-2 resampling
+# layers, the ResnetBlock output pass, the A-stationary projections (+ the res_conv tail), the temporal-attention core, the fused temporal / linear
+# attention blocks, the final block's tail, the stem
+A16_KERNELS = {"conv3x3", "s2", "affine", "proj", "narrow", "tattn", "tb", "la", "final", "stem"}
 PACK_FIELDS = ("TH", "TW", "C", "Cp", "N", "sn", "sc", "sh", "sw", "h0", "hs", "w0", "ws", "accumulate", "fmt")
 
 
@@ -52,8 +56,14 @@ class Act:
     C: int
     H: int
     W: int
-    n: int  # floats
+    n: int  # elements
     ptr: int = 0
+    bf: bool = False  # stored as bf16 (the "bf16" throughput mode keeps the two upper levels' feature maps in bf16, section 3 of DESIGN.md)
+    na: int = -1      # floats of arena it occupies (n, or n / 2 when bf)
+
+    def __post_init__(self):
+        if self.na < 0:
+            self.na = self.n // 2 if self.bf else self.n
 
     @property
     def ld(self):
@@ -298,6 +308,8 @@ class _Builder:
         # "bf16": the 3 x 3 convolutions and the fused attention blocks run ONE matrix pass on the operands' bf16 roundings (same packed weights, same
         # launch list); the bandwidth-bound kernels keep their three passes, which cost them no time.  fp32 activations in HBM either way.
         self.one = prec == "bf16"
+        self.a16 = bool(self.one and not training and getattr(model, "bf16_storage", True) and _enabled("a16"))
+        self.a16_ops = set(os.environ.get("VMM_A16_OPS", "all").split(","))
         # exact-fp32 mode: the 3x3 and projection kernels run their v_mfma_f32_32x32x2_f32 variants on fp32 fragment-order weights (fmt 4)
         self.f32frag = not self.x3 and getattr(model, "use_f32_frag_kernels", True)
         self.tape: List[Tuple[Callable[[], None], int, int]] = []  # (backward emitter, pgtop at block start, first unpack job)
@@ -319,18 +331,41 @@ class _Builder:
     def ptr(self, off: int) -> int:
         return self.base + off * 4
 
-    def act(self, C_: int, H: int, W: int) -> Act:
+    def act(self, C_: int, H: int, W: int, bf: bool = False) -> Act:
         n = self.B * self.T * H * W * C_
-        off = self.alloc(n)
-        return Act(off, C_, H, W, n, self.ptr(off))
+        off = self.alloc(n // 2 if bf else n)
+        return Act(off, C_, H, W, n, self.ptr(off), bool(bf))
 
     def free_act(self, a: Act) -> None:
-        self.free(a.off, a.n)
+        self.free(a.off, a.na)
+
+    # ---- bf16 STORAGE of the feature maps (precision "bf16", inference): the two upper levels' maps -- the bulk of the HBM traffic -- are kept as
+    # bf16, every kernel that touches them has an instance templated on the element type of its activation pointers.  An op whose kernel has no
+    # such instance (VMM_A16_OPS restricts the set: a development / bisection aid) gets fp32 copies of its inputs and makes an fp32 output.
+    def lvl16(self, H: int) -> bool:
+        return bool(self.a16 and 2 * H >= self.H)
+
+    def nat16(self, op: str, H: int) -> bool:
+        return self.lvl16(H) and op in A16_KERNELS and ("all" in self.a16_ops or op in self.a16_ops)
+
+    def cast(self, a: Act, bf: bool, temps: list) -> Act:
+        """`a` in the wanted storage type; a converted copy (appended to `temps`, freed by the caller with free_temps) when it is stored otherwise."""
+        if a is None or bool(a.bf) == bool(bf):
+            return a
+        c = self.act(a.C, a.H, a.W, bf)
+        self.step(self.lib.vmm_convert_act, (a.ptr, 1 if a.bf else 0, c.ptr, 1 if bf else 0, a.n), "storage conversion (fp32 <-> bf16)", nbytes=6.0 * a.n)
+        temps.append(c)
+        return c
+
+    def free_temps(self, temps: list) -> None:
+        for c in temps:
+            self.free_act(c)
+        temps.clear()
 
     def tmp_free(self, a) -> None:
         """Release a backward-phase temporary (allowed even in keep-all plans: it was allocated after every forward buffer)."""
         if isinstance(a, Act):
-            self.arena.free(a.off, a.n, force=True)
+            self.arena.free(a.off, a.na, force=True)
         else:
             self.arena.free(a[0], a[1], force=True)
 
@@ -496,11 +531,15 @@ class _Builder:
     def conv_desc(self, *, a1: Act, a2: Optional[Act] = None, w: int, bias: int = 0, Cout: int, KH: int = 1, KW: int = 1, stride: int = 1,
                   off: Tuple[int, int] = (0, 0), sgn: Tuple[int, int] = (1, 1), out_ptr: int, ldo: int, Hv: int, Wv: int, Hout: int = 0,
                   Wout: int = 0, oscale: int = 1, oo: Tuple[int, int] = (0, 0), res_ptr: int = 0, ldres: int = 0, rot_tab: int = 0,
-                  rot_ncols: int = 0, q_scale: float = 1.0, q_ncols: int = 0, a_coef: int = 0) -> "N.ConvDesc":
+                  rot_ncols: int = 0, q_scale: float = 1.0, q_ncols: int = 0, a_coef: int = 0, out_bf: bool = False) -> "N.ConvDesc":
         d = N.ConvDesc()
         d.a1, d.C1, d.lda1 = a1.ptr, a1.C, a1.ld
         if a2 is not None:
             d.a2, d.C2, d.lda2 = a2.ptr, a2.C, a2.ld
+            assert bool(getattr(a2, "bf", False)) == bool(getattr(a1, "bf", False)), "the two sources of a concatenation share a storage type"
+        # storage of the feature maps: bit 0 = a1 / a2 are bf16, bit 1 = out (and res, which is read at out's rows) are bf16
+        d.act_bf16 = (1 if getattr(a1, "bf", False) else 0) | (2 if out_bf else 0)
+        self._desc_a16 = bool(d.act_bf16)
         d.w, d.bias = w, bias or None
         d.res, d.ldres = res_ptr or None, ldres
         d.out, d.ldo = out_ptr, ldo
@@ -516,6 +555,8 @@ class _Builder:
         if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
             self.tickets_ptr = self.wslot(N_TICKETS)
         d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
+        if self._desc_a16:  # bf16-stored maps: the unsplit instances (no ordered atomic accumulation onto a bf16 output)
+            d.split_tickets, d.n_tickets = None, 0
         d.gn_part, d.gn_groups = None, self.G
         if KH > 1 or KW > 1:  # padding_mode 'circular' / 'circular_1d' (vddp.py:163-243): every spatial kernel wraps instead of zero-padding
             d.wrap_h, d.wrap_w = self.wrap_h, self.wrap_w
@@ -687,6 +728,15 @@ class _Builder:
                          (film_ptr + 4 * B * ldfilm) if film_ptr else None, ldfilm, B, C_, G, self.ptr(coef_off + B * C_ * 2), None)
                 self.step(self.lib.vmm_groupnorm_coef, (None, *args2, self.ptr(part_off), n_part, None, 0), prefix + ".norm coef (second half)")
             self.free(part_off, B * G * n_part * 2)
+        elif h.bf:  # (outside the fusing envelope: the statistics pass reads an fp32 copy)
+            tmp: list = []
+            hf = self.cast(h, False, tmp)
+            nslots = int(self.lib.vmm_groupnorm_stats_slots(B, rows_ps, C_))
+            part_off = self.alloc(B * G * nslots * 2)
+            self.step(self.lib.vmm_groupnorm_stats_partials, (hf.ptr, hf.ld, B, rows_ps, C_, G, self.ptr(part_off)), prefix + ".norm stats", nbytes=4.0 * h.n)
+            self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, self.ptr(part_off), nslots, None, 0), prefix + ".norm coef")
+            self.free(part_off, B * G * nslots * 2)
+            self.free_temps(tmp)
         elif rows_ps * (C_ // G) <= GN_DIRECT_MAX and (C_ // G) % 4 == 0:
             # small layer: one workgroup per (sample, group) reduces its slice itself (fixed order, no statistics launch, no atomics)
             self.step(self.lib.vmm_groupnorm_coef, (None, *coef_args, None, 0, h.ptr, h.ld), prefix + ".norm stats+coef", nbytes=4.0 * h.n)
@@ -742,62 +792,95 @@ class _Builder:
             mirror_in = bool(self.lib.vmm_conv3x3_accepts(C.byref(probe)))
         if mirror_in:
             self.B = half
-        h1 = self.act(Cout, H, W)
-        d1 = self.conv(a1=x1, a2=x2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
-                       Wv=W, what=name + ".block1.proj", halo=halo1)
+        # storage types ("bf16" mode, section 3 of DESIGN.md): each op runs on bf16-stored maps where its kernel has such an instance, else on fp32 copies
+        tmps: list = []
+        n1 = self.nat16("conv3x3", H) and halo1
+        n2 = self.nat16("conv3x3", H) and halo2
+        xa1, xa2 = self.cast(x1, n1, tmps), self.cast(x2, n1, tmps)
+        h1 = self.act(Cout, H, W, bf=n1)
+        d1 = self.conv(a1=xa1, a2=xa2, w=w1, bias=self.wraw(name + ".block1.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h1.ptr, ldo=Cout, Hv=H,
+                       Wv=W, what=name + ".block1.proj", halo=halo1, out_bf=n1)
         c1_off, c1_n, c1_ptr, st1 = self.gn_coef(h1, name + ".block1", film_ptr, 2 * Cout, conv_desc=d1 if halo1 else None, mirror=mirror_in)
         if mirror_in:
             self.B = 2 * half
         w2, gw2 = self.pack_conv(name + ".block2.proj.weight", frag=halo2)
-        h2 = self.act(Cout, H, W)
-        d2 = self.conv(a1=h1, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
-                       a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2)
+        h1b = self.cast(h1, n2, tmps)
+        h2 = self.act(Cout, H, W, bf=n2)
+        d2 = self.conv(a1=h1b, w=w2, bias=self.wraw(name + ".block2.proj.bias"), Cout=Cout, KH=3, KW=3, off=(-1, -1), out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
+                       a_coef=c1_ptr, what=name + ".block2.proj", halo=halo2, out_bf=n2)
         if mirror_in:
             d2.a_img_mod = half * self.T
         # (h1 and its coefficients are conv2's INPUT: they are released only after the GroupNorm partial sums of conv2's output have
         # their buffer -- conv2 writes those while it is still reading h1, so the two must never share memory)
         c2_off, c2_n, c2_ptr, st2 = self.gn_coef(h2, name + ".block2", 0, 0, conv_desc=d2 if halo2 else None)
+        if h1b is not h1:
+            tmps.remove(h1b)
+            self.free_act(h1b)
         self.free_act(h1)
         self.free(c1_off, c1_n)
         has_res = (name + ".res_conv.weight") in self.shapes
         out = self.act(Cout, H, W) if self.training else h2  # training keeps the pre-norm h2 for the backward pass
         dr, gwr = None, 0
-        if (has_res and tail is None and not self.training and self.x3 and _enabled("res_tail")
-                and self.proj_ok(x1.C + (x2.C if x2 is not None else 0), Cout)):
+        kin = x1.C + (x2.C if x2 is not None else 0)
+        if (has_res and tail is None and not self.training and self.x3 and _enabled("res_tail") and self.proj_ok(kin, Cout)):
             # out = silu(GN(h2)) + res_conv(x) in ONE launch: the projection kernel takes h2 as its residual and normalises it on the way in
             # (in place: out = h2); no res_conv output buffer, no separate output pass
+            narrow = self.narrow_ok(kin, Cout) and _enabled("narrow_tail")
+            nt = self.nat16("narrow" if narrow else "proj", H)
+            xt1, xt2, h2t = self.cast(x1, nt, tmps), self.cast(x2, nt, tmps), self.cast(h2, nt, tmps)
             wr, _ = self.pack_linear(name + ".res_conv.weight", frag=2)
-            dr = self.conv_desc(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2.ptr, ldo=Cout, Hv=H, Wv=W,
-                                res_ptr=h2.ptr, ldres=Cout)
-            kin = x1.C + (x2.C if x2 is not None else 0)
-            tail_fn = (self.lib.vmm_proj_narrow_bf16x3_res_silu if (self.narrow_ok(kin, Cout) and _enabled("narrow_tail"))
+            dr = self.conv_desc(a1=xt1, a2=xt2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2t.ptr, ldo=Cout, Hv=H, Wv=W,
+                                res_ptr=h2t.ptr, ldres=Cout, out_bf=nt)
+            tail_fn = (self.lib.vmm_proj_narrow_bf16x3_res_silu if narrow
                        else self.lib.vmm_proj_bf16_res_silu if self.one else self.lib.vmm_proj_bf16x3_res_silu)
             self.step(tail_fn, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
                       flops=2.0 * rows * kin * Cout, nbytes=4.0 * rows * (kin + 2 * Cout))
+            if h2t is not h2:  # (the converted copy IS the block's output)
+                tmps.remove(h2t)
+                self.free_act(h2)
+                h2 = h2t
+            self.free_temps(tmps)
             self.free(c2_off, c2_n)
             self.plan.named[name] = h2
             return h2
         if has_res:
-            pjr = self.proj_ok(x1.C + (x2.C if x2 is not None else 0), Cout)
+            pjr = self.proj_ok(kin, Cout)
+            npj = self.nat16("proj", H) and pjr and not self.narrow_ok(kin, Cout)
+            xr1, xr2 = self.cast(x1, npj, tmps), self.cast(x2, npj, tmps)
             wr, gwr = self.pack_linear(name + ".res_conv.weight", frag=2 if pjr else False)
-            r = self.act(Cout, H, W)
-            dr = self.conv(a1=x1, a2=x2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv",
-                           proj=pjr)
-            res_ptr, ldres = r.ptr, Cout
+            r = self.act(Cout, H, W, bf=npj)
+            dr = self.conv(a1=xr1, a2=xr2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=r.ptr, ldo=Cout, Hv=H, Wv=W, what=name + ".res_conv",
+                           proj=pjr, out_bf=npj)
+            res_act = r
         else:
             assert x2 is None and x1.C == Cout
-            r, res_ptr, ldres = None, x1.ptr, x1.ld
+            r, res_act = None, x1
         if tail is not None:
             assert not self.training
-            tail(h2, c2_ptr, res_ptr, ldres)
+            nf = self.nat16("final", H)
+            h2f, rf = self.cast(h2, nf, tmps), self.cast(res_act, nf, tmps)
+            tail(h2f, c2_ptr, rf.ptr, rf.ld, nf)
             if r is not None:
                 self.free_act(r)
+            self.free_temps(tmps)
             self.free(c2_off, c2_n)
             self.free_act(h2)
             return None
-        self.step(self.lib.vmm_affine_silu, (h2.ptr, Cout, c2_ptr, res_ptr, ldres, out.ptr, Cout, rows, self.T * H * W, Cout), name + " out", nbytes=12.0 * h2.n)
+        na = self.nat16("affine", H)
+        h2a, ra = self.cast(h2, na, tmps), self.cast(res_act, na, tmps)
+        if self.training:
+            outa = out
+        elif h2a is h2:
+            outa = h2
+        else:  # the converted copy of h2 becomes the block's output (written in place)
+            tmps.remove(h2a)
+            self.free_act(h2)
+            out = outa = h2 = h2a
+        self.step(self.lib.vmm_affine_silu_a16 if na else self.lib.vmm_affine_silu,
+                  (h2a.ptr, Cout, c2_ptr, ra.ptr, ra.ld, outa.ptr, Cout, rows, self.T * H * W, Cout), name + " out", nbytes=(6.0 if na else 12.0) * h2.n)
         if r is not None:
             self.free_act(r)
+        self.free_temps(tmps)
         self.free(c2_off, c2_n)
         self.plan.named[name] = out
 
@@ -891,12 +974,16 @@ class _Builder:
             ws_n = int(self.lib.vmm_linattn_block_workspace(B, T, HW))
             ws = self.alloc(ws_n)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
-            out = self.act(x.C, x.H, x.W)
+            tmps: list = []
+            nla = self.nat16("la", x.H)
+            xc = self.cast(x, nla, tmps)
+            out = self.act(x.C, x.H, x.W, bf=nla)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * hid * 32
-            self.step(self.lib.vmm_linattn_block_bf16 if self.one else self.lib.vmm_linattn_block_bf16x3,
-                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(p + ".to_out.bias"), ek or None, ev or None,
+            self.step(self.lib.vmm_linattn_block_bf16_a16 if nla else self.lib.vmm_linattn_block_bf16 if self.one else self.lib.vmm_linattn_block_bf16x3,
+                      (xc.ptr, xc.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(p + ".to_out.bias"), ek or None, ev or None,
                        ntok_s, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
-                      name + " fused block", flops=flops, nbytes=12.0 * x.n)
+                      name + " fused block", flops=flops, nbytes=(6.0 if nla else 12.0) * x.n)
+            self.free_temps(tmps)
             self.free(ws, ws_n)  # (a no-op in training plans: the backward reads the key-softmax partials and context fragments it holds)
             self.plan.named[name] = out
             if self.training:
@@ -933,6 +1020,8 @@ class _Builder:
                         self.token_kv_bwd(site)
                 self.on_backward(bwd_fused, pg_start, uj_start)
             return out
+        x_orig, tmps_x = x, []
+        x = self.cast(x, False, tmps_x)  # (the unfused chain runs on fp32 maps; a bf16-stored input -- only when the fused block does not apply -- is converted)
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
         fuse_ln = pj and (not self.training or ln_tr)  # ... with the PreNorm LayerNorm run while the rows are staged (training: statistics kept for the wgrad)
@@ -972,6 +1061,7 @@ class _Builder:
         do = self.conv(a1=o, w=wo, bias=self.wraw(name + ".fn.fn.to_out.bias"), Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld,
                        what=name + " to_out", proj=pjo)
         self.free_act(o)
+        self.free_temps(tmps_x)
         self.plan.named[name] = out
 
         def bwd():
@@ -1022,13 +1112,17 @@ class _Builder:
             wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2)
             wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
-            out = self.act(x.C, x.H, x.W)
+            tmps: list = []
+            ntb = self.nat16("tb", x.H) and x.C == 64  # (the C = 128 kernel has no bf16-storage instance: fp32 copies there)
+            xc = self.cast(x, ntb, tmps)
+            out = self.act(x.C, x.H, x.W, bf=ntb)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok_s)
             pfc_ = 1 if self.m.per_frame_cond else 0
-            self.step(self.lib.vmm_temporal_block_bf16 if self.one else self.lib.vmm_temporal_block_bf16x3,
-                      (x.ptr, x.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, ntok_s, self.bias_ptr,
+            self.step(self.lib.vmm_temporal_block_bf16_a16 if ntb else self.lib.vmm_temporal_block_bf16 if self.one else self.lib.vmm_temporal_block_bf16x3,
+                      (xc.ptr, xc.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, ntok_s, self.bias_ptr,
                        pfc_, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
-                      name + " fused block", flops=flops, nbytes=8.0 * x.n)
+                      name + " fused block", flops=flops, nbytes=(4.0 if ntb else 8.0) * x.n)
+            self.free_temps(tmps)
             self.plan.named[name] = out
             if self.training:
                 wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True)
@@ -1066,8 +1160,15 @@ class _Builder:
         pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
         ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
         fuse_ln = pj and (not self.training or ln_tr)  # ... with the PreNorm LayerNorm run while the rows are staged (training: statistics kept for the wgrad)
+        ntok = self.ntok if site else 0
+        # bf16-stored maps through the unfused chain (the C = 128 level of the 22-frame configuration): to_qkv and to_out on the A-stationary projection
+        # kernel, the core on vmm_temporal_attention, all three with bf16 instances; anything else gets an fp32 copy of x and makes an fp32 output
+        n16 = bool(self.nat16("proj", x.H) and self.nat16("tattn", x.H) and temporal and not focus and pj and fuse_ln and self.proj_ok(hid, x.C)
+                   and not self.narrow_ok(hid, x.C) and not (heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16))
+        tmps_x: list = []
+        x = self.cast(x, n16, tmps_x)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
-        qkv = self.act(3 * hid, x.H, x.W)
+        qkv = self.act(3 * hid, x.H, x.W, bf=n16)
         q_scale = 32 ** -0.5
         if not pj and self.split_k_ok(x.C, 3 * hid):
             self.proj_split_k(y, p + ".to_qkv.weight", 3 * hid, qkv.ptr, name + " to_qkv", rot_tab=self.rot_ptr if temporal else 0,
@@ -1077,11 +1178,11 @@ class _Builder:
             wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2 if pj else False)
             dq = self.conv(a1=y, w=wq, Cout=3 * hid, out_ptr=qkv.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W, rot_tab=self.rot_ptr if temporal else 0,
                            rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid, what=name + " to_qkv", proj=pj,
-                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0)
+                           ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0,
+                           out_bf=n16)
         if not fuse_ln:
             self.free_act(y)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
-        ntok = self.ntok if site else 0
         pfc = 1 if self.m.per_frame_cond else 0
         if (temporal and not focus and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
                 and getattr(self.m, "use_fused_temporal", True)):
@@ -1092,13 +1193,15 @@ class _Builder:
                       (qkv.ptr, 3 * hid, x.ptr, x.ld, wo, ek or None, ev or None, ntok, self.bias_ptr, pfc, out.ptr, out.ld, B, T, HW, x.C, heads),
                       name + " core+to_out", flops=2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok), nbytes=4.0 * rows * (3 * hid + 2 * x.C))
             self.free_act(qkv)
+            self.free_temps(tmps_x)
             self.plan.named[name] = out
             return out
-        o = self.act(hid, x.H, x.W)
+        o = self.act(hid, x.H, x.W, bf=n16)
         lse_ptr = self.ptr(self.alloc(rows * heads)) if self.training else 0
         if temporal:
-            self.step(self.lib.vmm_temporal_attention, (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
-                                                        lse_ptr or None), name + " core", nbytes=4.0 * rows * 4 * hid)
+            self.step(self.lib.vmm_temporal_attention_a16 if n16 else self.lib.vmm_temporal_attention,
+                      (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
+                       lse_ptr or None), name + " core", nbytes=(2.0 if n16 else 4.0) * rows * 4 * hid)
             if focus:  # masked samples: softmax over their own frame alone = 1, the output is the value row
                 self.step(self.lib.vmm_focus_rows, (0, qkv.ptr + 8 * hid, 3 * hid, o.ptr, hid, self.focus_ptr, B, T * HW, hid), name + " focus (o = v)",
                           nbytes=8.0 * rows * hid)
@@ -1112,9 +1215,10 @@ class _Builder:
         self.free_act(qkv)
         pjo = self.proj_ok(hid, x.C)
         wo, gwo = self.pack_linear(p + ".to_out.weight", frag=2 if pjo else False)
-        out = self.act(x.C, x.H, x.W)
-        do = self.conv(a1=o, w=wo, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out", proj=pjo)
+        out = self.act(x.C, x.H, x.W, bf=n16)
+        do = self.conv(a1=o, w=wo, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr, ldres=x.ld, what=name + " to_out", proj=pjo, out_bf=n16)
         self.free_act(o)
+        self.free_temps(tmps_x)
         self.plan.named[name] = out
 
         def bwd():
@@ -1162,6 +1266,8 @@ class _Builder:
         rows = B * T * HW
         ek, ev = self.ekv_info[site][1], self.ekv_info[site][2]
         ntok = self.ntok
+        tmps_x: list = []
+        x = self.cast(x, False, tmps_x)  # (no bf16-storage instances of the cross-attention kernels)
         if temporal and ntok != T:
             raise ValueError(f"cross-attention at the temporal sites adds the ({T} x {T}) positional bias to the ({T} x {ntok}) scores: "
                              "cond_attention_tokens must equal the number of frames (vddp.py:513)")
@@ -1201,6 +1307,7 @@ class _Builder:
         do = self.conv(a1=o, w=wo, bias=self.wraw(p + ".to_out.bias") if linear else 0, Cout=x.C, out_ptr=out.ptr, ldo=x.C, Hv=x.H, Wv=x.W, res_ptr=x.ptr,
                        ldres=x.ld, what=name + " to_out", proj=pjo)
         self.free_act(o)
+        self.free_temps(tmps_x)
         self.plan.named[name] = out
 
         def bwd():
@@ -1511,11 +1618,14 @@ class _Builder:
         k = m.init_kernel_size
         if Cx > 4:
             raise NotImplementedError("more than 4 input channels")
-        x = self.act(m.init_dim, H, W)
+        stem_ok = bool(self.x3 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")))
+        nstem = stem_ok and self.nat16("stem", H)
+        x = self.act(m.init_dim, H, W, bf=nstem)
         if self.x3 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")):
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
-            self.step(lib.vmm_stem_conv_bf16x3, (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
+            self.step(lib.vmm_stem_conv_bf16x3_a16 if nstem else lib.vmm_stem_conv_bf16x3,
+                      (xin.ptr, wi, self.wraw("init_conv.bias"), x.ptr, m.init_dim, B * T, H, W, m.init_dim, k), "init_conv",
                       flops=2.0 * rows0 * k * k * Cx * 64, nbytes=4.0 * rows0 * (4 + 64))
             dinit = gwi = None
             if tr:  # the weight gradient works from the layer's descriptor and the plain packed layout (the operand copy itself is not used)
@@ -1543,8 +1653,8 @@ class _Builder:
         if self.mirrored:
             self.B = B = 2 * B
             rows0 = B * T * H * W
-            both = self.act(x.C, H, W)
-            self.step(lib.vmm_copy2, (x.ptr, both.ptr, both.ptr + 4 * x.n, x.n), "shared prefix -> both guidance branches", nbytes=12.0 * x.n)
+            both = self.act(x.C, H, W, bf=x.bf)
+            self.step(lib.vmm_copy2, (x.ptr, both.ptr, both.ptr + 4 * x.na, x.na), "shared prefix -> both guidance branches", nbytes=12.0 * x.na)
             self.free_act(x)
             x = both
         r = x  # kept until the final block (vddp.py:744; no clone needed, every op is out of place)
@@ -1577,23 +1687,34 @@ class _Builder:
                 pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
                 xs = x
                 nm = f"downs.{i}.4"
-                d = self.act(x.C, x.H // 2, x.W // 2)
                 co_, ci_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
-                if self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0):
+                s2_ok = bool(self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 0))
+                tmps: list = []
+                in16 = s2_ok and self.nat16("s2", xs.H)
+                out16 = in16 and self.nat16("s2", xs.H // 2)
+                xsc = self.cast(xs, in16, tmps)
+                d = self.act(x.C, x.H // 2, x.W // 2, bf=out16)
+                if s2_ok:
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
                     wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
-                    self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
-                              (xs.ptr, xs.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
-                                                           self.tickets() if _enabled("s2_split") else 0, N_TICKETS), nm,
-                              flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
+                    if in16:  # bf16-stored input (and output, unless this layer leaves the bf16 levels)
+                        self.step(lib.vmm_conv_s2_acc_bf16_a16, (xsc.ptr, xsc.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
+                                                                1 if out16 else 2), nm, flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_,
+                                  nbytes=2.0 * xs.n + (2.0 if out16 else 4.0) * d.n + 4.0 * 16 * ci_ * co_)
+                    else:
+                        self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                                  (xsc.ptr, xsc.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
+                                                               self.tickets() if _enabled("s2_split") else 0, N_TICKETS), nm,
+                                  flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
                     dd = gwd = None
                     if tr:  # the weight gradient wants the layer's descriptor and a k-major gradient slot (no forward launch from them)
                         _, gwd = self.pack_conv(nm + ".weight")
                         dd = self.conv_desc(a1=xs, w=wd, Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C, Hv=xs.H // 2, Wv=xs.W // 2)
                 else:
                     wd, gwd = self.pack_conv(nm + ".weight")
-                    dd = self.conv(a1=xs, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C,
+                    dd = self.conv(a1=xsc, w=wd, bias=self.wraw(nm + ".bias"), Cout=xs.C, KH=4, KW=4, stride=2, off=(-1, -1), out_ptr=d.ptr, ldo=xs.C,
                                    Hv=xs.H // 2, Wv=xs.W // 2, what=nm)
+                self.free_temps(tmps)
 
                 def down_bwd(nm=nm, xs=xs, d=d, dd=dd, gwd=gwd):
                     gd, _ = self.grad_of(d)
@@ -1633,22 +1754,31 @@ class _Builder:
                 xs = x
                 nm = f"ups.{i}.4"
                 ci_, co_ = self.shapes[nm + ".weight"][0], self.shapes[nm + ".weight"][1]
-                u = self.act(co_, xs.H * 2, xs.W * 2)
                 phases = []
                 one_launch = self.x3  # bf16x3: the four phases as ONE launch (they are small at the coarse levels)
                 s2 = self.x3 and not wrap and _enabled("s2") and lib.vmm_conv_s2_supported(B * T, xs.H, xs.W, ci_, co_, 1)
+                tmps_u: list = []
+                out16 = bool(s2) and self.nat16("s2", xs.H * 2)
+                in16 = out16 and self.nat16("s2", xs.H)
+                xsc = self.cast(xs, in16, tmps_u)
+                u = self.act(co_, xs.H * 2, xs.W * 2, bf=out16)
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
                     wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
-                    self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
-                              (xs.ptr, xs.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1, 0, 0), nm,
-                              flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
+                    if out16:  # bf16-stored output (the input too, unless this layer enters the bf16 levels)
+                        self.step(lib.vmm_conv_s2_acc_bf16_a16, (xsc.ptr, xsc.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1,
+                                                                1 if in16 else 3), nm, flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_,
+                                  nbytes=(2.0 if in16 else 4.0) * xs.n + 2.0 * u.n + 4.0 * 16 * ci_ * co_)
+                    else:
+                        self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                                  (xsc.ptr, xsc.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1, 0, 0), nm,
+                                  flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
                 for ph in range(2 if (not s2 or tr) else 0):  # (training: the phase descriptors feed the weight gradients even when the forward is one s2 launch)
                     for pw in range(2):
                         # ConvTranspose (Cin, Cout, 1, 4, 4), output phase (ph, pw): taps kh = (1-ph) + 2*kh', dh = ph - kh'
                         wp, gwp = self.pack(nm + ".weight", 4 * ci_ * co_, TH=2, TW=2, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, h0=1 - ph, hs=2,
                                             w0=1 - pw, ws=2)
-                        kw_ = dict(a1=xs, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
+                        kw_ = dict(a1=xsc, w=wp, bias=self.wraw(nm + ".bias"), Cout=co_, KH=2, KW=2, off=(ph, pw), sgn=(-1, -1), out_ptr=u.ptr, ldo=co_,
                                    Hv=xs.H, Wv=xs.W, Hout=xs.H * 2, Wout=xs.W * 2, oscale=2, oo=(ph, pw))
                         du = self.conv_desc(**kw_) if (one_launch or s2) else self.conv(what=nm + f" phase {ph}{pw}", **kw_)
                         phases.append((du, gwp))
@@ -1658,6 +1788,7 @@ class _Builder:
                     rows_in = B * T * xs.H * xs.W
                     self.step(lib.vmm_conv_igemm_bf16x3_batched, (arr, 4), nm + " (4 phases)", flops=4 * 2.0 * rows_in * 4 * ci_ * co_,
                               nbytes=4.0 * (rows_in * ci_ + 16 * ci_ * co_ + 4 * rows_in * co_))
+                self.free_temps(tmps_u)
 
                 def up_bwd(nm=nm, xs=xs, u=u, phases=phases, ci_=ci_, co_=co_):
                     gu, _ = self.grad_of(u)
@@ -1681,9 +1812,10 @@ class _Builder:
         fc0 = self.shapes["final_conv.0.block1.proj.weight"][0]
         if not tr and fc0 == 64 and m.out_dim <= 4 and _enabled("final_tail"):
             # the last block's output pass and the final 1x1 convolution in one kernel: the block's output is never stored
-            def fused_tail(h2, c2_ptr, res_ptr, ldres):
-                self.step(lib.vmm_affine_silu_pointwise_to_ncthw, (h2.ptr, h2.ld, c2_ptr, res_ptr, ldres, 64, self.wraw("final_conv.1.weight"),
-                                                                   self.wraw("final_conv.1.bias"), B, m.out_dim, T, H * W, self.ptr(out_off)),
+            def fused_tail(h2, c2_ptr, res_ptr, ldres, bf16_maps=False):
+                self.step(lib.vmm_affine_silu_pointwise_to_ncthw_a16 if bf16_maps else lib.vmm_affine_silu_pointwise_to_ncthw,
+                          (h2.ptr, h2.ld, c2_ptr, res_ptr, ldres, 64, self.wraw("final_conv.1.weight"),
+                           self.wraw("final_conv.1.bias"), B, m.out_dim, T, H * W, self.ptr(out_off)),
                           "final_conv.0 out + final_conv.1", nbytes=4.0 * (2 * h2.n + B * m.out_dim * T * H * W))
             self.resnet_block("final_conv.0", x, r, None, tail=fused_tail)
             self.free_act(x)
