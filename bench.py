@@ -293,10 +293,14 @@ def bench_config4(vm, dev, timed_region, world, B: int = 8, frames: int = 22, si
     out = {"workload": f"configs[3]: {frames}x{size}x{size}, batch {B} per GPU, dim 64 (random init), CNN signal embedding + 16 tokens", "batch_per_gpu": B}
     modes = [("bf16x3", "fp32 activations in HBM, split-bf16 MFMA (parity mode, 2e-4 vs the oracle at this size)")]
     if "bf16" in getattr(vm.Unet3D, "PRECISIONS", ()):
-        modes.append(("bf16", "fp32 activations in HBM, ONE MFMA pass on bf16-rounded operands (throughput mode, 2e-2 vs the oracle at this size)"))
+        modes.append(("bf16", "bf16 activations in HBM at the two upper levels (192 x 192 and 96 x 96: one rounding per stored element), ONE MFMA pass on "
+                              "bf16-rounded operands, fp32 accumulation / norms / softmax (throughput mode, 2e-2 vs the oracle at this size)"))
+        modes.append(("bf16_fp32_storage", "the same single-pass arithmetic with fp32 activations in HBM (Unet3D.bf16_storage = False): what the storage type alone buys"))
     with torch.no_grad():
-        for prec, note in modes:
+        for key, note in modes:
+            prec = "bf16" if key.startswith("bf16") and key != "bf16x3" else key
             m.precision = prec
+            m.bf16_storage = key != "bf16_fp32_storage"
             m._plans.clear()
             n_f, n_s = 4, 3
             m(x, t, cond=cond, null_cond_prob=0.0)
@@ -305,9 +309,11 @@ def bench_config4(vm, dev, timed_region, world, B: int = 8, frames: int = 22, si
             stp = timed_region(lambda: [diff.p_sample(x, t, cond=cond, guidance_scale=W_GUIDE) for _ in range(n_s)]) / n_s
             plan = m.get_plan(B, frames, size, size, 51, dev)
             fl = sum(f for _, f, _ in plan.meta)
-            out[prec] = {"arithmetic": note, "denoiser_forward_ms": round(fwd * 1e3, 2), "forward_TFLOPs": round(fl / fwd / 1e12, 1),
+            out[key] = {"arithmetic": note, "denoiser_forward_ms": round(fwd * 1e3, 2), "forward_TFLOPs": round(fl / fwd / 1e12, 1),
                          "guided_step_ms": round(stp * 1e3, 2), "sampled_frames_per_sec": round(world * B * frames / (stp * TIMESTEPS), 3),
-                         "launches_per_forward": len(plan.meta), "plan_GB": round(plan.arena_floats * 4 / 1e9, 1)}
+                         "launches_per_forward": len(plan.meta), "plan_GB": round(plan.arena_floats * 4 / 1e9, 1),
+                         "storage_conversions": sum(1 for fn, _, _ in plan.steps if fn.__name__ == "vmm_convert_act")}
+    m.bf16_storage = True
     m._plans.clear()
     del m, diff
     torch.cuda.empty_cache()
@@ -564,8 +570,8 @@ def main():
             el16, st16, img16 = sampler_leg(n16, 2)
             model.precision = "bf16x3"
             bf16_mode = {"ms_per_step": round(el16 / n16 * 1e3, 3), "frames_per_sec": round(world * B_PER_GPU * T / (TIMESTEPS * el16 / n16), 4), "steps": n16,
-                         "arithmetic": "one MFMA pass on bf16-rounded operands in the 3x3 / stride-2 convolutions, projections and fused attention blocks; "
-                                       "fp32 activations and accumulation (2e-2 relative on the denoiser output)",
+                         "arithmetic": "one MFMA pass on bf16-rounded operands in the 3x3 / stride-2 convolutions, projections and fused attention blocks; bf16-stored feature maps at the two upper levels; "
+                                       "fp32 accumulation, norms, softmax (2e-2 relative on the denoiser output)",
                          "hipgraph": st16.graph is not None, "output_finite": bool(torch.isfinite(img16).all().item())}
 
     # ---- BASELINE.json configs[4]: the guidance sweep w in {0, 1, 3, 5} (vddp.py:715-728: w == 1 runs the conditional branch alone -- a B-row

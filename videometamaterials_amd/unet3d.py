@@ -120,6 +120,9 @@ class Unet3D(nn.Module):
         # and the fused attention blocks (~1e-2 relative on the denoiser output; tests/test_gpu_hires.py states and checks the tolerance).
         self.precision = "bf16x3"
         self.train_precision = "fp32"
+        # precision "bf16" only: the feature maps of the two upper levels live in HBM as bf16 (one rounding per stored element; half the bytes of the
+        # bandwidth-bound passes, half the plan memory).  False: the same single-pass arithmetic over fp32-stored maps.
+        self.bf16_storage = True
 
     # ------------------------------------------------------------------ parameters (names = reference module tree)
     def _conv(self, name, cout, cin, k, bias=True):
@@ -313,7 +316,8 @@ class Unet3D(nn.Module):
         # (the measurement switches that change a plan's structure are part of its identity: flipping VMM_DISABLE between calls must not
         # hand back a plan built under the other setting)
         key = (B, T, H, W, cond_len, str(device), training, self.train_precision if training else self.precision, bool(mirrored),
-               os.environ.get("VMM_DISABLE", ""), bool(getattr(self, "use_x3_wgrad", True)), bool(getattr(self, "use_x3_wgrad_generic", False)), bool(focus))
+               os.environ.get("VMM_DISABLE", ""), bool(getattr(self, "use_x3_wgrad", True)), bool(getattr(self, "use_x3_wgrad_generic", False)), bool(focus),
+               bool(getattr(self, "bf16_storage", True)), os.environ.get("VMM_A16_OPS", "all"))
         pl = self._plans.get(key)
         if pl is None:
             pl = _plan.build_plan(self, B, T, H, W, cond_len, device, training=training, mirrored=mirrored, focus=focus)
