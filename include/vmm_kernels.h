@@ -515,8 +515,10 @@ int vmm_copy2(const float* x, float* out_a, float* out_b, int64_t n, vmm_stream_
  * writes dfilm [B][ldfilm] (scale | shift) when given.  stats = (mean, rstd) from vmm_groupnorm_coef. */
 int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, int32_t ldh, const float* coef, const float* stats,
                       const float* gamma, const float* beta, const float* film, int32_t ldfilm, int32_t B, int32_t rows_per_sample,
-                      int32_t C, int32_t G, float* scratch /* [B*C*2 + B*G*2] */, float* dh, int32_t lddh, int32_t accumulate,
+                      int32_t C, int32_t G, float* scratch /* vmm_groupnorm_bwd_scratch() floats */, float* dh, int32_t lddh, int32_t accumulate,
                       float* dgamma, float* dbeta, float* dfilm, vmm_stream_t stream);
+/* floats of scratch vmm_groupnorm_bwd needs: one (P1, P2) partial row of C channels per workgroup of its reduce sweep + the group means */
+int64_t vmm_groupnorm_bwd_scratch(int32_t B, int32_t rows_per_sample, int32_t C, int32_t G);
 /* scratch: NULL (dgamma by atomics) or VMM_LN_BWD_MAX_BLOCKS * C floats (one partial row per workgroup + vmm_sum_partials) */
 #define VMM_LN_BWD_MAX_BLOCKS 2048
 int vmm_channel_layernorm_bwd(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, float* dx, int32_t lddx,

@@ -1234,6 +1234,60 @@ def test_groupnorm_film_silu(gpu, C_, G):
         assert relerr(coef2.cpu(), coef.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("C_,G,B,T,H,W,with_film", [(16, 8, 2, 3, 12, 12, True), (64, 8, 3, 5, 24, 20, True), (64, 8, 2, 3, 12, 12, False),
+                                                    (128, 8, 2, 2, 12, 12, True), (512, 8, 2, 3, 4, 4, True), (96, 8, 1, 2, 8, 8, False),
+                                                    (1024, 8, 2, 1, 4, 4, True)])
+def test_groupnorm_film_silu_backward(gpu, C_, G, B, T, H, W, with_film):
+    """vmm_groupnorm_bwd (vddp.py:273-285 under autograd): dh, dgamma, dbeta, dscale / dshift against torch autograd of
+    silu(group_norm(h) * (scale + 1) + shift); the per-workgroup partial rows are summed in a fixed order, so dh repeats bit for bit."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(B, C_, T, H, W, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = torch.randn(C_, generator=g).requires_grad_(True)
+    beta = torch.randn(C_, generator=g).requires_grad_(True)
+    film = torch.randn(B, 2 * C_, generator=g).requires_grad_(True)
+    y = F.group_norm(x, G, gamma, beta, eps=1e-5)
+    if with_film:
+        y = y * (film[:, :C_, None, None, None] + 1) + film[:, C_:, None, None, None]
+    z = F.silu(y)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    xr, dzr = rows_of(x.detach()).to(gpu), rows_of(dz).to(gpu)
+    rps = T * H * W
+    sums = torch.empty(B * G * 2, dtype=torch.float64, device=gpu)
+    coef = torch.empty(B, C_, 2, device=gpu)
+    stats = torch.empty(B * G * 2, device=gpu)
+    gg, bg, fg = gamma.detach().to(gpu), beta.detach().to(gpu), film.detach().to(gpu)
+    fptr, ldf = (fg.data_ptr(), 2 * C_) if with_film else (None, 0)
+    N.check(lib.vmm_groupnorm_stats(xr.data_ptr(), C_, B, rps, C_, G, sums.data_ptr(), _s()), "stats")
+    N.check(lib.vmm_groupnorm_coef(sums.data_ptr(), rps * (C_ // G), 1e-5, gg.data_ptr(), bg.data_ptr(), fptr, ldf, B, C_, G, coef.data_ptr(),
+                                   stats.data_ptr(), None, 0, None, 0, _s()), "coef")
+    nsc = int(lib.vmm_groupnorm_bwd_scratch(B, rps, C_, G))
+    assert nsc >= B * C_ * 2 + B * G * 2
+    scratch = torch.full((nsc,), float("nan"), device=gpu)
+    outs = []
+    for rep in range(2):
+        dh = torch.full_like(xr, float("nan"))
+        dgam, dbet = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
+        dfilm = torch.full((B, 2 * C_), float("nan"), device=gpu)
+        N.check(lib.vmm_groupnorm_bwd(dzr.data_ptr(), C_, xr.data_ptr(), C_, coef.data_ptr(), stats.data_ptr(), gg.data_ptr(), bg.data_ptr(), fptr, ldf,
+                                      B, rps, C_, G, scratch.data_ptr(), dh.data_ptr(), C_, 0, dgam.data_ptr(), dbet.data_ptr(),
+                                      dfilm.data_ptr() if with_film else None, _s()), "gn bwd")
+        torch.cuda.synchronize()
+        outs.append(dh)
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(dh.cpu(), rows_of(x.grad)) < 2e-5
+    assert relerr(dgam.cpu(), gamma.grad) < 2e-5
+    assert relerr(dbet.cpu(), beta.grad) < 2e-5
+    if with_film:
+        assert relerr(dfilm.cpu(), film.grad) < 2e-5
+    # accumulate = 1: dh += the same gradient
+    N.check(lib.vmm_groupnorm_bwd(dzr.data_ptr(), C_, xr.data_ptr(), C_, coef.data_ptr(), stats.data_ptr(), gg.data_ptr(), bg.data_ptr(), fptr, ldf,
+                                  B, rps, C_, G, scratch.data_ptr(), dh.data_ptr(), C_, 1, dgam.data_ptr(), dbet.data_ptr(), None, _s()), "gn bwd acc")
+    torch.cuda.synchronize()
+    assert relerr(dh.cpu(), 2 * rows_of(x.grad)) < 2e-5
+
+
 @pytest.mark.parametrize("C_", [16, 32, 64, 128, 512])
 def test_channel_layernorm(gpu, C_):
     N, lib = _lib()

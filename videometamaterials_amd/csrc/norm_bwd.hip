@@ -4,21 +4,34 @@
 //   dy = dz * silu'(y);  per (sample, channel):  P1 = sum_rows dy,  P2 = sum_rows dy * hhat,  hhat = (h - mean_g) * rstd_g
 //   dh = a*dy - rstd_g * (m1_g + hhat * m2_g),   m1_g = sum_{c in g} gamma'_c P1_c / n,  m2_g = sum_{c in g} gamma'_c P2_c / n
 //   dgamma_c += sum_b (1+scale_bc) P2_bc ; dbeta_c += sum_b (1+scale_bc) P1_bc ; dscale_bc = gamma_c P2_bc + beta_c P1_bc ; dshift_bc = P1_bc
-// Two HBM sweeps over (dz, h): reduce, then apply.
+// Two HBM sweeps over (dz, h): reduce (per-workgroup partial rows, summed in a fixed order by the coefficient launch), then apply.
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
 
 __device__ __forceinline__ float silu_grad(float y) {
-  const float s = 1.0f / (1.0f + expf(-y));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
   return s * (1.0f + y * (1.0f - s));
 }
 
-// grid (blocks_per_sample, B); P[b][c] = (P1, P2) accumulated with fp32 atomics (zeroed by the launcher)
+// Row unroll of the two sweeps: U rows of (dz, h) in flight per thread before the first exp.
+constexpr int GNB_U = 4;
+
+__host__ __device__ inline int gnb_blocks(int B, int rows_per_sample, int C) {
+  const int rslots = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
+  int blocks = (rows_per_sample + rslots * GNB_U * 2 - 1) / (rslots * GNB_U * 2);
+  const int cap = 2048 / (B > 0 ? B : 1) > 0 ? 2048 / (B > 0 ? B : 1) : 1;
+  blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+  const int rpb = (rows_per_sample + blocks - 1) / blocks;
+  return (rows_per_sample + rpb - 1) / rpb;
+}
+
+// grid (blocks_per_sample, B); part[b][block][c] = (P1, P2) of the block's rows: one plain store per workgroup and channel, summed in a
+// fixed order by gn_bwd_coef_kernel (no atomics, no zeroing launch)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ h, int ldh,
                                                             const float* __restrict__ coef, const float* __restrict__ stats, int rows_per_sample,
-                                                            int C, int G, int rows_per_block, float* __restrict__ P) {
+                                                            int C, int G, int rows_per_block, float* __restrict__ part) {
   const int b = blockIdx.y;
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
@@ -36,16 +49,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       mu[j] = stats[(b * G + g) * 2];
       rs[j] = stats[(b * G + g) * 2 + 1];
     }
-    const long long base = (long long)b * rows_per_sample;
-    for (int r = r0 + rl; r < r1; r += rslots) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h + (base + r) * ldh + c);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(dz + (base + r) * lddz + c);
-      const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float* hp = h + (long long)b * rows_per_sample * ldh + c;
+    const float* gp = dz + (long long)b * rows_per_sample * lddz + c;
+    for (int r = r0 + rl; r < r1; r += rslots * GNB_U) {
+      f32x4 hv[GNB_U], gv[GNB_U];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float dy = gg[j] * silu_grad(a[j] * hh[j] + bb[j]);
-        p1[j] += dy;
-        p2[j] += dy * (hh[j] - mu[j]) * rs[j];
+      for (int u = 0; u < GNB_U; ++u) {
+        const int ru = r + u * rslots;
+        const bool ok = ru < r1;
+        hv[u] = ok ? *reinterpret_cast<const f32x4*>(hp + (long long)ru * ldh) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        gv[u] = ok ? *reinterpret_cast<const f32x4*>(gp + (long long)ru * lddz) : (f32x4){0.f, 0.f, 0.f, 0.f};  // dz = 0: no contribution
+      }
+#pragma unroll
+      for (int u = 0; u < GNB_U; ++u) {
+        const float hh[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w}, gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dy = gg[j] * silu_grad(a[j] * hh[j] + bb[j]);
+          p1[j] += dy;
+          p2[j] += dy * (hh[j] - mu[j]) * rs[j];
+        }
       }
     }
   }
@@ -53,73 +76,115 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s1[tid * 4 + j] = p1[j]; s2[tid * 4 + j] = p2[j]; }
   __syncthreads();
+  float* pr = part + ((long long)b * gridDim.x + blockIdx.x) * C * 2;
   for (int ch = tid; ch < C; ch += 256) {
     const int c4 = ch >> 2, j = ch & 3;
     float t1 = 0.f, t2 = 0.f;
     for (int k = 0; k < rslots; ++k) { t1 += s1[(k * c4n + c4) * 4 + j]; t2 += s2[(k * c4n + c4) * 4 + j]; }
-    atomicAdd(&P[((long long)b * C + ch) * 2], t1);
-    atomicAdd(&P[((long long)b * C + ch) * 2 + 1], t2);
+    *reinterpret_cast<float2*>(pr + ch * 2) = make_float2(t1, t2);
   }
 }
 
-// one thread per (b, c): group means m1, m2 and the parameter / FiLM gradients
-__global__ void gn_bwd_coef_kernel(const float* __restrict__ P, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ film, int ldfilm, float inv_n, int B, int C, int G, float* __restrict__ m12,
-                                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  const int Cg = C / G, g = c / Cg;
-  const float p1 = P[i * 2], p2 = P[i * 2 + 1];
-  const float sc1 = film ? film[(long long)b * ldfilm + c] + 1.0f : 1.0f;
-  atomicAdd(&dgamma[c], sc1 * p2);
-  atomicAdd(&dbeta[c], sc1 * p1);
-  if (dfilm) {
-    dfilm[(long long)b * ldfilm + c] = gamma[c] * p2 + beta[c] * p1;
-    dfilm[(long long)b * ldfilm + C + c] = p1;
-  }
-  if (c == g * Cg) {
-    float m1 = 0.f, m2 = 0.f;
-    for (int cc = c; cc < c + Cg; ++cc) {
-      const float gp = gamma[cc] * (film ? film[(long long)b * ldfilm + cc] + 1.0f : 1.0f);
-      m1 += gp * P[((long long)b * C + cc) * 2];
-      m2 += gp * P[((long long)b * C + cc) * 2 + 1];
+// grid (channel chunks, B): sums the workgroup partials of CH channels (fixed order), then per (b, c): the parameter / FiLM gradients and,
+// per group, the means m1, m2 the apply sweep needs.  CH is a multiple of the group width.
+__global__ __launch_bounds__(256) void gn_bwd_coef_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, float inv_n,
+                                                          int C, int G, int CH, float* __restrict__ m12, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dfilm) {
+  __shared__ f32x4 red[256];
+  __shared__ float P[2048];
+  const int b = blockIdx.y, c0 = blockIdx.x * CH, tid = threadIdx.x;
+  const int nv = CH >> 1;  // f32x4 pieces of a partial row's CH (P1, P2) pairs
+  const int nvl = min(nv, 256), nsl = 256 / nvl, slice = tid / nvl;
+  const float* pb = part + ((long long)b * nblk * C + c0) * 2;
+  for (int v = tid % nvl; v < nv; v += nvl) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (slice < nsl)
+      for (int k = slice; k < nblk; k += nsl) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(pb + (long long)k * C * 2 + v * 4);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+    red[tid] = acc;
+    __syncthreads();
+    if (slice == 0) {
+      for (int k = 1; k < nsl; ++k) {
+        const f32x4 x = red[k * nvl + (tid % nvl)];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      P[v * 4] = acc.x; P[v * 4 + 1] = acc.y; P[v * 4 + 2] = acc.z; P[v * 4 + 3] = acc.w;
     }
-    m12[(b * G + g) * 2] = m1 * inv_n;
-    m12[(b * G + g) * 2 + 1] = m2 * inv_n;
+    __syncthreads();
+  }
+  const int Cg = C / G;
+  for (int ch = tid; ch < CH; ch += 256) {
+    const int c = c0 + ch, g = c / Cg;
+    const float p1 = P[ch * 2], p2 = P[ch * 2 + 1];
+    const float sc1 = film ? film[(long long)b * ldfilm + c] + 1.0f : 1.0f;
+    atomicAdd(&dgamma[c], sc1 * p2);
+    atomicAdd(&dbeta[c], sc1 * p1);
+    if (dfilm) {
+      dfilm[(long long)b * ldfilm + c] = gamma[c] * p2 + beta[c] * p1;
+      dfilm[(long long)b * ldfilm + C + c] = p1;
+    }
+    if (c == g * Cg) {
+      float m1 = 0.f, m2 = 0.f;
+      for (int cc = 0; cc < Cg; ++cc) {
+        const float gp = gamma[c + cc] * (film ? film[(long long)b * ldfilm + c + cc] + 1.0f : 1.0f);
+        m1 += gp * P[(ch + cc) * 2];
+        m2 += gp * P[(ch + cc) * 2 + 1];
+      }
+      m12[(b * G + g) * 2] = m1 * inv_n;
+      m12[(b * G + g) * 2 + 1] = m2 * inv_n;
+    }
   }
 }
 
-// dh (=|+=) a*dy - rstd*(m1 + hhat*m2)
+// dh (=|+=) a*dy - rstd*(m1 + hhat*m2) = a*dy - (k0 + k1*h);  grid (blocks_per_sample, B), the per-channel constants in registers
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ h, int ldh,
                                                            const float* __restrict__ coef, const float* __restrict__ stats,
-                                                           const float* __restrict__ m12, float* __restrict__ dh, int lddh, long long rows,
-                                                           int rows_per_sample, int C, int G, int accumulate) {
+                                                           const float* __restrict__ m12, float* __restrict__ dh, int lddh,
+                                                           int rows_per_sample, int C, int G, int rows_per_block, int accumulate) {
+  const int b = blockIdx.y;
   const int c4n = C >> 2;
-  const long long total = rows * c4n;
-  const int Cg = C / G;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / c4n;
-    const int c = (int)(i - r * c4n) * 4;
-    const int b = (int)(r / rows_per_sample);
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + r * ldh + c);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(dz + r * lddz + c);
-    const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
-    float o[4];
+  const int tid = threadIdx.x;
+  const int col4 = tid % c4n, rl = tid / c4n, rslots = 256 / c4n;
+  if (rl >= rslots) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows_per_sample);
+  const int c = col4 * 4;
+  float a[4], bb[4], k0[4], k1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = coef[((long long)b * C + c + j) * 2], bb = coef[((long long)b * C + c + j) * 2 + 1];
-      const int g = (c + j) / Cg;
-      const float mu = stats[(b * G + g) * 2], rs = stats[(b * G + g) * 2 + 1];
-      const float dy = gg[j] * silu_grad(a * hh[j] + bb);
-      o[j] = a * dy - rs * (m12[(b * G + g) * 2] + (hh[j] - mu) * rs * m12[(b * G + g) * 2 + 1]);
+  for (int j = 0; j < 4; ++j) {
+    a[j] = coef[((long long)b * C + c + j) * 2];
+    bb[j] = coef[((long long)b * C + c + j) * 2 + 1];
+    const int g = (c + j) / (C / G);
+    const float mu = stats[(b * G + g) * 2], rs = stats[(b * G + g) * 2 + 1];
+    const float m1 = m12[(b * G + g) * 2], m2 = m12[(b * G + g) * 2 + 1];
+    k1[j] = rs * rs * m2;
+    k0[j] = rs * m1 - mu * k1[j];
+  }
+  const float* hp = h + (long long)b * rows_per_sample * ldh + c;
+  const float* gp = dz + (long long)b * rows_per_sample * lddz + c;
+  float* op = dh + (long long)b * rows_per_sample * lddh + c;
+  for (int r = r0 + rl; r < r1; r += rslots * GNB_U) {
+    f32x4 hv[GNB_U], gv[GNB_U], ov[GNB_U];
+#pragma unroll
+    for (int u = 0; u < GNB_U; ++u) {
+      const int ru = min(r + u * rslots, r1 - 1);
+      hv[u] = *reinterpret_cast<const f32x4*>(hp + (long long)ru * ldh);
+      gv[u] = *reinterpret_cast<const f32x4*>(gp + (long long)ru * lddz);
+      if (accumulate) ov[u] = *reinterpret_cast<const f32x4*>(op + (long long)ru * lddh);
     }
-    float* op = dh + r * lddh + c;
-    if (accumulate) {
-      const f32x4 old = *reinterpret_cast<const f32x4*>(op);
-      o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+#pragma unroll
+    for (int u = 0; u < GNB_U; ++u) {
+      const int ru = r + u * rslots;
+      if (ru >= r1) break;
+      const float hh[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w}, gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = a[j] * (gg[j] * silu_grad(a[j] * hh[j] + bb[j])) - (k0[j] + k1[j] * hh[j]);
+      if (accumulate) { o[0] += ov[u].x; o[1] += ov[u].y; o[2] += ov[u].z; o[3] += ov[u].w; }
+      *reinterpret_cast<f32x4*>(op + (long long)ru * lddh) = (f32x4){o[0], o[1], o[2], o[3]};
     }
-    *reinterpret_cast<f32x4*>(op) = (f32x4){o[0], o[1], o[2], o[3]};
   }
 }
 
@@ -221,29 +286,31 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const float* __restric
 
 }  // namespace
 
+extern "C" int64_t vmm_groupnorm_bwd_scratch(int32_t B, int32_t rows_per_sample, int32_t C, int32_t G) {
+  if (B <= 0 || rows_per_sample <= 0 || C <= 0 || (C & 3) || C > 1024 || G <= 0) return 0;
+  return (int64_t)B * gnb_blocks(B, rows_per_sample, C) * C * 2 + (int64_t)B * G * 2;
+}
+
 extern "C" int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, int32_t ldh, const float* coef, const float* stats,
                                  const float* gamma, const float* beta, const float* film, int32_t ldfilm, int32_t B,
-                                 int32_t rows_per_sample, int32_t C, int32_t G, float* scratch /* [B*C*2 + B*G*2] */, float* dh,
+                                 int32_t rows_per_sample, int32_t C, int32_t G, float* scratch /* vmm_groupnorm_bwd_scratch floats */, float* dh,
                                  int32_t lddh, int32_t accumulate, float* dgamma, float* dbeta, float* dfilm, vmm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) || C > 1024 || C % G || (lddz & 3) || (ldh & 3) || (lddh & 3)) return -1;
-  float* P = scratch;
-  float* m12 = scratch + (long long)B * C * 2;
-  if (int rc = vmm_zero_async(P, sizeof(float) * B * C * 2, s)) return rc;
-  const int rslots = 256 / (C >> 2);
-  int blocks = max(1, min(cdiv(rows_per_sample, rslots * 8), max(1, 2048 / max(B, 1))));
+  const int blocks = gnb_blocks(B, rows_per_sample, C);
   const int rpb = cdiv(rows_per_sample, blocks);
-  blocks = cdiv(rows_per_sample, rpb);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(blocks, B), dim3(256), 0, s, dz, lddz, h, ldh, coef, stats, rows_per_sample, C, G, rpb, P);
+  float* part = scratch;
+  float* m12 = scratch + (long long)B * blocks * C * 2;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(blocks, B), dim3(256), 0, s, dz, lddz, h, ldh, coef, stats, rows_per_sample, C, G, rpb, part);
   VMM_LAUNCH_CHECK();
   const float inv_n = 1.0f / ((float)rows_per_sample * (float)(C / G));
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, P, gamma, beta, film, ldfilm, inv_n, B, C, G, m12, dgamma,
+  const int Cg = C / G;
+  const int CH = (C > 64 && C % 64 == 0 && 64 % Cg == 0) ? 64 : C;  // channel chunk of a coefficient workgroup: whole groups
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(C / CH, B), dim3(256), 0, s, part, blocks, gamma, beta, film, ldfilm, inv_n, C, G, CH, m12, dgamma,
                      dbeta, dfilm);
   VMM_LAUNCH_CHECK();
-  const long long rows = (long long)B * rows_per_sample;
-  const int ab = (int)min((long long)cdiv(rows * (C >> 2), 256), 8192LL);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ab), dim3(256), 0, s, dz, lddz, h, ldh, coef, stats, m12, dh, lddh, rows, rows_per_sample, C, G,
-                     accumulate);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks, B), dim3(256), 0, s, dz, lddz, h, ldh, coef, stats, m12, dh, lddh, rows_per_sample, C, G,
+                     rpb, accumulate);
   VMM_LAUNCH_CHECK();
   return 0;
 }

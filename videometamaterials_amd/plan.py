@@ -752,7 +752,7 @@ class _Builder:
 
     def gn_bwd(self, prefix: str, dz_ptr: int, h: Act, coef_ptr: int, stats_ptr: int, film_ptr: int, ldfilm: int, dh_ptr: int, dfilm_ptr: int) -> None:
         B, G, C_ = self.B, self.G, h.C
-        n_sc = B * C_ * 2 + B * G * 2
+        n_sc = int(self.lib.vmm_groupnorm_bwd_scratch(B, self.T * h.H * h.W, C_, G))
         sc = self.alloc(n_sc)
         gnw = self.pg(prefix + ".norm.weight") or self.scratch(C_)
         gnb = self.pg(prefix + ".norm.bias") or self.scratch(C_)
