@@ -44,6 +44,15 @@ def test_minibatch_assembly_matches_reference_dataset(gpu, name):
     assert np.array_equal(x4.cpu().numpy(), want[[1, N - 1]]) and np.array_equal(lab4.cpu().numpy(), gold["labels"][[1, N - 1]])
     with pytest.raises(IndexError):
         ds.batch([-N - 1])
+    # device-resident indices out of range: no synchronisation inside batch() (the rows are clamped for the launch), the error is latched on
+    # the device and raised by check_indices() at the caller's next synchronisation point, then cleared
+    ds.check_indices()
+    x5, _ = ds.batch(torch.tensor([0, N + 3], device=gpu))
+    assert np.array_equal(x5.cpu().numpy(), want[[0, N - 1]])
+    ds.batch(torch.tensor([1], device=gpu))  # a later good batch does not clear the latch
+    with pytest.raises(IndexError):
+        ds.check_indices()
+    ds.check_indices()
 
 
 def test_min_max_values_csv_like_the_reference(gpu, tmp_path):

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) evc[h][r] = (4 * g + r < ntok) ? a.ev[((long long)b * ntok + 4 * g + r) * HID + head * DH + c + 16 * h] : 0.f;
+    for (int r = 0; r < 4; ++r) evc[h][r] = (4 * g + r < ntok) ? a.ev[((long long)b * ntok + 4 * g + r) * HID + head * DH + 2 * c + h] : 0.f;
+  // (value / output columns: lane c of the two 16-column halves owns channels 2 c and 2 c + 1 of the head, so that a value is ONE 8-byte load
+  // -- 4-byte for bf16-stored rows -- and an output ONE store per row, 16 lanes covering the head's 32 contiguous channels; two separate
+  // element loads at c and c + 16 were half-line requests, and 2-byte ones with bf16 storage: 2.4 vs 1.6 ms at configs[3]'s C = 128 level)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // bias in the score layout, per (query tile, key tile): register r <-> key 16 jk + 4 g + r, lane <-> query 16 iq + c
   float bB[NT][NT][4];
@@ -83,9 +86,9 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
     for (int r = 0; r < 4; ++r) {
       const int tv = 4 * g + r;
       const bool ok = okp && tv < T;
-      const ST* vrow = qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
-      nvc[0][r] = ok ? ld1(vrow) : 0.f;
-      nvc[1][r] = ok ? ld1(vrow + 16) : 0.f;
+      const float2 vp = ld2(qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + 2 * c);
+      nvc[0][r] = ok ? vp.x : 0.f;
+      nvc[1][r] = ok ? vp.y : 0.f;
     }
   };
   if constexpr (NT == 1) request(blk);
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
       for (int r = 0; r < 4; ++r) {
         const int tv = 16 * jk + 4 * g + r;
         const bool ok = tv < T;
-        const ST* vrow = qkv + (row0 + (long long)(ok ? tv : 0) * a.HW) * a.ldqkv + 2 * HID + head * DH + c;
-        vc[jk][0][r] = ok ? ld1(vrow) : 0.f;
-        vc[jk][1][r] = ok ? ld1(vrow + 16) : 0.f;
+        const float2 vp = ld2(qkv + (row0 + (long long)(ok ? tv : 0) * a.HW) * a.ldqkv + 2 * HID + head * DH + 2 * c);
+        vc[jk][0][r] = ok ? vp.x : 0.f;
+        vc[jk][1][r] = ok ? vp.y : 0.f;
       }
     }
 #pragma unroll
@@ -177,12 +180,10 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
         }
       if (a.lse && g == 0 && qok) a.lse[rq * HEADS + head] = m + logf(l);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int to = 16 * iq + 4 * g + r;
-          if (to < T) st1(outp + (row0 + (long long)to * a.HW) * a.ldo + head * DH + c + 16 * h, O[h][r]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int to = 16 * iq + 4 * g + r;
+        if (to < T) st2(outp + (row0 + (long long)to * a.HW) * a.ldo + head * DH + 2 * c, O[0][r], O[1][r]);
+      }
     }
   }
 }

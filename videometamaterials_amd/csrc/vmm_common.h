@@ -105,6 +105,13 @@ __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cas
 __device__ __forceinline__ void st4(bf16s* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16_pair(v.x, v.y), pack_bf16_pair(v.z, v.w));
 }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const bf16s* p) {
+  const unsigned u = *reinterpret_cast<const unsigned*>(p);
+  return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void st2(bf16s* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack_bf16_pair(a, b); }
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16s* p) { return __uint_as_float((unsigned)*p << 16); }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }

@@ -112,6 +112,7 @@ class Dataset:
         self._src = torch.tensor(src, dtype=torch.int32, device=dev)
         self._coef = coef.to(dev)
         self._labels_dev = self.labels.to(dev)
+        self._bad_index = torch.zeros((), dtype=torch.bool, device=dev)  # latched by batch() on device-resident indices out of range
 
     def __len__(self) -> int:
         return self.frames.shape[0]
@@ -120,11 +121,16 @@ class Dataset:
         """(B, channels, T, H, W) fp32 in [0, 1] and the (B, L) labels of dataset rows ``indices``, on the device, in one launch."""
         n, nf, f, H, W = self.frames.shape
         if isinstance(indices, torch.Tensor) and indices.is_cuda:
-            # device-resident indices (a device sampler): wrapped and range-checked without a host round trip -- an index outside
-            # [-n, n) is clamped into range on the device and reported by the check below only in debug runs (VMM_DEBUG_SYNC)
+            # device-resident indices (a device sampler): wrapped and range-checked without a host round trip.  An index outside [-n, n) is
+            # clamped into range for the launch (no out-of-bounds read) and latched in a device-side flag that `check_indices()` turns into
+            # the IndexError of the host path at the caller's next natural synchronisation point (where the loop reads the loss);
+            # VMM_DEBUG_SYNC checks on the spot.
             idx = indices.to(torch.int64).reshape(-1)
-            if os.environ.get("VMM_DEBUG_SYNC") and (idx.numel() == 0 or int(idx.min()) < -n or int(idx.max()) >= n):
+            if idx.numel() == 0:
                 raise IndexError("dataset index out of range")
+            self._bad_index |= ((idx < -n) | (idx >= n)).any()
+            if os.environ.get("VMM_DEBUG_SYNC"):
+                self.check_indices()
             idx = torch.where(idx < 0, idx + n, idx).clamp_(0, n - 1).to(torch.int32).contiguous()
         else:
             # the usual case, a sampler's list / numpy array: validated on the host (no device -> host synchronisation on the training
@@ -141,6 +147,13 @@ class Dataset:
         N.check(N.lib().vmm_fields_to_samples(self.frames.data_ptr(), nf, f, H * W, idx.data_ptr(), idx.numel(), self._src.data_ptr(), self._coef.data_ptr(),
                                               nch, T, out.data_ptr(), stream), "vmm_fields_to_samples")
         return out, self._labels_dev[idx.long()]
+
+    def check_indices(self) -> None:
+        """Raise the IndexError a batch() call with device-resident indices could not raise without a synchronisation (one device -> host read;
+        call it where the training loop already waits for the device, e.g. when it logs the loss).  The flag is cleared."""
+        if bool(self._bad_index):
+            self._bad_index.zero_()
+            raise IndexError("dataset index out of range (device-resident indices of an earlier batch() call; the batch was assembled from clamped rows)")
 
     def __getitem__(self, index: int) -> Tuple[torch.Tensor, torch.Tensor]:
         x, lab = self.batch([int(index)])
