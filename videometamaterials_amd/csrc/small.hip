@@ -284,8 +284,18 @@ __global__ void rotary_rows_kernel(float* __restrict__ x, const float* __restric
   float* p = x + i * 2;
   const float c = tab[(n * half + fi) * 2], s = tab[(n * half + fi) * 2 + 1];
   const float a = p[0], b = p[1];
-  p[0] = a * c - b * s;
-  p[1] = b * c + a * s;
+  // (scalar arithmetic on purpose, see LABNOTES 9.8: left to the SLP vectoriser this was v_pk_mul_f32 / two v_pk_fma_f32 / s_nop 0 / v_mov_b32 of the second
+  // fma's HIGH half, and under multi-process load the v_mov of lanes 48..63 occasionally read the register BEFORE the packed fma's second pass had
+  // written it -- p[1] came out as b * c, once in ~30 forwards of four concurrent processes, never in a process running alone)
+  float as = a * s;
+  asm volatile("" : "+v"(as));
+  float bs = b * s;
+  asm volatile("" : "+v"(bs));
+  float p0 = fmaf(a, c, -bs);
+  asm volatile("" : "+v"(p0));
+  const float p1 = fmaf(b, c, as);
+  p[0] = p0;
+  p[1] = p1;
 }
 
 __global__ void relpos_bias_kernel(const float* __restrict__ emb, const int32_t* __restrict__ buckets, int n, int heads,

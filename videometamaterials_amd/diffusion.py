@@ -9,6 +9,7 @@ x0 prediction, exact radix-select quantile, posterior update) with no host sync 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -311,6 +312,8 @@ class _GraphedStep:
         self.s = torch.empty(B, device=dev)
         self.noise = torch.zeros(shape, device=dev) if self.inject else None
         self.scratch = torch.empty(B * Q_STRIDE, dtype=torch.int32, device=dev)
+        if os.environ.get("VMM_POISON_ARENA"):
+            self.x0.fill_(float("nan")); self.ax0.fill_(float("nan")); self.s.fill_(float("nan")); self.scratch.fill_(-1)
         n = self.img.numel() // B
         if n % 4:
             raise NotImplementedError("the captured sampling step takes samples of a multiple of four elements (use_graph = False samples any shape)")

@@ -88,6 +88,7 @@ class _Arena:
         self.top = 0
         self.peak = 0
         self.keep_all = keep_all
+        self.log: List[Tuple[int, int]] = []  # every allocation in order (debug: tools/stress_concurrent.py checksums them with VMM_KEEP_ALL=1)
 
     def alloc(self, n: int) -> int:
         n = (n + ALIGN - 1) // ALIGN * ALIGN
@@ -97,10 +98,12 @@ class _Arena:
                     self.free_list.pop(i)
                 else:
                     self.free_list[i] = (off + n, sz - n)
+                self.log.append((off, n))
                 return off
         off = self.top
         self.top += n
         self.peak = max(self.peak, self.top)
+        self.log.append((off, n))
         return off
 
     def free(self, off: int, n: int, force: bool = False) -> None:
@@ -286,7 +289,7 @@ class _Builder:
         self.device = device
         self.base, self.wbase, self.pgbase, self.gsbase = bases
         self.training = training
-        self.arena = _Arena(keep_all=training)
+        self.arena = _Arena(keep_all=training or bool(os.environ.get("VMM_KEEP_ALL")))  # (VMM_KEEP_ALL: debug, no slot of an inference plan is reused)
         self.wtop = self.pgtop = self.gstop = 0
         self.plan = Plan()
         self.plan.training = training
@@ -555,7 +558,7 @@ class _Builder:
         if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
             self.tickets_ptr = self.wslot(N_TICKETS)
         d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
-        if self._desc_a16:  # bf16-stored maps: the unsplit instances (no ordered atomic accumulation onto a bf16 output)
+        if self._desc_a16 or not _enabled("conv_split"):  # bf16-stored maps: the unsplit instances (no ordered atomic accumulation onto a bf16 output)
             d.split_tickets, d.n_tickets = None, 0
         d.gn_part, d.gn_groups = None, self.G
         if KH > 1 or KW > 1:  # padding_mode 'circular' / 'circular_1d' (vddp.py:163-243): every spatial kernel wraps instead of zero-padding
@@ -1881,6 +1884,8 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     sizing = _Builder(model, B, T, H, W, cond_len, device, (1 << 40, 1 << 41, 1 << 42, 1 << 43), training, mirrored, focus)
     sizing.build()
     arena = torch.empty(sizing.arena.peak + ALIGN, dtype=torch.float32, device=device)
+    if os.environ.get("VMM_POISON_ARENA"):  # debug runs: NaN in every activation slot, so that a kernel that reads what no launch of the plan wrote shows
+        arena.fill_(float("nan"))
     wbuf = torch.zeros(sizing.wtop + ALIGN, dtype=torch.float32, device=device)
     pgrad = torch.zeros(sizing.pgtop + ALIGN, dtype=torch.float32, device=device) if training else None
     gscr = torch.zeros(sizing.gstop + ALIGN, dtype=torch.float32, device=device) if training else None
@@ -1889,6 +1894,7 @@ def _build_plan(model, B: int, T: int, H: int, W: int, cond_len: int, device, tr
     plan = b.build()
     assert b.arena.peak == sizing.arena.peak and b.wtop == sizing.wtop and b.pgtop == sizing.pgtop and b.gstop == sizing.gstop
     plan.arena, plan.wbuf, plan.pgrad, plan.gscratch = arena, wbuf, pgrad, gscr
+    plan.alloc_log = list(b.arena.log)
     plan.shape = (B, T, H, W, cond_len)
     plan.mirrored = b.mirrored
     for off, host in b.job_uploads:
