@@ -1,0 +1,21 @@
+"""Bit-reproducibility of the denoiser while several processes share the GPU (LABNOTES 9.8: a packed-fp32 instruction sequence in the token-key
+rotation gave a different result once in ~30 forwards ONLY when other processes' waves were on the same SIMDs -- which is the situation of
+two-rank tests on a one-GPU box, and of any deployment that shares a GPU).  tools/stress_concurrent.py draws the same seeded guided forward
+repeatedly in every process and exits 0 iff every digest of every process is the same."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode,n", [("unet", 60), ("graph", 10)])
+def test_results_do_not_depend_on_other_processes_on_the_gpu(gpu, mode, n):
+    env = dict(os.environ, STRESS_MODE=mode)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_concurrent.py"), "3", str(n), "lagr16"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "'distinct_digests': 1" in r.stdout, r.stdout[-2000:]
