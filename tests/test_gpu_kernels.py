@@ -1783,6 +1783,52 @@ def test_temporal_attention_backward(gpu, B, T, HW, ntok, use_bias, bias_on_cond
         assert relerr(dbias.cpu(), bias.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,T,HW,per_frame_tok", [(2, 11, 144, True), (1, 3, 64, False), (2, 4, 36, True), (1, 2, 400, False)])
+def test_spatial_attention_backward(gpu, B, T, HW, per_frame_tok):
+    """vmm_attention_bwd mode 1 (mid spatial attention, vddp.py:687-689 under autograd: softmax over [the frame's conditioning token | the frame's
+    pixels] per (frame, head)) against torch autograd in float64.  HW < 256 takes the two LDS-staged kernels (keys / values staged for the query
+    pass, queries for the key pass), HW = 400 the generic pair."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    heads, dh = 8, 32
+    hid, scale = heads * dh, dh ** -0.5
+    ntok = T if per_frame_tok else 0
+    raw = torch.randn(B, T, HW, 3 * hid, generator=g, dtype=torch.float64, requires_grad=True)
+    ek = torch.randn(B, ntok, hid, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    ev = torch.randn(B, ntok, hid, generator=g, dtype=torch.float64, requires_grad=True) if ntok else None
+    q = raw[..., :hid].reshape(B, T, HW, heads, dh) * scale
+    k = raw[..., hid:2 * hid].reshape(B, T, HW, heads, dh)
+    v = raw[..., 2 * hid:].reshape(B, T, HW, heads, dh)
+    sim = torch.einsum("btihd,btjhd->bthij", q, k)
+    if ntok:  # frame t sees token t only
+        simt = torch.einsum("btihd,bthd->bthi", q, ek.reshape(B, T, heads, dh))[..., None]
+        sim = torch.cat([simt, sim], -1)
+    lse = torch.logsumexp(sim, -1)  # (B, T, heads, HW)
+    attn = (sim - lse[..., None]).exp()
+    out = torch.einsum("bthij,btjhd->btihd", attn[..., (1 if ntok else 0):], v)
+    if ntok:
+        out = out + attn[..., 0].permute(0, 1, 3, 2)[..., None] * ev.reshape(B, T, 1, heads, dh)
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    (out * dout).sum().backward()
+    f = lambda t: t.detach().float().contiguous().to(gpu)
+    qkv_g = f(torch.cat([q.flatten(-2), k.flatten(-2), v.flatten(-2)], -1).reshape(-1, 3 * hid))
+    out_g, dout_g = f(out.reshape(-1, hid)), f(dout.reshape(-1, hid))
+    lse_g = f(lse.permute(0, 1, 3, 2).reshape(-1, heads))  # rows (b, t, pix) x heads
+    ek_g, ev_g = (f(ek), f(ev)) if ntok else (None, None)
+    rows = B * T * HW
+    dqkv = torch.full((rows, 3 * hid), float("nan"), device=gpu)
+    dek, dev_ = torch.zeros(B, max(ntok, 1), hid, device=gpu), torch.zeros(B, max(ntok, 1), hid, device=gpu)
+    dbuf = torch.zeros(int(lib.vmm_attention_bwd_scratch(1, B, T, HW, heads, ntok)), device=gpu)
+    p = lambda t: t.data_ptr() if t is not None else None
+    N.check(lib.vmm_attention_bwd(1, p(qkv_g), 3 * hid, p(ek_g), p(ev_g), ntok, 1 if ntok else 0, None, 0, p(out_g), p(dout_g), hid, p(lse_g), None,
+                                  scale, p(dqkv), p(dek), p(dev_), None, p(dbuf), B, T, HW, heads, dh, _s()), "attention bwd (spatial)")
+    torch.cuda.synchronize()
+    assert relerr(dqkv.cpu(), raw.grad.reshape(rows, 3 * hid)) < 2e-5
+    if ntok:
+        assert relerr(dek.cpu(), ek.grad) < 2e-5
+        assert relerr(dev_.cpu(), ev.grad) < 2e-5
+
+
 @pytest.mark.parametrize("HW,ntok", [(144, 11), (100, 0), (2304, 5)])
 def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
     """heads = 8 takes the fp32 matrix-core row passes (linattn_rows.hip): vmm_linattn_apply forward and the row pass of

@@ -203,6 +203,65 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, const floa
   if (bias && dbias && (!is_tok || g.bias_on_cond) && lane < n) atomicAdd(&dbias[((long long)head * n + lane) * n + (is_tok ? j : jj)], bias_acc);
 }
 
+// ---------------------------------------------------------------- pass A for the mid spatial attention: the frame's keys and values staged in LDS
+// The thread-per-query kernel above walks its keys through two dependent global loads each (k_j, then v_j): with 144 keys and about one wave per
+// SIMD that chain of 288 L2 round trips was the whole 150 us of the launch.  Same arithmetic in the same order (bit-identical results), the
+// key / value rows of the (sample, frame, head) read from LDS (uniform address: broadcast).
+__global__ __launch_bounds__(256) void spatial_attn_bwd_q_kernel(AttnGeom g, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
+                                                                 const float* __restrict__ ev, const float* __restrict__ O,
+                                                                 const float* __restrict__ dO, int ldo, const float* __restrict__ lse, float q_scale,
+                                                                 float* __restrict__ dqkv, float* __restrict__ Dbuf) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // K[HW][32] | V[HW][32]
+  const int HW = g.HW, hid = g.heads * DH;
+  float* Ks = sm;
+  float* Vs = Ks + HW * DH;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % g.heads;
+  const int bt = blockIdx.x / g.heads, t = bt % g.T, b = bt / g.T;
+  const long long row0 = (long long)bt * HW;
+  for (int e = tid; e < HW * (DH / 4); e += 256) {
+    const int r = e >> 3, c = (e & 7) * 4;
+    *reinterpret_cast<f32x4*>(Ks + r * DH + c) = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ldqkv + hid + head * DH + c);
+    *reinterpret_cast<f32x4*>(Vs + r * DH + c) = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * ldqkv + 2 * hid + head * DH + c);
+  }
+  __syncthreads();
+  if (tid >= HW) return;
+  const long long rq = row0 + tid;
+  float q[DH], go[DH], dq[DH], tmp[DH];
+  ld32(q, qkv + rq * ldqkv + head * DH);
+  ld32(go, dO + rq * ldo + head * DH);
+  ld32(tmp, O + rq * ldo + head * DH);
+  const float Dv = dot32r(go, tmp);
+  const float L = lse[rq * g.heads + head];
+  Dbuf[rq * g.heads + head] = Dv;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+  if (ek) {
+    const int j0 = g.tok_per_frame ? t : 0, j1 = g.tok_per_frame ? t + 1 : g.ntok;
+    for (int j = j0; j < j1; ++j) {
+      ld32(tmp, ek + ((long long)b * g.ntok + j) * hid + head * DH);
+      const float p = __expf(dot32r(q, tmp) - L);
+      float vv[DH];
+      ld32(vv, ev + ((long long)b * g.ntok + j) * hid + head * DH);
+      const float ds = p * (dot32r(go, vv) - Dv);
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
+    }
+  }
+  for (int j = 0; j < HW; ++j) {
+    ld32(tmp, Ks + j * DH);
+    const float p = __expf(dot32r(q, tmp) - L);
+    float vv[DH];
+    ld32(vv, Vs + j * DH);
+    const float ds = p * (dot32r(go, vv) - Dv);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DH; ++d) dq[d] *= q_scale;
+  st32(dqkv + rq * ldqkv + head * DH, dq);
+}
+
 // ---------------------------------------------------------------- pass B for the mid spatial attention (mode 1, HW <= 256 keys per frame)
 // The generic pass B maps lanes to the inner index, which here is the frame (T = 11 of 64 lanes busy, one wave per key).  This
 // one takes a workgroup per (sample, frame, head): q, dO, logsumexp and D of the frame's HW queries are staged once in LDS, thread j
@@ -518,10 +577,21 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
   hipStream_t s = (hipStream_t)stream;
   AttnGeom g{mode, B, T, HW, heads, ek ? ntok : 0, tok_per_frame, bias_on_cond};
   const long long total = (long long)B * ninner * heads * n;
-  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, out, dout, ldo, lse, rot_tab, q_scale,
-                     dqkv, dbuf);
+  const bool mid_spatial = mode == 1 && HW < 256 && !bias && !rot_tab && (g.ntok == 0 || (tok_per_frame && g.ntok == T));
+  if (mid_spatial) {
+    static bool attr_q = false;
+    if (!attr_q) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_q = true;
+    }
+    hipLaunchKernelGGL(spatial_attn_bwd_q_kernel, dim3((unsigned)(B * T * heads)), dim3(256), sizeof(float) * (size_t)HW * 2 * DH, s, g, qkv, ldqkv, ek, ev, out,
+                       dout, ldo, lse, q_scale, dqkv, dbuf);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, out, dout, ldo, lse, rot_tab, q_scale,
+                       dqkv, dbuf);
+  }
   VMM_LAUNCH_CHECK();
-  if (mode == 1 && HW < 256 && !bias && !rot_tab && (g.ntok == 0 || (tok_per_frame && g.ntok == T))) {  // mid spatial attention
+  if (mid_spatial) {
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
