@@ -1783,6 +1783,50 @@ def test_temporal_attention_backward(gpu, B, T, HW, ntok, use_bias, bias_on_cond
         assert relerr(dbias.cpu(), bias.grad) < 2e-5
 
 
+def test_dense_backward_batched(gpu):
+    """vmm_dense_bwd_batched (autograd of the small Linear layers around the network: FiLM projections vddp.py:293-296, token keys / values :344-345,
+    the embedding MLPs :633-660) against torch autograd, one launch over jobs of both kernels: no output activation (tiled kernel: 64 columns per
+    workgroup, rows in LDS) and SiLU / GELU outputs (wave per column, g written back over dy), = and += accumulation, ragged N, shared x."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(31)
+    act = {0: lambda v: v, 1: F.silu, 2: lambda v: F.gelu(v)}
+    specs = [dict(rows=4, K=256, N=128, act_in=1, act_out=0, acc=0, bias=True), dict(rows=44, K=64, N=256, act_in=0, act_out=0, acc=1, bias=False),
+             dict(rows=70, K=64, N=100, act_in=0, act_out=0, acc=0, bias=True), dict(rows=4, K=64, N=256, act_in=0, act_out=2, acc=0, bias=True),
+             dict(rows=4, K=256, N=1024, act_in=1, act_out=0, acc=1, bias=True), dict(rows=9, K=16, N=64, act_in=0, act_out=1, acc=0, bias=True)]
+    jobs = (N.DenseBwdJob * len(specs))()
+    keep, checks = [], []
+    for i, sp in enumerate(specs):
+        x = torch.randn(sp["rows"], sp["K"], generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(sp["N"], sp["K"], generator=g, dtype=torch.float64) / sp["K"] ** 0.5).requires_grad_(True)
+        b = torch.randn(sp["N"], generator=g, dtype=torch.float64, requires_grad=True) if sp["bias"] else None
+        y = act[sp["act_out"]](F.linear(act[sp["act_in"]](x), w, b))
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        (y * dy).sum().backward()
+        f = lambda t: t.detach().float().contiguous().to(gpu)
+        xg, wg, dyg = f(x), f(w), f(dy)
+        bg = f(b) if b is not None else None
+        pre_w, pre_b = torch.randn(sp["N"], sp["K"], generator=g).to(gpu), torch.randn(sp["N"], generator=g).to(gpu)
+        dwg, dbg = (pre_w.clone(), pre_b.clone()) if sp["acc"] else (torch.full_like(pre_w, float("nan")), torch.full_like(pre_b, float("nan")))
+        dxg = torch.zeros(sp["rows"], sp["K"], device=gpu)
+        keep += [xg, wg, dyg, bg, dwg, dbg, dxg]
+        j = jobs[i]
+        j.x, j.w, j.b, j.dy, j.dx, j.dw, j.db = xg.data_ptr(), wg.data_ptr(), bg.data_ptr() if bg is not None else None, dyg.data_ptr(), dxg.data_ptr(), dwg.data_ptr(), dbg.data_ptr() if bg is not None else None
+        j.rows, j.K, j.N, j.ldx, j.lddy, j.lddx = sp["rows"], sp["K"], sp["N"], sp["K"], sp["N"], sp["K"]
+        j.act_in, j.act_out, j.accumulate = sp["act_in"], sp["act_out"], sp["acc"]
+        checks.append((sp, dwg, dbg if b is not None else None, dxg, w.grad, b.grad if b is not None else None, x.grad, pre_w, pre_b))
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(gpu)
+    max_n = max(sp["N"] for sp in specs)
+    max_x = max(sp["rows"] * ((sp["K"] + 63) // 64) for sp in specs)
+    N.check(lib.vmm_dense_bwd_batched(table.data_ptr(), len(specs), max_n, max_x, _s()), "dense bwd")
+    torch.cuda.synchronize()
+    for sp, dwg, dbg, dxg, gw, gb, gx, pre_w, pre_b in checks:
+        base_w, base_b = (pre_w.cpu(), pre_b.cpu()) if sp["acc"] else (0.0, 0.0)
+        assert relerr(dwg.cpu() - base_w, gw) < 2e-5, sp
+        if dbg is not None:
+            assert relerr(dbg.cpu() - base_b, gb) < 2e-5, sp
+        assert relerr(dxg.cpu(), gx) < 2e-5, sp
+
+
 @pytest.mark.parametrize("B,T,HW,per_frame_tok", [(2, 11, 144, True), (1, 3, 64, False), (2, 4, 36, True), (1, 2, 400, False)])
 def test_spatial_attention_backward(gpu, B, T, HW, per_frame_tok):
     """vmm_attention_bwd mode 1 (mid spatial attention, vddp.py:687-689 under autograd: softmax over [the frame's conditioning token | the frame's

@@ -15,9 +15,68 @@ __device__ __forceinline__ float act_grad(float v, int act) {
 
 // Stage 1, one wave per (job, output column o): recompute z = act_in(x) W^T + b, g = dy * act_out'(z) (written back over dy),
 // dW[o,:] (=|+=) sum_r g_r act_in(x_r,:), db[o] (=|+=) sum_r g_r.      K <= 1024, rows processed in chunks of 64.
+// Jobs without an output activation (the FiLM projections and the token key / value layers: the 54 jobs of the last embedding level, whose launch
+// closes the backward) take dense_bwd_w_tile_kernel below; the wave-per-column kernel keeps the rest.
+__device__ __forceinline__ bool dense_bwd_tiled(const vmm_dense_bwd_job& jb) { return jb.act_out == 0 && jb.K <= 256 && (jb.K & 3) == 0 && jb.rows > 0; }
+
+// Workgroup = 64 output columns of one job: act_in(x) and dy of 32 rows at a time in LDS, thread (column o = tid >> 2, quarter kq = tid & 3) owns
+// dW[o][kq + 4 i]: one LDS read of g and K / 4 of x per row.  (The wave-per-column kernel walked the rows through dependent global loads, one in
+// flight per wave: 0.2 ms for a level of 44-row jobs.)  g = dy (no output activation), so nothing is written back over dy.
+template <int NK>  // K / 4 <= NK: accumulators per thread (compile-time bound, so that a 64-column job does not walk 64 predicated slots)
+__device__ __forceinline__ void dense_bwd_w_tile(const vmm_dense_bwd_job& jb, int o0, float* xs, float* gs) {
+  constexpr int RC = 32, XP = 260, GP = 65;
+  const int tid = threadIdx.x, o = tid >> 2, kq = tid & 3, nk = jb.K >> 2;
+  float acc[NK];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) acc[i] = 0.f;
+  float db = 0.f;
+  for (int r0 = 0; r0 < jb.rows; r0 += RC) {
+    const int nr = min(RC, jb.rows - r0);
+    __syncthreads();
+    for (int e = tid; e < nr * nk; e += 256) {
+      const int r = e / nk, k4 = (e - r * nk) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(jb.x + (long long)(r0 + r) * jb.ldx + k4);
+      float* d = xs + r * XP + k4;
+      d[0] = act_f(v.x, jb.act_in); d[1] = act_f(v.y, jb.act_in); d[2] = act_f(v.z, jb.act_in); d[3] = act_f(v.w, jb.act_in);
+    }
+    for (int e = tid; e < nr * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      gs[r * GP + c] = o0 + c < jb.N ? jb.dy[(long long)(r0 + r) * jb.lddy + o0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < nr; ++r) {
+      const float g = gs[r * GP + o];
+      db += g;
+      const float* xr = xs + r * XP + kq;
+#pragma unroll
+      for (int i = 0; i < NK; ++i)
+        if (i < nk) acc[i] = fmaf(g, xr[4 * i], acc[i]);
+    }
+  }
+  if (o0 + o >= jb.N) return;
+  if (jb.dw) {
+    float* p = jb.dw + (long long)(o0 + o) * jb.K + kq;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+      if (i < nk) p[4 * i] = jb.accumulate ? p[4 * i] + acc[i] : acc[i];
+  }
+  if (kq == 0 && jb.db) jb.db[o0 + o] = jb.accumulate ? jb.db[o0 + o] + db : db;
+}
+
+__global__ __launch_bounds__(256) void dense_bwd_w_tile_kernel(const vmm_dense_bwd_job* __restrict__ jobs) {
+  const vmm_dense_bwd_job jb = jobs[blockIdx.y];
+  const int o0 = blockIdx.x * 64;
+  if (!dense_bwd_tiled(jb) || o0 >= jb.N) return;
+  __shared__ float xs[32 * 260], gs[32 * 65];
+  if (jb.K <= 64) dense_bwd_w_tile<16>(jb, o0, xs, gs);
+  else if (jb.K <= 128) dense_bwd_w_tile<32>(jb, o0, xs, gs);
+  else dense_bwd_w_tile<64>(jb, o0, xs, gs);
+}
+
 __global__ __launch_bounds__(256) void dense_bwd_w_kernel(const vmm_dense_bwd_job* __restrict__ jobs) {
   __shared__ float gsh[4][64];
   const vmm_dense_bwd_job jb = jobs[blockIdx.y];
+  if (dense_bwd_tiled(jb)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int o = blockIdx.x * 4 + wv;
   if (o >= jb.N) return;
@@ -79,14 +138,20 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const vmm_dense_bwd_jo
   // is to parallelise; dx is accumulated with atomics anyway
   const int o0 = blockIdx.z * 128, o1 = min(jb.N, o0 + 128);
   if (o0 >= o1) return;
-  float acc = 0.f, acc2 = 0.f;
+  // (eight independent products per trip: with two, the 128-feature slice was 64 dependent L2 round trips -- 50 of the launch's 67 us)
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* dyr = jb.dy + (long long)r * jb.lddy;
   int o = o0;
-  for (; o + 1 < o1; o += 2) {
-    acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
-    acc2 = fmaf(jb.dy[(long long)r * jb.lddy + o + 1], jb.w[(long long)(o + 1) * jb.K + k], acc2);
+  for (; o + 7 < o1; o += 8) {
+    float d8[8], w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { d8[u] = dyr[o + u]; w8[u] = jb.w[(long long)(o + u) * jb.K + k]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] = fmaf(d8[u], w8[u], a8[u]);
   }
-  if (o < o1) acc = fmaf(jb.dy[(long long)r * jb.lddy + o], jb.w[(long long)o * jb.K + k], acc);
-  atomicAdd(&jb.dx[(long long)r * jb.lddx + k], (acc + acc2) * act_grad(jb.x[(long long)r * jb.ldx + k], jb.act_in));
+  for (; o < o1; ++o) a8[0] = fmaf(dyr[o], jb.w[(long long)o * jb.K + k], a8[0]);
+  const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  atomicAdd(&jb.dx[(long long)r * jb.lddx + k], acc * act_grad(jb.x[(long long)r * jb.ldx + k], jb.act_in));
 }
 
 // tokens[b,f,d] = cond[b,f]*w[d] + bias[d] (or null token), pooled = mean_f of the un-dropped tokens; thread per d
@@ -384,6 +449,8 @@ extern "C" int vmm_dense_bwd_batched(const vmm_dense_bwd_job* jobs_dev, int32_t 
                                      vmm_stream_t stream) {
   if (njobs <= 0) return 0;
   hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(cdiv(max_N, 4), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dense_bwd_w_tile_kernel, dim3(cdiv(max_N, 64), njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   VMM_LAUNCH_CHECK();
   if (max_xunits > 0) {
     hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(cdiv(max_xunits, 4), njobs, cdiv(max_N, 128)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
