@@ -572,6 +572,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       if (tid == 0)
         while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
       __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (pairs with the release below)
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -600,7 +601,11 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores / atomics have been performed
+    // Release at AGENT scope before the ticket is passed on.  With a workgroup-scope fence (a bare s_waitcnt) the ticket -- another address, another
+    // memory channel -- could become visible to the next split on another XCD before this split's write-through stores had been performed at the
+    // memory side; its atomic adds then landed first and were overwritten.  Seen as one training step in ~800 with a handful of gradients off by 1e-2
+    // of their scale, only with several processes on the GPU (LABNOTES 9.8); the few-tile layers that split are too small for the fence to show.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
