@@ -560,9 +560,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   }
 
   // epilogue.  Split channel reduction (gridDim.y > 1): the splits of one output tile add their partial sums in split order, so the
-  // result does not depend on scheduling.  Split 0 writes through to memory; split y waits for ticket == y, adds with device-scope
-  // fp32 atomics (performed at the memory side, coherent across the XCDs' L2s without cache write-backs), waits for their
-  // completion and passes the ticket on (the last one resets it to 0).  Workgroups are dispatched y-major, i.e. split y - 1 is
+  // result does not depend on scheduling.  Split 0 writes through to memory; split y waits for ticket == y (acquire), adds with device-scope
+  // fp32 atomics (performed at the memory side, coherent across the XCDs' L2s), and passes the ticket on behind an agent-scope release
+  // (the last one resets it to 0).  Workgroups are dispatched y-major, i.e. split y - 1 is
   // always resident before split y.
   if constexpr (SPLIT) {
     // acc[i][j]: rows = pixels (r & 3) + 8 (r >> 2) + 4 lk of row tile i, column = output channel j*32 + lrow
