@@ -1,6 +1,6 @@
 """Bit-reproducibility of the sampler while several processes share the GPU (kernels of different processes interleave on the CUs, so a missing
 fence / an order-dependent reduction that never shows in a process running alone has a chance to):
-    python tools/stress_concurrent.py [processes = 3] [samples per process = 12] [config = lagr16]
+    python tools/stress_concurrent.py [processes = 3] [samples per process = 12] [config = lagr16 | any of tests/helpers.CONFIGS | full]
 Every process draws the same seeded sample() repeatedly; all digests of all processes must be equal.  VMM_DISABLE=... narrows a mismatch down."""
 import hashlib
 import os
@@ -18,9 +18,15 @@ def worker(rank, n, cfg, q):
     import helpers
     import videometamaterials_amd as vm
     dev = torch.device("cuda:0")
-    kw, (B, T, H, W), cl = helpers.CONFIGS[cfg]
-    model = vm.Unet3D(**kw)
-    model.load_state_dict(helpers.synth_state_dict(helpers.load_shapes(cfg)))
+    if cfg == "full":  # the benchmark model (Lagrangian widths, 11 x 96 x 96), random init
+        import bench
+        kw, (B, T, H, W), cl = bench.LAGRANGIAN, (2, bench.T, bench.HW, bench.HW), 11
+        torch.manual_seed(0)
+        model = vm.Unet3D(**kw)
+    else:
+        kw, (B, T, H, W), cl = helpers.CONFIGS[cfg]
+        model = vm.Unet3D(**kw)
+        model.load_state_dict(helpers.synth_state_dict(helpers.load_shapes(cfg)))
     if os.environ.get("STRESS_PREC"):
         model.precision = os.environ["STRESS_PREC"]
     for a in os.environ.get("STRESS_OFF", "").split(","):  # model switches, e.g. use_fused_temporal
