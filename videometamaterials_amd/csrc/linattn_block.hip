@@ -150,22 +150,27 @@ __global__ __launch_bounds__(512) void linattn_ctx_kernel(const LAArgs a) {
   f32x4 gam[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) gam[v] = *reinterpret_cast<const f32x4*>(a.gamma + v * 64 + (tid & 15) * 4);
-  auto load_x = [&](int t, f32x4 (&d)[NV]) {
+  // (raw bits, unpacked where they are used: a prefetch unpacked where it is requested waits for its HBM round trip in front of the barrier)
+  using XRaw = decltype(ldraw4(xin));
+  auto load_x = [&](int t, XRaw (&d)[NV]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < t_end) d[v] = ld4(xin + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + v * 64 + (tid & 15) * 4);
+      d[v] = XRaw{};
+      if (t < t_end) d[v] = ldraw4(xin + ((long long)frame * a.HW + t * 32 + (tid >> 4)) * a.ldx + v * 64 + (tid & 15) * 4);
     }
+  };
+  auto unpack = [&](const XRaw (&r)[NV], f32x4 (&d)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) d[v] = unpack4(r[v]);
   };
   float m = -INFINITY, ssum = 0.f;
   f32x16 ctx = zero16();  // rows e, column d = lrow
-  f32x4 x_next[NV];
+  XRaw x_next[NV];
   load_x(t_begin, x_next);
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
     f32x4 x_cur[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) x_cur[v] = x_next[v];
+    unpack(x_next, x_cur);
     load_x(t + 1, x_next);
     stage_norm_row<CC>(a, x_cur, gam, ytile[buf], tid);
     __syncthreads();
@@ -300,12 +305,17 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
     bias[v] = a.bias_out ? *reinterpret_cast<const f32x4*>(a.bias_out + v * 64 + rc) : f32x4{0.f, 0.f, 0.f, 0.f};
     gam[v] = *reinterpret_cast<const f32x4*>(a.gamma + v * 64 + rc);
   }
-  auto load_x = [&](int t, f32x4 (&d)[NV]) {
+  using XRaw = decltype(ldraw4(xin));  // raw bits, unpacked at the point of use (see the context kernel)
+  auto load_x = [&](int t, XRaw (&d)[NV]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      d[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < t_end) d[v] = ld4(xin + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
+      d[v] = XRaw{};
+      if (t < t_end) d[v] = ldraw4(xin + ((long long)frame * a.HW + t * 32 + rp) * a.ldx + v * 64 + rc);
     }
+  };
+  auto unpack = [&](const XRaw (&r)[NV], f32x4 (&d)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) d[v] = unpack4(r[v]);
   };
 #ifndef VMM_LA_PIPE
 #define VMM_LA_PIPE 1
@@ -317,9 +327,13 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
     unsigned short* yt0 = reinterpret_cast<unsigned short*>(red + 2 * LH * 32 * 64);
     auto red_of = [&](int b2) { return red + b2 * (LH * 32 * 64); };
     auto yt_of = [&](int b2) { return yt0 + b2 * (32 * YP); };
-    f32x4 xa[NV], xb[NV];
+    XRaw xa[NV], xb[NV];
     load_x(t_begin, xa);
-    stage_norm_row<CC>(a, xa, gam, yt_of(0), tid);
+    {
+      f32x4 xu[NV];
+      unpack(xa, xu);
+      stage_norm_row<CC>(a, xu, gam, yt_of(0), tid);
+    }
     load_x(t_begin + 1, xb);
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
@@ -365,8 +379,12 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
         rb[px * 64 + lrow] = pc[0][r];
         rb[px * 64 + 32 + lrow] = pc[1][r];
       }
-      stage_norm_row<CC>(a, xb, gam, yt_of(buf ^ 1), tid);  // the next tile's rows (zeros past the end)
-      f32x4 xc[NV];
+      {
+        f32x4 xu[NV];
+        unpack(xb, xu);
+        stage_norm_row<CC>(a, xu, gam, yt_of(buf ^ 1), tid);  // the next tile's rows (zeros past the end)
+      }
+      XRaw xc[NV];
       load_x(t + 2, xc);
       __syncthreads();
       f32x4 acc = bias[0];
@@ -375,20 +393,20 @@ __global__ __launch_bounds__(512) void linattn_apply_kernel(const LAArgs a) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(red_of(buf) + (w * 32 + rp) * 64 + rc);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-      acc.x += xa[0].x; acc.y += xa[0].y; acc.z += xa[0].z; acc.w += xa[0].w;  // residual: the element this thread normalised
+      const f32x4 xr = unpack4(xa[0]);
+      acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;  // residual: the element this thread normalised
       st4(outp + (row0 + rp) * a.ldo + rc, acc);
 #pragma unroll
       for (int v = 0; v < NV; ++v) { xa[v] = xb[v]; xb[v] = xc[v]; }
     }
     return;
   }
-  f32x4 x_next[NV];
+  XRaw x_next[NV];
   load_x(t_begin, x_next);
   for (int t = t_begin; t < t_end; ++t) {
     const long long row0 = (long long)frame * a.HW + t * 32;
     f32x4 x_cur[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) x_cur[v] = x_next[v];
+    unpack(x_next, x_cur);
     load_x(t + 1, x_next);
     stage_norm_row<CC>(a, x_cur, gam, ytile, tid);
     __syncthreads();  // tile rows visible; also: every wave has finished the previous tile's head sum (red is free again)

@@ -806,11 +806,12 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
   // with a lane-dependent branch around a load the compiler stops counting and waits for vmcnt(0) at the first use of ANY loaded
   // value, i.e. for a full HBM round trip of whatever was requested last.
   const int rfc[2] = {min(rft[0], T - 1), min(rft[1], T - 1)};
-  auto load_x = [&](int j, f32x4 (&v)[2]) {
+  using XRaw = decltype(ldraw4(xin));  // raw bits of four elements (bf16-stored maps: unpacked where they are USED, not where they are requested)
+  auto load_x = [&](int j, XRaw (&v)[2]) {
     const int jc = min(max(j, 0), nt - 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      v[i] = ld4(xin + (((long long)b * T + rfc[i]) * HW + (long long)(p_begin + jc) * NP + rpx[i]) * a.ldx + rcol);
+      v[i] = ldraw4(xin + (((long long)b * T + rfc[i]) * HW + (long long)(p_begin + jc) * NP + rpx[i]) * a.ldx + rcol);
   };
   // sum over the 16 lanes of a row, every lane gets it: four rotate-and-add steps inside the DPP row (no LDS permutes, no waits)
   auto row_sum16 = [](float v) {
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
   for (int jj = 0; jj < NK; ++jj) f[jj] = 0.f;
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) g[jj] = 0.f;
-  f32x4 xv[2];
+  XRaw xv[2];
   load_x(grp ? 0 : -1, xv);
   __syncthreads();
 
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 x = rft[i] < T ? xv[i] : z4;
+            const f32x4 x = rft[i] < T ? unpack4(xv[i]) : z4;
             const float mean = row_sum16((x.x + x.y) + (x.z + x.w)) * (1.0f / TC);
             const f32x4 c = {x.x - mean, x.y - mean, x.z - mean, x.w - mean};
             const float rstd = __builtin_amdgcn_rsqf(row_sum16((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.0f / TC) + a.eps);  // 1 ulp
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(512, 2) void temporal_block2_kernel(const TBArgs a)
               const f32x4 v = *reinterpret_cast<const f32x4*>(rb + w * rows * TC);
               acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            acc.x += xv[i].x; acc.y += xv[i].y; acc.z += xv[i].z; acc.w += xv[i].w;
+            const f32x4 xr = unpack4(xv[i]);
+            acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w;
             st4(outp + x_row(j, i) * a.ldo + rcol, acc);
           }
         }

@@ -101,6 +101,15 @@ __device__ __forceinline__ f32x4 ld4(const bf16s* p) {
   const uint2 u = *reinterpret_cast<const uint2*>(p);
   return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
 }
+// Raw form of a four-element load, for values that are requested early and consumed later: ld4(const bf16s*) unpacks where it is written, i.e. the
+// compiler waits for the load THERE -- a prefetch issued before a barrier then stalls the barrier for an HBM round trip (LABNOTES 9.11).  ldraw4 keeps
+// the bits, unpack4 at the point of use.
+__device__ __forceinline__ f32x4 ldraw4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ uint2 ldraw4(const bf16s* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ f32x4 unpack4(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 unpack4(const uint2& u) {
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16s* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16_pair(v.x, v.y), pack_bf16_pair(v.z, v.w));
