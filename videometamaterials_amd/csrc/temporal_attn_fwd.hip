@@ -43,6 +43,33 @@ __device__ __forceinline__ void load_row8(float (&dst)[8], const float* p, bool 
   dst[4] = w.x; dst[5] = w.y; dst[6] = w.z; dst[7] = w.w;
 }
 
+// Raw forms for values requested one pixel ahead (NT == 1): the bits travel through the prefetch registers and are unpacked where the pixel is
+// computed -- an unpack at the request is where the compiler waits for the load (LABNOTES 9.11).
+template <typename ST> struct Raw8;
+template <> struct Raw8<float> { f32x4 a, b; };
+template <> struct Raw8<bf16s> { uint4 u; };
+__device__ __forceinline__ void ldraw8(Raw8<float>& r, const float* p, bool ok) {
+  r.a = f32x4{0.f, 0.f, 0.f, 0.f}; r.b = r.a;
+  if (ok) { r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 4); }
+}
+__device__ __forceinline__ void ldraw8(Raw8<bf16s>& r, const bf16s* p, bool ok) {
+  r.u = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) r.u = *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&d)[8]) {
+  d[0] = r.a.x; d[1] = r.a.y; d[2] = r.a.z; d[3] = r.a.w; d[4] = r.b.x; d[5] = r.b.y; d[6] = r.b.z; d[7] = r.b.w;
+}
+__device__ __forceinline__ void unpack8(const Raw8<bf16s>& r, float (&d)[8]) {
+  d[0] = __uint_as_float(r.u.x << 16); d[1] = __uint_as_float(r.u.x & 0xffff0000u);
+  d[2] = __uint_as_float(r.u.y << 16); d[3] = __uint_as_float(r.u.y & 0xffff0000u);
+  d[4] = __uint_as_float(r.u.z << 16); d[5] = __uint_as_float(r.u.z & 0xffff0000u);
+  d[6] = __uint_as_float(r.u.w << 16); d[7] = __uint_as_float(r.u.w & 0xffff0000u);
+}
+__device__ __forceinline__ float2 ldraw2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ unsigned ldraw2(const bf16s* p) { return *reinterpret_cast<const unsigned*>(p); }
+__device__ __forceinline__ float2 unpack2(const float2& v) { return v; }
+__device__ __forceinline__ float2 unpack2(unsigned u) { return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)); }
+
 // NT = frame tiles of 16 (T <= 16 NT): queries and frame keys are walked tile by tile, the conditioning tokens are one more key tile
 template <int NT, typename ST = float>
 __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMArgs a) {
@@ -76,19 +103,19 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
 
   // T <= 16 (the training shapes): the next pixel's k / v / q are requested during this pixel's arithmetic (a pixel was load latency + 50 MFMAs +
   // stores in sequence, the same for both waves of a SIMD: 3.85 TB/s)
-  float nk[8], nvc[2][4], nqr[8];
+  Raw8<ST> nk, nqr;
+  decltype(ldraw2(qkv)) nv[4];
+  bool nvok[4] = {false, false, false, false};
   auto request = [&](int pn) {
     const bool okp = pn < a.HW;
     const long long r0 = (long long)b * T * a.HW + min(pn, a.HW - 1);
-    load_row8(nk, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + HID + head * DH + 8 * g, okp && c < T);
-    load_row8(nqr, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + head * DH + 8 * g, okp && c < T);
+    ldraw8(nk, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + HID + head * DH + 8 * g, okp && c < T);
+    ldraw8(nqr, qkv + (r0 + (long long)c * a.HW) * a.ldqkv + head * DH + 8 * g, okp && c < T);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int tv = 4 * g + r;
-      const bool ok = okp && tv < T;
-      const float2 vp = ld2(qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + 2 * c);
-      nvc[0][r] = ok ? vp.x : 0.f;
-      nvc[1][r] = ok ? vp.y : 0.f;
+      nvok[r] = okp && tv < T;
+      nv[r] = ldraw2(qkv + (r0 + (long long)min(tv, T - 1) * a.HW) * a.ldqkv + 2 * HID + head * DH + 2 * c);
     }
   };
   if constexpr (NT == 1) request(blk);
@@ -99,12 +126,14 @@ __global__ __launch_bounds__(512) void temporal_attn_fwd_mfma_kernel(const TFMAr
     float kr[NT][8], vc[NT][2][4];
     float qpre[8];
     if constexpr (NT == 1) {
+      unpack8(nk, kr[0]);
+      unpack8(nqr, qpre);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { kr[0][j] = nk[j]; qpre[j] = nqr[j]; }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vc[0][h][r] = nvc[h][r];
+      for (int r = 0; r < 4; ++r) {
+        const float2 vp = unpack2(nv[r]);
+        vc[0][0][r] = nvok[r] ? vp.x : 0.f;
+        vc[0][1][r] = nvok[r] ? vp.y : 0.f;
+      }
       request(pix + a.blocks_per_sample);
     }
 #pragma unroll
