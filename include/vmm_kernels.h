@@ -91,16 +91,8 @@ int vmm_conv3x3_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 int vmm_conv3x3_fuses_gn(const vmm_conv_desc* d);
 /* host-only query: 1 when vmm_conv3x3_bf16x3 / vmm_conv3x3_f32 would take d as it stands (a_mode, a_img_mod, wrap_h / wrap_w, res ...), else 0 */
 int vmm_conv3x3_accepts(const vmm_conv_desc* d);
-/* The same convolution as Winograd F(2x2, 3x3) on the split-bf16 matrix cores (conv3x3_wino.hip): 16 transform-domain products per 2 x 2 output
- * tile and (cin, cout) instead of 36, input / output transforms in fp32 (exact constants), operands split after the transform: fp32-class
- * results (7e-6 relative against 4.7e-6 for the direct kernel on the same data).  d->w = fmt-8 output of vmm_pack_weights.  Envelope: 3 x 3 /
- * stride 1 / zero padding 1, even H and W whose tile grid (H / 2 x W / 2) divides into blocks of 32..64 tiles with an input patch of at most 324
- * pixels, C1 / C2 multiples of 16, Cout a multiple of 64; fused operand transform (a_mode 1), a_img_mod, bias, residual as in
- * vmm_conv3x3_bf16x3; GroupNorm partial sums in d->gn_part with n = vmm_conv3x3_wino_fuses_gn(d) slots per (sample, group) (0 = not produced).
- * Returns 1 (nothing launched) outside the envelope; vmm_conv3x3_wino_accepts is the host-only query for that. */
-int vmm_conv3x3_wino_bf16x3(const vmm_conv_desc* d, vmm_stream_t stream);
-int vmm_conv3x3_wino_fuses_gn(const vmm_conv_desc* d);
-int vmm_conv3x3_wino_accepts(const vmm_conv_desc* d);
+/* (the Winograd F(2x2, 3x3) variant of this convolution -- built, parity-green, slower -- is declared in vmm_experiments.h and compiled only into
+ * libvmm_hip_exp.so) */
 /* 1x1 / Linear specialisation (to_qkv, to_out vddp.py:319,325,413,421; res_conv vddp.py:297): a workgroup stages its rows' full K
  * extent once in LDS and sweeps all output columns, weights read straight into registers in MFMA fragment order (d->w = fmt-2 output
  * of vmm_pack_weights), 16-byte epilogue stores; same epilogue options as vmm_conv_igemm_*.  ln_gamma != NULL: the rows pass through

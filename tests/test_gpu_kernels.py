@@ -181,8 +181,11 @@ def test_conv3x3_bf16_single_pass(gpu, B, T, H, W, C1, C2, Cout, fused):
                                                       (3, 11, 48, 48, 64, 0, 128, True)])
 def test_conv3x3_winograd_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused):
     """Winograd F(2x2, 3x3) form of the 3x3 convolution (weights G g G^T in fragment order, fmt 8): image borders, partial tile blocks (48 / 36 / 50 of 64
-    tiles), two sources, fused per-sample GN+SiLU operand, bias, residual, the GroupNorm partial sums of the epilogue; same tolerance as the direct kernel."""
+    tiles), two sources, fused per-sample GN+SiLU operand, bias, residual, the GroupNorm partial sums of the epilogue; same tolerance as the direct kernel.
+    An experiment (include/vmm_experiments.h): runs in the process test_experiments_library starts on libvmm_hip_exp.so, skipped on the product library."""
     N, lib = _lib()
+    if not N.experiments_built():
+        pytest.skip("product library: the Winograd kernel lives in libvmm_hip_exp.so")
     g = torch.Generator().manual_seed(21)
     Cin = C1 + C2
     x1 = torch.randn(B, C1, T, H, W, generator=g)
@@ -1919,15 +1922,20 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
         assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_persistent_conv3x3_variants(gpu, mode):
-    """The persistent wave-specialised 3 x 3 kernel is opt-in (VMM_C3_PERSISTENT, read once per process; default 0):
-    the 3 x 3 kernel tests and the denoiser goldens again in a process that uses it for the 64-column 2-D layers (1) / every shape (2)."""
+@pytest.mark.parametrize("env", [{"VMM_C3_PERSISTENT": "1"}, {"VMM_C3_PERSISTENT": "2"}, {"VMM_C3_NJ1": "1"}, {}])
+def test_experiments_library(gpu, env):
+    """libvmm_hip_exp.so (VMM_EXPERIMENTS=1 build, made by __graft_entry__.build()): the kernels that lost their A/B stay parity-green.  The
+    persistent wave-specialised 3 x 3 kernel for the 64-column 2-D layers (1) / every shape (2), the 32-column-wave-tile instance at three
+    workgroups per CU (VMM_C3_NJ1), each selected per process (read once): the 3 x 3 kernel tests and the denoiser goldens again; {}: the Winograd kernel."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VMM_C3_PERSISTENT=mode)
-    env.pop("VMM_C3_LEGACY", None)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k",
-                        "conv3x3_halo or fused_gn or forward_matches_reference_golden"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    exp = os.path.join(root, "videometamaterials_amd", "libvmm_hip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("libvmm_hip_exp.so not built (VMM_EXPERIMENTS=1 python -m videometamaterials_amd.build)")
+    e = dict(os.environ, VMM_LIB_PATH=exp, **env)
+    e.pop("VMM_C3_LEGACY", None)
+    sel = "conv3x3_halo or fused_gn or forward_matches_reference_golden or shared_source" if env else "winograd"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k", sel],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -4,6 +4,7 @@ import json
 import os
 import pickle
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -33,6 +34,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert dp_declared == set(N.DP_SIGNATURES), dp_declared ^ set(N.DP_SIGNATURES)
     for name in dp_declared:
         assert getattr(lib, name) is not None
+    # experiments (include/vmm_experiments.h) are declared apart and are NOT in the product library
+    ex_hdr = open(os.path.join(ROOT, "include", "vmm_experiments.h")).read()
+    ex_declared = set(re.findall(r"^(?:int|int64_t) (vmm_\w+)\(", ex_hdr, flags=re.M))
+    assert ex_declared == set(N.EXPERIMENT_SIGNATURES) and not (ex_declared & declared)
+    if "VMM_LIB_PATH" not in os.environ:
+        import subprocess
+        syms = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r" T (vmm_\w+)", syms))
+        assert exported == declared | dp_declared, exported ^ (declared | dp_declared)
+        assert not [s_ for s_ in exported if "wino" in s_ or "persistent" in s_ or "_pw" in s_]
 
 
 def test_dp_engine_rejects_bad_arguments_without_a_gpu():
@@ -286,6 +297,69 @@ def test_optimizer_state_of_the_wrong_size_is_rejected():
     obj["optimizer"]["state"] = {i + 1: good}  # the same moments one index off (init_conv.bias): must raise, not bind 3 k floats to a 16-float parameter
     with pytest.raises(ValueError, match="does not fit"):
         tr.load_state_dict(obj)
-    obj["optimizer"]["param_groups"][0]["params"] = list(range(len(names) - 1))  # a checkpoint of this repo's earlier layout (no rotary slot)
+    # equal element counts are not enough: a moment of another SHAPE (a checkpoint written in another parameter order) must not bind
+    w = params["init_conv.weight"]
+    other = {"step": torch.tensor(3.0), "exp_avg": torch.ones(w.shape[1], w.shape[0], *w.shape[2:]), "exp_avg_sq": torch.ones(w.shape[1], w.shape[0], *w.shape[2:])}
+    if other["exp_avg"].shape != w.shape:
+        obj["optimizer"]["state"] = {i: other}
+        with pytest.raises(ValueError, match="does not fit"):
+            tr.load_state_dict(obj)
+    # a reference checkpoint whose rotary table is a buffer (one slot fewer, same order): accepted, indices after the slot shift by one
+    obj["optimizer"]["param_groups"][0]["params"] = list(range(len(names) - 1))
+    last = len(names) - 1
+    pl = params[names[last]]
+    obj["optimizer"]["state"] = {i: good, last - 1: {"step": torch.tensor(3.0), "exp_avg": torch.full_like(pl, 2.0).cpu(), "exp_avg_sq": torch.ones_like(pl).cpu()}}
+    tr.load_state_dict(obj)
+    assert float(tr._moments[names[last]][0].sum()) == 2.0 * pl.numel()
+    obj["optimizer"]["param_groups"][0]["params"] = list(range(len(names) - 2))  # any other count is another model
     with pytest.raises(ValueError, match="optimizer state covers"):
         tr.load_state_dict(obj)
+
+
+@pytest.mark.parametrize("ops", ["all", "conv3x3", "proj", "conv3x3,proj"])
+def test_storage_conversions_fit_their_arena_slots(monkeypatch, ops):
+    """Sizing-only build (no GPU) of the mirrored "bf16" plan with the unfused temporal attention and kernel families switched back to fp32 I/O
+    (VMM_A16_OPS): every vmm_convert_act writes into an allocation that holds all the elements it converts.  (Round-4 advisor: resnet_block's
+    mirror_in path cast x1 while self.B was half the batch; the copy was half the size the conversion wrote.)"""
+    import videometamaterials_amd as vm
+    from videometamaterials_amd import plan as P
+    kw, _, _ = helpers.CONFIGS["lagr64"]
+    model = vm.Unet3D(**kw)
+    model.precision = "bf16"
+    model.use_fused_temporal = False
+    monkeypatch.setenv("VMM_A16_OPS", ops)
+    seen = []
+
+    class Checked(P._Builder):
+        def step(self, fn, args, what, flops=0.0, nbytes=0.0):
+            if fn.__name__ == "vmm_convert_act":
+                _, _, dst, dst_bf, n = args
+                off, size = self.arena.log[-1]  # cast() allocates the destination right before the launch
+                assert self.ptr(off) == dst, what
+                assert size >= (n // 2 if dst_bf else n), (what, size, n, dst_bf)
+                seen.append(n)
+            return super().step(fn, args, what, flops, nbytes)
+
+    with torch.inference_mode(False), torch.no_grad():
+        Checked(model, 2, 11, 96, 96, 11, torch.device("cpu"), (1 << 40, 1 << 41, 1 << 42, 1 << 43), False, True, False).build()
+    assert seen  # (the unfused temporal attention has no 2-byte path: the plan does convert)
+
+
+def test_agent_release_fences_keep_their_wait(tmp_path):
+    """ISA check of the ticket hand-over in the 3 x 3 kernel's split epilogue (LABNOTES 9.8): every agent-scope release (buffer_wbl2 sc1) is followed by
+    s_waitcnt vmcnt(0) before the barrier / ticket store.  ROCm 7.2 may drop the wait the fence itself implies (MI355X_MICROARCH.md, "Compiler hazard");
+    the source spells it out in inline asm, and this compiles the file (hipcc cross-compiles without a GPU) and looks."""
+    import shutil
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_isa
+    from videometamaterials_amd import build as b
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "c3.s"
+    subprocess.run([hipcc, *b.FLAGS, "-w", "-S", "--cuda-device-only", "-o", str(out), os.path.join(b.CSRC, "conv3x3_bf16x3.hip")], check=True)
+    ks = scan_isa.kernels(str(out))
+    assert sum(k["wbl2"] for k in ks) > 0  # the split instances are there
+    assert sum(k["wbl2_bad"] for k in ks) == 0
+    assert scan_isa.unguarded_release_fences(["buffer_wbl2 sc1", "s_barrier"]) == 1  # (the detector itself)

@@ -15,6 +15,8 @@ if __name__ == "__main__":
     b.build(verbose=False)
     objs = []
     for s in sorted(glob.glob(os.path.join(b.CSRC, "*.hip"))):
+        if not b.EXPERIMENTS and os.path.basename(s) in b.EXPERIMENT_SOURCES:
+            continue
         stem = os.path.basename(s)[:-4]
         o = os.path.join(b.OBJDIR, stem + ".o")
         if stem in names:

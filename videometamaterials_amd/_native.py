@@ -109,9 +109,6 @@ SIGNATURES = {
     "vmm_conv3x3_f32": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_accepts": [C.POINTER(ConvDesc)],
-    "vmm_conv3x3_wino_bf16x3": [C.POINTER(ConvDesc), c_ptr],
-    "vmm_conv3x3_wino_fuses_gn": [C.POINTER(ConvDesc)],
-    "vmm_conv3x3_wino_accepts": [C.POINTER(ConvDesc)],
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
@@ -243,6 +240,13 @@ SIGNATURES = {
     "vmm_lincomb": [c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_ptr, c_i64, c_ptr],
 }
 
+# include/vmm_experiments.h: entry points of libvmm_hip_exp.so only (VMM_EXPERIMENTS=1 build; bound when the loaded library exports them)
+EXPERIMENT_SIGNATURES = {
+    "vmm_conv3x3_wino_bf16x3": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv3x3_wino_fuses_gn": [C.POINTER(ConvDesc)],
+    "vmm_conv3x3_wino_accepts": [C.POINTER(ConvDesc)],
+}
+
 # include/vmm_dp.h: the data-parallel engine (RCCL bound at run time; nothing here runs unless a DP engine is created)
 c_ptrp = C.POINTER(c_ptr)
 DP_SIGNATURES = {
@@ -289,8 +293,18 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = RESTYPES.get(name, C.c_int)
+        for name, argtypes in EXPERIMENT_SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.argtypes = argtypes
+                fn.restype = C.c_int
         _lib = handle
     return _lib
+
+
+def experiments_built() -> bool:
+    """True when the loaded library is the experiments build (libvmm_hip_exp.so via VMM_LIB_PATH)."""
+    return all(hasattr(lib(), name) for name in EXPERIMENT_SIGNATURES)
 
 
 def check(code: int, what: str) -> None:

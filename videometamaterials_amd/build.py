@@ -1,6 +1,11 @@
 """Build libvmm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m videometamaterials_amd.build [--force]
+    VMM_EXPERIMENTS=1 python -m videometamaterials_amd.build     # -> libvmm_hip_exp.so (select it with VMM_LIB_PATH)
+
+The product library holds the kernels a plan can launch.  The experiments that were built, are parity-green and lost their A/B inside the captured
+step -- the Winograd F(2x2, 3x3) convolution (conv3x3_wino.hip, include/vmm_experiments.h), the persistent wave-specialised 3 x 3 kernel and the
+three-workgroups-per-CU instance (-DVMM_EXPERIMENTS=1 sections of conv3x3_bf16x3.hip) -- are compiled only into the second library.
 """
 from __future__ import annotations
 
@@ -12,10 +17,18 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libvmm_hip.so")
-OBJDIR = os.path.join(HERE, "_obj")
+EXPERIMENTS = os.environ.get("VMM_EXPERIMENTS", "0") not in ("", "0")
+OUT = os.path.join(HERE, "libvmm_hip_exp.so" if EXPERIMENTS else "libvmm_hip.so")
+OBJDIR = os.path.join(HERE, "_obj_exp" if EXPERIMENTS else "_obj")
+EXPERIMENT_SOURCES = {"conv3x3_wino.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-munsafe-fp-atomics"]
+# -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
+#   matrix pipe (55 % for the scalar forms; MI355X_MICROARCH.md "price of one filler beside MFMAs", LABNOTES 7.6).  Measured on one box, libraries
+#   alternating (LABNOTES 10.2): captured sampling step 13.31 -> 13.08 ms, training step 33.97 -> 33.75 ms; it also removes the compiler-made packed
+#   sequences of the kind LABNOTES 9.8 suspected behind the rotated-token-key corruption (the hand-written v_pk intrinsics stay).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+if EXPERIMENTS:
+    FLAGS.append("-DVMM_EXPERIMENTS=1")
 
 
 def _stale(target: str, deps) -> bool:
@@ -27,7 +40,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = [s for s in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) if EXPERIMENTS or os.path.basename(s) not in EXPERIMENT_SOURCES]
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     os.makedirs(OBJDIR, exist_ok=True)
     objs, jobs = [], []

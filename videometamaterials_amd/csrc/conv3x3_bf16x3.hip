@@ -31,6 +31,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// VMM_EXPERIMENTS (python -m videometamaterials_amd.build with VMM_EXPERIMENTS=1 in the environment -> libvmm_hip_exp.so): the kernels that were built,
+// are parity-green and measured SLOWER inside the captured step -- the persistent wave-specialised kernel (LABNOTES 7.3, 7.8) and the 32-column-wave-tile
+// instance at three workgroups per CU (LABNOTES 10.1).  The product library contains neither.
+#ifndef VMM_EXPERIMENTS
+#define VMM_EXPERIMENTS 0
+#endif
 #ifndef VMM_C3_INTERLEAVE
 #define VMM_C3_INTERLEAVE 1
 #endif
@@ -56,6 +62,7 @@ struct C3Args {
   int cps_shift;                 // TS == 2: log2(channel chunks per sub-pixel)
   unsigned tpf_magic, tx_magic;  // floor(2^32 / d) + 1 for d = tiles_per_frame, tiles_x: n / d = mulhi(n, magic) for n d < 2^32 -- a run-time
                                  // division is expanded on the VECTOR unit (v_rcp_iflag) and leaves the wave-uniform tile coordinates in VGPRs
+  int gn_fine = 0;               // 2-D tiles of 16 pixel rows writing GroupNorm slots in the 8-pixel-row layout of the 32-column-wave-tile instance (slot 2k: sums, 2k + 1: zeros)
   unsigned long long* trace = nullptr;  // VMM_C3_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (16 slots per workgroup)
 };
 
@@ -74,8 +81,13 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
 // A16 (single-pass mode only): storage of the feature maps -- 0: fp32 in, fp32 out; 1: bf16 in, bf16 out; 2: bf16 in, fp32 out; 3: fp32 in, bf16 out
 // (the level boundaries of the resampling layers).  bf16 in: a patch item is 8 bytes, and without the fused transform the stored bits ARE the hi
 // plane (no conversion at all between HBM and the LDS patch); bf16 out: the epilogue rounds once, the GroupNorm sums come from the fp32 accumulators.
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0>
+// NJ: 32-column MFMA tiles per wave -- 2: the 64 x 64 wave tile; 1 (unsplit bf16x3 layers with 64 output channels on 2-D tiles): a 64-pixel x 32-column
+// wave tile, 2 x 2 waves = 128 pixels x 64 columns per workgroup, half the accumulators and half the patch items per thread: <= 168 registers, i.e.
+// THREE workgroups per CU (launch bound 3) to cover each other's memory latencies (LABNOTES 10.1).
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0, int NJ = 2>
 __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
+  static_assert(NJ == 2 || (NJ == 1 && !SPLIT && !F32 && !TS && !ONE && A16 == 0), "32-column wave tiles: the unsplit split-bf16 3 x 3 instances");
+  constexpr int WCOLS = NJ * 32;  // output columns per wave
   static_assert(!ONE || !F32, "single pass: bf16 operands");
   static_assert(A16 == 0 || (ONE && !SPLIT), "bf16-stored maps: the unsplit single-pass instances");
   constexpr bool IN16 = A16 == 1 || A16 == 2, OUT16 = A16 == 1 || A16 == 3;
@@ -115,7 +127,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   const int G = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int tile_id = C3_XCD_ORDER ? xcd * (G >> 3) + min(xcd, G & 7) + jx : (int)blockIdx.x;
   const int mtile = tile_id / a.n_tiles;
-  const int n0 = (tile_id % a.n_tiles) * (WN * 64);
+  const int n0 = (tile_id % a.n_tiles) * (WN * WCOLS);
   const int Cin = p.C1 + p.C2;
   const int nchunks = (TS == 2 ? 4 : 1) * Cin / CK;
   const int c_begin = blockIdx.y * a.chunks_per_split;
@@ -262,7 +274,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   // `last` (wave-uniform; unsplit 3 x 3 layers): the tile's last chunk has nothing to prefetch, and the request cannot be skipped without a
   // branch in the step -- it used to re-read its own patch (41 KB per workgroup for nothing).  It fetches the epilogue's bias pieces instead:
   // item ps < 8 = the 16 bytes that bias piece (j, g) = (ps >> 2, ps & 3) of this lane needs, so the epilogue finds them in registers.
-  constexpr int NBIAS = (!SPLIT && !TS && !IN16) ? (MAXP < 8 ? MAXP : 8) : 0;  // bias pieces that ride in the prefetch registers
+  constexpr int NBIAS = (!SPLIT && !TS && !IN16) ? (MAXP < 4 * NJ ? MAXP : 4 * NJ) : 0;  // bias pieces that ride in the prefetch registers
   auto load_patch_item = [&](int cc, int ps, bool last) {
     const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
@@ -281,7 +293,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       // the epilogue waited, vmcnt being in order, for every output store)
       int lko = lane;
       asm volatile("" : "+v"(lko));
-      const float* qb = p.bias ? p.bias + (n0 + wn * 64 + 4 * (lko >> 5) + (ps < NBIAS ? (ps >> 2) * 32 + 8 * (ps & 3) : 0)) : p.a1;
+      const float* qb = p.bias ? p.bias + (n0 + wn * WCOLS + 4 * (lko >> 5) + (ps < NBIAS ? (ps >> 2) * 32 + 8 * (ps & 3) : 0)) : p.a1;
       q = last ? qb : q;
     }
     preg[ps] = *reinterpret_cast<const f32x4*>(q);
@@ -337,31 +349,31 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 
   // weight fragments: plane (column tile nt, k16 step ks, hi|lo) = 64 lanes x 16 bytes contiguous
   const uint4* wf = reinterpret_cast<const uint4*>(p.w);
-  const uint4* bbase[2];
+  const uint4* bbase[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) bbase[j] = wf + (long long)((n0 + wn * 64) / 32 + j) * a.KS * 128 + lane;
+  for (int j = 0; j < NJ; ++j) bbase[j] = wf + (long long)((n0 + wn * WCOLS) / 32 + j) * a.KS * 128 + lane;
   const int cin16 = (TS == 2 ? 4 : 1) * Cin / 16;
   // TS: the unit's corner of the 3 x 3 taps -- rows tr0, tr0 + 1 and columns tc0, tc0 + 1.  TS == 1: the output phase of this wave's 64
   // columns (phase-major columns); TS == 2: the sub-pixel of the channel chunk.
-  const int phase = TS == 1 ? (n0 + wn * 64) / p.Cout : 0;
+  const int phase = TS == 1 ? (n0 + wn * WCOLS) / p.Cout : 0;
   auto corner = [&](int cc, int& tr0, int& tc0) {
     if (TS == 1) { tr0 = phase >> 1; tc0 = phase & 1; }
     else { const int sub = sub_of(cc); tr0 = 1 - (sub >> 1); tc0 = 1 - (sub & 1); }
   };
   auto load_b = [&](uint4 (&d)[4], int ks) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const uint4* q = bbase[j] + (long long)ks * 128;
       d[2 * j] = q[0];
       if constexpr (!ONE) d[2 * j + 1] = q[64];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -428,7 +440,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[i][e], wb[j][e], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j][e], pa[i][e], acc[i][j], 0, 0, 0);
           }
@@ -446,25 +458,34 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       if constexpr (SPLIT) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pix, wgt, c, 0, 0, 0);
       else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0);
     };
-    if constexpr (ONE) {
+    if constexpr (ONE && NJ == 2) {
       acc[0][0] = mm(ah0, bh0, acc[0][0]);
       acc[0][1] = mm(ah0, bh1, acc[0][1]);
       acc[1][0] = mm(ah1, bh0, acc[1][0]);
       acc[1][1] = mm(ah1, bh1, acc[1][1]);
       return;
     }
-    acc[0][0] = mm(al0, bh0, acc[0][0]);
-    acc[0][1] = mm(al0, bh1, acc[0][1]);
-    acc[1][0] = mm(al1, bh0, acc[1][0]);
-    acc[1][1] = mm(al1, bh1, acc[1][1]);
-    acc[0][0] = mm(ah0, bl0, acc[0][0]);
-    acc[0][1] = mm(ah0, bl1, acc[0][1]);
-    acc[1][0] = mm(ah1, bl0, acc[1][0]);
-    acc[1][1] = mm(ah1, bl1, acc[1][1]);
-    acc[0][0] = mm(ah0, bh0, acc[0][0]);
-    acc[0][1] = mm(ah0, bh1, acc[0][1]);
-    acc[1][0] = mm(ah1, bh0, acc[1][0]);
-    acc[1][1] = mm(ah1, bh1, acc[1][1]);
+    if constexpr (NJ == 1) {  // 64 x 32 wave tile: six MFMAs per k16 step, consecutive ones on different accumulators
+      acc[0][0] = mm(al0, bh0, acc[0][0]);
+      acc[1][0] = mm(al1, bh0, acc[1][0]);
+      acc[0][0] = mm(ah0, bl0, acc[0][0]);
+      acc[1][0] = mm(ah1, bl0, acc[1][0]);
+      acc[0][0] = mm(ah0, bh0, acc[0][0]);
+      acc[1][0] = mm(ah1, bh0, acc[1][0]);
+    } else {
+      acc[0][0] = mm(al0, bh0, acc[0][0]);
+      acc[0][1] = mm(al0, bh1, acc[0][1]);
+      acc[1][0] = mm(al1, bh0, acc[1][0]);
+      acc[1][1] = mm(al1, bh1, acc[1][1]);
+      acc[0][0] = mm(ah0, bl0, acc[0][0]);
+      acc[0][1] = mm(ah0, bl1, acc[0][1]);
+      acc[1][0] = mm(ah1, bl0, acc[1][0]);
+      acc[1][1] = mm(ah1, bl1, acc[1][1]);
+      acc[0][0] = mm(ah0, bh0, acc[0][0]);
+      acc[0][1] = mm(ah0, bh1, acc[0][1]);
+      acc[1][0] = mm(ah1, bh0, acc[1][0]);
+      acc[1][1] = mm(ah1, bh1, acc[1][1]);
+    }
   };
 
   // software pipeline over the 18 k16 steps q = 2 tap + half of a chunk: the weight fragments of step q + PFB and the patch fragments
@@ -517,7 +538,22 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
       if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
       mma_step(aa[q & 1], bb[q % NB]);
-      if constexpr (C3_INTERLEAVE && !ONE) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
+      if constexpr (C3_INTERLEAVE && NJ == 1) {  // six MFMAs: two weight-fragment requests, four LDS fragment reads, the step's patch item
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if constexpr (C3_INTERLEAVE && !ONE && NJ == 2) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
         // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
         // longest way), not in front of them as one block during which the matrix pipe runs dry
 #pragma unroll
@@ -587,8 +623,8 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
           orow = g0 + m;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wn * 64 + j * 32 + lrow;
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * WCOLS + j * 32 + lrow;
           float v = acc[i][j][r];
           float* o = p.out + orow * p.ldo + col;
           if (first) {
@@ -606,6 +642,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     // memory side; its atomic adds then landed first and were overwritten.  Seen as one training step in ~800 with a handful of gradients off by 1e-2
     // of their scale, only with several processes on the GPU (LABNOTES 9.8); the few-tile layers that split are too small for the fence to show.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (MI355X_MICROARCH.md "Compiler hazard (ROCm 7.2, gfx950)": hipcc may drop the s_waitcnt vmcnt(0) behind buffer_wbl2 once it can prove the wave's
+    // vmcnt scoreboard empty; inline asm is invisible to that pass, so the wait between the write-back and the ticket is spelled out.  tools/scan_isa.py
+    // checks the built code object for it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
@@ -613,18 +653,18 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     // The eight bias pieces of the lane are requested together and folded into the accumulators after ONE wait (a load -> wait ->
     // add -> store chain per 16-byte piece serialised sixteen L2 latencies per tile); the residual pieces likewise per pixel.
     {
-      f32x4 bv[2][4];
+      f32x4 bv[NJ][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           bv[j][g] = !p.bias                ? f32x4{0.f, 0.f, 0.f, 0.f}
                      : (j * 4 + g < NBIAS) ? preg[(j * 4 + g < NBIAS) ? j * 4 + g : 0]  // (requested during the last chunk's steps)
-                                           : *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + j * 32 + 8 * g + 4 * lk);
+                                           : *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WCOLS - (TS == 1 ? phase * p.Cout : 0) + j * 32 + 8 * g + 4 * lk);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             acc[i][j][4 * g] += bv[j][g].x; acc[i][j][4 * g + 1] += bv[j][g].y; acc[i][j][4 * g + 2] += bv[j][g].z; acc[i][j][4 * g + 3] += bv[j][g].w;
@@ -646,10 +686,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
           orow = (long long)im * 4 * HW + (2 * y + (phase >> 1)) * 2 * W + 2 * x + (phase & 1);
         }
       }
-      const int c0 = n0 + wn * 64 - (TS == 1 ? phase * p.Cout : 0) + 4 * lk;
-      f32x4 rv[2][4];
+      const int c0 = n0 + wn * WCOLS - (TS == 1 ? phase * p.Cout : 0) + 4 * lk;
+      f32x4 rv[NJ][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           rv[j][g] = !p.res ? f32x4{0.f, 0.f, 0.f, 0.f}
@@ -657,7 +697,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
                              : *reinterpret_cast<const f32x4*>(p.res + orow * p.ldres + c0 + j * 32 + 8 * g);
       float* orp = p.out + orow * p.ldo + c0;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = {acc[i][j][4 * g] + rv[j][g].x, acc[i][j][4 * g + 1] + rv[j][g].y, acc[i][j][4 * g + 2] + rv[j][g].z,
@@ -683,7 +723,9 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       auto wave_sums = [&](bool setB) -> float {
         float gv[16];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int k = 8 * NJ; k < 16; ++k) gv[k] = 0.f;  // (32-column wave tiles: runs 4 .. 7 do not exist)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float s1 = 0.f, s2 = 0.f;  // (the bias is already in the accumulators)
@@ -727,7 +769,7 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
       }
       __syncthreads();
       auto put_slot = [&](float* q, float v) { *q = v; };
-      if (tid < WN * 16) {
+      if (tid < WN * 16 && (NJ == 2 || (tid & 15) < 8)) {  // (32-column wave tiles: runs 0 .. 3)
         const int wn2 = tid >> 4, slot = tid & 15, run = slot >> 1;
         float vA = 0.f, vB = 0.f;
 #pragma unroll
@@ -735,14 +777,25 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
           vA += sc[(w2 * WN + wn2) * 16 + slot];
           vB += sc[64 + (w2 * WN + wn2) * 16 + slot];
         }
-        const int cout0 = n0 + wn2 * 64 + (run >> 2) * 32 + (run & 3) * 8;
+        const int cout0 = n0 + wn2 * WCOLS + (run >> 2) * 32 + (run & 3) * 8;
         const int cpg = p.Cout / p.gn_groups, rpg = cpg >> 3;
         const int grp = cout0 / cpg, rig = (cout0 - grp * cpg) >> 3;
         if (MODE) {
           const int fr = img - smpA * p.a_imgs_per_sample;
+          if (NJ == 2 && a.gn_fine) {
+            // the slot list is laid out for tiles of 8 pixel rows (vmm_conv3x3_fuses_gn does not know which arithmetic will run): this tile of 16 rows
+            // covers the fine tiles (2 ty, tx) and (2 ty + 1, tx); the first gets the sums, the second zeros
+            const int t = mtile - img * a.tiles_per_frame, tyi = t / a.tiles_x, txi = t - tyi * a.tiles_x;
+            const int n_contrib = p.a_imgs_per_sample * 2 * a.tiles_per_frame * rpg;
+            float* base = p.gn_part + (((long long)smpA * p.gn_groups + grp) * n_contrib) * 2 + (slot & 1);
+            const int k0 = (fr * 2 * a.tiles_per_frame + (2 * tyi) * a.tiles_x + txi) * rpg + rig;
+            put_slot(base + k0 * 2, vA);
+            put_slot(base + (k0 + a.tiles_x * rpg) * 2, 0.f);
+          } else {
           const int n_contrib = p.a_imgs_per_sample * a.tiles_per_frame * rpg;
           const int k = (fr * a.tiles_per_frame + (mtile - img * a.tiles_per_frame)) * rpg + rig;
           put_slot(p.gn_part + (((long long)smpA * p.gn_groups + grp) * n_contrib + k) * 2 + (slot & 1), vA);
+          }
         } else {
           // sample s owns the tiles floor(s R / BM) .. floor(((s + 1) R - 1) / BM): ceil(R / BM) or one more of them.  Its slot list has
           // room for the larger count; the sample's last tile zeroes the spare slot when the count is the smaller one.
@@ -770,12 +823,21 @@ __global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Arg
   conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0, ONE, A16>(a);
 }
 
+#if VMM_EXPERIMENTS
+// 32-column wave tiles (NJ = 1): 2 x 2 waves = 128 pixels (8 x 16) x 64 columns, three workgroups per CU
+template <int MAXP, int MODE, int PFB>
+__global__ __launch_bounds__(256, 3) void conv3x3_x3n_kernel(const C3Args a) {
+  conv3x3_x3_body<2, 2, MAXP, MODE, PFB, false, false, 0, false, 0, 1>(a);
+}
+#endif
+
 // the resampling layers (TS = 1: Upsample, 2: Downsample) under their own kernel name, so that profiles keep them apart from the 3 x 3 family
 template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false, int A16 = 0>
 __global__ __launch_bounds__(256, 2) void conv_s2_kernel(const C3Args a) {
   conv3x3_x3_body<WM, WN, MAXP, MODE, 1, SPLIT, false, TS, ONE, A16>(a);
 }
 
+#if VMM_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Persistent, wave-specialised variant of the same contraction (unsplit layers).  One workgroup of EIGHT waves per CU walks a list of
 // 256-pixel x 64-column output tiles in 16-channel chunks (nine k16 steps, one per tap):
@@ -1442,6 +1504,8 @@ bool plan_pw(const vmm_conv_desc& d, PWArgs& a) {
   return true;
 }
 
+#endif  // VMM_EXPERIMENTS (persistent kernel)
+
 inline int* c3_launch_counter() { static int n = 0; return &n; }  // one count over all instances
 
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false>
@@ -1483,6 +1547,21 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
   return 0;
 }
 
+#if VMM_EXPERIMENTS
+template <int MAXP, int MODE, int PFB>
+int launch_c3n(const C3Args& a, int mtiles, hipStream_t s) {
+  const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x3n_kernel<MAXP, MODE, PFB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_x3n_kernel<MAXP, MODE, PFB>), dim3((unsigned)(mtiles * a.n_tiles), 1), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+#endif
+
 template <int WM, int WN, int MAXP, int MODE, int TS, bool SPLIT = false, bool ONE = false, int A16 = 0>
 int launch_s2(const C3Args& a, int mtiles, hipStream_t s, int ksplit = 1) {
   const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;  // (+ three rows of zeros for the masked taps of flat row tiles)
@@ -1512,7 +1591,23 @@ int launch_c3_a16(const C3Args& a, int mtiles, hipStream_t s) {
 }
 
 // shape planning shared by the launcher and the query below; returns 0 and fills a / mtiles / ksplit / gn, or the launcher's status
-int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& gn) {
+// 64-column layers on 2-D tiles: the 32-column-wave-tile instance (128-pixel tiles, three workgroups per CU) for the split-bf16 arithmetic, and its
+// GroupNorm slot layout (tiles of 8 pixel rows) for every arithmetic.  A function of the descriptor (and the process environment) alone.
+static bool c3_nj1(const vmm_conv_desc& d) {
+#if VMM_EXPERIMENTS
+  static const int on = [] {
+    const char* e = getenv("VMM_C3_NJ1");
+    const char* pw = getenv("VMM_C3_PERSISTENT");
+    return (e ? atoi(e) : 0) && !(pw && atoi(pw));
+  }();
+  return on && d.Cout == 64 && d.Win >= 32 && d.Win % 16 == 0 && d.Hin % 16 == 0;
+#else
+  (void)d;
+  return false;
+#endif
+}
+
+int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& gn, bool x3 = false) {
   const bool shape_ok = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.off_h == -1 && d.off_w == -1 && d.sgn_h == 1 && d.sgn_w == 1 &&
                         d.Hv == d.Hin && d.Wv == d.Win && d.oscale == 1 && d.Hout == d.Hv && d.Wout == d.Wv && d.ooh == 0 && d.oow == 0 &&
                         d.rot_ncols == 0 && d.q_ncols == 0;
@@ -1573,11 +1668,25 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
        (d.Cout / d.gn_groups) % 8 == 0 && d.nimg % d.a_imgs_per_sample == 0 &&
        (a.mode == 1 || (long long)d.Hin * d.Win * d.a_imgs_per_sample >= BM);
   if (!gn) a.p.gn_part = nullptr;
+  a.gn_fine = 0;
+  if (a.mode == 1 && ksplit == 1 && c3_nj1(d)) {
+    if (x3) {  // 8 x 16 pixel tiles, 2 x 2 waves of 64 pixels x 32 columns
+      a.tiles_per_frame = a.tiles_x * (d.Hin / 8);
+      a.tpf_magic = (unsigned)(0x100000000ull / (unsigned)a.tiles_per_frame) + 1u;
+      a.PR = (8 + 2) * 18;
+      mtiles = d.nimg * a.tiles_per_frame;
+      a.n_tiles = 1;
+      a.gn_fine = 2;  // (marks the instance for the dispatcher)
+    } else {
+      a.gn_fine = 1;
+    }
+  }
   return 0;
 }
 
 }  // namespace
 
+#if VMM_EXPERIMENTS
 // unsplit layers run the persistent wave-specialised kernel (VMM_C3_LEGACY=1 in the environment keeps the one-tile-per-workgroup
 // kernel for A/B measurements; read once)
 // 0: never (default), 1: 2-D tiles of 64-column layers, 2: every shape inside its envelope.
@@ -1606,21 +1715,28 @@ static bool c3_pw_this_launch() {
   static int n = 0;
   return only < 0 || n++ == only;
 }
+#endif
 
 template <bool F32, bool ONE = false>
 int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t s) {
+#if VMM_EXPERIMENTS
   PWArgs pa;
-  if (!ONE && c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
+  if (!ONE && a.gn_fine != 2 && c3_use_pw(a.p, ksplit, pa) && c3_pw_this_launch()) {
     pa.p.gn_part = pa.mode == 1 ? a.p.gn_part : nullptr;  // (cleared by plan_c3 when the statistics are not fused; the persistent kernel fuses them for 2-D tiles only)
     if (getenv("VMM_PW_LOG")) fprintf(stderr, "[pw] Cin %d+%d Cout %d %dx%d nimg %d mode %d units %d a_mode %d gn %p res %p lda %d %d ldo %d\n", a.p.C1, a.p.C2, a.p.Cout, a.p.Hin,
                                       a.p.Win, a.p.nimg, pa.mode, pa.n_units, a.p.a_mode, (void*)pa.p.gn_part, (void*)a.p.res, a.p.lda1, a.p.lda2, a.p.ldo);
     return pa.mode ? launch_pw<1, F32>(pa, s) : launch_pw<0, F32>(pa, s);
   }
+#endif
   if (ksplit > 1) {
     if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32, ONE>(a, mtiles, ksplit, s);
     return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32, ONE>(a, mtiles, ksplit, s);
   }
   if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32, ONE>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32, ONE>(a, mtiles, 1, s);
+#if VMM_EXPERIMENTS
+  if constexpr (!F32 && !ONE)
+    if (a.gn_fine == 2) return launch_c3n<6, 1, 2>(a, mtiles, s);
+#endif
   // (weight fragments two steps ahead where the registers allow it: with the requests interleaved into the MFMA stream one step is less
   // than an L2 round trip)
   constexpr int PF = F32 ? 1 : 2;
@@ -1636,10 +1752,12 @@ extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
   bool gn = false;
   if (plan_c3(*dp, a, mtiles, ksplit, gn) != 0 || !gn) return 0;
   const int rpg = (dp->Cout / dp->gn_groups) >> 3;
+#if VMM_EXPERIMENTS
   PWArgs pa;
   if (c3_use_pw(*dp, ksplit, pa))  // the persistent kernel (2-D tiles only) leaves one slot per 64-pixel wave tile of its 256-pixel tiles
     return pa.mode == 1 ? dp->a_imgs_per_sample * pa.tiles_per_frame * 4 * rpg : 0;
-  if (a.mode == 1) return dp->a_imgs_per_sample * a.tiles_per_frame * rpg;
+#endif
+  if (a.mode == 1) return dp->a_imgs_per_sample * a.tiles_per_frame * rpg * (a.gn_fine ? 2 : 1);
   const int BM = dp->Cout >= 128 ? 128 : 256;
   const long long R = (long long)dp->Hin * dp->Win * dp->a_imgs_per_sample;
   return (int)((R + BM - 1) / BM + 1) * rpg;  // flat row tiles: the most tiles a sample can touch
@@ -1664,7 +1782,7 @@ extern "C" int vmm_conv3x3_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) 
   int mtiles, ksplit;
   bool gn = false;
   if (d.act_bf16) return -1;  // (bf16-stored maps: the single-pass entry point only)
-  const int rc = plan_c3(d, a, mtiles, ksplit, gn);
+  const int rc = plan_c3(d, a, mtiles, ksplit, gn, true);
   if (rc != 0) return rc;
   if (a.total_rows <= 0) return 0;
   const bool wide = d.Cout >= 128;

@@ -97,16 +97,20 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_kernel(const float* __restric
   const int nv = CH >> 1;  // f32x4 pieces of a partial row's CH (P1, P2) pairs
   const int nvl = min(nv, 256), nsl = 256 / nvl, slice = tid / nvl;
   const float* pb = part + ((long long)b * nblk * C + c0) * 2;
-  for (int v = tid % nvl; v < nv; v += nvl) {
+  // (uniform trip count: the barriers below must be reached by every thread -- with `v < nv` as the loop condition a CH whose piece count is not a
+  // multiple of 256 (C = 640: nv = 320) sent the threads through different numbers of barriers; round-4 advisor)
+  for (int v0 = 0; v0 < nv; v0 += nvl) {
+    const int v = v0 + tid % nvl;
+    const bool live = v < nv;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (slice < nsl)
+    if (slice < nsl && live)
       for (int k = slice; k < nblk; k += nsl) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(pb + (long long)k * C * 2 + v * 4);
         acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
       }
     red[tid] = acc;
     __syncthreads();
-    if (slice == 0) {
+    if (slice == 0 && live) {
       for (int k = 1; k < nsl; ++k) {
         const f32x4 x = red[k * nvl + (tid % nvl)];
         acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;

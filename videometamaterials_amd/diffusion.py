@@ -69,6 +69,7 @@ class GaussianDiffusion(nn.Module):
         self.is_ddim_sampling = self.sampling_timesteps < timesteps
         self.ddim_sampling_eta = ddim_sampling_eta
         self._graph_cache = {}
+        self.graph_cache_size = 6  # captured steps kept (LRU); bench.py's guidance sweep needs five
         self.use_graph = True
         self.register_load_state_dict_pre_hook(GaussianDiffusion._ckpt_pre_hook)
 
@@ -255,10 +256,14 @@ class GaussianDiffusion(nn.Module):
         # everything the captured launch list bakes in: shapes, guidance weight, thresholding mode / rank, the denoiser's arithmetic, the sampler
         key = (shape, w, cond.shape[-1], str(cond.device), bool(self.use_dynamic_thres), float(self.dynamic_thres_percentile),
                self.denoise_fn.precision, bool(inject), (self.sampling_timesteps, float(self.ddim_sampling_eta)) if ddim else None)
-        st = self._graph_cache.get(key)
+        st = self._graph_cache.pop(key, None)
         if st is None:
             st = _GraphedStep(self, shape, cond.shape[-1], w, inject=inject, ddim=ddim)
-            self._graph_cache[key] = st
+            # a small LRU: every entry owns its img / x0 / noise buffers and an instantiated graph, and a guidance sweep over many scales or shapes
+            # would otherwise grow device memory for the life of the model (round-4 advisor).  Evicted entries are freed with their last reference.
+            while len(self._graph_cache) >= self.graph_cache_size:
+                self._graph_cache.pop(next(iter(self._graph_cache)))
+        self._graph_cache[key] = st  # (re-inserted: most recently used last)
         st.refresh_weights()
         st.set_cond(cond)
         return st

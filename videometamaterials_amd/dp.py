@@ -444,8 +444,13 @@ class DataParallelTrainer:
             names = self._optimizer_param_names()
             params = dict(self.unet.named_parameters())
             n_ckpt = sum(len(g["params"]) for g in opt["param_groups"])
-            if n_ckpt != len(names):
-                raise ValueError(f"optimizer state covers {n_ckpt} parameters, this model has {len(names)} (reference order, frozen rotary table included)")
+            if n_ckpt == len(names) - 1 and None in names:
+                # a reference checkpoint written under a rotary_embedding_torch release that registers `freqs` as a buffer (the pinned 0.2.3 makes it
+                # a frozen nn.Parameter): the same order without the frozen slot
+                names = [n for n in names if n is not None]
+            elif n_ckpt != len(names):
+                raise ValueError(f"optimizer state covers {n_ckpt} parameters, this model has {len(names)} (reference order, frozen rotary table included) "
+                                 f"or {len(names) - 1} (without it)")
             dev = next(self.unet.parameters()).device
             if not hasattr(self, "_moments"):
                 self._moments = {}
@@ -454,8 +459,10 @@ class DataParallelTrainer:
                 if n is None:
                     continue  # (the frozen rotary table: torch never creates state for it)
                 for key in ("exp_avg", "exp_avg_sq"):  # a moment bound to a parameter of another size would be read out of bounds by vmm_adam_step
-                    if st[key].numel() != params[n].numel():
-                        raise ValueError(f"optimizer state {i} ({key}: {st[key].numel()} elements) does not fit parameter {n} ({params[n].numel()})")
+                    # (shapes, not element counts: to_q / to_k / to_v and many convolutions have equal sizes, and a checkpoint written in another
+                    # parameter order -- e.g. by this package before round 4 -- must not bind silently; flat moments of the right length are accepted)
+                    if tuple(st[key].shape) != tuple(params[n].shape) and not (st[key].dim() == 1 and st[key].numel() == params[n].numel()):
+                        raise ValueError(f"optimizer state {i} ({key}: shape {tuple(st[key].shape)}) does not fit parameter {n} {tuple(params[n].shape)}")
                 if n in self._moments:  # keep the storage the device job tables point at
                     self._moments[n][0].copy_(st["exp_avg"].reshape(-1))
                     self._moments[n][1].copy_(st["exp_avg_sq"].reshape(-1))

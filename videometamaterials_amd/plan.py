@@ -355,7 +355,11 @@ class _Builder:
         """`a` in the wanted storage type; a converted copy (appended to `temps`, freed by the caller with free_temps) when it is stored otherwise."""
         if a is None or bool(a.bf) == bool(bf):
             return a
-        c = self.act(a.C, a.H, a.W, bf)
+        # sized from the SOURCE: resnet_block's mirror_in path casts while self.B is temporarily half the batch, and vmm_convert_act converts a.n
+        # elements whatever self.B says (round-4 advisor: the copy was half the size it needed, the conversion wrote past its arena slot)
+        off = self.alloc(a.n // 2 if bf else a.n)
+        c = Act(off, a.C, a.H, a.W, a.n, self.ptr(off), bool(bf))
+        assert c.na >= (a.n // 2 if bf else a.n)
         self.step(self.lib.vmm_convert_act, (a.ptr, 1 if a.bf else 0, c.ptr, 1 if bf else 0, a.n), "storage conversion (fp32 <-> bf16)", nbytes=6.0 * a.n)
         temps.append(c)
         return c
