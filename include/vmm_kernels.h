@@ -67,6 +67,11 @@ typedef struct vmm_conv_desc {
    * bit 1 = out (and res) point at bf16; 0 = fp32 everywhere.  Honoured by the single-pass entry points (vmm_conv3x3_bf16, vmm_conv_s2_acc_bf16,
    * vmm_proj_bf16, vmm_proj_bf16_res_silu); every other kernel returns -1 for a non-zero value.  ld* stay in ELEMENTS. */
   int32_t act_bf16;
+  /* EXPERIMENTS library only (libvmm_hip_exp.so; the product library ignores both fields): workspace of sk_slots partial output tiles of 128 x 128
+   * floats for the BALANCED launch of the few-tile 3 x 3 layers (a grid of two workgroups per CU shares the launch's (tile, channel chunk) iterations
+   * evenly; the pieces of a tile are added in a fixed order, so results stay bit-reproducible).  Needs split_tickets with n_tickets >= 2048 + sk_slots
+   * (entries 2048.. are the pieces' flags, zero before and after every launch).  NULL: one workgroup per tile. */
+  float* sk_work; int32_t sk_slots;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;

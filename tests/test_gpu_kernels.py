@@ -333,6 +333,91 @@ def test_conv3x3_halo_bf16x3(gpu, B, T, H, W, C1, C2, Cout, fused, exact):
             assert T * H * W < (128 if Cout >= 128 else 256)
 
 
+@pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused,slots", [(1, 11, 12, 12, 256, 0, 512, False, 64), (1, 11, 12, 12, 256, 0, 512, True, 40), (1, 11, 12, 12, 256, 0, 512, False, 200),
+                                                            (2, 3, 12, 12, 128, 128, 256, True, 24), (1, 2, 48, 48, 128, 0, 128, True, 24), (1, 3, 24, 24, 256, 0, 128, False, 16),
+                                                            
+                                                            # a full grid (two workgroups per CU) by the library's own rule: the sampler's 24 x 24 level at batch 8
+                                                            (8, 11, 24, 24, 128, 0, 256, True, 512)])
+@pytest.mark.parametrize("arith", ["x3", "f32", "one"])
+def test_conv3x3_balanced_launch(gpu, B, T, H, W, C1, C2, Cout, fused, slots, arith):
+    """The balanced ("stream-K") launch of the few-tile 3 x 3 layers (conv3x3_sk_kernel: a grid of `slots` workgroups shares the (tile, channel chunk)
+    iterations evenly; tails / middles of tiles travel as partial tiles, heads collect them in iteration order): against F.conv2d, against the
+    one-workgroup-per-tile launch of the same descriptor, bit-reproducible over repeated launches, flags left zero, fused GroupNorm sums."""
+    N, lib = _lib()
+    if not N.experiments_built():
+        pytest.skip("product library: the balanced launch lives in libvmm_hip_exp.so (test_experiments_library runs this test there)")
+    kernel, tol, fmt = {"x3": (lib.vmm_conv3x3_bf16x3, 5e-5, 2), "f32": (lib.vmm_conv3x3_f32, 3e-6, 4), "one": (lib.vmm_conv3x3_bf16, 2e-2, 2)}[arith]
+    g = torch.Generator().manual_seed(31)
+    Cin = C1 + C2
+    x1 = torch.randn(B, C1, T, H, W, generator=g)
+    x2 = torch.randn(B, C2, T, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    xa, coef = x1, None
+    if fused:
+        coef = torch.randn(B, C1, 2, generator=g)
+        xa = F.silu(x1 * coef[:, :, 0][:, :, None, None, None] + coef[:, :, 1][:, :, None, None, None])
+    xin = torch.cat([xa, x2], 1) if C2 else xa
+    ref = F.conv2d(xin.permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W), w, b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    K = 9 * Cin
+    Kpad = (K + 31) // 32 * 32
+    wg = w.contiguous().to(gpu)
+    packed = torch.zeros((Cout + 31) // 32 * 32 * Kpad, device=gpu)
+    job = (N.PackJob * 1)()
+    j = job[0]
+    j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
+    j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, fmt
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
+    N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
+    d = N.ConvDesc()
+    x1r, bg = rows_of(x1).to(gpu), b.to(gpu)
+    x2r = rows_of(x2).to(gpu) if C2 else None
+    cg = coef.to(gpu) if fused else None
+    out = torch.zeros(B * T * H * W, Cout, device=gpu)
+    d.a1, d.C1, d.lda1, d.w, d.bias, d.out, d.ldo = x1r.data_ptr(), C1, C1, packed.data_ptr(), bg.data_ptr(), out.data_ptr(), Cout
+    if C2:
+        d.a2, d.C2, d.lda2 = x2r.data_ptr(), C2, C2
+    d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, H, W, H, W, 1
+    d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+    d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, W, 1, Cout, 32, 1.0
+    d.a_imgs_per_sample = T
+    if fused:
+        d.a_mode, d.a_coef = 1, cg.data_ptr()
+    # reference launch: one workgroup per tile (no workspace, no tickets: neither a split channel reduction nor the balanced grid)
+    N.check(kernel(C.byref(d), _s()), "conv3x3 plain")
+    torch.cuda.synchronize()
+    plain = out.clone()
+    assert relerr(plain.cpu(), ref) < tol
+    tickets = torch.zeros(4096, dtype=torch.int32, device=gpu)
+    work = torch.full((slots * 128 * 128,), float("nan"), device=gpu)
+    d.split_tickets, d.n_tickets = tickets.data_ptr(), tickets.numel()
+    d.sk_work, d.sk_slots = work.data_ptr(), slots
+    G = 8
+    d.gn_part, d.gn_groups = 1, G
+    n_part = lib.vmm_conv3x3_fuses_gn(C.byref(d))
+    assert n_part > 0
+    part = torch.full((B * G, n_part, 2), float("nan"), device=gpu)
+    d.gn_part = part.data_ptr()
+    out.fill_(7.0)
+    N.check(kernel(C.byref(d), _s()), "conv3x3 balanced")
+    torch.cuda.synchronize()
+    first = out.clone()
+    assert relerr(first.cpu(), ref) < tol
+    assert relerr(first.cpu(), plain.cpu()) < (1e-2 if arith == "one" else 2e-6)  # the same products, summed piecewise
+    assert not torch.isnan(work).all()  # the balanced grid ran (partial tiles were published) ...
+    assert int(tickets.abs().sum()) == 0  # ... and every flag is back to zero
+    y = ref.reshape(B, T * H * W, G, Cout // G).double()
+    want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], -1)
+    assert relerr(part.cpu().double().sum(1).reshape(B, G, 2), want) < (5e-3 if arith == "one" else 2e-5)
+    for _ in range(3):
+        out.fill_(7.0)
+        N.check(kernel(C.byref(d), _s()), "conv3x3 balanced")
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    assert int(tickets.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("exact", [False, True])
 def test_conv3x3_shared_source_frames(gpu, exact):
     """a_img_mod of the descriptor (mirrored plans): the frames of the batch's second half read the first half's rows of a1 -- one
@@ -1926,7 +2011,8 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
 def test_experiments_library(gpu, env):
     """libvmm_hip_exp.so (VMM_EXPERIMENTS=1 build, made by __graft_entry__.build()): the kernels that lost their A/B stay parity-green.  The
     persistent wave-specialised 3 x 3 kernel for the 64-column 2-D layers (1) / every shape (2), the 32-column-wave-tile instance at three
-    workgroups per CU (VMM_C3_NJ1), each selected per process (read once): the 3 x 3 kernel tests and the denoiser goldens again; {}: the Winograd kernel."""
+    workgroups per CU (VMM_C3_NJ1), each selected per process (read once): the 3 x 3 kernel tests and the denoiser goldens again; {}: the Winograd kernel, the balanced ("stream-K")
+    launch of the few-tile 3 x 3 layers (kernel test + the goldens: plans built on this library use it)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1935,7 +2021,7 @@ def test_experiments_library(gpu, env):
         pytest.skip("libvmm_hip_exp.so not built (VMM_EXPERIMENTS=1 python -m videometamaterials_amd.build)")
     e = dict(os.environ, VMM_LIB_PATH=exp, **env)
     e.pop("VMM_C3_LEGACY", None)
-    sel = "conv3x3_halo or fused_gn or forward_matches_reference_golden or shared_source" if env else "winograd"
+    sel = "conv3x3_halo or fused_gn or forward_matches_reference_golden or shared_source" if env else "winograd or balanced or forward_matches_reference_golden"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k", sel],
                        cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -44,9 +44,10 @@ __device__ __forceinline__ float val(unsigned h) {  // a float in [-2, 2) with a
                : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9")
 
 // SEQ 0: the original with hipcc's own `s_nop 0`; 2: no wait state at all (does the hardware interlock the read by itself?); 3: `s_nop 1`;
+// 4: the STORE of v[8:9] right behind the v_mov, result read back from memory (hypothesis B, see there);
 // 1: what today's hipcc emits for `p[0] = a c - b s; p[1] = b c + a s` -- v_pk_mul / s_nop 0 / an in-place cross-half v_pk_fma, read at once
 template <int SEQ>
-__global__ __launch_bounds__(256) void pk_kernel(int trips, unsigned seed, unsigned* counts) {
+__global__ __launch_bounds__(256) void pk_kernel(int trips, unsigned seed, unsigned* counts, float* out) {
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned bad = 0, bad_bc = 0, bad_p0 = 0;
   for (int it = 0; it < trips; ++it) {
@@ -70,6 +71,33 @@ __global__ __launch_bounds__(256) void pk_kernel(int trips, unsigned seed, unsig
                    : "=v"(p0), "=v"(p1)
                    : "v"(a), "v"(b), "v"(c), "v"(s)
                    : "v2", "v3", "v4", "v5", "v6", "v7");
+    if constexpr (SEQ == 4) {
+      // hypothesis B: not the v_mov's read of v3 but the STORE's read of v9 is early -- the original stored v[8:9] right behind the v_mov, and what the
+      // p0 instruction leaves in v9 (its unused high half) is b c + 0 in the original too.  Store from inside the sequence, read back from memory.
+      float* q = out + (size_t)tid * 2;
+      asm volatile("v_mov_b32 v6, %1\n\t"
+                   "v_mov_b32 v7, %2\n\t"
+                   "v_mov_b32 v4, %3\n\t"
+                   "v_mov_b32 v5, %4\n\t"
+                   "v_mov_b32 v10, 0\n\t"
+                   "v_mov_b32 v11, 0\n\t"
+                   "s_nop 4\n\t"
+                   "v_pk_mul_f32 v[2:3], v[6:7], v[4:5] op_sel:[1,1] op_sel_hi:[1,0]\n\t"               // v2 = b s, v3 = b c
+                   "v_pk_fma_f32 v[8:9], v[6:7], v[4:5], v[10:11] op_sel_hi:[1,0,1]\n\t"                // v9 = b c + 0 (the unused half of the p0 instruction)
+                   "v_pk_fma_f32 v[8:9], v[6:7], v[4:5], v[2:3] op_sel_hi:[0,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"  // v8 = a c - b s = p0 (v9 = a c - b s too)
+                   "v_pk_fma_f32 v[10:11], v[6:7], v[4:5], v[10:11] op_sel_hi:[1,0,1]\n\t"              // v11 = b c
+                   "v_mov_b32 v9, v11\n\t"                                                             // v9 = b c: what a too-early store would carry
+                   "v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[2:3] op_sel_hi:[1,0,1]\n\t"                  // v3 = s a + v3 = p1
+                   "s_nop 0\n\t"
+                   "v_mov_b32 v9, v3\n\t"
+                   "global_store_dwordx2 %0, v[8:9], off\n\t"
+                   "s_waitcnt vmcnt(0)\n\t"
+                   :
+                   : "v"(q), "v"(a), "v"(b), "v"(c), "v"(s)
+                   : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "memory");
+      p0 = __builtin_nontemporal_load(q);
+      p1 = __builtin_nontemporal_load(q + 1);
+    }
     // the same roundings as the instruction sequence: one product rounded, then a fused multiply-add
     const float want0 = fmaf(a, c, -(b * s));
     const float want1 = SEQ == 1 ? fmaf(b, c, a * s) : fmaf(s, a, b * c);
@@ -88,6 +116,8 @@ __global__ __launch_bounds__(256) void pk_kernel(int trips, unsigned seed, unsig
 int main(int argc, char** argv) {
   const int seq = argc > 1 ? atoi(argv[1]) : 0, launches = argc > 2 ? atoi(argv[2]) : 400;
   unsigned *cnt, h[4] = {0, 0, 0, 0};
+  float* out;
+  hipMalloc(&out, (size_t)256 * 8 * 256 * 8);
   hipMalloc(&cnt, 16);
   hipMemset(cnt, 0, 16);
   hipStream_t st;
@@ -95,10 +125,11 @@ int main(int argc, char** argv) {
   const int blocks = 256 * 8, trips = 2000;  // 8 blocks of 4 waves per CU = 8 waves per SIMD; 2048 * 4 * 2000 = 16.4 M wave-executions per launch
   for (int l = 0; l < launches; ++l) {
     const unsigned seed = 0x1234567u * (l + 1);
-    if (seq == 0) hipLaunchKernelGGL(pk_kernel<0>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt);
-    else if (seq == 1) hipLaunchKernelGGL(pk_kernel<1>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt);
-    else if (seq == 2) hipLaunchKernelGGL(pk_kernel<2>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt);
-    else hipLaunchKernelGGL(pk_kernel<3>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt);
+    if (seq == 0) hipLaunchKernelGGL(pk_kernel<0>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt, out);
+    else if (seq == 1) hipLaunchKernelGGL(pk_kernel<1>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt, out);
+    else if (seq == 2) hipLaunchKernelGGL(pk_kernel<2>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt, out);
+    else if (seq == 3) hipLaunchKernelGGL(pk_kernel<3>, dim3(blocks), dim3(256), 0, st, trips, seed, cnt, out);
+    else hipLaunchKernelGGL(pk_kernel<4>, dim3(blocks), dim3(256), 0, st, trips / 4, seed, cnt, out);
   }
   hipStreamSynchronize(st);
   hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost);

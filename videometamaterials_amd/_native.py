@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("gn_part", c_ptr), ("gn_groups", c_i32),
         ("wrap_h", c_i32), ("wrap_w", c_i32), ("a_img_mod", c_i32),
         ("act_bf16", c_i32),
+        ("sk_work", c_ptr), ("sk_slots", c_i32),
     ]
 
 

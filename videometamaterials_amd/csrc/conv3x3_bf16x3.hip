@@ -33,7 +33,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // VMM_EXPERIMENTS (python -m videometamaterials_amd.build with VMM_EXPERIMENTS=1 in the environment -> libvmm_hip_exp.so): the kernels that were built,
 // are parity-green and measured SLOWER inside the captured step -- the persistent wave-specialised kernel (LABNOTES 7.3, 7.8) and the 32-column-wave-tile
-// instance at three workgroups per CU (LABNOTES 10.1).  The product library contains neither.
+// instance at three workgroups per CU (LABNOTES 10.1), the balanced ("stream-K") launch of the few-tile layers (LABNOTES 10.4: faster launch by launch on the
+// layers it was made for, no faster inside the captured step).  The product library contains none of them.
 #ifndef VMM_EXPERIMENTS
 #define VMM_EXPERIMENTS 0
 #endif
@@ -62,6 +63,7 @@ struct C3Args {
   int cps_shift;                 // TS == 2: log2(channel chunks per sub-pixel)
   unsigned tpf_magic, tx_magic;  // floor(2^32 / d) + 1 for d = tiles_per_frame, tiles_x: n / d = mulhi(n, magic) for n d < 2^32 -- a run-time
                                  // division is expanded on the VECTOR unit (v_rcp_iflag) and leaves the wave-uniform tile coordinates in VGPRs
+  int sk_tiles = 0;              // balanced launch: output tiles of the launch (row tiles x column tiles)
   int gn_fine = 0;               // 2-D tiles of 16 pixel rows writing GroupNorm slots in the 8-pixel-row layout of the 32-column-wave-tile instance (slot 2k: sums, 2k + 1: zeros)
   unsigned long long* trace = nullptr;  // VMM_C3_TRACE=<launch>: wave 0 of every workgroup stamps s_memtime at its phase boundaries (16 slots per workgroup)
 };
@@ -84,8 +86,20 @@ __device__ __forceinline__ void split2c(float x0, float x1, unsigned& hi, unsign
 // NJ: 32-column MFMA tiles per wave -- 2: the 64 x 64 wave tile; 1 (unsplit bf16x3 layers with 64 output channels on 2-D tiles): a 64-pixel x 32-column
 // wave tile, 2 x 2 waves = 128 pixels x 64 columns per workgroup, half the accumulators and half the patch items per thread: <= 168 registers, i.e.
 // THREE workgroups per CU (launch bound 3) to cover each other's memory latencies (LABNOTES 10.1).
-template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0, int NJ = 2>
-__device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
+// One segment of work: channel chunks [c_begin, c_end) of output tile `tile_id`.  The one-tile-per-workgroup kernels call it once; the balanced ("stream-K")
+// instances (SK, below) call it for every piece of a workgroup's share of the launch's (tile, chunk) iterations: sk_mode 0 = the segment is a whole tile
+// (ordinary epilogue), 1 = a tile's tail or middle (the accumulators are PUBLISHED as a partial tile and the segment ends), 2 = a tile's head (the partial
+// tiles of the workgroups that own the rest of the tile are added, in iteration order, then the ordinary epilogue runs).
+struct SKSeg {
+  int mode = 0;
+  int self = 0;     // partial-tile slot / flag of this workgroup (its index in iteration order)
+  int first = 0;    // mode 2: slots first .. first + count - 1 hold the rest of the tile
+  int count = 0;
+};
+
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0, int NJ = 2, bool SK = false>
+__device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_id, const int c_begin, const int c_end, const SKSeg sk) {
+  static_assert(!SK || (NJ == 2 && !SPLIT && !TS && A16 == 0 && WM == 2 && WN == 2), "balanced instances: the unsplit 128 x 128 tiles");
   static_assert(NJ == 2 || (NJ == 1 && !SPLIT && !F32 && !TS && !ONE && A16 == 0), "32-column wave tiles: the unsplit split-bf16 3 x 3 instances");
   constexpr int WCOLS = NJ * 32;  // output columns per wave
   static_assert(!ONE || !F32, "single pass: bf16 operands");
@@ -124,14 +138,10 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
   // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
   // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in
   // one L2 instead of being fetched once per XCD.
-  const int G = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int tile_id = C3_XCD_ORDER ? xcd * (G >> 3) + min(xcd, G & 7) + jx : (int)blockIdx.x;
   const int mtile = tile_id / a.n_tiles;
   const int n0 = (tile_id % a.n_tiles) * (WN * WCOLS);
   const int Cin = p.C1 + p.C2;
   const int nchunks = (TS == 2 ? 4 : 1) * Cin / CK;
-  const int c_begin = blockIdx.y * a.chunks_per_split;
-  const int c_end = min(nchunks, c_begin + a.chunks_per_split);
   if (c_begin >= c_end) return;
 
   int img = 0, ty0 = 0, tx0 = 0, g0 = 0;
@@ -649,6 +659,57 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ticket, blockIdx.y + 1 == gridDim.y ? 0 : (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
+    if constexpr (SK) {
+      // Partial tiles travel through memory as this workgroup's own register image (16 pieces of 16 bytes per thread, piece q of all threads
+      // contiguous: 4 KB per store instruction), written THROUGH to memory and read past the caches (sc0 sc1 on both sides: the two workgroups sit on
+      // different CUs, often different XCDs, whose L1 / L2 are not coherent with each other -- MI355X_MICROARCH.md, "Valid forms").  One flag per
+      // publisher: stores drained (vmcnt(0)) by every wave, barrier, relaxed agent-scope flag store; the reader polls with one lane, and resets the
+      // flag (the array is all zero again when the launch ends).
+      constexpr int SLOT = WM * 64 * WN * 64;  // floats per partial tile
+      int* flags = a.p.split_tickets + 2048;
+      int lt = tid;
+      asm volatile("" : "+v"(lt));  // (the piece addresses are formed HERE: hoisted above the step loops they were spilled to scratch)
+      if (sk.mode == 1) {
+        float* slot = a.p.sk_work + (long long)sk.self * SLOT + lt * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot + ((i * 2 + j) * 4 + g) * 1024), "v"(v) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + sk.self, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      if (sk.mode == 2) {
+        for (int pj = sk.first; pj < sk.first + sk.count; ++pj) {  // fixed order: the sum does not depend on timing
+          if (tid == 0)
+            while (__hip_atomic_load(flags + pj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+          __syncthreads();
+          const float* slot = a.p.sk_work + (long long)pj * SLOT + lt * 4;
+          // (four pieces at a time: sixteen in flight cost 64 registers on top of the accumulators -- scratch)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              f32x4 v[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[g]) : "v"(slot + ((i * 2 + j) * 4 + g) * 1024) : "memory");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                acc[i][j][4 * g] += v[g].x; acc[i][j][4 * g + 1] += v[g].y; acc[i][j][4 * g + 2] += v[g].z; acc[i][j][4 * g + 3] += v[g].w;
+              }
+            }
+          if (tid == 0) __hip_atomic_store(flags + pj, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     // acc[i][j]: rows = output channels (r & 3) + 8 (r >> 2) + 4 lk of column tile j, column = pixel i*32 + lrow of this wave.
     // The eight bias pieces of the lane are requested together and folded into the accumulators after ONE wait (a load -> wait ->
     // add -> store chain per 16-byte piece serialised sixteen L2 latencies per tile); the residual pieces likewise per pixel.
@@ -814,6 +875,57 @@ __device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
     stamp(13);
   }
 }
+
+template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, int TS, bool ONE = false, int A16 = 0, int NJ = 2>
+__device__ __forceinline__ void conv3x3_x3_body(const C3Args& a) {
+  // Workgroup b runs on XCD b % 8 (dispatch order), each XCD has its own L2.  Tiles are numbered so that an XCD works on a CONTIGUOUS
+  // range of them: the column tiles of one row tile (which read the same patch) and neighbouring row tiles (which share halo rows) meet in
+  // one L2 instead of being fetched once per XCD.
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int tile_id = C3_XCD_ORDER ? xcd * (G >> 3) + min(xcd, G & 7) + jx : (int)blockIdx.x;
+  const int nchunks = (TS == 2 ? 4 : 1) * (a.p.C1 + a.p.C2) / CK;
+  const int c_begin = blockIdx.y * a.chunks_per_split;
+  conv3x3_x3_tile<WM, WN, MAXP, MODE, PFB, SPLIT, F32, TS, ONE, A16, NJ, false>(a, tile_id, c_begin, min(nchunks, c_begin + a.chunks_per_split), SKSeg{});
+}
+
+#if VMM_EXPERIMENTS
+// Balanced launch of the few-tile layers (12 x 12 and 24 x 24 levels: 198 .. 792 tiles of 128 x 128 for 512 workgroup slots, i.e. 140 CUs with two
+// long-lived workgroups and 116 with one that finishes early; LABNOTES 10.4).  A grid of exactly two workgroups per CU; workgroup g (in ITERATION order:
+// XCD b % 8 owns a contiguous eighth, so that a tile's pieces and the column tiles sharing a patch meet in one L2) owns iterations
+// [g total / G, (g + 1) total / G) of the launch's tile-major list of (tile, 32-channel chunk) iterations: the tail of one tile, whole tiles, the head of
+// another.  At most its FIRST segment is a tail / middle piece (published early, never waited for); a head is always its last, so the pieces it
+// collects were published long before, or -- a piece that is some workgroup's whole share -- at the same moment.  No workgroup waits before it has
+// published, hence no cycle of waits whatever the dispatch order or residency; sums are added in iteration order (bit-reproducible).
+template <int MAXP, int MODE, int PFB, bool F32, bool ONE>
+__global__ __launch_bounds__(256, 2) void conv3x3_sk_kernel(const C3Args a) {
+  const int G = gridDim.x, b = blockIdx.x;
+  const int gi = (b & 7) * (G >> 3) + (b >> 3);  // (G is a multiple of 8)
+  const int nchunks = (a.p.C1 + a.p.C2) / CK;
+  const long long total = (long long)a.sk_tiles * nchunks;
+  int it = (int)(total * gi / G);
+  const int it1 = (int)(total * (gi + 1) / G);
+  bool first = true;
+  while (it < it1) {
+    const int tile = it / nchunks, c0 = it - tile * nchunks, c1 = min(nchunks, c0 + (it1 - it));
+    SKSeg sk;
+    sk.self = gi;
+    if (c0 > 0) {
+      sk.mode = 1;
+    } else if (c1 < nchunks) {
+      sk.mode = 2;
+      sk.first = gi + 1;
+      const long long tile_end = (long long)(tile + 1) * nchunks;
+      int n = 0;
+      while (gi + 1 + n < G && total * (gi + 1 + n) / G < tile_end) ++n;
+      sk.count = n;
+    }
+    if (!first) __syncthreads();  // every wave is done with the previous segment's patch (and epilogue scratch) in LDS
+    first = false;
+    conv3x3_x3_tile<2, 2, MAXP, MODE, PFB, false, F32, 0, ONE, 0, 2, true>(a, tile, c0, c1, sk);
+    it += c1 - c0;
+  }
+}
+#endif  // VMM_EXPERIMENTS (balanced launch)
 
 template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, bool ONE = false, int A16 = 0>
 #ifndef VMM_C3_WGS
@@ -1548,6 +1660,19 @@ int launch_c3(const C3Args& a, int mtiles, int ksplit, hipStream_t s) {
 }
 
 #if VMM_EXPERIMENTS
+template <int MAXP, int MODE, int PFB, bool F32, bool ONE>
+int launch_c3_sk(const C3Args& a, int grid, hipStream_t s) {
+  const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_sk_kernel<MAXP, MODE, PFB, F32, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_sk_kernel<MAXP, MODE, PFB, F32, ONE>), dim3((unsigned)grid, 1), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int MAXP, int MODE, int PFB>
 int launch_c3n(const C3Args& a, int mtiles, hipStream_t s) {
   const size_t shm = sizeof(unsigned short) * ((size_t)a.PR + 3) * CROW;
@@ -1655,11 +1780,39 @@ int plan_c3(const vmm_conv_desc& d, C3Args& a, int& mtiles, int& ksplit, bool& g
   // How far: a split keeps at least four 32-channel chunks and there are at most four of them.  (Round 3, tools/bench_wino.py with WINO_TICKETS=1,
   // 11 / 22 / 44 frames: the earlier "up to eight" was never the best choice -- 256 -> 256 at 12 x 12, 44 frames: 71 us with eight splits, 50 with
   // two or none; 512 -> 512, 22 frames: 84 / 74 / 92 us with eight / four / none -- the ordered ticket epilogue serialises a tile's splits.)
+  // Balanced launch (conv3x3_sk_kernel): 128 x 128 tiles that fill the two workgroup slots per CU unevenly.  slots = 2 x CUs; a plain launch runs
+  // ceil(tiles / slots) rounds, of which the last is partly empty.  Measured on the Lagrangian sampler (LABNOTES 10.4): it pays where the tiles are more
+  // than one round (24 x 24 level: 792 tiles, 0.183 -> 0.168 ms) or very long (1024 -> 512 at 12 x 12: 0.172 -> 0.162 ms); one under-full round of
+  // 512 -> 512 tiles is as fast unbalanced (0.159 vs 0.161 ms: the CUs with ONE resident workgroup finish early and the chip's clock, not the slot
+  // count, sets the pace), and layers of a few chunks per workgroup lose to the partial-tile traffic.  A caller that passes FEWER slots than two per
+  // CU has chosen the grid itself (the kernel tests do, to reach every segment pattern on small shapes).
+  a.sk_tiles = 0;
+  int sk_grid = 0;
+#if VMM_EXPERIMENTS
+  if (wide && d.sk_work && d.split_tickets && !d.a_img_mod && !d.act_bf16) {
+    static const int sk_env = [] { const char* e = getenv("VMM_C3_SK"); return e ? atoi(e) : 1; }();  // 0: off (A/B runs)
+    static const int n_cu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const bool chosen = d.sk_slots < 2 * n_cu;
+    const int grid = min(2 * n_cu, (int)d.sk_slots) & ~7;
+    const long long rounds = grid ? (blocks + grid - 1) / grid : 0;
+    const bool uneven = blocks * 100 < rounds * grid * 85;
+    if (sk_env && grid >= 8 && nch >= 4 && blocks * nch >= 2LL * grid && d.n_tickets >= 2048 + grid &&
+        (chosen || (uneven && blocks <= 3LL * grid && (blocks >= grid || nch >= 32)))) {
+      a.sk_tiles = (int)blocks;
+      sk_grid = grid;
+    }
+  }
+#endif
   static const int ksplit_max = [] { const char* e = getenv("VMM_C3_KSPLIT_MAX"); return e ? atoi(e) : 4; }();  // (measurement aid)
-  if (blocks < 128 && d.split_tickets && d.n_tickets >= blocks)
+  if (!a.sk_tiles && blocks < 128 && d.split_tickets && d.n_tickets >= blocks)
     ksplit = (int)max(1LL, min((long long)min(nch / 4, ksplit_max), 2048 / max(blocks, 1LL)));
   a.chunks_per_split = (int)cdiv(nch, ksplit);
   ksplit = (int)cdiv(nch, a.chunks_per_split);
+  if (a.sk_tiles) a.chunks_per_split = sk_grid;  // (carries the grid size to the dispatcher; the balanced kernel does not use the field)
   if (d.a_img_mod && (a.mode == 0 || ksplit > 1 || d.a_img_mod < 0 || d.a_img_mod >= d.nimg)) return 1;  // shared source frames: unsplit 2-D tiles only
   // GroupNorm statistics of the output in the epilogue: unsplit 2-D tiles (one frame, hence one sample, per workgroup), groups of whole
   // 8-channel runs, no residual in the output
@@ -1732,6 +1885,10 @@ int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t 
     if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<2, 2, 6, 0, 2, true, F32, ONE>(a, mtiles, ksplit, s);
     return a.mode ? launch_c3<4, 1, 11, 1, 1, true, F32, ONE>(a, mtiles, ksplit, s) : launch_c3<4, 1, 11, 0, 1, true, F32, ONE>(a, mtiles, ksplit, s);
   }
+#if VMM_EXPERIMENTS
+  if (wide && a.sk_tiles)
+    return a.mode ? launch_c3_sk<6, 1, 2, F32, ONE>(a, a.chunks_per_split, s) : launch_c3_sk<6, 0, 2, F32, ONE>(a, a.chunks_per_split, s);
+#endif
   if (wide) return a.mode ? launch_c3<2, 2, 6, 1, 2, false, F32, ONE>(a, mtiles, 1, s) : launch_c3<2, 2, 6, 0, 2, false, F32, ONE>(a, mtiles, 1, s);
 #if VMM_EXPERIMENTS
   if constexpr (!F32 && !ONE)

@@ -36,6 +36,7 @@ LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 # 100-200 K-element slice in ~45 us, the two-launch path (statistics over many workgroups + coefficients) takes ~30 us, so only tiny
 # layers go direct
 GN_DIRECT_MAX = 1 << 14
+SK_SLOTS = 512    # partial-tile slots of the balanced 3 x 3 launch (two workgroups per CU; entries 2048.. of the tickets are their flags)
 N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
 # op classes whose kernels have an instance over bf16-STORED feature maps ("bf16" mode; _Builder.nat16): 3 x 3 convolutions, the stride-2 resampling
@@ -323,6 +324,7 @@ class _Builder:
         self.job_uploads: List[Tuple[int, torch.Tensor]] = []
         self.raw_slots: Dict[str, int] = {}
         self.tickets_ptr: Optional[int] = None
+        self.sk_ptr: Optional[int] = None
 
     # ---------------------------------------------------------------- memory
     def alloc(self, n: int) -> int:
@@ -562,6 +564,12 @@ class _Builder:
         if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
             self.tickets_ptr = self.wslot(N_TICKETS)
         d.split_tickets, d.n_tickets = self.tickets_ptr, N_TICKETS
+        if KH == 3 and KW == 3 and stride == 1 and Cout >= 128 and not self._desc_a16 and _enabled("conv_sk") and N.experiments_built():
+            # workspace of the balanced launch of the few-tile 3 x 3 layers (conv3x3_sk_kernel): one partial 128 x 128 tile per workgroup of a grid of two
+            # per CU; shared by every convolution of the (single-stream) plan like the tickets
+            if self.sk_ptr is None:
+                self.sk_ptr = self.wslot(SK_SLOTS * 128 * 128)
+            d.sk_work, d.sk_slots = self.sk_ptr, SK_SLOTS
         if self._desc_a16 or not _enabled("conv_split"):  # bf16-stored maps: the unsplit instances (no ordered atomic accumulation onto a bf16 output)
             d.split_tickets, d.n_tickets = None, 0
         d.gn_part, d.gn_groups = None, self.G
