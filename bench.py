@@ -235,11 +235,14 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     fl = sum(f for _, f, _ in pl.meta) + sum(f for _, f, _ in pl.bwd_meta)
     out = {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
            "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
-           "arithmetic": "fp32 (exact fp32 MFMA)" if precision == "fp32" else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32",
+           "arithmetic": ("fp32 (exact fp32 MFMA)" if precision == "fp32"
+                          else "bf16: ONE MFMA pass on bf16-rounded operands in forward, data gradients, 3x3 / 1x1 / to_qkv weight gradients and the recomputing attention "
+                               "backward; fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "bf16"
+                          else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32"),
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
            "arena_GB": round(pl.arena_floats * 4 / 1e9, 2), "launches_per_step": len(pl.steps) + len(pl.bwd_steps),
            "attention": ("fused blocks forward (no qkv rows / attention outputs / softmax statistics stored), recomputing backward kernels at the C = 64 sites"
-                         if any(fn.__name__.endswith("block_bwd_bf16x3") for fn, _, _ in pl.bwd_steps) else "unfused (qkv rows through HBM)"),
+                         if any("block_bwd_bf16" in fn.__name__ for fn, _, _ in pl.bwd_steps) else "unfused (qkv rows through HBM)"),
            "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if (world > 1 or rehearse) else 0,
            "dp_engine": (f"native: vmm_dp C ABI over RCCL {tr.engine.rccl_version} (include/vmm_dp.h)" if tr.engine is not None
                          else f"torch.distributed/{dist.get_backend()}" if dist is not None else "none (single rank)")}
@@ -600,6 +603,11 @@ def main():
         train = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, want_roofline=True)
         # the same step in exact-fp32 arithmetic (the parity mode: every gradient within 1e-3 of the reference's fp32 autograd)
         train["fp32_parity_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="fp32")
+        # the reduced-precision leg, BESIDE the headline: one matrix pass on bf16-rounded operands in every contraction that has such an instance
+        # (forward, data and weight gradients; fp32 master weights, activations, accumulation, norms, softmax, Adam) -- the counterpart of the
+        # reference's own recipe, fp16 autocast (main.py:34).  Gradient deviation against fp32 autograd: inside the reference's measured bf16-autocast
+        # deviation at both widths, inside its fp16-autocast deviation at dim 16 (tests/test_gpu_train.py, tests/golden/autocast_lagr*.json)
+        train["reduced_precision_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="bf16")
         model.train_precision = "bf16x3"
         model.eval()
         for k in [k for k, v in model._plans.items() if v.training]:  # the training plans keep every intermediate (19 GB at batch 4):

@@ -581,6 +581,21 @@ int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stre
 int64_t vmm_linattn_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok);
 int vmm_linattn_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 
+/* ---- the reduced-precision training leg (`train_precision = "bf16"`; the counterpart of the reference's fp16 autocast, main.py:34): the same backward
+ * kernels, same arguments, workspaces and envelopes as their _bf16x3 namesakes, with ONE matrix pass per product on the operands' bf16 roundings (fp32
+ * accumulation; the second compilation of their sources with -DVMM_SINGLE_PASS=1).  The forward and data-gradient contractions of that leg are the
+ * single-pass entry points of the sampling path (vmm_conv3x3_bf16, vmm_proj_bf16, vmm_temporal_block_bf16, vmm_linattn_block_bf16, ...). */
+int vmm_conv3x3_wgrad_bf16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                           vmm_stream_t stream);
+int vmm_conv1x1_wgrad_bf16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                           vmm_stream_t stream);
+int vmm_conv1x1_wgrad_bf16_ln(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
+                              const float* ln_gamma, vmm_stream_t stream);
+int vmm_qkv_bwd_bf16(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                     float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream);
+int vmm_temporal_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+int vmm_linattn_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
 typedef struct vmm_dense_bwd_job {
   const float* x; const float* w; const float* b; float* dy; float* dx; float* dw; float* db;

@@ -3,7 +3,7 @@ per-parameter relative deviation of the l1-loss gradients under torch.autocast(f
 reference on the CPU in the build container.  The numbers (not the gradients) are committed as tests/golden/autocast_lagr16.json;
 tests/test_gpu_train.py::test_split_bf16_l1_gradients_inside_the_reference_autocast_deviation holds the split-bf16 training mode against them.
 
-    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=tools/ref_shims:/root/reference:tests python tests/golden/make_golden_autocast.py
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=tools/ref_shims:/root/reference:tests python tests/golden/make_golden_autocast.py [lagr16 | lagr64]
 """
 import contextlib
 import json
@@ -20,7 +20,7 @@ import helpers  # noqa: E402
 from denoising_diffusion_pytorch import GaussianDiffusion, Unet3D  # noqa: E402  (the reference)
 
 torch.set_num_threads(8)
-CFG = "lagr16"
+CFG = sys.argv[1] if len(sys.argv) > 1 else "lagr16"  # (lagr64: the same yardstick at the real widths, for the reduced-precision training leg)
 
 
 def main():

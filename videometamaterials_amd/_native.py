@@ -114,12 +114,16 @@ SIGNATURES = {
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv3x3_wgrad_bf16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
     "vmm_conv1x1_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv1x1_wgrad_bf16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv1x1_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],
     "vmm_conv1x1_wgrad_bf16x3_ln": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv1x1_wgrad_bf16_ln": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_qkv_bwd_workspace": [c_i64, c_i32, c_i32],
     "vmm_qkv_bwd_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_qkv_bwd_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3_ln_stats": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr, c_ptr],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],
@@ -135,8 +139,10 @@ SIGNATURES = {
     "vmm_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bwd_workspace": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_temporal_block_bwd_bf16x3": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_temporal_block_bwd_bf16": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_linattn_block_bwd_workspace": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
     "vmm_linattn_block_bwd_bf16x3": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_linattn_block_bwd_bf16": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_linattn_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_apply_mfma": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_f32, c_ptr],
     "vmm_linattn_bwd_rows_mfma": [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_f32, c_ptr],

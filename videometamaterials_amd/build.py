@@ -21,6 +21,8 @@ EXPERIMENTS = os.environ.get("VMM_EXPERIMENTS", "0") not in ("", "0")
 OUT = os.path.join(HERE, "libvmm_hip_exp.so" if EXPERIMENTS else "libvmm_hip.so")
 OBJDIR = os.path.join(HERE, "_obj_exp" if EXPERIMENTS else "_obj")
 EXPERIMENT_SOURCES = {"conv3x3_wino.hip"}
+# compiled a second time with -DVMM_SINGLE_PASS=1 (object *_sp.o): the `_bf16` entry points of the backward kernels (vmm_common.h, VMM_X3)
+SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
 #   matrix pipe (55 % for the scalar forms; MI355X_MICROARCH.md "price of one filler beside MFMAs", LABNOTES 7.6).  Measured on one box, libraries
@@ -49,6 +51,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+        if os.path.basename(s) in SINGLE_PASS_SOURCES:
+            o = o[:-2] + "_sp.o"
+            objs.append(o)
+            if force or _stale(o, [s] + hdrs):
+                jobs.append([hipcc, *FLAGS, "-DVMM_SINGLE_PASS=1", "-c", s, "-o", o])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):

@@ -53,8 +53,10 @@ __device__ __forceinline__ f32x16 mfma1(const uint4& a, const uint4& b, f32x16 c
 }
 // three passes of the split product: lo.hi + hi.lo + hi.hi
 __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
-  c = mfma1(al, bh, c);
-  c = mfma1(ah, bl, c);
+  if constexpr (!VMM_SINGLE_PASS) {
+    c = mfma1(al, bh, c);
+    c = mfma1(ah, bl, c);
+  }
   c = mfma1(ah, bh, c);
   return c;
 }

@@ -479,6 +479,7 @@ bool supported(int HW, int C, int heads, int ntok) { return C == TC && heads == 
 }  // namespace
 
 // floats of workspace vmm_linattn_block_bwd_bf16x3 needs; 0 outside its envelope (C == 64, heads == 8, dim_head == 32, HW % 32 == 0)
+#if !VMM_SINGLE_PASS
 extern "C" int64_t vmm_linattn_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok) {
   if (!supported(HW, C, heads, ntok) || B <= 0 || T <= 0) return 0;
   int sps;
@@ -487,7 +488,8 @@ extern "C" int64_t vmm_linattn_block_bwd_workspace(int32_t B, int32_t T, int32_t
   return frames * ns * LH * 1024 + frames * ns * (HID * TC) + frames * LH * TAB + 2LL * T * B * ntok * HID;
 }
 
-extern "C" int vmm_linattn_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream) {
+#endif
+extern "C" int VMM_X3(vmm_linattn_block_bwd_, )(const vmm_attn_block_bwd* d, vmm_stream_t stream) {
   const int ntok = d->ek ? d->ntok : 0;
   if (!supported(d->HW, d->C, d->heads, ntok) || (d->ldx & 3) || (d->lddo & 3) || (d->lddqkv & 3) || !d->workspace || !d->fwd_workspace) return 1;
   if (d->B <= 0 || d->T <= 0) return 0;

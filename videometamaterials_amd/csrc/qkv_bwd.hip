@@ -196,9 +196,9 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
             Al[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
           }
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl, acc[j], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) if constexpr (!VMM_SINGLE_PASS) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl, acc[j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh, acc[j], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) if constexpr (!VMM_SINGLE_PASS) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh, acc[j], 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh, acc[j], 0, 0, 0);
         }
@@ -214,8 +214,10 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
           const unsigned char* bp = pb + 2 * GT_PLANE + ((rb0 + u) * 16 + l15) * RP + (kk * 32 + oct4 * 8) * 2;
           const bf16x8 Gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
           const bf16x8 Gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + GR_PLANE));
-          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gl, gyacc[u], 0, 0, 0);
-          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Gh, gyacc[u], 0, 0, 0);
+          if constexpr (!VMM_SINGLE_PASS) {
+            gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gl, gyacc[u], 0, 0, 0);
+            gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Gh, gyacc[u], 0, 0, 0);
+          }
           gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gh, gyacc[u], 0, 0, 0);
         }
       }
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(256) void qkv_bwd_reduce_kernel(const float* __rest
 
 }  // namespace
 
+#if !VMM_SINGLE_PASS
 extern "C" int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq) {
   if (C != CC || Nq != NQ || rows <= 0 || rows % CH) return 0;
   const long long nchunks = (rows + CH - 1) / CH;
@@ -292,7 +295,8 @@ extern "C" int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq) {
 // gy = g W (rows x 64, plain store) and dw_packed[c][n] += g^T y in one pass over g (rows x 768).  x / ln_stats / ln_gamma: y = x when ln_stats is
 // NULL, else y = (x - mean) rstd gamma with (mean, rstd) = ln_stats[r][2].  w_frag = vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand
 // (the to_qkv weight (768, 64) as it lies in torch).  Returns 1 (nothing launched) unless C == 64, Nq == 768 and rows is a multiple of 64.
-extern "C" int vmm_qkv_bwd_bf16x3(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+#endif
+extern "C" int VMM_X3(vmm_qkv_bwd_, )(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
                                   float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream) {
   if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 1) || (ldg & 1) || (ldgy & 3) || (ln_stats && !ln_gamma)) return 1;
   if (rows <= 0) return 0;

@@ -473,6 +473,7 @@ bool supported(int T, int ntok, int HW, int C, int heads) {
 }  // namespace
 
 // floats of workspace vmm_temporal_block_bwd_bf16x3 needs; 0 outside its envelope (C == 64, heads == 8, T <= 16, ntok <= 16, even HW)
+#if !VMM_SINGLE_PASS
 extern "C" int64_t vmm_temporal_block_bwd_workspace(int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, int32_t ntok) {
   if (!supported(T, ntok, HW, C, heads) || B <= 0) return 0;
   const Split s = choose_split(B, HW);
@@ -480,7 +481,8 @@ extern "C" int64_t vmm_temporal_block_bwd_workspace(int32_t B, int32_t T, int32_
   return G * (HID * TC) + G * (HEADS * T * T) + 2LL * s.nsplit * B * ntok * HID;
 }
 
-extern "C" int vmm_temporal_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t stream) {
+#endif
+extern "C" int VMM_X3(vmm_temporal_block_bwd_, )(const vmm_attn_block_bwd* d, vmm_stream_t stream) {
   const int ntok = d->ek ? d->ntok : 0;
   if (!supported(d->T, ntok, d->HW, d->C, d->heads) || (d->ldx & 3) || (d->lddo & 3) || !d->workspace) return 1;
   if (d->bias_on_cond && ntok && ntok != d->T) return -2;

@@ -6,6 +6,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Single-pass instances of the split-bf16 BACKWARD kernels (the reduced-precision training leg, `train_precision = "bf16"`): the translation units listed in
+// build.SINGLE_PASS_SOURCES are compiled a second time with -DVMM_SINGLE_PASS=1.  In that build every split product is its hi * hi pass alone (bf16-rounded
+// operands, fp32 accumulation), the lo planes are neither formed nor multiplied where the source guards them, and the entry points carry `_bf16` where
+// the three-pass build says `_bf16x3` (VMM_X3(vmm_qkv_bwd_, ) -> vmm_qkv_bwd_bf16x3 / vmm_qkv_bwd_bf16); host-only queries (workspace sizes) exist once.
+#ifndef VMM_SINGLE_PASS
+#define VMM_SINGLE_PASS 0
+#endif
+#if VMM_SINGLE_PASS
+#define VMM_X3(pre, post) pre##bf16##post
+#else
+#define VMM_X3(pre, post) pre##bf16x3##post
+#endif
+
 #define VMM_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -140,11 +140,11 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -265,12 +265,14 @@ static bool w1_setup(const vmm_conv_desc& d, int32_t lddy, W1Args& a, int& gz, i
 
 // floats of workspace vmm_conv1x1_wgrad_bf16x3 wants for this layer; 0 = outside the kernel's envelope (1 x 1, stride 1, identity rows, no fused
 // operand transform, C1 / C2 / Cout multiples of 64)
+#if !VMM_SINGLE_PASS
 extern "C" int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, int32_t lddy) {
   W1Args a;
   int gz = 0, tx = 0, ty = 0;
   if (!w1_setup(*dp, lddy, a, gz, tx, ty)) return 0;
   return (int64_t)gz * tx * ty * BLOCK_FLOATS + (int64_t)gz * dp->Cout;
 }
+#endif
 
 // dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] (and dbias[co] += sum_r dY[r][co] when dbias != NULL); d = the FORWARD descriptor of the layer;
 // workspace = vmm_conv1x1_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant).  Returns 1 (nothing launched) outside the envelope.
@@ -300,14 +302,14 @@ static int w1_launch(const vmm_conv_desc* dp, const float* dy, int32_t lddy, flo
   return 0;
 }
 
-extern "C" int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+extern "C" int VMM_X3(vmm_conv1x1_wgrad_, )(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
                                         vmm_stream_t stream) {
   return w1_launch(dp, dy, lddy, dw_packed, dbias, workspace, nullptr, nullptr, stream);
 }
 
 // The same with the layer's input normalised on the way in: x[r][ci] = (a1[r][ci] - mean[r]) * rstd[r] * ln_gamma[ci], (mean, rstd) = ln_stats[r][2] as
 // vmm_proj_bf16x3_ln_stats left them -- the weight gradient of a PreNorm(to_qkv) whose forward fused the LayerNorm (single source: C2 == 0).
-extern "C" int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
+extern "C" int VMM_X3(vmm_conv1x1_wgrad_, _ln)(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
                                            const float* ln_gamma, vmm_stream_t stream) {
   if (!ln_stats || !ln_gamma || dp->C2) return -1;
   return w1_launch(dp, dy, lddy, dw_packed, nullptr, workspace, ln_stats, ln_gamma, stream);

@@ -267,9 +267,9 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
         }
         // pass-major: consecutive MFMAs write different accumulators; lo products first
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[kw], acc[kh * 3 + kw], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[kw], acc[kh * 3 + kw], 0, 0, 0);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[kw], acc[kh * 3 + kw], 0, 0, 0);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[kw], acc[kh * 3 + kw], 0, 0, 0);
       }
@@ -427,6 +427,7 @@ static bool w9_setup(const vmm_conv_desc& d, int32_t lddy, W9Args& a, int& gz) {
 // floats of workspace vmm_conv3x3_wgrad_bf16x3 wants for this layer (partial blocks of every row slice + one bias row per slice); 0 = the
 // layer is outside the kernel's envelope (3 x 3 / stride 1 / pad 1, zero padding, C1 / C2 / Cout multiples of 64; a_mode 1 = the producer's
 // GroupNorm * FiLM -> SiLU on source a1 is applied in the loader)
+#if !VMM_SINGLE_PASS
 extern "C" int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, int32_t lddy) {
   W9Args a;
   int gz = 0;
@@ -438,7 +439,8 @@ extern "C" int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, i
 // Same contract as vmm_conv_wgrad_bf16x3 (which forwards the shapes inside this kernel's envelope here, without a workspace).  Returns 1
 // (nothing launched) outside the envelope.  workspace = vmm_conv3x3_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant): the row
 // slices leave partial blocks there and a second launch totals them in a fixed order (bit-reproducible); NULL: fp32 atomics into dw_packed.
-extern "C" int vmm_conv3x3_wgrad_bf16x3(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+#endif
+extern "C" int VMM_X3(vmm_conv3x3_wgrad_, )(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
                                         vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   W9Args a;

@@ -305,9 +305,9 @@ class _Builder:
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
         prec = getattr(model, "train_precision" if training else "precision", "fp32")
         if prec not in ("fp32", "bf16x3", "bf16"):
-            raise ValueError(f"unknown arithmetic mode {prec!r}: 'fp32' (exact), 'bf16x3' (split-bf16, fp32-class), 'bf16' (single pass, sampling only)")
-        if prec == "bf16" and training:
-            raise ValueError("precision 'bf16' is the single-pass THROUGHPUT mode of the sampling path (BASELINE.json configs[3]); training modes: 'fp32', 'bf16x3'")
+            raise ValueError(f"unknown arithmetic mode {prec!r}: 'fp32' (exact), 'bf16x3' (split-bf16, fp32-class), 'bf16' (single pass: the sampling throughput mode and the reduced-precision training leg)")
+        # (training in "bf16": the reduced-precision leg -- one matrix pass on bf16-rounded operands wherever a kernel has such an instance, fp32 master
+        # weights, fp32 activations in HBM, fp32 accumulation / norms / softmax / optimizer; the counterpart of the reference's fp16 autocast, main.py:34)
         self.x3 = prec in ("bf16x3", "bf16")
         # "bf16": the 3 x 3 convolutions and the fused attention blocks run ONE matrix pass on the operands' bf16 roundings (same packed weights, same
         # launch list); the bandwidth-bound kernels keep their three passes, which cost them no time.  fp32 activations in HBM either way.
@@ -607,7 +607,7 @@ class _Builder:
             wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
             ws = self.alloc(ws_n)
             ln = getattr(dq, "_ln", None)
-            self.step(self.lib.vmm_qkv_bwd_bf16x3, (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
+            self.step(self.lib.vmm_qkv_bwd_bf16 if self.one else self.lib.vmm_qkv_bwd_bf16x3, (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
                                                     self.ptr(ws), rows, x.C, n_out), what + " backward (data + weight gradient)",
                       flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 2 * x.C))
             self.tmp_free((ws, ws_n))
@@ -679,7 +679,7 @@ class _Builder:
             ws_n = int(self.lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), lddy))
             if ws_n:
                 ws = self.alloc(ws_n)
-                self.step(self.lib.vmm_conv3x3_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                self.step(self.lib.vmm_conv3x3_wgrad_bf16 if self.one else self.lib.vmm_conv3x3_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                           flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
@@ -692,10 +692,10 @@ class _Builder:
                 ws = self.alloc(ws_n)
                 if ln:
                     assert not gb_ptr
-                    self.step(self.lib.vmm_conv1x1_wgrad_bf16x3_ln, (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
+                    self.step(self.lib.vmm_conv1x1_wgrad_bf16_ln if self.one else self.lib.vmm_conv1x1_wgrad_bf16x3_ln, (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 else:
-                    self.step(self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                    self.step(self.lib.vmm_conv1x1_wgrad_bf16 if self.one else self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
@@ -1022,7 +1022,7 @@ class _Builder:
                     d.workspace = self.ptr(bws)
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
-                    self.step(self.lib.vmm_linattn_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
+                    self.step(self.lib.vmm_linattn_block_bwd_bf16 if self.one else self.lib.vmm_linattn_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
                               nbytes=4.0 * rows * (4 * x.C + 3 * hid))
                     self.tmp_free((bws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
@@ -1159,7 +1159,7 @@ class _Builder:
                     d.workspace = self.ptr(ws)
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
-                    self.step(self.lib.vmm_temporal_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
+                    self.step(self.lib.vmm_temporal_block_bwd_bf16 if self.one else self.lib.vmm_temporal_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
                               nbytes=4.0 * rows * (2 * x.C + 3 * hid))
                     self.tmp_free((ws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)

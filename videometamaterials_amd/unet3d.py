@@ -49,7 +49,7 @@ PRECISIONS = ("fp32", "bf16x3", "bf16")
 
 
 class Unet3D(nn.Module):
-    PRECISIONS = PRECISIONS  # arithmetic modes of `precision` (sampling); `train_precision` takes the first two
+    PRECISIONS = PRECISIONS  # arithmetic modes of `precision` (sampling) and `train_precision`
     def __init__(
         self,
         dim,
@@ -116,8 +116,11 @@ class Unet3D(nn.Module):
         # relative per contraction; the remaining layers' weight gradients are exact fp32).  Training defaults to fp32: with the reference's l1 loss
         # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3
         # (an order of magnitude inside the reference's own fp16-autocast deviation, tests/test_gpu_train.py).
-        # "bf16" (sampling only) = the throughput mode of BASELINE.json configs[3]: one matrix pass on bf16-rounded operands in the 3 x 3 convolutions
-        # and the fused attention blocks (~1e-2 relative on the denoiser output; tests/test_gpu_hires.py states and checks the tolerance).
+        # "bf16" = the throughput mode of BASELINE.json configs[3]: one matrix pass on bf16-rounded operands in the 3 x 3 convolutions
+        # and the fused attention blocks (~1e-2 relative on the denoiser output; tests/test_gpu_hires.py states and checks the tolerance).  As a
+        # `train_precision` it is the reduced-precision training leg (the counterpart of the reference's fp16 autocast, main.py:34): single-pass forward,
+        # data gradients, 3 x 3 / 1 x 1 / to_qkv weight gradients and recomputing attention backward over fp32 master weights and fp32-stored maps; its
+        # gradients stay inside the reference's own autocast deviation (tests/test_gpu_train.py).
         self.precision = "bf16x3"
         self.train_precision = "fp32"
         # precision "bf16" only: the feature maps of the two upper levels live in HBM as bf16 (one rounding per stored element; half the bytes of the
