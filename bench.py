@@ -402,6 +402,58 @@ def preflight(vm, dev, dist, world, rank, local_rank, backend) -> dict:
     return {"preflight": True, "n_gpus": world, "ok": bool(ok), "checks": checks}
 
 
+def clock_bound_probe(dev, rep: int = 40):
+    """Is the dominant kernel bound by its instruction stream or by the chip's clock / power management?  ONE representative launch of the 3 x 3 kernel
+    (512 -> 512 at 12 x 12, the sampler's batch of 8 x 11 frames) on random operands and on all-zero operands: identical code object, grid and
+    instruction stream, only the bits toggling in the matrix pipe differ (MI355X_MICROARCH.md "DVFS give-back"; tools/bench_c3_data.py, LABNOTES 10.5).
+    HIP events on the launch stream; a measurement of the kernel's environment, not part of any throughput number."""
+    import ctypes as C
+    import math
+    from videometamaterials_amd import _native as N
+    lib = N.lib()
+    s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    nimg, H, Cin, Cout = 88, 12, 512, 512
+    g = torch.Generator(device=dev).manual_seed(5)
+    out = torch.zeros(nimg * H * H, Cout, device=dev)
+    res = {}
+    for kind in ("random", "zero", "random"):
+        x = torch.randn(nimg * H * H, Cin, generator=g, device=dev)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g, device=dev) / math.sqrt(Cin * 9)).contiguous()
+        if kind == "zero":
+            x.zero_()
+            w.zero_()
+        nfl = Cout * 9 * Cin
+        packed = torch.zeros(nfl, device=dev)
+        job = (N.PackJob * 1)()
+        j = job[0]
+        j.torch_w, j.packed = w.data_ptr(), packed.data_ptr()
+        j.TH, j.TW, j.C, j.Cp, j.N = 3, 3, Cin, Cin, Cout
+        j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * 9, 9, 3, 1, 0, 1, 0, 1, 0, 2
+        tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(dev)
+        N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, nfl, 0, s()), "pack")
+        d = N.ConvDesc()
+        d.a1, d.C1, d.lda1, d.w, d.out, d.ldo = x.data_ptr(), Cin, Cin, packed.data_ptr(), out.data_ptr(), Cout
+        d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, H, H, H, 1
+        d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+        d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = H, H, 1, Cout, 32, 1.0
+        d.a_imgs_per_sample = 11
+        for _ in range(5):
+            N.check(lib.vmm_conv3x3_bf16x3(C.byref(d), s()), "conv3x3 probe")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rep):
+            lib.vmm_conv3x3_bf16x3(C.byref(d), s())
+        e1.record()
+        torch.cuda.synchronize()
+        res.setdefault(kind, []).append(e0.elapsed_time(e1) / rep * 1e3)
+    fl = 2.0 * 9 * Cin * Cout * nimg * H * H
+    r_us, z_us = min(res["random"]), res["zero"][0]
+    return {"layer": "3x3 512->512, 12x12, 88 frames (one launch of the dominant family)", "random_operands_us": round(r_us, 1), "zero_operands_us": round(z_us, 1),
+            "random_TFLOPs": round(fl / r_us / 1e6, 1), "zero_TFLOPs": round(fl / z_us / 1e6, 1), "zero_over_random_speed": round(r_us / z_us, 3),
+            "frac_of_roof_on_zero_operands": round(fl / z_us / 1e6 / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
+            "note": "same code object and grid; what real split-bf16 operand data costs is the clock governor's answer to the matrix pipe's switching activity"}
+
+
 def _respawn_under_torchrun(n: int) -> None:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU)."""
     import socket
@@ -647,6 +699,8 @@ def main():
                     "algorithmic_GFLOP_per_step": round(d_fl / reps / 1e9, 1), "algorithmic_GB_per_step": round(d_by / reps / 1e9, 2),
                     "algorithmic_bytes_per_launch": round(d_by / d_n), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
                     "mfma_pipe_util": pmc_mfma_util(dom), "share_of_denoiser_time": round(d_ms / total_ms, 3)}
+        if dom == "vmm_conv3x3_bf16x3" and not args.no_extras:
+            roofline["clock_bound_probe"] = clock_bound_probe(dev)
         attention = {}
         for k in ATTENTION_FAMILIES:
             if k in fam and fam[k][0] > 0:
