@@ -2042,8 +2042,10 @@ static int s2_run(const float* x, int32_t ldx, const float* w_frag, const float*
   const int nch = a.chunks_per_split;  // (s2_plan: all of them)
   static const int ksplit_max = [] { const char* e = getenv("VMM_C3_KSPLIT_MAX"); return e ? atoi(e) : 4; }();  // (measurement aid)
   int ksplit = 1;
-  // (below one workgroup per CU, not per half CU as for the 3 x 3 layers: nothing is lost by splitting here -- no fused GroupNorm sums)
-  static const int s2_blocks = [] { const char* e = getenv("VMM_S2_SPLIT_BELOW"); return e ? atoi(e) : 256; }();  // (measurement aid)
+  // (round 5, same box, environments alternating: splitting below 128 tiles instead of below 256 -- i.e. NOT splitting the 198-tile layers of the
+  // sampler's batch -- conv_s2 family 0.685 -> 0.638 ms per guided step, 0.90 -> 0.79 ms per training step: the ordered ticket epilogue costs more than
+  // the half-empty second workgroup slot)
+  static const int s2_blocks = [] { const char* e = getenv("VMM_S2_SPLIT_BELOW"); return e ? atoi(e) : 128; }();  // (measurement aid)
   if (blocks < s2_blocks && split_tickets && n_tickets >= blocks) ksplit = (int)max(1LL, min((long long)min(nch / 4, ksplit_max), 2048 / max(blocks, 1LL)));
   if (ksplit > 1) {
     a.chunks_per_split = (int)cdiv(nch, ksplit);
