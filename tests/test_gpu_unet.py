@@ -84,13 +84,13 @@ def test_bf16_throughput_mode_against_reference_golden(gpu, cfg_name):
     assert errs["cond"] > 2e-4, errs  # (it is not the three-pass path in disguise)
     used = {fn.__name__ for pl in model._plans.values() for fn, _, _ in pl.steps}
     assert "vmm_conv3x3_bf16" in used and "vmm_conv3x3_bf16x3" not in used, used
-    with pytest.raises(ValueError):
-        model.train_precision = "bf16"
-        model.get_plan(x.shape[0], x.shape[2], x.shape[3], x.shape[4], cond.shape[1], gpu, training=True)
-    with pytest.raises(ValueError):  # (an unknown mode is an error, not a silent fp32)
+    with pytest.raises(ValueError), torch.no_grad():  # (an unknown mode is an error, not a silent fp32)
         model.precision = "fp16"
         model._plans.clear()
         model(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0)
+    with pytest.raises(ValueError):  # (the same for the training arithmetic)
+        model.train_precision = "fp16"
+        model.get_plan(x.shape[0], x.shape[2], x.shape[3], x.shape[4], cond.shape[1], gpu, training=True)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])

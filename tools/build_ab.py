@@ -1,5 +1,5 @@
 """Measurement aid: a second library with extra -D flags on selected sources, for A/B runs of two builds on ONE box (box-to-box
-variance of the captured step is ~3 %):   python tools/build_ab.py conv3x3_bf16x3 -DVMM_C3_XCD_ORDER=0
+variance of the captured step is ~3 %):   python tools/build_ab.py conv3x3_bf16x3 -DVMM_C3_XCD_ORDER=0   (`all` = every source)
 writes videometamaterials_amd/libvmm_hip_ab.so (git-ignored; select it with VMM_LIB_PATH=$PWD/videometamaterials_amd/libvmm_hip_ab.so)."""
 import glob
 import os
@@ -19,13 +19,13 @@ if __name__ == "__main__":
             continue
         stem = os.path.basename(s)[:-4]
         o = os.path.join(b.OBJDIR, stem + ".o")
-        if stem in names:
+        if stem in names or "all" in names:
             o = os.path.join("/tmp", stem + "_ab.o")
             subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-c", s, "-o", o], check=True)
         objs.append(o)
         if os.path.basename(s) in b.SINGLE_PASS_SOURCES:
             o2 = os.path.join(b.OBJDIR, stem + "_sp.o")
-            if stem in names:
+            if stem in names or "all" in names:
                 o2 = os.path.join("/tmp", stem + "_sp_ab.o")
                 subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-DVMM_SINGLE_PASS=1", "-c", s, "-o", o2], check=True)
             objs.append(o2)
