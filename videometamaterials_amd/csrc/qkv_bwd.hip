@@ -22,6 +22,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef VMM_QB_SKIP
+#define VMM_QB_SKIP 0  // measurement builds only (tools/build_ab.py qkv_bwd -DVMM_QB_SKIP=n): bit 0 no weight-gradient MFMAs, bit 1 no data-gradient MFMAs,
+#endif                 // bit 2 no LDS image writes of the g pieces, bit 3 no global loads of g
 constexpr int CH = 64;                  // rows per chunk
 constexpr int NP = 96;                  // columns of g per piece (three 32-column fragments)
 constexpr int NPIECE = 8;               // 768 / 96
@@ -46,36 +49,47 @@ struct QBArgs {
   int nchunks, chunks_per_wg;
 };
 
-__global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+// The body of the kernel for one wave group and loader role (four instances, selected once per wave: no role branches inside the loops, so the
+// compiler's per-register load tracking sees one straight instruction stream per wave).
+//
+// Schedule.  Two wave groups (waves 0-3 / 4-7; a SIMD hosts one wave of each) run half an iteration apart: group 0 does its loader step BEFORE its
+// products of a piece, group 1 AFTER, so that on every SIMD one wave's loader phase -- the wait for its global loads, the splits, the LDS writes --
+// lies under the other wave's matrix phase.  A loader step = wait for everything outstanding (the next piece's g values and a set of W^T fragments:
+// both are needed now, so the wait-for-all the compiler emits costs nothing), stage the piece into the buffer the previous iteration read, request
+// the piece after it and the following fragment set.  Every load has a whole matrix phase + barrier to land; the W^T fragments live in two register
+// sets (group 0 requests piece p + 1's set before the products of piece p, group 1 piece p + 2's set into the registers piece p just released).
+// Per group: three g-loader waves (192 threads = 4 row groups x 48 column pairs) and one y-loader wave (64 threads x 2 items per chunk).
+template <int GRP, bool GROLE>
+__device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, oct4 = lane >> 4;
   const int c_begin = blockIdx.x * a.chunks_per_wg;
   const int n_ch = min(a.chunks_per_wg, a.nchunks - c_begin);
-  if (n_ch <= 0) return;
   const long long r_begin = (long long)c_begin * CH;
   unsigned char* const ybuf = sm + 2 * PIECE_BUF;
 
   // ---------------------------------------------------------------- loaders
-  // g pieces: threads 0..383 (waves 0-5): item = (8 rows `go`, column pair `gp`) of the piece; y chunks: threads 384..511 (waves 6-7): two items
-  // (8 rows, channel pair) per chunk, staged with pieces 0 and 1
-  const bool g_role = wave < 6;
-  const int go = g_role ? tid / 48 : 0, gp = g_role ? tid % 48 : 0;   // 8 row groups x 48 column pairs
-  const int yt = tid - 384, yo0 = (yt >> 5) & 3, ycp = yt & 31;        // item k (0 / 1): row group yo0 + 4 k, channel pair ycp
-  f32x2 gv[8];  // the role's rows in flight (g pieces for waves 0-5, y items for waves 6-7)
-  const f32x2 lg = (!g_role && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
-  // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform base + a 32-bit per-thread offset, so that the row pointers of the eight loads
-  // are not sixteen loop-invariant 64-bit registers per role -- hoisted and spilled by the compiler in the first version)
-  const int g_toff = (8 * go) * a.ldg + 2 * gp, y_toff0 = 8 * yo0 * a.ldx + 2 * ycp;
+  const int gt = tid - 256 * GRP;                                        // 0 .. 191 in the g role
+  const int go = GROLE ? 4 * GRP + gt / 48 : 0, gp = GROLE ? gt % 48 : 0;  // 8 row groups x 48 column pairs
+  const int yt = 64 * GRP + lane, yo0 = (yt >> 5) & 3, ycp = yt & 31;    // y item k (0 / 1): row group yo0 + 4 k, channel pair ycp
+  f32x2 gv[8];  // the role's rows in flight (a g piece, or a y item)
+  const f32x2 lg = (!GROLE && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
+  // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform row base (scalar registers) + ONE 32-bit per-thread offset: eight 64-bit
+  // vector-register addresses per role cost 16 registers each and pushed the first version into scratch, whose reloads sit on the same in-order
+  // counter as the prefetched rows)
+  unsigned g_toff = (unsigned)((8 * go) * a.ldg + 2 * gp), y_toff0 = (unsigned)(8 * yo0 * a.ldx + 2 * ycp);
   auto g_request = [&](long long r0, int piece) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
-    const float* gb = a.g + r0 * a.ldg + piece * NP;
+    const float* gb = a.g + r0 * a.ldg + piece * NP;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(gb + (g_toff + i * a.ldg));
+    for (int i = 0; i < 8; ++i) {
+      const float* rowp = gb + (long long)i * a.ldg;
+      gv[i] = (VMM_QB_SKIP & 8) ? f32x2{1.f, 2.f} : *reinterpret_cast<const f32x2*>(rowp + g_toff);
+    }
   };
-  auto g_stage = [&](long long r0, int buf) {
-    (void)r0;
+  auto g_stage = [&](int buf) {
     unsigned char* base = sm + buf * PIECE_BUF;
+    if ((VMM_QB_SKIP & 4) && gv[0][0] != 12345.f) return;
     float e0[8], e1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
   auto y_request = [&](long long r0, int k) {
     const float* yb = a.x + (r0 + 32 * k) * a.ldx;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(yb + (y_toff0 + i * a.ldx));
+    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(yb + (long long)i * a.ldx + y_toff0);
   };
   auto y_stage = [&](long long r0, int k, int buf) {
     unsigned char* base = ybuf + buf * YT_BUF + (yo0 + 4 * k) * 16;
@@ -145,10 +159,8 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
   // lane' = (oct4 & 1) * 32 + channel % 32
   const int wch = cb * 16 + l15;
   const uint4* wbase = wq + ((long long)((wch >> 5) * KS + (oct4 >> 1)) * 2) * 64 + (oct4 & 1) * 32 + (wch & 31);  // + (2 kk * 2 + lo) * 64
-  // The fragments of piece p + 1 are requested at the END of piece p, BEFORE the loader's next global loads: vmcnt retires in order, so a wait
-  // for these never waits for the HBM loads issued after them (requested inside the piece they would queue behind the g prefetch).
-  uint4 wf[3][2];
-  auto w_request = [&](int piece) {
+  uint4 wfA[3][2], wfB[3][2];
+  auto w_request = [&](int piece, uint4 (&wf)[3][2]) {
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
       wf[kk][0] = wbase[(long long)(2 * (3 * piece + kk) * 2) * 64];
@@ -156,19 +168,20 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
     }
   };
 
-  // ---------------------------------------------------------------- prologue: piece 0 of chunk 0, y of chunk 0
-  if (g_role) {
+  // ---------------------------------------------------------------- prologue: piece 0 of chunk 0 staged, piece 1 requested; y of chunk 0
+  if (GROLE) {
     g_request(r_begin, 0);
-    g_stage(r_begin, 0);
-    w_request(0);
-    g_request(r_begin, 1);
+    g_stage(0);
   } else {
     y_request(r_begin, 0);
     y_stage(r_begin, 0, 0);
     y_request(r_begin, 1);
     y_stage(r_begin, 1, 0);
-    w_request(0);
   }
+  w_request(0, wfA);
+  if (GRP == 1) w_request(1, wfB);
+  __builtin_amdgcn_sched_barrier(0);
+  if (GROLE) g_request(r_begin, 1);
   __syncthreads();
 
   for (int ch = 0; ch < n_ch; ++ch) {
@@ -176,12 +189,40 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
     const bool more_ch = ch + 1 < n_ch;
     f32x4 gyacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // [row block rb0 + u]
     const unsigned char* yb = ybuf + (ch & 1) * YT_BUF;
-#pragma unroll 1
-    for (int p = 0; p < NPIECE; ++p) {  // (a real loop: unrolled eight times the kernel needs 400-500 bytes of scratch per lane)
-      const int buf = p & 1;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
-      const unsigned char* pb = sm + buf * PIECE_BUF;
-      // ---- weight gradient: the piece's three column fragments x channel fragment c (36 MFMAs per owner and piece: well under the ~3.8 k cycles a
-      // piece takes at the HBM rate, and the eight waves take turns)
+
+    // One loader step of piece p: the next piece (in registers since the previous step) goes to the other buffer (read last in iteration p - 1: the
+    // barrier that ended it makes the buffer free for both groups) and the one after it is requested; the y loaders stage the next chunk's rows.
+    // The fragment request goes out BEFORE the g request: loads return in order, so the fragments (L2 hits, needed first) must not queue behind
+    // the HBM rows; with this order the wait for the rows at the next loader step covers them, and the products never wait for memory.
+    auto loader_step = [&](int p, int wpiece, uint4 (&wset)[3][2]) {
+      const bool last_piece = p == NPIECE - 1;
+      if (GROLE) {
+        if (!last_piece || more_ch) g_stage((p & 1) ^ 1);
+        w_request(wpiece, wset);
+        __builtin_amdgcn_sched_barrier(0);
+        // (unconditional: past the last piece the request repeats the chunk's own rows and is never staged -- a skipped request would give the
+        // compiler a path on which the fragment loads are the newest ones, and with it a tighter wait on every path)
+        const bool next_chunk = p + 2 >= NPIECE;
+        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 2) % NPIECE);
+      } else {  // the next chunk's y: one item at a time through the one register set
+        if (more_ch && p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
+        if (more_ch && p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
+        w_request(wpiece, wset);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_ch && p == 0) y_request(r0 + CH, 0);
+        if (more_ch && p == 3) y_request(r0 + CH, 1);
+      }
+    };
+    auto piece_step = [&](int p, uint4 (&cur)[3][2], uint4 (&nxt)[3][2]) {
+      const unsigned char* pb = sm + (p & 1) * PIECE_BUF;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
+      // (the lanes' 32-bit offsets are made opaque once per iteration: as loop invariants the compiler adds them to every wave-uniform row base
+      // outside the loop -- one 64-bit vector-register address per load -- instead of using the scalar-base + vector-offset addressing mode)
+      asm volatile("" : "+v"(g_toff), "+v"(y_toff0));
+      if (GRP == 0) {
+        loader_step(p, (p + 1) % NPIECE, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- weight gradient: the piece's three column fragments x channel fragment c (36 MFMAs per owner and piece; the eight waves take turns)
       auto wgrad_half = [&](f32x16 (&acc)[3], int c) {
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {  // (a real loop over the k16 steps: the step's four fragment pairs are read together, then 9 MFMAs pass-major)
@@ -203,12 +244,14 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
           for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh, acc[j], 0, 0, 0);
         }
       };
-      if (wave == p) wgrad_half(dwA, 0);
-      if (wave == ((p + 1) & 7)) wgrad_half(dwB, 1);
+      if (!(VMM_QB_SKIP & 1)) {
+        if (wave == p) wgrad_half(dwA, 0);
+        if (wave == ((p + 1) & 7)) wgrad_half(dwB, 1);
+      }
       // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over the piece's 96 columns (three k32 steps)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const bf16x8 Wh = __builtin_bit_cast(bf16x8, wf[kk][0]), Wl = __builtin_bit_cast(bf16x8, wf[kk][1]);
+      for (int kk = 0; kk < ((VMM_QB_SKIP & 2) ? 0 : 3); ++kk) {
+        const bf16x8 Wh = __builtin_bit_cast(bf16x8, cur[kk][0]), Wl = __builtin_bit_cast(bf16x8, cur[kk][1]);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const unsigned char* bp = pb + 2 * GT_PLANE + ((rb0 + u) * 16 + l15) * RP + (kk * 32 + oct4 * 8) * 2;
@@ -221,24 +264,16 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
           gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gh, gyacc[u], 0, 0, 0);
         }
       }
-      // ---- loaders.  First the W^T fragments of the next piece (see w_request), then the next piece (already in registers) goes to the other
-      // buffer and the one after it is requested
-      const bool last_piece = p == NPIECE - 1;
-      if (!last_piece || more_ch) w_request((p + 1) % NPIECE);
-      if (g_role) {
-        if (!last_piece || more_ch) {
-          g_stage(last_piece ? r0 + CH : r0, buf ^ 1);
-          const int pn = (p + 2) % NPIECE;
-          const bool next_chunk = p + 2 >= NPIECE;
-          if (!next_chunk || more_ch) g_request(next_chunk ? r0 + CH : r0, pn);
-        }
-      } else if (more_ch) {  // the next chunk's y: one item at a time through the one register set
-        if (p == 0) y_request(r0 + CH, 0);
-        if (p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
-        if (p == 3) y_request(r0 + CH, 1);
-        if (p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
+      if (GRP == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        loader_step(p, (p + 2) % NPIECE, cur);
       }
       __syncthreads();
+    };
+#pragma unroll 1
+    for (int p = 0; p < NPIECE; p += 2) {  // (two pieces per trip: the fragment sets alternate statically)
+      piece_step(p, wfA, wfB);
+      piece_step(p + 1, wfB, wfA);
     }
     // ---- the chunk's data gradient: lane = row (rb0 + u) * 16 + l15, registers = channels cb * 16 + 4 oct4 .. + 3
 #pragma unroll
@@ -258,6 +293,17 @@ __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
       dst[(((wave * 3 + f) * 2 + 0) * 4 + q) * 64 + lane] = f32x4{dwA[f][4 * q], dwA[f][4 * q + 1], dwA[f][4 * q + 2], dwA[f][4 * q + 3]};
       dst[(((wprev * 3 + f) * 2 + 1) * 4 + q) * 64 + lane] = f32x4{dwB[f][4 * q], dwB[f][4 * q + 1], dwB[f][4 * q + 2], dwB[f][4 * q + 3]};
     }
+}
+
+__global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  if (a.nchunks - (int)blockIdx.x * a.chunks_per_wg <= 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) {
+    if ((wave & 3) != 3) qkv_bwd_body<0, true>(a, sm); else qkv_bwd_body<0, false>(a, sm);
+  } else {
+    if ((wave & 3) != 3) qkv_bwd_body<1, true>(a, sm); else qkv_bwd_body<1, false>(a, sm);
+  }
 }
 
 // dw_packed[c][n] += sum over workgroups of the partial blocks (fixed order).  thread = (16-byte piece, slice lane)
