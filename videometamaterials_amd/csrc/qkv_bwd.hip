@@ -9,11 +9,13 @@
 // its values once and writes them into BOTH LDS images a piece needs:
 //   GT [column][row]  (16-byte fragments, rows contiguous)  -> "A" operand of the weight gradient  (contraction over rows)
 //   GR [row][column]  (4-byte pairs, columns contiguous)    -> "B" operand of the data gradient    (contraction over columns)
-// The weight gradient's 768 x 64 accumulators live in registers for the whole kernel (wave w owns channel fragment 0 of piece w and channel fragment 1 of
-// piece w - 1: 96 registers);
-// the data gradient's 64 x 64 tile of a chunk is sixteen 16 x 16 accumulators (two per wave, v_mfma_f32_16x16x32_bf16 with W^T fragments
-// straight from L1 / L2 as the A operand), stored with 16-byte pieces when the chunk's eight pieces are done.  One barrier per piece,
-// double-buffered images; per workgroup partial weight-gradient blocks + a fixed-order reduction, like the other weight-gradient kernels.
+// The weight gradient's 768 x 64 accumulators live in registers for the whole kernel: six 32 x 32 tiles per wave, one of which is at work in a piece
+// (tile t of piece p belongs to wave (p + t) mod 8: every wave has at most 12 MFMAs of weight gradient per piece; round 5 -- before, two owner waves did
+// 36 each and six waited at the barrier).  The data gradient's 64 x 64 tile of a chunk is four 32 x 32 accumulators, each shared by the two wave groups,
+// which split a piece's six k16 steps (W^T fragments straight from L1 / L2 as the A operand); the halves meet in LDS when the chunk's eight pieces are
+// done.  One barrier per piece, double-buffered images, the two wave groups half an iteration apart, two pieces of g in flight per loader thread (see
+// qkv_bwd_body); per workgroup partial weight-gradient blocks + a fixed-order reduction, like the other weight-gradient kernels.
+// 0.573 -> 0.50 ms per 96 x 96 site (batch 4) in round 5; what the knock-out builds (VMM_QB_SKIP) say about the rest: LABNOTES 10.9.
 #include "vmm_common.h"
 #include "../../include/vmm_kernels.h"
 
@@ -24,7 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef VMM_QB_SKIP
 #define VMM_QB_SKIP 0  // measurement builds only (tools/build_ab.py qkv_bwd -DVMM_QB_SKIP=n): bit 0 no weight-gradient MFMAs, bit 1 no data-gradient MFMAs,
-#endif                 // bit 2 no LDS image writes of the g pieces, bit 3 no global loads of g
+#endif                 // bit 2 no LDS image writes of the g pieces, bit 3 no global loads of g, bit 4 the staged values do not depend on the loads
 constexpr int CH = 64;                  // rows per chunk
 constexpr int NP = 96;                  // columns of g per piece (three 32-column fragments)
 constexpr int NPIECE = 8;               // 768 / 96
@@ -34,7 +36,8 @@ constexpr int RP = 2 * NP + 16;         // GR: bytes per row of a plane: 208 = 1
 constexpr int GT_PLANE = NP * TP, GR_PLANE = CH * RP;
 constexpr int PIECE_BUF = 2 * GT_PLANE + 2 * GR_PLANE;   // GT hi | GT lo | GR hi | GR lo = 54 272 bytes
 constexpr int YT_PLANE = CC * TP, YT_BUF = 2 * YT_PLANE;  // 18 432 bytes
-constexpr int LDS_BYTES = 2 * PIECE_BUF + 2 * YT_BUF;     // 145 408 bytes
+constexpr int LDS_BYTES = 2 * PIECE_BUF + 2 * YT_BUF;     // 145 408 bytes (+ GY_SCRATCH behind them)
+constexpr int GY_SCRATCH = 4 * 4 * 64 * 16;              // 16 384 bytes: group 1's halves of the chunk's data-gradient tiles
 constexpr int PART_FLOATS = NQ * CC;
 
 struct QBArgs {
@@ -54,16 +57,17 @@ struct QBArgs {
 //
 // Schedule.  Two wave groups (waves 0-3 / 4-7; a SIMD hosts one wave of each) run half an iteration apart: group 0 does its loader step BEFORE its
 // products of a piece, group 1 AFTER, so that on every SIMD one wave's loader phase -- the wait for its global loads, the splits, the LDS writes --
-// lies under the other wave's matrix phase.  A loader step = wait for everything outstanding (the next piece's g values and a set of W^T fragments:
-// both are needed now, so the wait-for-all the compiler emits costs nothing), stage the piece into the buffer the previous iteration read, request
-// the piece after it and the following fragment set.  Every load has a whole matrix phase + barrier to land; the W^T fragments live in two register
-// sets (group 0 requests piece p + 1's set before the products of piece p, group 1 piece p + 2's set into the registers piece p just released).
+// lies under the other wave's matrix phase.  A loader step = stage the next piece (in its register set since two steps: pieces of even / odd index own
+// one set each, so two pieces per thread are in flight and a load has two iterations to land) into the buffer the previous iteration read, request the
+// piece three ahead into the same registers.  The W^T fragments of the next piece are requested behind this piece's data-gradient products.  Loads
+// return in order, and the compiler sizes every wait for the worst path into the loop: the prologue therefore leaves its requests pending in exactly the
+// order the loop does, every request of the loop is unconditional, and the staged set's registers are pinned at the staging (see the comments there).
 // Per group: three g-loader waves (192 threads = 4 row groups x 48 column pairs) and one y-loader wave (64 threads x 2 items per chunk).
 template <int GRP, bool GROLE>
 __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, oct4 = lane >> 4;
+  const int l31 = lane & 31, half = lane >> 5;
   const int c_begin = blockIdx.x * a.chunks_per_wg;
   const int n_ch = min(a.chunks_per_wg, a.nchunks - c_begin);
   const long long r_begin = (long long)c_begin * CH;
@@ -73,21 +77,21 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   const int gt = tid - 256 * GRP;                                        // 0 .. 191 in the g role
   const int go = GROLE ? 4 * GRP + gt / 48 : 0, gp = GROLE ? gt % 48 : 0;  // 8 row groups x 48 column pairs
   const int yt = 64 * GRP + lane, yo0 = (yt >> 5) & 3, ycp = yt & 31;    // y item k (0 / 1): row group yo0 + 4 k, channel pair ycp
-  f32x2 gv[8];  // the role's rows in flight (a g piece, or a y item)
+  f32x2 gvA[8], gvB[8];  // the role's rows in flight: g pieces of even / odd index (TWO pieces ahead of the products), or a y item (set A)
   const f32x2 lg = (!GROLE && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
   // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform row base (scalar registers) + ONE 32-bit per-thread offset: eight 64-bit
   // vector-register addresses per role cost 16 registers each and pushed the first version into scratch, whose reloads sit on the same in-order
   // counter as the prefetched rows)
   unsigned g_toff = (unsigned)((8 * go) * a.ldg + 2 * gp), y_toff0 = (unsigned)(8 * yo0 * a.ldx + 2 * ycp);
-  auto g_request = [&](long long r0, int piece) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
-    const float* gb = a.g + r0 * a.ldg + piece * NP;  // wave-uniform
+  auto g_request = [&](long long r0, int piece, f32x2 (&gv)[8]) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
+    const float* gb = (VMM_QB_SKIP & 32) ? a.g + piece * NP : a.g + r0 * a.ldg + piece * NP;  // wave-uniform (bit 5: every chunk re-reads the first one -- L2 hits)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float* rowp = gb + (long long)i * a.ldg;
       gv[i] = (VMM_QB_SKIP & 8) ? f32x2{1.f, 2.f} : *reinterpret_cast<const f32x2*>(rowp + g_toff);
     }
   };
-  auto g_stage = [&](int buf) {
+  auto g_stage = [&](int buf, const f32x2 (&gv)[8]) {
     unsigned char* base = sm + buf * PIECE_BUF;
     if ((VMM_QB_SKIP & 4) && gv[0][0] != 12345.f) return;
     float e0[8], e1[8];
@@ -118,11 +122,13 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
     }
   };
   auto y_request = [&](long long r0, int k) {
+    f32x2 (&gv)[8] = gvA;
     const float* yb = a.x + (r0 + 32 * k) * a.ldx;
 #pragma unroll
     for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const f32x2*>(yb + (long long)i * a.ldx + y_toff0);
   };
   auto y_stage = [&](long long r0, int k, int buf) {
+    const f32x2 (&gv)[8] = gvA;
     unsigned char* base = ybuf + buf * YT_BUF + (yo0 + 4 * k) * 16;
     f32x2 st[8];
     if (a.ln_stats) {
@@ -144,155 +150,205 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   };
 
   // ---------------------------------------------------------------- accumulators
-  // piece p's 96 x 64 block is shared by TWO waves: wave p owns channel fragment 0 (dwA), wave p + 1 channel fragment 1 (dwB) -- each piece then costs
-  // its owners 36 MFMAs, not one wave 72
-  f32x16 dwA[3], dwB[3];   // [column fragment j of the piece]
+  // Weight gradient: a piece's 96 x 64 block is six 32 x 32 tiles t = (column fragment j = t % 3, channel fragment c = t / 3); in piece p wave w
+  // works on tile t = (w - p) mod 8 (two waves sit out): every piece costs a wave at most ONE tile (12 MFMAs) instead of costing two owner waves 36 each
+  // with six waiting at the barrier, and over a chunk every wave meets each of its six accumulators once (accumulator t of wave w = piece (w - t) mod 8).
+  f32x16 dw[6];
 #pragma unroll
-  for (int f = 0; f < 3; ++f)
+  for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dwA[f][r] = dwB[f][r] = 0.f;
-  // data-gradient units of this wave: 16 channels cb x 16 rows rb0, rb0 + 1 (the two units share their W^T fragments: six 16-byte loads per piece)
-  const int cb = wave >> 1, rb0 = 2 * (wave & 1);
+    for (int r = 0; r < 16; ++r) dw[t][r] = 0.f;
+  // Data gradient: the chunk's 64 x 64 tile of gy^T as four 32 x 32 tiles (rt = rows, ct = channels), each shared by the two wave groups, which split
+  // a piece's six k16 steps (kh = group: steps 3 kh .. 3 kh + 2); the halves meet in LDS when the chunk's eight pieces are done.  v_mfma_f32_32x32x16_bf16
+  // with W^T fragments straight from L1 / L2 as the A operand: 9 MFMAs on one accumulator (back-to-back issue) and 6 ds_read_b128 per piece and wave,
+  // where sixteen 16 x 16 accumulators cost 18 MFMAs in two dependent chains and 12 reads.
+  const int rt = wave & 1, ct = (wave >> 1) & 1;
   const uint4* wq = reinterpret_cast<const uint4*>(a.wfrag);
   constexpr int KS = NQ / 16;  // k16 planes per column tile of the fmt-2 weights
-  // W^T fragment for 16 x 16 x 32: lane = channel cb * 16 + l15, k = kk * 32 + oct4 * 8 .. + 7  <->  fmt-2 plane (nt = channel / 32, ks = 2 kk + (oct4 >> 1)),
-  // lane' = (oct4 & 1) * 32 + channel % 32
-  const int wch = cb * 16 + l15;
-  const uint4* wbase = wq + ((long long)((wch >> 5) * KS + (oct4 >> 1)) * 2) * 64 + (oct4 & 1) * 32 + (wch & 31);  // + (2 kk * 2 + lo) * 64
-  uint4 wfA[3][2], wfB[3][2];
-  auto w_request = [&](int piece, uint4 (&wf)[3][2]) {
+  // W^T fragment of k16 step ks for channels ct * 32 .. + 31: fmt-2 plane (nt = ct, ks), lane = (8-column group) * 32 + channel % 32
+  const uint4* wbase = wq + ((long long)(ct * KS + 3 * GRP) * 2) * 64 + lane;  // + ((piece * 6 + s) * 2 + plane) * 64
+  uint4 wf[3][2];
+  auto w_request = [&](int piece) {
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-      wf[kk][0] = wbase[(long long)(2 * (3 * piece + kk) * 2) * 64];
-      wf[kk][1] = wbase[(long long)(2 * (3 * piece + kk) * 2 + 1) * 64];
+    for (int sx = 0; sx < 3; ++sx) {
+      wf[sx][0] = wbase[(long long)((piece * 6 + sx) * 2) * 64];
+      wf[sx][1] = wbase[(long long)((piece * 6 + sx) * 2 + 1) * 64];
     }
   };
+  float* const gscr = reinterpret_cast<float*>(sm + LDS_BYTES);  // [4 tiles][4 register quads][64 lanes] x 16 bytes: group 1's halves of gy^T
 
   // ---------------------------------------------------------------- prologue: piece 0 of chunk 0 staged, piece 1 requested; y of chunk 0
   if (GROLE) {
-    g_request(r_begin, 0);
-    g_stage(0);
+    g_request(r_begin, 0, gvA);
+    g_stage(0, gvA);
   } else {
     y_request(r_begin, 0);
     y_stage(r_begin, 0, 0);
     y_request(r_begin, 1);
     y_stage(r_begin, 1, 0);
   }
-  w_request(0, wfA);
-  if (GRP == 1) w_request(1, wfB);
-  __builtin_amdgcn_sched_barrier(0);
-  if (GROLE) g_request(r_begin, 1);
+  // (The requests go out in the order in which the loop leaves them pending at its top -- group 0: set B, set A, fragments; group 1: set B, fragments,
+  // set A -- and not interleaved: the compiler sizes the waits inside the loop for the worst path into it, and a prologue that leaves the loads in
+  // another order tightens every wait of the steady state.)
+  // (compiler-level memory barriers between them: a scheduling barrier alone does not keep the two sets' loads, which share their address registers,
+  // from being merged into one interleaved run)
+  asm volatile("" ::: "memory");
+  if (GROLE) g_request(r_begin, 1, gvB);
+  asm volatile("" ::: "memory");
+  if (GRP == 1) w_request(0);
+  asm volatile("" ::: "memory");
+  if (GROLE) g_request(r_begin, 2, gvA);
+  asm volatile("" ::: "memory");
+  if (GRP == 0) w_request(0);
+  asm volatile("" ::: "memory");
   __syncthreads();
 
   for (int ch = 0; ch < n_ch; ++ch) {
     const long long r0 = r_begin + (long long)ch * CH;
     const bool more_ch = ch + 1 < n_ch;
-    f32x4 gyacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // [row block rb0 + u]
+    f32x16 gyacc;  // gy^T{channel ct * 32 + (r & 3) + 8 (r >> 2) + 4 half, row rt * 32 + l31}: this group's half of the sum over the 768 columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gyacc[r] = 0.f;
     const unsigned char* yb = ybuf + (ch & 1) * YT_BUF;
 
     // One loader step of piece p: the next piece (in registers since the previous step) goes to the other buffer (read last in iteration p - 1: the
     // barrier that ended it makes the buffer free for both groups) and the one after it is requested; the y loaders stage the next chunk's rows.
-    // The fragment request goes out BEFORE the g request: loads return in order, so the fragments (L2 hits, needed first) must not queue behind
-    // the HBM rows; with this order the wait for the rows at the next loader step covers them, and the products never wait for memory.
-    auto loader_step = [&](int p, int wpiece, uint4 (&wset)[3][2]) {
+    // One loader step of piece p: piece p + 1 (in its register set since the step of piece p - 2) goes to the other buffer (read last in iteration
+    // p - 1: the barrier that ended it makes the buffer free for both groups) and piece p + 3 is requested into the same registers -- two pieces are in
+    // flight per thread, so that a load has two iterations to land and a wait for a younger load (they return in order) never waits for memory.  The y
+    // loaders stage the next chunk's rows one item at a time.  (The g request is unconditional: past the last piece it repeats rows of the current
+    // chunk and is never staged; a skipped request would give the compiler a path with fewer loads behind the ones it waits for, i.e. a tighter wait
+    // on every path.)
+    auto loader_step = [&](int p, f32x2 (&gv)[8]) {
       const bool last_piece = p == NPIECE - 1;
       if (GROLE) {
-        if (!last_piece || more_ch) g_stage((p & 1) ^ 1);
-        w_request(wpiece, wset);
-        __builtin_amdgcn_sched_barrier(0);
-        // (unconditional: past the last piece the request repeats the chunk's own rows and is never staged -- a skipped request would give the
-        // compiler a path on which the fragment loads are the newest ones, and with it a tighter wait on every path)
-        const bool next_chunk = p + 2 >= NPIECE;
-        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 2) % NPIECE);
-      } else {  // the next chunk's y: one item at a time through the one register set
-        if (more_ch && p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
-        if (more_ch && p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
-        w_request(wpiece, wset);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more_ch && p == 0) y_request(r0 + CH, 0);
-        if (more_ch && p == 3) y_request(r0 + CH, 1);
+        if (VMM_QB_SKIP & 16) {  // measurement: the loads are issued and retired, but the staged values do not depend on them (no wait before the staging)
+          f32x2 cst[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cst[i] = f32x2{1.f + i, 2.f};
+          g_stage((p & 1) ^ 1, cst);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(gv[i]));
+        } else
+        // (the set's registers are pinned HERE: the splits are plain vector arithmetic, which the scheduler otherwise lifts across the barrier into the
+        // previous half-step -- and with them the wait for this set, a whole matrix phase early)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(gv[i]));
+        if (!last_piece || more_ch) g_stage((p & 1) ^ 1, gv);
+        __builtin_amdgcn_sched_barrier(0);  // (the request stays behind the staging: hoisted above it, it would sit between the staged set's loads and its wait)
+        const bool next_chunk = p + 3 >= NPIECE;
+        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 3) % NPIECE, gv);
+      } else if (more_ch) {
+        if (p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
+        if (p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
+        if (p == 0) y_request(r0 + CH, 0);
+        if (p == 3) y_request(r0 + CH, 1);
       }
     };
-    auto piece_step = [&](int p, uint4 (&cur)[3][2], uint4 (&nxt)[3][2]) {
+    auto piece_step = [&](int p, f32x2 (&gv)[8]) {  // gv: the register set of piece p + 1
       const unsigned char* pb = sm + (p & 1) * PIECE_BUF;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
       // (the lanes' 32-bit offsets are made opaque once per iteration: as loop invariants the compiler adds them to every wave-uniform row base
       // outside the loop -- one 64-bit vector-register address per load -- instead of using the scalar-base + vector-offset addressing mode)
       asm volatile("" : "+v"(g_toff), "+v"(y_toff0));
       if (GRP == 0) {
-        loader_step(p, (p + 1) % NPIECE, nxt);
+        loader_step(p, gv);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- weight gradient: the piece's three column fragments x channel fragment c (36 MFMAs per owner and piece; the eight waves take turns)
-      auto wgrad_half = [&](f32x16 (&acc)[3], int c) {
-#pragma unroll 1
-        for (int s = 0; s < 4; ++s) {  // (a real loop over the k16 steps: the step's four fragment pairs are read together, then 9 MFMAs pass-major)
-          bf16x8 Ah[3], Al[3];
-          const unsigned char* bp = yb + (c * 32 + l31) * TP + s * 32 + half * 16;
-          const bf16x8 Bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
-          const bf16x8 Bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + YT_PLANE));
+      // ---- weight gradient: this wave's tile of the piece (12 MFMAs; fragments of step s + 1 requested before the products of step s)
+      auto wg_tile = [&](f32x16& acc, int j, int c) {
+        const unsigned char* bp = yb + (c * 32 + l31) * TP + half * 16;
+        const unsigned char* ap = pb + (j * 32 + l31) * TP + half * 16;
+        uint4 F[2][4];  // [step parity][A hi, A lo, B hi, B lo]
+        auto rd = [&](int sx, uint4 (&f)[4]) {
+          f[0] = *reinterpret_cast<const uint4*>(ap + sx * 32);
+          f[1] = *reinterpret_cast<const uint4*>(ap + sx * 32 + GT_PLANE);
+          f[2] = *reinterpret_cast<const uint4*>(bp + sx * 32);
+          f[3] = *reinterpret_cast<const uint4*>(bp + sx * 32 + YT_PLANE);
+        };
+        rd(0, F[0]);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const unsigned char* ap = pb + (j * 32 + l31) * TP + s * 32 + half * 16;
-            Ah[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-            Al[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + GT_PLANE));
+        for (int sx = 0; sx < 4; ++sx) {
+          if (sx < 3) rd(sx + 1, F[(sx + 1) & 1]);
+          const bf16x8 Ah = __builtin_bit_cast(bf16x8, F[sx & 1][0]), Al = __builtin_bit_cast(bf16x8, F[sx & 1][1]);
+          const bf16x8 Bh = __builtin_bit_cast(bf16x8, F[sx & 1][2]), Bl = __builtin_bit_cast(bf16x8, F[sx & 1][3]);
+          if constexpr (!VMM_SINGLE_PASS) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
           }
-#pragma unroll
-          for (int j = 0; j < 3; ++j) if constexpr (!VMM_SINGLE_PASS) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bl, acc[j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) if constexpr (!VMM_SINGLE_PASS) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[j], Bh, acc[j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[j], Bh, acc[j], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
         }
       };
       if (!(VMM_QB_SKIP & 1)) {
-        if (wave == p) wgrad_half(dwA, 0);
-        if (wave == ((p + 1) & 7)) wgrad_half(dwB, 1);
-      }
-      // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over the piece's 96 columns (three k32 steps)
-#pragma unroll
-      for (int kk = 0; kk < ((VMM_QB_SKIP & 2) ? 0 : 3); ++kk) {
-        const bf16x8 Wh = __builtin_bit_cast(bf16x8, cur[kk][0]), Wl = __builtin_bit_cast(bf16x8, cur[kk][1]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned char* bp = pb + 2 * GT_PLANE + ((rb0 + u) * 16 + l15) * RP + (kk * 32 + oct4 * 8) * 2;
-          const bf16x8 Gh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
-          const bf16x8 Gl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + GR_PLANE));
-          if constexpr (!VMM_SINGLE_PASS) {
-            gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gl, gyacc[u], 0, 0, 0);
-            gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Gh, gyacc[u], 0, 0, 0);
-          }
-          gyacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Gh, gyacc[u], 0, 0, 0);
+        switch ((wave - p) & 7) {  // (wave-uniform: a scalar branch; the accumulator of every case is static)
+          case 0: wg_tile(dw[0], 0, 0); break;
+          case 1: wg_tile(dw[1], 1, 0); break;
+          case 2: wg_tile(dw[2], 2, 0); break;
+          case 3: wg_tile(dw[3], 0, 1); break;
+          case 4: wg_tile(dw[4], 1, 1); break;
+          case 5: wg_tile(dw[5], 2, 1); break;
+          default: break;
         }
       }
+      // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over this group's three k16 steps of the piece
+      if (!(VMM_QB_SKIP & 2)) {
+        const unsigned char* gp_ = pb + 2 * GT_PLANE + (rt * 32 + l31) * RP + (3 * GRP * 16 + half * 8) * 2;
+        uint4 G[3][2];
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          G[sx][0] = *reinterpret_cast<const uint4*>(gp_ + sx * 32);
+          G[sx][1] = *reinterpret_cast<const uint4*>(gp_ + sx * 32 + GR_PLANE);
+        }
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+          const bf16x8 Wh = __builtin_bit_cast(bf16x8, wf[sx][0]), Wl = __builtin_bit_cast(bf16x8, wf[sx][1]);
+          const bf16x8 Gh = __builtin_bit_cast(bf16x8, G[sx][0]), Gl = __builtin_bit_cast(bf16x8, G[sx][1]);
+          if constexpr (!VMM_SINGLE_PASS) {
+            gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gl, gyacc, 0, 0, 0);
+            gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl, Gh, gyacc, 0, 0, 0);
+          }
+          gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gh, gyacc, 0, 0, 0);
+        }
+      }
+      if (GRP == 1 && p == NPIECE - 1) {  // this group's half of the chunk's gy^T tile: read by group 0 behind this piece's barrier
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(gscr + (((wave & 3) * 4 + q) * 64 + lane) * 4) = f32x4{gyacc[4 * q], gyacc[4 * q + 1], gyacc[4 * q + 2], gyacc[4 * q + 3]};
+      }
+      // the W^T fragments of the next piece: behind this piece's data-gradient products (they overwrite the fragment registers)
+      __builtin_amdgcn_sched_barrier(0);
+      w_request((p + 1) % NPIECE);
       if (GRP == 1) {
         __builtin_amdgcn_sched_barrier(0);
-        loader_step(p, (p + 2) % NPIECE, cur);
+        loader_step(p, gv);
       }
       __syncthreads();
     };
 #pragma unroll 1
     for (int p = 0; p < NPIECE; p += 2) {  // (two pieces per trip: the fragment sets alternate statically)
-      piece_step(p, wfA, wfB);
-      piece_step(p + 1, wfB, wfA);
+      piece_step(p, gvB);
+      piece_step(p + 1, gvA);
     }
-    // ---- the chunk's data gradient: lane = row (rb0 + u) * 16 + l15, registers = channels cb * 16 + 4 oct4 .. + 3
+    // ---- the chunk's data gradient: group 0 adds group 1's half (fixed order) and stores; lane = row rt * 32 + l31, register quad q = channels
+    // ct * 32 + 8 q + 4 half .. + 3.  (Group 1 writes its next half seven barriers from here.)
+    if (GRP == 0) {
+      float* gyr = a.gy + (r0 + rt * 32 + l31) * a.ldgy + ct * 32 + 4 * half;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const long long row = r0 + (rb0 + u) * 16 + l15;
-      *reinterpret_cast<f32x4*>(a.gy + row * a.ldgy + cb * 16 + 4 * oct4) = gyacc[u];
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(gscr + (((wave & 3) * 4 + q) * 64 + lane) * 4);
+        *reinterpret_cast<f32x4*>(gyr + 8 * q) = f32x4{gyacc[4 * q] + o.x, gyacc[4 * q + 1] + o.y, gyacc[4 * q + 2] + o.z, gyacc[4 * q + 3] + o.w};
+      }
     }
   }
 
   // ---------------------------------------------------------------- the workgroup's partial weight-gradient block: [wave][f][c][q][lane] x 4 floats
   f32x4* dst = reinterpret_cast<f32x4*>(a.part) + (long long)blockIdx.x * (PART_FLOATS / 4);
-  const int wprev = (wave + 7) & 7;  // the piece whose channel fragment 1 this wave accumulated
 #pragma unroll
-  for (int f = 0; f < 3; ++f)
+  for (int t = 0; t < 6; ++t) {
+    const int pc = (wave - t) & 7, j = t % 3, c = t / 3;  // accumulator t of this wave: piece pc, column fragment j, channel fragment c
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      dst[(((wave * 3 + f) * 2 + 0) * 4 + q) * 64 + lane] = f32x4{dwA[f][4 * q], dwA[f][4 * q + 1], dwA[f][4 * q + 2], dwA[f][4 * q + 3]};
-      dst[(((wprev * 3 + f) * 2 + 1) * 4 + q) * 64 + lane] = f32x4{dwB[f][4 * q], dwB[f][4 * q + 1], dwB[f][4 * q + 2], dwB[f][4 * q + 3]};
-    }
+    for (int q = 0; q < 4; ++q)
+      dst[(((pc * 3 + j) * 2 + c) * 4 + q) * 64 + lane] = f32x4{dw[t][4 * q], dw[t][4 * q + 1], dw[t][4 * q + 2], dw[t][4 * q + 3]};
+  }
 }
 
 __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
@@ -359,7 +415,7 @@ extern "C" int VMM_X3(vmm_qkv_bwd_, )(const float* x, int32_t ldx, const float* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_bwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(qkv_bwd_x3_kernel, dim3(gx), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(qkv_bwd_x3_kernel, dim3(gx), dim3(512), LDS_BYTES + GY_SCRATCH, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   hipLaunchKernelGGL(qkv_bwd_reduce_kernel, dim3(PART_FLOATS / 4 / 32), dim3(256), 0, (hipStream_t)stream, workspace, gx, dw_packed);
   VMM_LAUNCH_CHECK();
