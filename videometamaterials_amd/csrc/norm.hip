@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
                                                       const float* __restrict__ beta, const float* __restrict__ film, int ldfilm, int B, int C, int G,
                                                       float* __restrict__ coef, float* __restrict__ stats_out, const float* __restrict__ partials,
                                                       int n_contrib, const float* __restrict__ x, int ldx, int rows_per_sample) {
-  __shared__ double red[2][256];
+  __shared__ double red[2][4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int tid = threadIdx.x;
   const int cpg = C / G;
@@ -87,13 +87,13 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
         s1 += (double)a1; s2 += (double)a2;
       }
     }
-    red[0][tid] = s1; red[1][tid] = s2;
+    // (wave shuffles, then the four wave sums through LDS: one barrier instead of the nine of a 256-wide LDS tree -- the launch is a pure latency
+    // chain between a convolution and its consumer, 38 times per denoiser pass)
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-      if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
-      __syncthreads();
-    }
-    s1 = red[0][0]; s2 = red[1][0];
+    s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   } else {
     s1 = sums[(b * G + g) * 2];
     s2 = sums[(b * G + g) * 2 + 1];

@@ -309,7 +309,12 @@ extern "C" int vmm_groupnorm_bwd(const float* dz, int32_t lddz, const float* h, 
   VMM_LAUNCH_CHECK();
   const float inv_n = 1.0f / ((float)rows_per_sample * (float)(C / G));
   const int Cg = C / G;
-  const int CH = (C > 64 && C % 64 == 0 && 64 % Cg == 0) ? 64 : C;  // channel chunk of a coefficient workgroup: whole groups
+  // channel chunk of a coefficient workgroup: whole groups, and as FEW of them as make eight channels -- the launch is a latency chain (a slice of a
+  // workgroup adds its share of the `blocks` partial rows one after the other): with 64 channels per workgroup the 96 x 96 sites ran 4 workgroups of
+  // 8 slices x 64 dependent loads (14 us a launch, 0.53 ms of the training step); with 8 channels it is 32 workgroups of 64 slices x 8 loads
+  int CH = Cg;
+  while (CH < 8 && CH * 2 <= C && C % (CH * 2) == 0) CH *= 2;
+  if (C % CH || (CH & 1)) CH = C;
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(C / CH, B), dim3(256), 0, s, part, blocks, gamma, beta, film, ldfilm, inv_n, C, G, CH, m12, dgamma,
                      dbeta, dfilm);
   VMM_LAUNCH_CHECK();
