@@ -532,7 +532,9 @@ extern "C" int vmm_conv_wgrad_f32(const vmm_conv_desc* dp, const float* dy, int3
 extern "C" int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream) {
   if ((C & 3) || (ldx & 3) || C > 1024) return -1;
   const int rslots = 256 / (C >> 2);
-  long long blocks = min((long long)cdiv(rows, rslots * 16), 1024LL);
+  // (at most one workgroup per CU: every workgroup ends with C same-address atomics, which serialise at ~100 ns each -- with 1 024 workgroups the
+  // 96 x 96 launches took 127 us, most of it in that queue; 57 us with 256)
+  long long blocks = min((long long)cdiv(rows, rslots * 16), 256LL);
   if (blocks < 1) blocks = 1;
   const long long rpb = cdiv(rows, blocks);
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)rows, C, out, rpb);
