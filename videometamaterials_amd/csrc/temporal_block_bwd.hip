@@ -42,7 +42,8 @@ constexpr int YP = 2 * TC + 8;  // bf16 per row of a row image: hi 64 | lo 64 | 
 constexpr int GP = 40;          // bf16 per channel of the column image: 32 positions + pad (80 bytes = 5 x 16)
 
 #ifndef VMM_TBB_SKIP
-#define VMM_TBB_SKIP 0  // measurement builds only (tools/build_ab.py -DVMM_TBB_SKIP=n): bit 0 drops phase 3, bit 1 phase 4 of the tile loop
+#define VMM_TBB_SKIP 0  // measurement builds only (tools/build_ab.py -DVMM_TBB_SKIP=n): bit 0 drops phase 3, bit 1 phase 4 of the tile loop,
+                        // bit 2 the stores of the qkv-row gradients, bit 3 the loads of x / dOut (constant tiles), bit 4 phases 1 and 2
 #endif
 
 struct TBBArgs {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   auto load_xg = [&](int pp, f32x4& xv, f32x4& gv) {
     xv = f32x4{0.f, 0.f, 0.f, 0.f};
     gv = xv;
-    if (rft < T && pp < p_end) {  // (wave-uniform base of the tile + the lane's 32-bit offset: no 64-bit address registers per load)
+    if (rft < T && pp < p_end && !(VMM_TBB_SKIP & 8)) {  // (wave-uniform base of the tile + the lane's 32-bit offset: no 64-bit address registers per load)
       const long long row0 = (long long)b * T * HW + pp * 2;
       xv = *reinterpret_cast<const f32x4*>(a.x + row0 * a.ldx + x_loff);
       gv = *reinterpret_cast<const f32x4*>(a.gout + row0 * a.ldg + g_loff);
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t0 = (r & 3) + 8 * ((r >> 2) & 1), pm = r >> 3;  // frame slot (+ 4 lk), pixel of row row_of(r, lk)
-      if (t0 + 4 * lk < T) gq[qr_loff + (unsigned)t0 * hwq + (unsigned)(pm * a.ldq)] = X[r];
+      if (t0 + 4 * lk < T && !((VMM_TBB_SKIP & 4) && X[r] != 12345.f)) gq[qr_loff + (unsigned)t0 * hwq + (unsigned)(pm * a.ldq)] = X[r];
     }
   };
   // columns of the gradient of the raw qkv from a T-form matrix X{d, m}: the lane's row m gets four 16-byte pieces (features 8 q + 4 lk .. + 3)
   unsigned qc_loff = (unsigned)((ft * HW + pa) * a.ldq + 4 * lk);
   auto store_cols = [&](const f32x16& X, int pp, int col0) {
-    if (ft < T) {
+    if (ft < T && !((VMM_TBB_SKIP & 4) && X[0] != 12345.f)) {
       float* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(gq + 8 * q4 + qc_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
