@@ -171,6 +171,13 @@ int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* d, const float* dy, int32_t
 int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq);
 int vmm_qkv_bwd_bf16x3(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
                        float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream);
+/* The same pass with the backward of the PreNorm channel LayerNorm (vddp.py:245-264; vmm_channel_layernorm_bwd) as its epilogue -- gy never reaches
+ * memory: dx[r][c] (= | +=, accumulate) rstd_r (gamma_c gy[r][c] - mean_c(gamma gy) - xhat[r][c] mean_c(gamma gy xhat)) and
+ * dgamma[c] += sum_r gy[r][c] xhat[r][c] (per-workgroup partial rows inside the workspace + the fixed-order vmm_sum_partials).  ln_stats, ln_gamma and dx
+ * are required; dx may be the buffer the residual gradient already lies in (accumulate = 1: read and written row by row).  Same envelope. */
+int vmm_qkv_bwd_ln_bf16x3(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                          float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace, int64_t rows, int32_t C,
+                          int32_t Nq, vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
@@ -593,6 +600,9 @@ int vmm_conv1x1_wgrad_bf16_ln(const vmm_conv_desc* d, const float* dy, int32_t l
                               const float* ln_gamma, vmm_stream_t stream);
 int vmm_qkv_bwd_bf16(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
                      float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream);
+int vmm_qkv_bwd_ln_bf16(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                        float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace, int64_t rows, int32_t C,
+                        int32_t Nq, vmm_stream_t stream);
 int vmm_temporal_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 int vmm_linattn_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 

@@ -2025,3 +2025,44 @@ def test_experiments_library(gpu, env):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k", sel],
                        cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("rows,acc", [(64, False), (1920, True), (70400, True), (20032, False)])
+def test_fused_to_qkv_backward_with_layernorm_epilogue(gpu, rows, acc):
+    """vmm_qkv_bwd_ln_bf16x3: the to_qkv backward with the PreNorm LayerNorm's backward as its epilogue (vddp.py:245-264 differentiated): dx (= | +=), dgamma
+    (+=), dW (+=) against torch autograd in fp64 of  qkv = LayerNorm(x) W^T  with the upstream gradient g; bit-reproducible."""
+    N, lib = _lib()
+    g_ = torch.Generator().manual_seed(rows + 1)
+    Cc, Nq = 64, 768
+    x = (torch.randn(rows, Cc, generator=g_) * 1.5 + 0.3).double().requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g_)).double().requires_grad_(True)
+    w = (torch.randn(Nq, Cc, generator=g_) / 8).double().requires_grad_(True)
+    g = torch.randn(rows, Nq, generator=g_)
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = 1 / (var + 1e-5).sqrt()
+    y = (x - mean) * rstd * gamma
+    (y @ w.t() * g.double()).sum().backward()
+    res = torch.randn(rows, Cc, generator=g_)
+    want_dx = x.grad + (res.double() if acc else 0)
+    wp = _pack_frag(N, lib, gpu, w.detach().float().t().contiguous(), 2)
+    xg, gg = x.detach().float().to(gpu), g.to(gpu)
+    stats = torch.cat([mean.detach(), rstd.detach()], 1).float().contiguous().to(gpu)
+    gam = gamma.detach().float().to(gpu)
+    n_ws = int(lib.vmm_qkv_bwd_workspace(rows, Cc, Nq))
+    outs = []
+    for _ in range(2):
+        ws = torch.full((n_ws,), float("nan"), device=gpu)
+        dx = res.clone().to(gpu) if acc else torch.full((rows, Cc), 7.0, device=gpu)
+        dw = torch.ones(Cc, Nq, device=gpu)
+        dgam = torch.ones(Cc, device=gpu)
+        rc = lib.vmm_qkv_bwd_ln_bf16x3(xg.data_ptr(), Cc, stats.data_ptr(), gam.data_ptr(), gg.data_ptr(), Nq, wp.data_ptr(), dx.data_ptr(), Cc, 1 if acc else 0,
+                                       dgam.data_ptr(), dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, _s())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert relerr(dx.cpu().double(), want_dx) < 5e-5
+        assert relerr(dw.cpu().double() - 1, w.grad.t()) < 5e-5
+        assert relerr(dgam.cpu().double() - 1, gamma.grad) < 5e-5
+        outs.append((dx, dw, dgam))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert lib.vmm_qkv_bwd_ln_bf16x3(xg.data_ptr(), Cc, None, gam.data_ptr(), gg.data_ptr(), Nq, wp.data_ptr(), dx.data_ptr(), Cc, 0, dgam.data_ptr(),
+                                     dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, _s()) == 1  # (the statistics are required)

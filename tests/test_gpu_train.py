@@ -252,8 +252,8 @@ def test_reduced_precision_training_leg_inside_the_reference_autocast_deviation(
     used = {fn.__name__ for fn, _, _ in pl.steps} | {fn.__name__ for fn, _, _ in pl.bwd_steps}
     assert "vmm_conv3x3_bf16" in used and "vmm_conv3x3_bf16x3" not in used
     if cfg_name == "lagr64":  # the single-pass backward instances take the layers their three-pass namesakes take
-        assert {"vmm_conv3x3_wgrad_bf16", "vmm_conv1x1_wgrad_bf16", "vmm_qkv_bwd_bf16", "vmm_temporal_block_bwd_bf16", "vmm_linattn_block_bwd_bf16"} <= used, sorted(used)
-        assert not {"vmm_conv3x3_wgrad_bf16x3", "vmm_qkv_bwd_bf16x3", "vmm_temporal_block_bwd_bf16x3", "vmm_linattn_block_bwd_bf16x3"} & used
+        assert {"vmm_conv3x3_wgrad_bf16", "vmm_conv1x1_wgrad_bf16", "vmm_qkv_bwd_ln_bf16", "vmm_temporal_block_bwd_bf16", "vmm_linattn_block_bwd_bf16"} <= used, sorted(used)
+        assert not {"vmm_conv3x3_wgrad_bf16x3", "vmm_qkv_bwd_bf16x3", "vmm_qkv_bwd_ln_bf16x3", "vmm_temporal_block_bwd_bf16x3", "vmm_linattn_block_bwd_bf16x3"} & used
     got = {model._ref_key(k): p.grad for k, p in model.named_parameters()}
     vals = np.array([float((got[k].double().cpu() - w.double()).norm() / w.double().norm()) for k, w in want.items()
                      if w is not None and float(w.double().norm()) > 0 and got.get(k) is not None])

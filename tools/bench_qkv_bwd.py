@@ -40,7 +40,16 @@ gy = torch.empty(rows, Cc, device=dev)
 dw = torch.zeros(Cc, Nq, device=dev)
 
 
+dx = torch.randn(rows, Cc, device=dev)
+dgam = torch.zeros(Cc, device=dev)
+LN = os.environ.get("QKV_LN") == "1"  # the variant with the LayerNorm backward as its epilogue
+
+
 def run():
+    if LN:
+        N.check(lib.vmm_qkv_bwd_ln_bf16x3(x.data_ptr(), Cc, stats.data_ptr(), gamma.data_ptr(), g.data_ptr(), Nq, packed.data_ptr(), dx.data_ptr(), Cc, 1,
+                                          dgam.data_ptr(), dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, s), "qkv_bwd_ln")
+        return
     N.check(lib.vmm_qkv_bwd_bf16x3(x.data_ptr(), Cc, stats.data_ptr(), gamma.data_ptr(), g.data_ptr(), Nq, packed.data_ptr(), gy.data_ptr(), Cc,
                                    dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, s), "qkv_bwd")
 

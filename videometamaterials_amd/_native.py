@@ -124,6 +124,8 @@ SIGNATURES = {
     "vmm_qkv_bwd_workspace": [c_i64, c_i32, c_i32],
     "vmm_qkv_bwd_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_qkv_bwd_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_qkv_bwd_ln_bf16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_qkv_bwd_ln_bf16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_proj_bf16x3_ln_stats": [C.POINTER(ConvDesc), c_ptr, c_f32, c_ptr, c_ptr],
     "vmm_conv_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_colsum_accumulate": [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr],

@@ -38,6 +38,7 @@ constexpr int PIECE_BUF = 2 * GT_PLANE + 2 * GR_PLANE;   // GT hi | GT lo | GR h
 constexpr int YT_PLANE = CC * TP, YT_BUF = 2 * YT_PLANE;  // 18 432 bytes
 constexpr int LDS_BYTES = 2 * PIECE_BUF + 2 * YT_BUF;     // 145 408 bytes (+ GY_SCRATCH behind them)
 constexpr int GY_SCRATCH = 4 * 4 * 64 * 16;              // 16 384 bytes: group 1's halves of the chunk's data-gradient tiles
+constexpr int LN_SUMS = 2 * 2 * 64 * 8;                  // 2 048 bytes: the four half-tile contributions to a row's LayerNorm-backward sums (163 840 in all)
 constexpr int PART_FLOATS = NQ * CC;
 
 struct QBArgs {
@@ -50,6 +51,9 @@ struct QBArgs {
   float* part;                       // [gridDim.x][PART_FLOATS]
   long long rows;
   int nchunks, chunks_per_wg;
+  // LayerNorm backward as the epilogue (vmm_qkv_bwd_ln_*): dx (=|+=) the gradient of the block INPUT through PreNorm, gy itself is not written
+  float* dx; int lddx; int accumulate;
+  float* dgamma_part;                // [2 gridDim.x][64]: partial rows of the gamma gradient
 };
 
 // The body of the kernel for one wave group and loader role (four instances, selected once per wave: no role branches inside the loops, so the
@@ -63,7 +67,7 @@ struct QBArgs {
 // return in order, and the compiler sizes every wait for the worst path into the loop: the prologue therefore leaves its requests pending in exactly the
 // order the loop does, every request of the loop is unconditional, and the staged set's registers are pinned at the staging (see the comments there).
 // Per group: three g-loader waves (192 threads = 4 row groups x 48 column pairs) and one y-loader wave (64 threads x 2 items per chunk).
-template <int GRP, bool GROLE>
+template <int GRP, bool GROLE, bool LNB>
 __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,7 +81,7 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   const int gt = tid - 256 * GRP;                                        // 0 .. 191 in the g role
   const int go = GROLE ? 4 * GRP + gt / 48 : 0, gp = GROLE ? gt % 48 : 0;  // 8 row groups x 48 column pairs
   const int yt = 64 * GRP + lane, yo0 = (yt >> 5) & 3, ycp = yt & 31;    // y item k (0 / 1): row group yo0 + 4 k, channel pair ycp
-  f32x2 gvA[8], gvB[8];  // the role's rows in flight: g pieces of even / odd index (TWO pieces ahead of the products), or a y item (set A)
+  f32x2 gvA[8];  // the role's rows in flight: the next g piece, or a y item
   const f32x2 lg = (!GROLE && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
   // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform row base (scalar registers) + ONE 32-bit per-thread offset: eight 64-bit
   // vector-register addresses per role cost 16 registers each and pushed the first version into scratch, whose reloads sit on the same in-order
@@ -187,21 +191,26 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
     y_request(r_begin, 1);
     y_stage(r_begin, 1, 0);
   }
-  // (The requests go out in the order in which the loop leaves them pending at its top -- group 0: set B, set A, fragments; group 1: set B, fragments,
-  // set A -- and not interleaved: the compiler sizes the waits inside the loop for the worst path into it, and a prologue that leaves the loads in
-  // another order tightens every wait of the steady state.)
-  // (compiler-level memory barriers between them: a scheduling barrier alone does not keep the two sets' loads, which share their address registers,
-  // from being merged into one interleaved run)
-  asm volatile("" ::: "memory");
-  if (GROLE) g_request(r_begin, 1, gvB);
+  // (The requests go out in the order in which the loop leaves them pending at its top -- group 0: the next piece, then the fragments; group 1: the
+  // fragments, then the next piece -- : the compiler sizes the waits inside the loop for the worst path into it, and a prologue that leaves the loads
+  // in another order tightens every wait of the steady state.  Compiler-level memory barriers between them: a scheduling barrier alone does not keep
+  // two runs of loads from being merged.)
   asm volatile("" ::: "memory");
   if (GRP == 1) w_request(0);
   asm volatile("" ::: "memory");
-  if (GROLE) g_request(r_begin, 2, gvA);
+  if (GROLE) g_request(r_begin, 1, gvA);
   asm volatile("" ::: "memory");
   if (GRP == 0) w_request(0);
   asm volatile("" ::: "memory");
   __syncthreads();
+  float dgam[16];  // LNB, group 0: sum over this lane's rows of gy * xhat for its sixteen channels
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dgam[r] = 0.f;
+  float* const lsum = reinterpret_cast<float*>(sm + LDS_BYTES + GY_SCRATCH);  // LNB: [group][ct][64 rows] (sum g, sum g xhat) of a wave's half tile
+  // LNB: the lane's 32-bit offsets into the chunk's rows (wave-uniform chunk base + ONE vector offset per array; made opaque once per chunk, else the
+  // compiler forms a 64-bit vector address per 16-byte piece outside the loops and spills them)
+  unsigned lx_off = (unsigned)((rt * 32 + l31) * a.ldx + ct * 32 + 4 * half), ld_off = (unsigned)((rt * 32 + l31) * a.lddx + ct * 32 + 4 * half);
+  unsigned lg_off = (unsigned)(ct * 32 + 4 * half), ls_off = (unsigned)(2 * (rt * 32 + l31));
 
   for (int ch = 0; ch < n_ch; ++ch) {
     const long long r0 = r_begin + (long long)ch * CH;
@@ -210,34 +219,26 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gyacc[r] = 0.f;
     const unsigned char* yb = ybuf + (ch & 1) * YT_BUF;
+    f32x2 st_ln;   // LNB: (mean, rstd) of this lane's row (xhat is formed twice, a quad at a time: sixteen registers across the barrier did not fit)
 
     // One loader step of piece p: the next piece (in registers since the previous step) goes to the other buffer (read last in iteration p - 1: the
     // barrier that ended it makes the buffer free for both groups) and the one after it is requested; the y loaders stage the next chunk's rows.
-    // One loader step of piece p: piece p + 1 (in its register set since the step of piece p - 2) goes to the other buffer (read last in iteration
-    // p - 1: the barrier that ended it makes the buffer free for both groups) and piece p + 3 is requested into the same registers -- two pieces are in
-    // flight per thread, so that a load has two iterations to land and a wait for a younger load (they return in order) never waits for memory.  The y
-    // loaders stage the next chunk's rows one item at a time.  (The g request is unconditional: past the last piece it repeats rows of the current
-    // chunk and is never staged; a skipped request would give the compiler a path with fewer loads behind the ones it waits for, i.e. a tighter wait
-    // on every path.)
-    auto loader_step = [&](int p, f32x2 (&gv)[8]) {
+    // One loader step of piece p: piece p + 1 (in registers since the previous step) goes to the other buffer (read last in iteration p - 1: the
+    // barrier that ended it makes the buffer free for both groups) and piece p + 2 is requested into the same registers.  (Two pieces in flight per
+    // thread were measured: no faster, 16 registers more.)  The y loaders stage the next chunk's rows one item at a time.  The g request is
+    // unconditional -- past the last piece it repeats rows of the current chunk and is never staged: a skipped request would give the compiler a path
+    // with fewer loads behind the ones it waits for, i.e. a tighter wait on every path.
+    auto loader_step = [&](int p) {
       const bool last_piece = p == NPIECE - 1;
       if (GROLE) {
-        if (VMM_QB_SKIP & 16) {  // measurement: the loads are issued and retired, but the staged values do not depend on them (no wait before the staging)
-          f32x2 cst[8];
+        // (the registers are pinned HERE: the splits are plain vector arithmetic, which the scheduler otherwise lifts across the barrier into the
+        // previous step -- and with them the wait for these rows, a whole matrix phase early)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) cst[i] = f32x2{1.f + i, 2.f};
-          g_stage((p & 1) ^ 1, cst);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(gv[i]));
-        } else
-        // (the set's registers are pinned HERE: the splits are plain vector arithmetic, which the scheduler otherwise lifts across the barrier into the
-        // previous half-step -- and with them the wait for this set, a whole matrix phase early)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(gv[i]));
-        if (!last_piece || more_ch) g_stage((p & 1) ^ 1, gv);
-        __builtin_amdgcn_sched_barrier(0);  // (the request stays behind the staging: hoisted above it, it would sit between the staged set's loads and its wait)
-        const bool next_chunk = p + 3 >= NPIECE;
-        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 3) % NPIECE, gv);
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(gvA[i]));
+        if (!last_piece || more_ch) g_stage((p & 1) ^ 1, gvA);
+        __builtin_amdgcn_sched_barrier(0);  // (the request stays behind the staging)
+        const bool next_chunk = p + 2 >= NPIECE;
+        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 2) % NPIECE, gvA);
       } else if (more_ch) {
         if (p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
         if (p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
@@ -245,13 +246,13 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
         if (p == 3) y_request(r0 + CH, 1);
       }
     };
-    auto piece_step = [&](int p, f32x2 (&gv)[8]) {  // gv: the register set of piece p + 1
+    auto piece_step = [&](int p) {
       const unsigned char* pb = sm + (p & 1) * PIECE_BUF;  // (NPIECE is even: piece p of every chunk lives in buffer p & 1)
       // (the lanes' 32-bit offsets are made opaque once per iteration: as loop invariants the compiler adds them to every wave-uniform row base
       // outside the loop -- one 64-bit vector-register address per load -- instead of using the scalar-base + vector-offset addressing mode)
       asm volatile("" : "+v"(g_toff), "+v"(y_toff0));
       if (GRP == 0) {
-        loader_step(p, gv);
+        loader_step(p);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- weight gradient: this wave's tile of the piece (12 MFMAs; fragments of step s + 1 requested before the products of step s)
@@ -292,22 +293,45 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
       // ---- data gradient: gy^T[channel][row] += W^T[channel][n] g^T[n][row] over this group's three k16 steps of the piece
       if (!(VMM_QB_SKIP & 2)) {
         const unsigned char* gp_ = pb + 2 * GT_PLANE + (rt * 32 + l31) * RP + (3 * GRP * 16 + half * 8) * 2;
-        uint4 G[3][2];
-#pragma unroll
-        for (int sx = 0; sx < 3; ++sx) {
-          G[sx][0] = *reinterpret_cast<const uint4*>(gp_ + sx * 32);
-          G[sx][1] = *reinterpret_cast<const uint4*>(gp_ + sx * 32 + GR_PLANE);
-        }
+        uint4 G[2][2];  // (two steps of fragments in flight)
+        G[0][0] = *reinterpret_cast<const uint4*>(gp_);
+        G[0][1] = *reinterpret_cast<const uint4*>(gp_ + GR_PLANE);
+        G[1][0] = *reinterpret_cast<const uint4*>(gp_ + 32);
+        G[1][1] = *reinterpret_cast<const uint4*>(gp_ + 32 + GR_PLANE);
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx) {
           const bf16x8 Wh = __builtin_bit_cast(bf16x8, wf[sx][0]), Wl = __builtin_bit_cast(bf16x8, wf[sx][1]);
-          const bf16x8 Gh = __builtin_bit_cast(bf16x8, G[sx][0]), Gl = __builtin_bit_cast(bf16x8, G[sx][1]);
+          const bf16x8 Gh = __builtin_bit_cast(bf16x8, G[sx & 1][0]), Gl = __builtin_bit_cast(bf16x8, G[sx & 1][1]);
+          if (sx == 0) {
+            G[0][0] = *reinterpret_cast<const uint4*>(gp_ + 64);
+            G[0][1] = *reinterpret_cast<const uint4*>(gp_ + 64 + GR_PLANE);
+          }
           if constexpr (!VMM_SINGLE_PASS) {
             gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gl, gyacc, 0, 0, 0);
             gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl, Gh, gyacc, 0, 0, 0);
           }
           gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gh, gyacc, 0, 0, 0);
         }
+      }
+      if (LNB && p == NPIECE - 1) {
+        // LayerNorm backward, first half (every wave, on its OWN half tile -- the row sums are linear in gy): xhat of this lane's row and sixteen
+        // channels, the half tile's contribution to (sum_c g, sum_c g xhat), g = gamma gy; the four contributions of a row meet in LDS behind the barrier
+        asm volatile("" : "+v"(lx_off), "+v"(ld_off), "+v"(lg_off), "+v"(ls_off));
+        const float* xb = a.x + r0 * a.ldx;  // wave-uniform
+        st_ln = *reinterpret_cast<const f32x2*>(a.ln_stats + 2 * r0 + ls_off);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + lx_off + 8 * q);
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_gamma + lg_off + 8 * q);
+          const f32x4 xq = {(xv.x - st_ln[0]) * st_ln[1], (xv.y - st_ln[0]) * st_ln[1], (xv.z - st_ln[0]) * st_ln[1], (xv.w - st_ln[0]) * st_ln[1]};
+          const float g0 = gyacc[4 * q] * gm.x, g1 = gyacc[4 * q + 1] * gm.y, g2 = gyacc[4 * q + 2] * gm.z, g3 = gyacc[4 * q + 3] * gm.w;
+          s1 += (g0 + g1) + (g2 + g3);
+          s2 += (g0 * xq.x + g1 * xq.y) + (g2 * xq.z + g3 * xq.w);
+        }
+        s1 += lane_xor(s1, 5);
+        s2 += lane_xor(s2, 5);
+        if (half == 0) *reinterpret_cast<f32x2*>(lsum + ((GRP * 2 + ct) * 64 + rt * 32 + l31) * 2) = f32x2{s1, s2};
       }
       if (GRP == 1 && p == NPIECE - 1) {  // this group's half of the chunk's gy^T tile: read by group 0 behind this piece's barrier
 #pragma unroll
@@ -319,18 +343,15 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
       w_request((p + 1) % NPIECE);
       if (GRP == 1) {
         __builtin_amdgcn_sched_barrier(0);
-        loader_step(p, gv);
+        loader_step(p);
       }
       __syncthreads();
     };
 #pragma unroll 1
-    for (int p = 0; p < NPIECE; p += 2) {  // (two pieces per trip: the fragment sets alternate statically)
-      piece_step(p, gvB);
-      piece_step(p + 1, gvA);
-    }
+    for (int p = 0; p < NPIECE; ++p) piece_step(p);
     // ---- the chunk's data gradient: group 0 adds group 1's half (fixed order) and stores; lane = row rt * 32 + l31, register quad q = channels
     // ct * 32 + 8 q + 4 half .. + 3.  (Group 1 writes its next half seven barriers from here.)
-    if (GRP == 0) {
+    if (GRP == 0 && !LNB) {
       float* gyr = a.gy + (r0 + rt * 32 + l31) * a.ldgy + ct * 32 + 4 * half;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -338,10 +359,51 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
         *reinterpret_cast<f32x4*>(gyr + 8 * q) = f32x4{gyacc[4 * q] + o.x, gyacc[4 * q + 1] + o.y, gyacc[4 * q + 2] + o.z, gyacc[4 * q + 3] + o.w};
       }
     }
+    if (GRP == 0 && LNB) {
+      // LayerNorm backward, second half: dx = rstd (g - mean_c g - xhat mean_c (g xhat)) (vddp.py:245-254 differentiated), added to the gradient that
+      // reached the block input past the attention (the residual) when the caller says so; dgamma_c += gy_c xhat_c (this lane's row)
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // (fixed order: group 0 ct 0, ct 1, group 1 ct 0, ct 1)
+        const f32x2 v = *reinterpret_cast<const f32x2*>(lsum + (k * 64 + rt * 32 + l31) * 2);
+        a1 += v[0];
+        a2 += v[1];
+      }
+      a1 *= 1.0f / CC;
+      a2 *= 1.0f / CC;
+      float* dxr = a.dx + r0 * a.lddx + ld_off;  // (wave-uniform base + the lane's offset)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(gscr + (((wave & 3) * 4 + q) * 64 + lane) * 4);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(a.ln_gamma + lg_off + 8 * q);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + r0 * a.ldx + lx_off + 8 * q);
+        const f32x4 xq = {(xv.x - st_ln[0]) * st_ln[1], (xv.y - st_ln[0]) * st_ln[1], (xv.z - st_ln[0]) * st_ln[1], (xv.w - st_ln[0]) * st_ln[1]};
+        const float gy0 = gyacc[4 * q] + o.x, gy1 = gyacc[4 * q + 1] + o.y, gy2 = gyacc[4 * q + 2] + o.z, gy3 = gyacc[4 * q + 3] + o.w;
+        dgam[4 * q] += gy0 * xq.x; dgam[4 * q + 1] += gy1 * xq.y; dgam[4 * q + 2] += gy2 * xq.z; dgam[4 * q + 3] += gy3 * xq.w;
+        f32x4 d = {st_ln[1] * (gy0 * gm.x - a1 - xq.x * a2), st_ln[1] * (gy1 * gm.y - a1 - xq.y * a2),
+                   st_ln[1] * (gy2 * gm.z - a1 - xq.z * a2), st_ln[1] * (gy3 * gm.w - a1 - xq.w * a2)};
+        if (a.accumulate) d += *reinterpret_cast<const f32x4*>(dxr + 8 * q);
+        *reinterpret_cast<f32x4*>(dxr + 8 * q) = d;
+      }
+    }
   }
 
   // ---------------------------------------------------------------- the workgroup's partial weight-gradient block: [wave][f][c][q][lane] x 4 floats
   f32x4* dst = reinterpret_cast<f32x4*>(a.part) + (long long)blockIdx.x * (PART_FLOATS / 4);
+  if (LNB && GRP == 0) {  // the gamma gradient of this workgroup: sum over the 32 rows (lanes) of a half, one partial row per (workgroup, rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = dgam[r];
+#pragma unroll
+      for (int bit = 4; bit >= 0; --bit) v += lane_xor(v, bit);
+      dgam[r] = v;
+    }
+    if (l31 == 0) {
+      float* pg = a.dgamma_part + ((long long)blockIdx.x * 2 + rt) * CC + ct * 32 + 4 * half;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(pg + 8 * q) = f32x4{dgam[4 * q], dgam[4 * q + 1], dgam[4 * q + 2], dgam[4 * q + 3]};
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 6; ++t) {
     const int pc = (wave - t) & 7, j = t % 3, c = t / 3;  // accumulator t of this wave: piece pc, column fragment j, channel fragment c
@@ -351,14 +413,15 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   }
 }
 
+template <bool LNB>
 __global__ __launch_bounds__(512) void qkv_bwd_x3_kernel(const QBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   if (a.nchunks - (int)blockIdx.x * a.chunks_per_wg <= 0) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave < 4) {
-    if ((wave & 3) != 3) qkv_bwd_body<0, true>(a, sm); else qkv_bwd_body<0, false>(a, sm);
+    if ((wave & 3) != 3) qkv_bwd_body<0, true, LNB>(a, sm); else qkv_bwd_body<0, false, LNB>(a, sm);
   } else {
-    if ((wave & 3) != 3) qkv_bwd_body<1, true>(a, sm); else qkv_bwd_body<1, false>(a, sm);
+    if ((wave & 3) != 3) qkv_bwd_body<1, true, LNB>(a, sm); else qkv_bwd_body<1, false, LNB>(a, sm);
   }
 }
 
@@ -391,13 +454,42 @@ extern "C" int64_t vmm_qkv_bwd_workspace(int64_t rows, int32_t C, int32_t Nq) {
   if (C != CC || Nq != NQ || rows <= 0 || rows % CH) return 0;
   const long long nchunks = (rows + CH - 1) / CH;
   const long long nwg = nchunks < 256 ? nchunks : 256;
-  return nwg * PART_FLOATS;
+  return nwg * (PART_FLOATS + 2 * CC);  // partial weight-gradient blocks + (vmm_qkv_bwd_ln_*) two partial rows of the gamma gradient per workgroup
 }
 
 // gy = g W (rows x 64, plain store) and dw_packed[c][n] += g^T y in one pass over g (rows x 768).  x / ln_stats / ln_gamma: y = x when ln_stats is
 // NULL, else y = (x - mean) rstd gamma with (mean, rstd) = ln_stats[r][2].  w_frag = vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand
 // (the to_qkv weight (768, 64) as it lies in torch).  Returns 1 (nothing launched) unless C == 64, Nq == 768 and rows is a multiple of 64.
+//
+// vmm_qkv_bwd_ln_*: the same pass with the backward of the PreNorm LayerNorm (vddp.py:245-264) as its epilogue -- gy never reaches memory:
+//   dx (=|+=, `accumulate`) rstd (gamma gy - mean_c(gamma gy) - xhat mean_c(gamma gy xhat)),   dgamma[c] += sum_rows gy[r][c] xhat[r][c]
+// (ln_stats and ln_gamma required; dgamma leaves as two partial rows per workgroup + the fixed-order vmm_sum_partials).  Replaces
+// vmm_channel_layernorm_bwd behind the fused to_qkv backward: one 16-byte-per-element sweep and a launch less per attention block.
 #endif
+namespace {
+int qkv_bwd_launch(QBArgs& a, float* dw_packed, float* workspace, float* dgamma, vmm_stream_t stream) {
+  a.nchunks = (int)((a.rows + CH - 1) / CH);
+  const int nwg = a.nchunks < 256 ? a.nchunks : 256;
+  a.chunks_per_wg = (a.nchunks + nwg - 1) / nwg;
+  const int gx = (a.nchunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  a.part = workspace;
+  a.dgamma_part = workspace + (long long)nwg * PART_FLOATS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_bwd_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_bwd_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (a.dx) hipLaunchKernelGGL(qkv_bwd_x3_kernel<true>, dim3(gx), dim3(512), LDS_BYTES + GY_SCRATCH + LN_SUMS, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(qkv_bwd_x3_kernel<false>, dim3(gx), dim3(512), LDS_BYTES + GY_SCRATCH, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qkv_bwd_reduce_kernel, dim3(PART_FLOATS / 4 / 32), dim3(256), 0, (hipStream_t)stream, workspace, gx, dw_packed);
+  VMM_LAUNCH_CHECK();
+  if (a.dx && dgamma) return vmm_sum_partials(a.dgamma_part, 2 * gx, CC, CC, dgamma, stream);
+  return 0;
+}
+}  // namespace
+
 extern "C" int VMM_X3(vmm_qkv_bwd_, )(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
                                   float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream) {
   if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 1) || (ldg & 1) || (ldgy & 3) || (ln_stats && !ln_gamma)) return 1;
@@ -405,19 +497,20 @@ extern "C" int VMM_X3(vmm_qkv_bwd_, )(const float* x, int32_t ldx, const float* 
   QBArgs a;
   a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = g; a.ldg = ldg;
   a.wfrag = reinterpret_cast<const unsigned char*>(w_frag);
-  a.gy = gy; a.ldgy = ldgy; a.part = workspace; a.rows = rows;
-  a.nchunks = (int)((rows + CH - 1) / CH);
-  const int nwg = a.nchunks < 256 ? a.nchunks : 256;
-  a.chunks_per_wg = (a.nchunks + nwg - 1) / nwg;
-  const int gx = (a.nchunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_bwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(qkv_bwd_x3_kernel, dim3(gx), dim3(512), LDS_BYTES + GY_SCRATCH, (hipStream_t)stream, a);
-  VMM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(qkv_bwd_reduce_kernel, dim3(PART_FLOATS / 4 / 32), dim3(256), 0, (hipStream_t)stream, workspace, gx, dw_packed);
-  VMM_LAUNCH_CHECK();
-  return 0;
+  a.gy = gy; a.ldgy = ldgy; a.rows = rows;
+  a.dx = nullptr; a.lddx = 0; a.accumulate = 0;
+  return qkv_bwd_launch(a, dw_packed, workspace, nullptr, stream);
+}
+
+extern "C" int VMM_X3(vmm_qkv_bwd_ln_, )(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg,
+                                     const float* w_frag, float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace,
+                                     int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream) {
+  if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 3) || (ldg & 1) || (lddx & 3) || !ln_stats || !ln_gamma || !dx) return 1;
+  if (rows <= 0) return 0;
+  QBArgs a;
+  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = g; a.ldg = ldg;
+  a.wfrag = reinterpret_cast<const unsigned char*>(w_frag);
+  a.gy = nullptr; a.ldgy = 0; a.rows = rows;
+  a.dx = dx; a.lddx = lddx; a.accumulate = accumulate;
+  return qkv_bwd_launch(a, dw_packed, workspace, dgamma, stream);
 }

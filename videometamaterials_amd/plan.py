@@ -595,18 +595,30 @@ class _Builder:
             return False
         return kp in (32, 64, 128, 256) and k % 4 == 0 and cout % 32 == 0
 
-    def qkv_backward(self, dq: "N.ConvDesc", wname: str, x: Act, gqkv: Act, gwq: int, what: str) -> Act:
+    def qkv_backward(self, dq: "N.ConvDesc", wname: str, x: Act, gqkv: Act, gwq: int, what: str, ln_gamma_name: Optional[str] = None) -> Optional[Act]:
         """Backward of to_qkv: the weight gradient into gwq and the data gradient gy (returned; the caller's LayerNorm backward consumes and frees it).
-        At the C = 64 levels both come from ONE pass over the 3 KB rows of gqkv (qkv_bwd.hip); elsewhere a weight-gradient and a data-gradient launch."""
+        At the C = 64 levels both come from ONE pass over the 3 KB rows of gqkv (qkv_bwd.hip); elsewhere a weight-gradient and a data-gradient launch.
+        ln_gamma_name (the PreNorm's gamma; only with the forward's LayerNorm statistics in dq._ln): where the one-pass kernel takes the layer, the
+        LayerNorm backward runs as its epilogue (vmm_qkv_bwd_ln_*) -- the gradient of x is complete, gy never exists and None is returned."""
         rows = self.B * self.T * x.H * x.W
         n_out = gqkv.C
-        gy = self.act(x.C, x.H, x.W)
         ws_n = int(self.lib.vmm_qkv_bwd_workspace(rows, x.C, n_out)) if (self.x3 and gwq and dq is not None and getattr(self.m, "use_x3_wgrad", True)
                                                                           and _enabled("qkv_bwd")) else 0
+        ln = getattr(dq, "_ln", None) if dq is not None else None
+        if ws_n and ln and ln_gamma_name and not (x.ld & 3) and _enabled("qkv_bwd_ln"):
+            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
+            ws = self.alloc(ws_n)
+            gx, acc = self.grad_of(x)
+            gg = self.pg(ln_gamma_name) or self.scratch(x.C)
+            self.step(self.lib.vmm_qkv_bwd_ln_bf16 if self.one else self.lib.vmm_qkv_bwd_ln_bf16x3,
+                      (dq.a1, dq.lda1, ln[0], ln[1], gqkv.ptr, n_out, wd, gx.ptr, x.C, acc, gg, gwq, self.ptr(ws), rows, x.C, n_out),
+                      what + " backward (data + weight gradient, LayerNorm backward)", flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 3 * x.C))
+            self.tmp_free((ws, ws_n))
+            return None
+        gy = self.act(x.C, x.H, x.W)
         if ws_n:
             wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
             ws = self.alloc(ws_n)
-            ln = getattr(dq, "_ln", None)
             self.step(self.lib.vmm_qkv_bwd_bf16 if self.one else self.lib.vmm_qkv_bwd_bf16x3, (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
                                                     self.ptr(ws), rows, x.C, n_out), what + " backward (data + weight gradient)",
                       flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 2 * x.C))
@@ -1026,11 +1038,12 @@ class _Builder:
                               nbytes=4.0 * rows * (4 * x.C + 3 * hid))
                     self.tmp_free((bws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
-                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
+                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv", ln_gamma_name=name + ".fn.norm.gamma")
                     self.tmp_free(gqkv)
                     self.tmp_free((stats, 2 * rows))
-                    self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
-                    self.tmp_free(gy)
+                    if gy is not None:  # (else the LayerNorm backward ran as the epilogue of the to_qkv backward)
+                        self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+                        self.tmp_free(gy)
                     if site:
                         self.token_kv_bwd(site)
                 self.on_backward(bwd_fused, pg_start, uj_start)
@@ -1163,11 +1176,12 @@ class _Builder:
                               nbytes=4.0 * rows * (2 * x.C + 3 * hid))
                     self.tmp_free((ws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
-                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv")
+                    gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv", ln_gamma_name=name + ".fn.norm.gamma")
                     self.tmp_free(gqkv)
                     self.tmp_free((stats, 2 * rows))
-                    self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
-                    self.tmp_free(gy)
+                    if gy is not None:  # (else the LayerNorm backward ran as the epilogue of the to_qkv backward)
+                        self.layernorm_bwd(x, name + ".fn.norm.gamma", gy.ptr)
+                        self.tmp_free(gy)
                     if site:
                         self.token_kv_bwd(site)
                 self.on_backward(bwd_fused, pg_start, uj_start)
