@@ -36,6 +36,8 @@ LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 # 100-200 K-element slice in ~45 us, the two-launch path (statistics over many workgroups + coefficients) takes ~30 us, so only tiny
 # layers go direct
 GN_DIRECT_MAX = 1 << 14
+# workgroups a launch of the exact-fp32 weight-gradient kernel is split into (row slices x 64 x 64 tiles): every workgroup ends with 4 096 fp32 atomics
+WGRAD_F32_WGS = int(os.environ.get("VMM_WGRAD_F32_WGS", "2048"))
 SK_SLOTS = 512    # partial-tile slots of the balanced 3 x 3 launch (two workgroups per CU; entries 2048.. of the tickets are their flags)
 N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
@@ -718,7 +720,7 @@ class _Builder:
         else:                                                  # 64 x 64 workgroup tiles, exact fp32
             fn = self.lib.vmm_conv_wgrad_f32
             tiles = -(-K // 64) * -(-d.Cout // 64)
-            nsplit = max(1, min(-(-2048 // tiles), max(1, M // 256)))
+            nsplit = max(1, min(-(-WGRAD_F32_WGS // tiles), max(1, M // 256)))
         sc = self.alloc(nsplit * d.Cout) if gb_ptr else None  # one partial row of the bias gradient per row slice
         self.step(fn, (C.byref(d), dy_ptr, lddy, gw_ptr, nsplit, gb_ptr or None, self.ptr(sc) if gb_ptr else None), what + " wgrad", flops=2.0 * M * K * d.Cout,
                   nbytes=4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout))
