@@ -48,8 +48,9 @@ __device__ __forceinline__ unsigned pj_split(float a, float b, unsigned& lo) { r
 // ONE: the "bf16" throughput mode (BASELINE.json configs[3]): hi planes only, one matrix pass per product
 // A16 (single-pass instances): the rows, the residual and the output are bf16-STORED feature maps (the "bf16" mode's two upper levels): half-width
 // staging loads, one rounding per stored output element; LayerNorm, q-scale, rotary, bias and the residual sum stay fp32.
-template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false, bool A16 = false>
+template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false, bool A16 = false, bool KSPLIT2 = false>
 __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
+  static_assert(!KSPLIT2 || (WN == 2 && !KSPLIT4 && !A16 && KS % 4 == 0), "k split between the two column waves of the 2 x 2 arrangement");
   static_assert(!ONE || !F32, "single pass: bf16 operands");
   static_assert(!A16 || (ONE && !KSPLIT4), "bf16-stored maps: the single-pass instances without the k split");
   constexpr int BM = WM * 64, BN = WN * 64;
@@ -172,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
   // Cout <= 64 under the 1 x 4 wave arrangement (K = 256: a 64-row tile is all the LDS holds) leaves one column slice: the four waves then
   // split the k16 steps of that slice instead of three of them idling, and wave 0 sums the partial accumulators through LDS.
   constexpr bool ksplit4 = KSPLIT4;
-  const int wn = ksplit4 ? 0 : wn_id;
+  // KSPLIT2: Cout <= 64 under the 2 x 2 arrangement (K = 128) leaves the two column waves of a row pair ONE column slice: they split its k16 steps
+  // and then the epilogue (each takes one of the pair's two 32-row tiles) instead of one of them idling through products, residual transform and stores.
+  const int wn = (ksplit4 || KSPLIT2) ? 0 : wn_id;
   auto load_b = [&](uint4 (&d)[4], int nc, int s) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -271,9 +274,10 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
       }
     }
   }
-  auto store_chunk = [&](int nc) {
+  auto store_chunk = [&](int nc, int only_i = -1) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (only_i >= 0 && i != only_i) continue;  // (wave-uniform)
       const int m = mrow[i];
       if (m < a.M) {  // the only per-lane condition of the epilogue
         const float* resrow = p.res ? p.res + (long long)m * p.ldres : nullptr;
@@ -378,6 +382,40 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     }
     return;
   }
+  if constexpr (KSPLIT2) {
+    const int s_begin = wn_id * (KS / 2);
+    zero_acc();
+    load_b(bb[0], nc_begin, s_begin);
+    load_a(aa[0], s_begin);
+#pragma unroll
+    for (int q = 0; q < KS / 2; ++q) {
+      if (q + 1 < KS / 2) {
+        load_b(bb[(q + 1) & 1], nc_begin, s_begin + q + 1);
+        load_a(aa[(q + 1) & 1], s_begin + q + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(aa[q & 1], bb[q & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // every wave hands the row tile its partner owns (tile i belongs to column wave i) over through LDS -- the row tile is no longer needed
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(At);
+    const int give = wn_id ^ 1, partner = wm * WN + (wn_id ^ 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * 2 + j) * 16 + r) * 64 + lane] = give ? acc[1][j][r] : acc[0][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float o = red[((partner * 2 + j) * 16 + r) * 64 + lane];
+        if (wn_id) acc[1][j][r] += o; else acc[0][j][r] += o;
+      }
+    store_chunk(nc_begin, wn_id);
+    return;
+  }
   load_b(bb[0], nc_begin, 0);
   load_a(aa[0], 0);
   for (int nc = nc_begin; nc < nc_end; ++nc) {
@@ -418,6 +456,20 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
 }
 
 inline int* pj_launch_counter() { static int n = 0; return &n; }
+
+template <int WM, int WN, int KS, bool F32, bool ONE>
+int launch_pj_k2(const PJArgs& a, hipStream_t s) {  // the KSPLIT2 instance: one column slice, one workgroup row per row tile
+  constexpr int BM = WM * 64;
+  const size_t shm = sizeof(unsigned short) * (size_t)BM * (2 * KS * 16 + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_x3_kernel<WM, WN, KS, F32, false, ONE, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((proj_x3_kernel<WM, WN, KS, F32, false, ONE, false, true>), dim3((unsigned)cdiv(a.M, BM), 1), dim3(256), shm, s, a);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
 
 template <int WM, int WN, int KS, bool F32, bool KSPLIT4 = false, bool ONE = false>
 int launch_pj(const PJArgs& a, hipStream_t s) {
@@ -523,6 +575,8 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   if (KP == 64) return launch_pj<4, 1, 4, F32, false, ONE>(a, s);
   if (KP <= 128) {
     if (KP == 96) return 1;
+    static const bool k2 = [] { const char* e = getenv("VMM_PJ_KSPLIT2"); return !e || e[0] != '0'; }();  // (0: A/B runs)
+    if (KP == 128 && d.Cout <= 64 && a.n_chunks == 1 && k2) return launch_pj_k2<2, 2, 8, F32, ONE>(a, s);
     return launch_pj<2, 2, 8, F32, false, ONE>(a, s);
   }
   if (KP == 256) return d.Cout <= 64 ? launch_pj<1, 4, 16, F32, true, ONE>(a, s) : launch_pj<1, 4, 16, F32, false, ONE>(a, s);
