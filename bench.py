@@ -59,6 +59,13 @@ def _committed(name: str):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
+def profile_id(which: str):
+    """Which committed rocprofv3 pass the replayed counter fields describe (profiles/latest_id.json: {"traffic": "r05_c", "sq": "r05_c"}); those fields are
+    properties of the BUILDER's profiled run of this command, not of the run that prints the line."""
+    ids = _committed("latest_id.json") or {}
+    return ids.get(which)
+
+
 def pmc_traffic(family: str):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/traffic_latest.json, made by
     tools/profile_bench.sh on this same bench command: separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
@@ -164,6 +171,22 @@ def cpu_baseline(quick: bool = False):
 
     train = timed(train_step, 1 if quick else 4)[0 if quick else 1:]  # (first optimisation step = warm-up of the autograd graph / Adam state)
     step_s, train_s = statistics.median(step), statistics.median(train)
+    # BASELINE.json configs[0] -- Unet3D(dim=16, channels=1), 4 frames of 32 x 32, batch 2 -- one optimisation step
+    cfg1 = dict(dim=16, channels=1)
+    m1 = vm.Unet3D(**cfg1)
+    sd1 = {k: v.detach().clone().requires_grad_(not k.endswith("freqs")) for k, v in m1.state_dict().items()}
+    c1 = uo.UnetCfg(**cfg1)
+    x1, t1, cond1 = torch.rand(2, 1, 4, 32, 32, generator=g) * 2 - 1, torch.randint(0, TIMESTEPS, (2,), generator=g), torch.randn(2, 51, generator=g)
+    n1 = torch.randn(2, 1, 4, 32, 32, generator=g)
+    opt1 = torch.optim.Adam([v for v in sd1.values() if v.requires_grad], lr=1e-4)
+    z1 = torch.zeros(2, dtype=torch.bool)
+
+    def cfg1_step():
+        opt1.zero_grad(set_to_none=True)
+        do.p_losses(sch, lambda a, c: uo.unet3d_forward(sd1, c1, a, c, cond1, z1), x1, t1, n1).backward()
+        opt1.step()
+
+    cfg1_s = statistics.median(timed(cfg1_step, 6)[1:])
     scale = B_PER_GPU / b  # per-sample cost is batch independent
     return {"value": round(B_PER_GPU * T / (TIMESTEPS * step_s * scale), 6), "unit": "frames/s", "cores": nthreads, "cpu_model": _cpu_model_name(),
             "kind": "port", "kind_detail": "oracle (parity-pinned CPU restatement of the reference; the reference itself cannot travel to the GPU box)",
@@ -173,7 +196,9 @@ def cpu_baseline(quick: bool = False):
                        + "; x256 steps for a full sample"),
             "guided_step_s": round(step_s * scale, 3), "guided_step_s_samples": [round(v, 3) for v in step], "batch_measured": b,
             "train_step_s": round(train_s * scale, 3), "train_step_s_samples": [round(v, 3) for v in train],
-            "train_denoising_steps_per_sec": round(B_PER_GPU / (train_s * scale), 5), "forward_s": round(fwd[0], 3)}
+            "train_denoising_steps_per_sec": round(B_PER_GPU / (train_s * scale), 5), "forward_s": round(fwd[0], 3),
+            "cfg1_train_step_s": round(cfg1_s, 4), "cfg1_train_denoising_steps_per_sec": round(2 / cfg1_s, 3),
+            "cfg1_note": "BASELINE.md 3.2(d): configs[0] = Unet3D(dim=16, channels=1), 4x32x32, batch 2, one optimisation step (fwd + bwd + Adam), median of 5"}
 
 
 def _family_times(meta, ms_lists):
@@ -236,6 +261,9 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     out = {"optimizer_steps_per_sec": round(1e3 / ms, 4), "denoising_steps_per_sec": round(world * B_PER_GPU * 1e3 / ms, 3), "ms_per_step": round(ms, 2),
            "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
            "arithmetic": ("fp32 (exact fp32 MFMA)" if precision == "fp32"
+                          else "fp16: ONE MFMA pass on fp16-rounded operands (the reference's autocast dtype, main.py:34) in forward, data gradients, 3x3 / 1x1 / to_qkv weight "
+                               "gradients and the recomputing attention backward; static loss scale 2^16 with the skip-on-overflow check of GradScaler (vddp.py:1629-1633); "
+                               "fp32 master weights, activations, accumulation, norms, softmax, Adam" if precision == "fp16"
                           else "bf16: ONE MFMA pass on bf16-rounded operands in forward, data gradients, 3x3 / 1x1 / to_qkv weight gradients and the recomputing attention "
                                "backward; fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "bf16"
                           else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32"),
@@ -273,6 +301,29 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
     if tr.engine is not None:
         tr.engine.close()  # the next leg builds its own communicator
     return out
+
+
+def bench_cfg1(vm, dev, steps: int = 20):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable plumbing case: Unet3D(dim=16, channels=1), 4 frames of 32 x 32, batch 2) on the GPU: one
+    optimisation step (forward + backward + Adam) through the same trainer, in the drop-in's default training arithmetic.  Launch-bound at this size."""
+    from videometamaterials_amd.dp import DataParallelTrainer
+    torch.manual_seed(0)
+    m = vm.Unet3D(dim=16, channels=1).to(dev)
+    d = vm.GaussianDiffusion(m, image_size=32, num_frames=4, channels=1, timesteps=TIMESTEPS, loss_type="l1", sampling_timesteps=TIMESTEPS).to(dev)
+    tr = DataParallelTrainer(d, train_lr=1e-4, engine="torch")
+    g = torch.Generator().manual_seed(7)
+    x, c = torch.rand(2, 1, 4, 32, 32, generator=g).to(dev), torch.randn(2, 51, generator=g).to(dev)
+    for _ in range(3):
+        tr.train_step(x, c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(x, c)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": "configs[0]: Unet3D(dim=16, channels=1), 4x32x32, batch 2, one optimisation step (fwd + bwd + Adam)", "ms_per_step": round(ms, 3),
+            "denoising_steps_per_sec": round(2e3 / ms, 1), "arithmetic": m.train_precision, "loss": float(loss),
+            "launches_per_step": len(tr._plan.steps) + len(tr._plan.bwd_steps)}
 
 
 HIRES = dict(dim=64, dim_mults=(1, 2, 4, 8), channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
@@ -660,12 +711,17 @@ def main():
         # reference's own recipe, fp16 autocast (main.py:34).  Gradient deviation against fp32 autograd: inside the reference's measured bf16-autocast
         # deviation at both widths, inside its fp16-autocast deviation at dim 16 (tests/test_gpu_train.py, tests/golden/autocast_lagr*.json)
         train["reduced_precision_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="bf16")
+        # the reference's OWN training arithmetic (main.py:34 mixed_precision='fp16', vddp.py:1619-1633 GradScaler): fp16 operands on the matrix cores in one
+        # pass, fp32 accumulation / master weights / activations, static loss scale with the non-finite check that skips the step
+        if "fp16" in getattr(vm.Unet3D, "PRECISIONS", ()):
+            train["reference_precision_variant"] = bench_training(vm, model, diff, dev, dist, world, rank, steps=nst, precision="fp16")
         model.train_precision = "bf16x3"
         model.eval()
         for k in [k for k, v in model._plans.items() if v.training]:  # the training plans keep every intermediate (19 GB at batch 4):
             del model._plans[k]                                       # released before the configs[3] leg
         torch.cuda.empty_cache()
 
+    cfg1_gpu = bench_cfg1(vm, dev) if (not args.no_train and not args.no_extras and world == 1 and dist is None) else None
     # ---- BASELINE.json configs[3]: 22 frames x 192 x 192, batch 8 per GPU (the HBM stress configuration)
     config4 = None
     if not args.no_config4 and not args.no_extras:
@@ -691,8 +747,10 @@ def main():
         # so its roof for ALGORITHMIC flops is the dense bf16 peak / 3
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom.endswith("bf16x3") else PEAK_FP32_MFMA_TFLOPS
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach_tflops / peak, 4), "traffic": pmc_traffic(dom),
-                    "traffic_note": "HBM bytes per launch, mean over the family, from profiles/traffic_latest.json (rocprofv3 PMC passes of this command)",
+                    "frac": round(ach_tflops / peak, 4), "traffic": pmc_traffic(dom), "traffic_profile": profile_id("traffic"), "mfma_pipe_util_profile": profile_id("sq"),
+                    "traffic_note": "HBM bytes per launch, mean over the family, REPLAYED from the committed rocprofv3 PMC passes of this command on the builder's box "
+                                    "(profiles/<traffic_profile>_traffic.json = traffic_latest.json; mfma_pipe_util likewise from profiles/<mfma_pipe_util_profile>_sq.json); "
+                                    "achieved / frac / avg_launch_ms are measured live in this run",
                     "peak_note": "dense bf16 MFMA 2500 TFLOP/s / 3 passes (split-bf16 operands, fp32-class result)" if dom.endswith("bf16x3")
                     else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                     "launches_per_step": d_n // reps, "avg_launch_ms": round(d_ms / d_n, 4),
@@ -713,8 +771,16 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(quick=args.cpu_baseline_quick)
+        tr_var = "split-bf16 (fp32-class; the drop-in's default train_precision)"
+        c4 = (config4 or {}).get("bf16") or {}
+        # Key order = what survives a consumer that keeps only the END of the line: the contract's scalars first (parsed by name), the bulky per-leg detail in
+        # the middle, and roofline / attention / cpu_baseline / summary -- the objects a review reads -- LAST.
         out = {
             "metric": "sampled frames/sec (guided DDPM sampling, 11x96x96 video)", "value": round(frames_per_s, 4), "unit": "frames/s",
+            "train_ms_per_step": train["ms_per_step"] if train else None, "train_variant": tr_var if train else None,
+            "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
+            "train_fp16_ms_per_step": (train.get("reference_precision_variant") or {}).get("ms_per_step") if train else None,
+            "cfg4_bf16_forward_ms": c4.get("denoiser_forward_ms"),
             "n_gpus": world, "rccl_ranks": world if (world > 1 and backend == "nccl") else (1 if world == 1 else 0), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
@@ -727,12 +793,34 @@ def main():
                        "batch_per_gpu": B_PER_GPU, "frames": T, "image": HW, "timesteps": TIMESTEPS, "guidance_scale": W_GUIDE,
                        "hipgraph": stepper.graph is not None, "launches_per_step": len(pl.steps),
                        "parallelism": f"independent sampling shards x{world} (no data-path collective)" + ("" if backend == "nccl" or world == 1
-                                                                                                           else f" [{backend} rehearsal, not RCCL]")},
+                                                                                                           else f" [{backend} rehearsal, not RCCL]"),
+                       "train_ms_per_step": train["ms_per_step"] if train else None, "train_variant": tr_var if train else None,
+                       "cfg4_bf16_forward_ms": c4.get("denoiser_forward_ms")},
             "denoising_sample_steps_per_sec": round(world * B_PER_GPU / (ms_per_step * 1e-3), 3),
             "full_sample": full_sample, "fp32_exact": fp32_exact, "bf16_throughput_mode": bf16_mode,
             "denoiser_ms_by_kernel_family": families, "denoiser_event_ms": round(fwd_ms, 3), "output_finite": finite,
-            "train_denoising_steps_per_sec": train["denoising_steps_per_sec"] if train else None,
-            "training": train, "config4": config4, "guidance_sweep": guidance_sweep, "roofline": roofline, "attention": attention, "cpu_baseline": cpu,
+            "training": train, "config4": config4, "guidance_sweep": guidance_sweep, "cfg1_gpu": cfg1_gpu,
+            "attention": attention, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        tv = lambda key: ({k: (train.get(key) or {}).get(k) for k in ("ms_per_step", "denoising_steps_per_sec", "launches_per_step", "arena_GB")}  # noqa: E731
+                          if train and train.get(key) else None)
+        rt = (train or {}).get("roofline_training") or {}
+        out["summary"] = {
+            "sampling": {"ms_per_guided_step": round(ms_per_step, 3), "frames_per_sec": round(frames_per_s, 4), "dtype": "bf16x3 (split-bf16, fp32-class)",
+                         "fp32_exact_ms": (fp32_exact or {}).get("ms_per_step"), "bf16_mode_ms": (bf16_mode or {}).get("ms_per_step"),
+                         "dominant_kernel": dom, "roofline_frac": roofline["frac"], "launches_per_step": len(pl.steps)},
+            "training": {"headline_variant": tr_var, "ms_per_step": train["ms_per_step"], "denoising_steps_per_sec": train["denoising_steps_per_sec"],
+                         "launches_per_step": train["launches_per_step"], "event_ms_forward": rt.get("event_ms_forward"), "event_ms_backward": rt.get("event_ms_backward"),
+                         "fp32_parity_variant": tv("fp32_parity_variant"),
+                         "reference_precision_variant (fp16 operands, loss scaling: main.py:34)": tv("reference_precision_variant"),
+                         "bf16_single_pass_variant": tv("reduced_precision_variant")} if train else None,
+            "config4": {k: {"denoiser_forward_ms": v.get("denoiser_forward_ms"), "guided_step_ms": v.get("guided_step_ms")} for k, v in (config4 or {}).items()
+                        if isinstance(v, dict)} or config4,
+            "attention_ms": {k: v["ms_per_step"] for k, v in attention.items()},
+            "attention_mfma_pipe_util": {k: v["mfma_pipe_util"] for k, v in attention.items() if v.get("mfma_pipe_util") is not None},
+            "counter_profiles": {"traffic": profile_id("traffic"), "sq": profile_id("sq")},
+            "cpu_baseline": {k: cpu.get(k) for k in ("value", "guided_step_s", "train_step_s", "cfg1_train_step_s", "cores", "cpu_model")} if cpu else None,
+            "cfg1_gpu_train_ms": (cfg1_gpu or {}).get("ms_per_step"),
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

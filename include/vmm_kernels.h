@@ -313,11 +313,14 @@ int vmm_linattn_cross_context(const float* ek, const float* ev, int32_t ntok, in
 /* backward of the two (training with cond_attention = 'cross-attention'; loss.backward() through vddp.py:354-363 / 476-485).
  * vmm_cross_attention_bwd: q = the rows the forward consumed, dout [rows][heads*dh]; writes dq = the gradient of the RAW to_q output (the
  * projection epilogue's rotation -- rot_tab [T][dh/2][2] (cos, sin) or NULL -- and q_scale are undone here), ADDS the token gradients into
- * dek / dev [B][ntok][heads*dh] and the bias gradient into dbias [heads][T][T] (NULL allowed).  heads = 8, ntok <= 16.
+ * dek / dev [B][ntok][heads*dh] and the bias gradient into dbias [heads][T][T] (NULL allowed).  Any number of heads <= 64, dh a multiple of 4
+ * in 4..128 (the temporal sites follow attn_dim_head, vddp.py:615), ntok <= 32; scratch = vmm_cross_attention_bwd_scratch floats (0 -- and NULL
+ * accepted -- where the one-pass kernel applies: 8 heads of 32, at most 16 tokens; otherwise the per-row ds / p records of the two-pass form).
  * vmm_linattn_cross_bwd: ctx / kstat as vmm_linattn_cross_context left them, dctx = [B*T*heads][dh*dh] scratch; writes dq, ADDS dek / dev. */
+int64_t vmm_cross_attention_bwd_scratch(int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t ntok);
 int vmm_cross_attention_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* bias, const float* dout,
-                            int32_t lddo, const float* rot_tab, float q_scale, float* dq, int32_t lddq, float* dek, float* dev, float* dbias, int32_t B,
-                            int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
+                            int32_t lddo, const float* rot_tab, float q_scale, float* dq, int32_t lddq, float* dek, float* dev, float* dbias,
+                            float* scratch, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
 int vmm_linattn_cross_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* ctx, const float* kstat,
                           const float* dout, int32_t lddo, float* dctx, float* dq, int32_t lddq, float* dek, float* dev, int32_t B, int32_t T, int32_t HW,
                           int32_t heads, int32_t dh, vmm_stream_t stream);

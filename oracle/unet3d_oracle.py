@@ -106,15 +106,20 @@ def sinusoidal_embedding(time: Tensor, dim: int) -> Tensor:
 
 
 def rotary_rotate(t: Tensor, freqs: Optional[Tensor] = None) -> Tensor:
-    """Interleaved-pair RoPE along dim -2, positions 0..n-1."""
+    """Interleaved-pair RoPE along dim -2, positions 0..n-1.  The reference builds ONE RotaryEmbedding(min(32, attn_dim_head))
+    (vddp.py:612): the leading rot = min(32, d) features of every head are rotated with frequencies theta^(-2i/rot), the features beyond them pass
+    through unchanged (rotary_embedding_torch's apply_rotary_emb with start_index = 0)."""
     d = t.shape[-1]
+    rot = min(32, d)
     if freqs is None:
-        freqs = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+        freqs = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
     pos = torch.arange(t.shape[-2]).float()
     ang = (pos[:, None] * freqs[None, :]).repeat_interleave(2, dim=-1)
-    pairs = t.reshape(*t.shape[:-1], d // 2, 2)
-    rot = torch.stack((-pairs[..., 1], pairs[..., 0]), dim=-1).reshape(t.shape)
-    return t * ang.cos() + rot * ang.sin()
+    head, tail = t[..., :rot], t[..., rot:]
+    pairs = head.reshape(*head.shape[:-1], rot // 2, 2)
+    swapped = torch.stack((-pairs[..., 1], pairs[..., 0]), dim=-1).reshape(head.shape)
+    head = head * ang.cos() + swapped * ang.sin()
+    return torch.cat((head, tail), dim=-1) if tail.shape[-1] else head
 
 
 def _pad_frames(x2: Tensor, pad: int, mode: str) -> Tensor:
@@ -251,7 +256,6 @@ def softmax_attention(
     position only.  Inert on every shipped config (prob_focus_present = 0)."""
     b, b2, n, c = x.shape
     heads, dh = cfg.attn_heads, dim_head
-    assert dh <= 32, "rotary restatement rotates the whole head (rot_dim == dim_head <= 32)"
     qkv = F.linear(x, sd[p + ".to_qkv.weight"])
     if focus is not None and (cfg.cond_attention == "none" or tokens is None) and bool(focus.all()):  # vddp.py:438-443
         return F.linear(qkv.chunk(3, dim=-1)[-1], sd[p + ".to_out.weight"])

@@ -58,6 +58,42 @@ def unet_goldens(only=None):
         print(cfg_name, {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
 
 
+def gradient_goldens(only=None):
+    """Parameter gradients of the l1 training loss (vddp.py:1044-1060, 1622-1629) as the REAL reference's autograd computes them, for the
+    configurations of helpers.GRADIENT_CONFIGS (constructor keywords off their defaults): every parameter whose gradient has fewer than 6000
+    elements plus a fixed list of large ones -> tests/golden/grads_<config>.npz."""
+    for cfg_name in helpers.GRADIENT_CONFIGS:
+        if only and cfg_name not in only:
+            continue
+        model = build(cfg_name)
+        kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+        x, t, cond = helpers.synth_inputs(cfg_name)
+        diff = GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=256, loss_type="l1", use_dynamic_thres=True,
+                                 sampling_timesteps=256)
+        g = torch.Generator().manual_seed(7)
+        x0 = torch.rand((B, kw["channels"], T, H, W), generator=g) * 2 - 1
+        noise = torch.randn((B, kw["channels"], T, H, W), generator=g)
+        out = {"x0": x0.numpy(), "noise": noise.numpy(), "t": t.numpy()}
+        model.train()
+        model.zero_grad()
+        loss = diff.p_losses(x0, t, cond=cond, noise=noise, null_cond_prob=0.0)
+        loss.backward()
+        out["loss_train"] = loss.detach().numpy()
+        big = {"downs.0.0.block1.proj.weight", "downs.1.2.fn.fn.to_qkv.weight", "downs.0.3.fn.fn.fn.to_qkv.weight", "downs.0.3.fn.fn.fn.to_out.weight",
+               "downs.0.3.fn.fn.fn.to_k.weight", "mid_temporal_attn.fn.fn.fn.to_qkv.weight", "mid_spatial_attn.fn.fn.fn.to_qkv.weight", "ups.3.0.block1.proj.weight",
+               "init_temporal_attn.fn.fn.fn.to_qkv.weight", "init_temporal_attn.fn.fn.fn.to_out.weight", "ups.3.3.fn.fn.fn.to_v.weight", "downs.0.4.weight"}
+        nograd = []
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                nograd.append(k)
+            elif p.numel() < 6000 or k in big:
+                out["grad/" + k] = p.grad.numpy()
+        out["nograd"] = np.array(sorted(nograd))
+        np.savez_compressed(os.path.join(HERE, f"grads_{cfg_name}.npz"), **out)
+        print("gradients", cfg_name, float(loss), len([k for k in out if k.startswith("grad/")]), "tensors;", len(nograd), "without gradient")
+        model.eval()
+
+
 FOCUS_CASES = {"plumb16": ([1, 0], [1, 1]), "focus16s": ([1, 0, 1], [1, 1, 1], [0, 1, 0])}
 
 
@@ -198,9 +234,12 @@ if __name__ == "__main__":
         print("relpos row written")
     elif sys.argv[1:] == ["--focus"]:
         focus_goldens()
+    elif sys.argv[1:2] == ["--grads"]:  # python make_golden.py --grads [<config> ...]
+        gradient_goldens(only=sys.argv[2:])
     elif len(sys.argv) > 1:  # python make_golden.py <config> [...]: only the Unet3D goldens of the named configs (adding one leaves the rest untouched)
         unet_goldens(only=sys.argv[1:])
     else:
         unet_goldens()
         ng = diffusion_goldens()
         table_goldens(ng)
+        gradient_goldens()

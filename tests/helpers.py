@@ -59,7 +59,49 @@ CONFIGS = {
                    cond_att_GRU=True), (2, 5, 16, 16), 34),  # (the CNN embedding of the same signal needs 32 .. 63 samples)
     "circ1d16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
                       per_frame_cond=True, cond_bias=True, padding_mode="circular_1d"), (2, 11, 32, 32), 11),
+    # ---- the constructor keywords main.py:62-80 forwards from model.yaml, off their defaults (vddp.py:575-626, 669-710) ----
+    # attn_heads (vddp.py:581, 615, 617, 679, 687): heads of all three attention families and of the relative-position bias; 4 (Lagrangian wiring)
+    # and 3 (not a divisor of the 256-thread row kernels' block; CNN tokens)
+    "heads4": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                    per_frame_cond=True, cond_bias=True, attn_heads=4), (2, 11, 16, 16), 11),
+    "heads3": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=7, use_temporal_attention_cond=True,
+                    per_frame_cond=False, attn_heads=3), (2, 6, 16, 16), 51),
+    # attn_dim_head (vddp.py:582, 612, 615): the TEMPORAL attentions only (the linear and the mid spatial attention keep their default 32);
+    # 16 = the rotary embedding shrinks with the head (RotaryEmbedding(16)), 64 = partial rotary (the leading 32 features of every head rotate)
+    "dh16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                  per_frame_cond=True, cond_bias=True, attn_dim_head=16), (2, 11, 16, 16), 11),
+    "dh64": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                  per_frame_cond=True, cond_bias=True, attn_dim_head=64), (2, 11, 16, 16), 11),
+    # ... at the real widths (where attn_dim_head = 32 would take the fused attention blocks), and under 'cross-attention' (to_q rotated alone)
+    "dh64w64": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                     per_frame_cond=True, cond_bias=True, attn_dim_head=64), (1, 11, 16, 16), 11),
+    "dh16w64": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                     per_frame_cond=False, attn_dim_head=16), (2, 6, 16, 16), 51),
+    "dh64cross": (dict(dim=16, channels=3, cond_attention="cross-attention", cond_attention_tokens=6, use_temporal_attention_cond=True,
+                       per_frame_cond=False, attn_dim_head=64), (2, 6, 16, 16), 51),
+    "dh24": (dict(dim=16, channels=1, attn_dim_head=24, attn_heads=2), (2, 4, 16, 16), 51),  # neither a power of two nor a multiple of 32
+    # resnet_groups (vddp.py:586, 669): GroupNorm groups of every Block; 4 at dim 16 (4 ... 32 channels per group), 16 at the real widths
+    "groups4": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                     per_frame_cond=True, cond_bias=True, resnet_groups=4), (2, 11, 16, 16), 11),
+    "groups16w64": (dict(dim=64, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                         per_frame_cond=True, cond_bias=True, resnet_groups=16), (1, 11, 16, 16), 11),
+    # out_dim (vddp.py:576, 706-710): channels of final_conv.1; init_kernel_size (vddp.py:584, 621-626): the stem's (1, k, k) kernel
+    "outdim5": (dict(dim=16, channels=3, out_dim=5, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                     per_frame_cond=True, cond_bias=True), (2, 11, 16, 16), 11),
+    "k5": (dict(dim=16, channels=3, init_kernel_size=5, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                per_frame_cond=True, cond_bias=True), (2, 11, 16, 16), 11),
+    "k3": (dict(dim=16, channels=1, init_kernel_size=3, padding_mode="circular"), (2, 4, 16, 16), 51),
+    "k9w64": (dict(dim=64, channels=3, init_kernel_size=9, init_dim=64, cond_attention="self-stacked", cond_attention_tokens=16,
+                   use_temporal_attention_cond=True, per_frame_cond=True, cond_bias=True), (1, 11, 16, 16), 11),
+    # all of them at once (init_dim given explicitly: the reference's final_conv reads cat(x, r) as 2 * dim channels, so init_dim == dim is the only
+    # value its forward accepts, vddp.py:706, 820): the configuration of the golden GRADIENT set (tests/golden/grads_ctor16.npz)
+    "ctor16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                    per_frame_cond=True, cond_bias=True, attn_heads=4, attn_dim_head=16, resnet_groups=4, init_kernel_size=5, init_dim=16),
+               (2, 11, 16, 16), 11),
 }
+
+# configurations whose golden file also holds the reference's parameter gradients of the l1 training loss (make_golden.py: gradient_goldens)
+GRADIENT_CONFIGS = ("ctor16", "dh64")
 
 
 def _seed_for(name: str, seed: int) -> int:

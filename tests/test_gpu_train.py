@@ -21,6 +21,9 @@ def _setup(cfg_name, dev):
     model = vm.Unet3D(**kw)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
+    # the exact-fp32 training arithmetic (every gradient within 1e-3 of the reference's fp32 autograd); the drop-in's default is the split-bf16 one
+    # (tests below that concern it set it themselves)
+    model.train_precision = "fp32"
     diff = vm.GaussianDiffusion(model, image_size=H, num_frames=T, channels=kw["channels"], timesteps=256, loss_type="l1", use_dynamic_thres=True,
                                 sampling_timesteps=256).to(dev)
     return kw, sd, model, diff
@@ -93,9 +96,52 @@ def test_backward_matches_reference_golden_gradients(gpu):
     assert {k for k, p in named.items() if p.grad is None} == nograd
 
 
+@pytest.mark.parametrize("cfg_name", helpers.GRADIENT_CONFIGS)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_backward_matches_reference_golden_gradients_off_default_constructor_keywords(gpu, cfg_name, precision):
+    """Constructor keywords off their defaults (attn_heads, attn_dim_head incl. partial rotary, resnet_groups, init_kernel_size; vddp.py:575-626):
+    the reference's own autograd gradients of the l1 training loss (tests/golden/grads_<config>.npz, made by make_golden.py --grads) -- every
+    parameter under 6000 elements and a fixed list of large ones -- and the set of parameters that receive no gradient.  fp32: the 1e-3 bar;
+    split-bf16 (the drop-in's default training arithmetic): the l1 loss's sign flips move single gradients by a few 1e-3 (unet3d.py), bar 2e-2."""
+    kw, sd, model, diff = _setup(cfg_name, gpu)
+    model.train_precision = precision
+    gold = np.load(os.path.join(helpers.GOLDEN_DIR, f"grads_{cfg_name}.npz"))
+    _, t, cond = helpers.synth_inputs(cfg_name)
+    assert np.array_equal(gold["t"], t.numpy())
+    x0, noise = torch.from_numpy(gold["x0"]), torch.from_numpy(gold["noise"])
+    loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss_train"])) < 1e-4 * float(gold["loss_train"])
+    named = dict(model.named_parameters())
+    tol = TOL if precision == "fp32" else 2e-2
+    bad, n = [], 0
+    for key in gold.files:
+        if key.startswith("grad/"):
+            name, want = key[5:], torch.from_numpy(gold[key])
+            got = named[name].grad
+            n += 1
+            if float(want.abs().max()) == 0:
+                if got is not None and float(got.abs().max()) != 0:
+                    bad.append((name, "expected zero"))
+                continue
+            if got is None:
+                bad.append((name, "missing"))
+                continue
+            err = helpers.rel_err(got.cpu(), want)
+            if err > tol:
+                bad.append((name, f"{err:.3e}"))
+    assert n > 200 and not bad, bad
+    nograd = {str(k) for k in gold["nograd"] if not str(k).endswith("freqs")}
+    assert {k for k, p in named.items() if p.grad is None} == nograd
+
+
 @pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
                                                ("hires64t22", False), ("circ64", False), ("circ1d16", False), ("cross16", False), ("cross64", False),
-                                               ("cross64", True), ("cross16s", False), ("concat16", False), ("concat16", True), ("concat16c", False), ("gru16", False), ("gru16", True)])
+                                               ("cross64", True), ("cross16s", False), ("concat16", False), ("concat16", True), ("concat16c", False), ("gru16", False), ("gru16", True),
+                                               # constructor keywords off their defaults (vddp.py:575-626)
+                                               ("heads4", False), ("heads3", False), ("heads3", True), ("dh16", False), ("dh64", True), ("dh64w64", False),
+                                               ("dh16w64", False), ("dh64cross", False), ("dh24", False), ("groups4", False), ("groups16w64", False),
+                                               ("k5", False), ("k3", False), ("k9w64", False), ("ctor16", False)])
 def test_every_parameter_gradient_matches_oracle_autograd(gpu, cfg_name, mask_val):
     kw, sd, model, diff = _setup(cfg_name, gpu)
     x, t, cond = helpers.synth_inputs(cfg_name)

@@ -92,6 +92,26 @@ def test_hostmath_integer_tables_bit_exact():
     assert hm.strip_padding(gathered, [2, 1, 3], 3)[:, 0].int().tolist() == tabs["remove_padding_2_1_3"]
 
 
+def test_hostmath_rotary_table_spans_min_32_dim_head():
+    """RotaryEmbedding(min(32, attn_dim_head)) (vddp.py:612): the table's leading min(32, dh) / 2 pairs are the oracle's angles (pinned by the
+    reference goldens dh16 / dh64 / dh24), the pairs beyond them the exact identity."""
+    from oracle import unet3d_oracle as uo
+    from videometamaterials_amd import hostmath
+    for dh in (4, 8, 16, 24, 32, 48, 64, 128):
+        tab = hostmath.rotary_table(7, dh)
+        assert tab.shape == (7, dh // 2, 2)
+        span = min(32, dh) // 2
+        assert torch.equal(tab[:, span:, 0], torch.ones(7, dh // 2 - span)) and torch.equal(tab[:, span:, 1], torch.zeros(7, dh // 2 - span))
+        x = torch.randn(7, dh)
+        e, o = x[:, 0::2], x[:, 1::2]
+        rot = torch.stack([e * tab[..., 0] - o * tab[..., 1], o * tab[..., 0] + e * tab[..., 1]], -1).reshape(7, dh)
+        assert torch.allclose(rot, uo.rotary_rotate(x), atol=1e-6)
+        assert torch.equal(rot[:, 2 * span:], x[:, 2 * span:])
+    assert torch.equal(hostmath.rotary_table(11, 32)[..., 0], (torch.arange(11).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]).cos())
+    with pytest.raises(ValueError):
+        hostmath.rotary_table(4, 7)
+
+
 def test_hostmath_schedule_and_quantile_rank():
     from videometamaterials_amd import hostmath as hm
     gold = np.load(os.path.join(helpers.GOLDEN_DIR, "diffusion_lagr16.npz"))
@@ -133,6 +153,20 @@ def test_constructor_rejections():
         vm.Unet3D(dim=16, cond_attention="bogus")
     with pytest.raises(AssertionError):
         vm.Unet3D(dim=16, init_kernel_size=6)
+    for dh in (6, 2, 132, 30):  # (head widths that do not move in 16-byte pieces / beyond the kernels' register budget: refused at construction, loudly)
+        with pytest.raises(NotImplementedError, match="attn_dim_head"):
+            vm.Unet3D(dim=16, attn_dim_head=dh)
+    for dh in (4, 8, 16, 24, 32, 48, 64, 96, 128):
+        m = vm.Unet3D(dim=16, attn_dim_head=dh, attn_heads=2)
+        assert m.state_dict()["downs.0.3.fn.fn.fn.to_qkv.weight"].shape == (3 * 2 * dh, 16)
+        assert m.state_dict()["downs.0.2.fn.fn.to_qkv.weight"].shape == (3 * 2 * 32, 16, 1, 1)       # the linear attention keeps dim_head = 32 (vddp.py:679)
+        assert m.state_dict()["mid_spatial_attn.fn.fn.fn.to_qkv.weight"].shape == (3 * 2 * 32, 128)  # ... and so does the mid spatial one (vddp.py:687)
+        assert m.state_dict()["downs.0.3.fn.fn.fn.rotary_emb.freqs"].shape == (min(32, dh) // 2,)      # RotaryEmbedding(min(32, attn_dim_head)), vddp.py:612
+    # init_dim != dim constructs (state_dict-compatible) and fails in forward like the reference (vddp.py:706, 820)
+    m = vm.Unet3D(dim=16, init_dim=24)
+    assert m.state_dict()["init_conv.weight"].shape[0] == 24 and m.state_dict()["final_conv.0.block1.proj.weight"].shape[1] == 32
+    with pytest.raises(RuntimeError, match="init_dim"):
+        m._check_inputs(torch.zeros(1, 3, 2, 8, 8), torch.zeros(1, 51), None, 0.0)
     with pytest.raises(AssertionError):
         vm.GaussianDiffusion(vm.Unet3D(dim=16), image_size=8, num_frames=2, timesteps=10, sampling_timesteps=20)
     d = vm.GaussianDiffusion(vm.Unet3D(dim=16), image_size=8, num_frames=2, channels=3, timesteps=10, sampling_timesteps=5)
@@ -311,6 +345,16 @@ def test_optimizer_state_of_the_wrong_size_is_rejected():
     obj["optimizer"]["state"] = {i: good, last - 1: {"step": torch.tensor(3.0), "exp_avg": torch.full_like(pl, 2.0).cpu(), "exp_avg_sq": torch.ones_like(pl).cpu()}}
     tr.load_state_dict(obj)
     assert float(tr._moments[names[last]][0].sum()) == 2.0 * pl.numel()
+    # ... but only when the checkpoint's own `model` entries follow this tree's parameter order: the same one-slot-short count from a checkpoint written
+    # in ANOTHER order (two equal-shaped parameters swapped: the per-index shape check cannot see it) is refused
+    import collections
+    keys = list(obj["model"].keys())
+    a, b = keys.index("denoise_fn.downs.0.3.fn.fn.fn.to_k.weight"), keys.index("denoise_fn.downs.0.3.fn.fn.fn.to_v.weight")
+    keys[a], keys[b] = keys[b], keys[a]
+    swapped = dict(obj, model=collections.OrderedDict((k, obj["model"][k]) for k in keys))
+    with pytest.raises(ValueError, match="parameter order"):
+        tr.load_state_dict(swapped)
+    tr.load_state_dict(dict(obj, model=collections.OrderedDict(("module." + k, v) for k, v in obj["model"].items())))  # (a DDP-wrapped save: same order)
     obj["optimizer"]["param_groups"][0]["params"] = list(range(len(names) - 2))  # any other count is another model
     with pytest.raises(ValueError, match="optimizer state covers"):
         tr.load_state_dict(obj)

@@ -169,3 +169,32 @@ def test_training_gradients():
                 assert helpers.rel_err(got, want) < 2e-4, name
     got_nograd = {k for k, v in sd.items() if v.requires_grad and (v.grad is None)}
     assert got_nograd == nograd
+
+
+@pytest.mark.parametrize("cfg_name", helpers.GRADIENT_CONFIGS)
+def test_training_gradients_off_default_constructor_keywords(cfg_name):
+    """Autograd through the oracle against the reference's own gradients with the constructor keywords off their defaults (attn_heads, attn_dim_head
+    incl. the partial rotary of widths above 32, resnet_groups, init_kernel_size; vddp.py:575-626): tests/golden/grads_<config>.npz."""
+    cfg, sd, _ = _load(cfg_name)
+    gold = np.load(os.path.join(helpers.GOLDEN_DIR, f"grads_{cfg_name}.npz"))
+    x, t, cond = helpers.synth_inputs(cfg_name)
+    B = x.shape[0]
+    sd = {k: v.clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
+    sch = do.schedule_buffers(256)
+    x0, noise = torch.from_numpy(gold["x0"]), torch.from_numpy(gold["noise"])
+    loss = do.p_losses(sch, lambda a, b: uo.unet3d_forward(sd, cfg, a, b, cond, torch.zeros(B, dtype=torch.bool)), x0, t, noise)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(gold["loss_train"])) < 1e-5
+    n = 0
+    for key in gold.files:
+        if key.startswith("grad/"):
+            name, want = key[5:], torch.from_numpy(gold[key])
+            got = sd[name].grad if sd[name].grad is not None else torch.zeros_like(want)
+            n += 1
+            if float(want.abs().max()) == 0:
+                assert float(got.abs().max()) == 0, name
+            else:
+                assert helpers.rel_err(got, want) < 2e-4, name
+    assert n > 200
+    nograd = {str(k) for k in gold["nograd"] if not str(k).endswith("freqs")}
+    assert {k for k, v in sd.items() if v.requires_grad and (v.grad is None)} == nograd

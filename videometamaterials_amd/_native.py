@@ -215,8 +215,9 @@ SIGNATURES = {
     "vmm_linattn_apply": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_cross_attention": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_cross_context": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
-    "vmm_cross_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_f32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
-                                c_i32, c_i32, c_ptr],
+    "vmm_cross_attention_bwd_scratch": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
+    "vmm_cross_attention_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_f32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32,
+                                c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_cross_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32,
                               c_i32, c_ptr],
     "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
@@ -278,7 +279,7 @@ DP_SIGNATURES = {
     "vmm_dp_finalize": [c_ptr],
 }
 
-RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64, "vmm_linattn_block_bwd_workspace": c_i64, "vmm_groupnorm_bwd_scratch": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_cross_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64, "vmm_linattn_block_bwd_workspace": c_i64, "vmm_groupnorm_bwd_scratch": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

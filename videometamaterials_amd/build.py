@@ -22,6 +22,8 @@ OUT = os.path.join(HERE, "libvmm_hip_exp.so" if EXPERIMENTS else "libvmm_hip.so"
 OBJDIR = os.path.join(HERE, "_obj_exp" if EXPERIMENTS else "_obj")
 EXPERIMENT_SOURCES = {"conv3x3_wino.hip"}
 # compiled a second time with -DVMM_SINGLE_PASS=1 (object *_sp.o): the `_bf16` entry points of the backward kernels (vmm_common.h, VMM_X3)
+# (object suffix, VMM_SINGLE_PASS value): 1 = bf16-rounded operands (`_bf16` entry points), 2 = fp16-rounded operands (`_fp16`: the reference's autocast dtype)
+SINGLE_PASS_MODES = (("_sp", 1),)
 SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
@@ -40,6 +42,16 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_changed(cmd) -> bool:
+    """An object is also stale when the command that made it differs from the one about to run (a changed FLAGS list or per-object define must not leave
+    a library linked from objects of two flag sets): the command line is kept beside the object as <object>.cmd."""
+    stamp, want = cmd[-1] + ".cmd", " ".join(cmd)
+    try:
+        return open(stamp).read() != want
+    except OSError:
+        return True
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [s for s in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) if EXPERIMENTS or os.path.basename(s) not in EXPERIMENT_SOURCES]
@@ -49,13 +61,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        if force or _stale(o, [s] + hdrs) or _flags_changed(cmd):
+            jobs.append(cmd)
         if os.path.basename(s) in SINGLE_PASS_SOURCES:
-            o = o[:-2] + "_sp.o"
-            objs.append(o)
-            if force or _stale(o, [s] + hdrs):
-                jobs.append([hipcc, *FLAGS, "-DVMM_SINGLE_PASS=1", "-c", s, "-o", o])
+            for tag, mode in SINGLE_PASS_MODES:
+                o2 = o[:-2] + tag + ".o"
+                objs.append(o2)
+                cmd = [hipcc, *FLAGS, f"-DVMM_SINGLE_PASS={mode}", "-c", s, "-o", o2]
+                if force or _stale(o2, [s] + hdrs) or _flags_changed(cmd):
+                    jobs.append(cmd)
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -64,6 +79,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if res.returncode != 0:
                     sys.stderr.write(res.stdout + res.stderr)
                     raise RuntimeError(f"hipcc failed on {cmd[-3]}")
+                with open(cmd[-1] + ".cmd", "w") as f:
+                    f.write(" ".join(cmd))
     if jobs or not os.path.exists(OUT):
         res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT], capture_output=True, text=True)
         if res.returncode != 0:

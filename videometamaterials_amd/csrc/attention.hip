@@ -1,7 +1,9 @@
 // Attention cores for gfx950.  Inputs are the rows written by the projection
 // GEMM (igemm_conv.hip) with q already scaled and q,k already rotated by its epilogue, so the cores are pure
-// softmax/weighted-sum arithmetic.  dim_head is fixed at 32 (vddp.py:314,401; model.yaml:16).
+// softmax/weighted-sum arithmetic.  dim_head = 32 for the linear and the mid spatial attention (their constructor default, vddp.py:314, 401:
+// Unet3D does not forward attn_dim_head to them, vddp.py:679, 687); the temporal attention core takes any multiple of 4 up to 128 (vddp.py:615).
 #include "vmm_common.h"
+#include "head_vec.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
@@ -40,10 +42,32 @@ __device__ __forceinline__ void online_step(float s, const float* vrow, float& m
 }
 
 // ---------------------------------------------------------------- temporal attention: one thread per (b, pixel, head, query frame)
+// The one attention family whose head width follows the constructor (attn_dim_head, vddp.py:582, 615): templated on the head slice
+// (head_vec.h); dh = 32 is the instance of every shipped configuration.
+template <int DM, bool EX>
+__device__ __forceinline__ void online_step_hv(float s, const float* vrow, int dh, float& m, float& l, float (&acc)[DM]) {
+  const float mn = fmaxf(m, s);
+  const float f = __expf(m - mn);
+  const float p = __expf(s - mn);
+  l = l * f + p;
+#pragma unroll
+  for (int i = 0; i < DM / 4; ++i) {
+    if (HeadVec<DM, EX>::on(i, dh)) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vrow + i * 4);
+      acc[i * 4 + 0] = fmaf(p, v.x, acc[i * 4 + 0] * f); acc[i * 4 + 1] = fmaf(p, v.y, acc[i * 4 + 1] * f);
+      acc[i * 4 + 2] = fmaf(p, v.z, acc[i * 4 + 2] * f); acc[i * 4 + 3] = fmaf(p, v.w, acc[i * 4 + 3] * f);
+    }
+  }
+  m = mn;
+}
+
+template <int DM, bool EX>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
                                                             const float* __restrict__ ev, int ntok, const float* __restrict__ bias,
                                                             int bias_on_cond, float* __restrict__ out, int ldo, int B, int T, int HW,
-                                                            int heads, float* __restrict__ lse) {
+                                                            int heads, int dh_, float* __restrict__ lse) {
+  using HV = HeadVec<DM, EX>;
+  const int dh = EX ? DM : dh_;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * HW * heads * T;
   if (gid >= total) return;
@@ -52,35 +76,36 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
   const long long bp = gid / ((long long)T * heads);
   const int pix = (int)(bp % HW);
   const int b = (int)(bp / HW);
-  const int hid = heads * DH;
+  const int hid = heads * dh;
   const long long row0 = (long long)b * T * HW + pix;  // row of frame 0
-  float q[DH], acc[DH];
-  load32(q, qkv + (row0 + (long long)i * HW) * ldqkv + head * DH);
-#pragma unroll
-  for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+  float q[DM], acc[DM];
+  HV::ld(q, qkv + (row0 + (long long)i * HW) * ldqkv + head * dh, dh);
+  HV::zero(acc);
   float m = -INFINITY, l = 0.f;
   const float* brow = bias ? bias + ((long long)head * T + i) * T : nullptr;
   if (ek) {
     for (int j = 0; j < ntok; ++j) {
-      const float* kr = ek + ((long long)b * ntok + j) * hid + head * DH;
-      float s = dot32(q, kr);
+      const float* kr = ek + ((long long)b * ntok + j) * hid + head * dh;
+      float s = HV::dot(q, kr, dh);
       if (brow && bias_on_cond) s += brow[j];
-      online_step(s, ev + ((long long)b * ntok + j) * hid + head * DH, m, l, acc);
+      online_step_hv<DM, EX>(s, ev + ((long long)b * ntok + j) * hid + head * dh, dh, m, l, acc);
     }
   }
   for (int j = 0; j < T; ++j) {
-    const float* r = qkv + (row0 + (long long)j * HW) * ldqkv + head * DH;
-    float s = dot32(q, r + hid);
+    const float* r = qkv + (row0 + (long long)j * HW) * ldqkv + head * dh;
+    float s = HV::dot(q, r + hid, dh);
     if (brow) s += brow[j];
-    online_step(s, r + 2 * hid, m, l, acc);
+    online_step_hv<DM, EX>(s, r + 2 * hid, dh, m, l, acc);
   }
   const float inv = 1.0f / l;
   if (lse) lse[(row0 + (long long)i * HW) * heads + head] = m + logf(l);
-  float* o = out + (row0 + (long long)i * HW) * ldo + head * DH;
+  float* o = out + (row0 + (long long)i * HW) * ldo + head * dh;
 #pragma unroll
-  for (int d = 0; d < DH / 4; ++d) {
-    f32x4 v = {acc[d * 4] * inv, acc[d * 4 + 1] * inv, acc[d * 4 + 2] * inv, acc[d * 4 + 3] * inv};
-    *reinterpret_cast<f32x4*>(o + d * 4) = v;
+  for (int d = 0; d < DM / 4; ++d) {
+    if (HV::on(d, dh)) {
+      f32x4 v = {acc[d * 4] * inv, acc[d * 4 + 1] * inv, acc[d * 4 + 2] * inv, acc[d * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(o + d * 4) = v;
+    }
   }
 }
 
@@ -277,15 +302,19 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 extern "C" int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, const float* ev, int32_t ntok,
                                       const float* bias, int32_t bias_on_cond, float* out, int32_t ldo, int32_t B, int32_t T,
                                       int32_t HW, int32_t heads, int32_t dh, float* lse, vmm_stream_t stream) {
-  if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
+  if (!vmm_head_dim_ok(dh) || heads < 1 || (ldqkv & 3) || (ldo & 3)) return -1;
   if (bias_on_cond && ek && ntok != T) return -2;  // the reference's in-place add needs tokens == frames
-  {  // LDS-staged workgroup-per-pixel kernel (temporal_attn_fwd.hip) where it applies
+  {  // LDS-staged workgroup-per-pixel kernel (temporal_attn_fwd.hip) where it applies (8 heads of 32)
     const int rc = vmm_temporal_attention_staged(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, ldo, B, T, HW, heads, dh, lse, stream);
     if (rc != 1) return rc;
   }
   const long long total = (long long)B * HW * heads * T;
-  hipLaunchKernelGGL(temporal_attn_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, ldqkv, ek, ev, ntok,
-                     bias, bias_on_cond, out, ldo, B, T, HW, heads, lse);
+  if (total <= 0) return 0;
+#define VMM_CALL(DM, EX)                                                                                                                    \
+  hipLaunchKernelGGL((temporal_attn_kernel<DM, EX>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, qkv, ldqkv, ek, ev, ntok, bias, \
+                     bias_on_cond, out, ldo, B, T, HW, heads, dh, lse)
+  VMM_HEADVEC_DISPATCH(dh, VMM_CALL);
+#undef VMM_CALL
   VMM_LAUNCH_CHECK();
   return 0;
 }
@@ -340,13 +369,18 @@ extern "C" int vmm_linattn_context_bf16x3(const float* qkv, int32_t ldqkv, const
 
 extern "C" int vmm_linattn_apply(const float* qkv, int32_t ldqkv, const float* ctx, float* out, int32_t ldo, int32_t B, int32_t T,
                                  int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
-  if (dh != DH || (ldqkv & 3) || (ldo & 3) || heads > 64 || 256 % heads) return -1;
-  {  // fp32 matrix-core row pass (linattn_rows.hip) where it applies
+  if (dh != DH || (ldqkv & 3) || (ldo & 3) || heads < 1 || heads > 36) return -1;  // (the fallback keeps every head's 32 x 32 context in LDS: 36 heads = 148 KB)
+  {  // fp32 matrix-core row pass (linattn_rows.hip) where it applies (heads a multiple of 4)
     const int rc = vmm_linattn_apply_mfma(qkv, ldqkv, ctx, out, ldo, B * T, HW, heads, 0.17677669529663687f /* 32^-0.5, vddp.py:316 */, stream);
     if (rc != 1) return rc;
   }
-  const int rows_per_block = 256 / heads;
+  const int rows_per_block = 256 / heads;  // (threads beyond rows_per_block * heads idle: any number of heads)
   const size_t shm = sizeof(float) * heads * (DH * DH + 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(linattn_apply_kernel, dim3(cdiv(HW, rows_per_block), B * T), dim3(256), shm, (hipStream_t)stream, qkv, ldqkv,
                      ctx, out, ldo, HW, heads, 0.17677669529663687f /* 32^-0.5, vddp.py:316 */);
   VMM_LAUNCH_CHECK();

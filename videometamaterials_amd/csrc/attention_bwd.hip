@@ -1,4 +1,5 @@
-// Backward of the attention cores (training path), gfx950.  dim_head = 32.
+// Backward of the attention cores (training path), gfx950.  dim_head = 32 for the mid spatial and the linear attention (vddp.py:314, 401, 679, 687);
+// the generic softmax passes A / B are templated on the head slice (attn_dim_head of the temporal attentions, vddp.py:615).
 //
 // Softmax attention (temporal: keys = frames of one pixel; mid spatial: keys = pixels of one frame), flash-style:
 //   forward saved  L = logsumexp per (query row, head) and O;   D = dO . O
@@ -10,6 +11,7 @@
 //
 // Linear attention: see the formulas next to each kernel.
 #include "vmm_common.h"
+#include "head_vec.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
@@ -32,17 +34,6 @@ __device__ __forceinline__ float dot32r(const float (&a)[DH], const float (&b)[D
   for (int i = 0; i < DH; i += 4) { s0 = fmaf(a[i], b[i], s0); s1 = fmaf(a[i + 1], b[i + 1], s1); s2 = fmaf(a[i + 2], b[i + 2], s2); s3 = fmaf(a[i + 3], b[i + 3], s3); }
   return (s0 + s1) + (s2 + s3);
 }
-// transpose of the interleaved-pair rotation by position `pos`
-__device__ __forceinline__ void unrotate(float (&g)[DH], const float* __restrict__ tab, int pos) {
-#pragma unroll
-  for (int f = 0; f < DH / 2; ++f) {
-    const float c = tab[(pos * (DH / 2) + f) * 2], s = tab[(pos * (DH / 2) + f) * 2 + 1];
-    const float a = g[2 * f], b = g[2 * f + 1];
-    g[2 * f] = a * c + b * s;
-    g[2 * f + 1] = b * c - a * s;
-  }
-}
-
 struct AttnGeom {
   int mode;  // 0 temporal (batch = (b, pix), n = T, stride = HW), 1 spatial (batch = (b, t), n = HW, stride = 1)
   int B, T, HW, heads, ntok, tok_per_frame, bias_on_cond;
@@ -52,11 +43,15 @@ __device__ __forceinline__ long long geom_row0(const AttnGeom& g, int b, int inn
 }
 
 // ---------------------------------------------------------------- pass A: thread per (batch element, head, query)
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnGeom g, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
+// (templated on the head slice, head_vec.h: the temporal attentions follow attn_dim_head, vddp.py:582, 615; dh = 32 is the shipped instance)
+template <int DM, bool EX>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnGeom g, int dh_, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
                                                          const float* __restrict__ ev, const float* __restrict__ bias,
                                                          const float* __restrict__ O, const float* __restrict__ dO, int ldo,
                                                          const float* __restrict__ lse, const float* __restrict__ rot, float q_scale,
                                                          float* __restrict__ dqkv, float* __restrict__ Dbuf) {
+  using HV = HeadVec<DM, EX>;
+  const int dh = EX ? DM : dh_;
   const int n = g.mode == 0 ? g.T : g.HW;
   const int ninner = g.mode == 0 ? g.HW : g.T;
   const long long total = (long long)g.B * ninner * g.heads * n;
@@ -69,58 +64,60 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnGeom g, const float
   const long long row0 = geom_row0(g, b, inner);
   const long long stride = g.mode == 0 ? g.HW : 1;
   const long long rq = row0 + i * stride;
-  const int hid = g.heads * DH;
-  float q[DH], go[DH], dq[DH], tmp[DH];
-  ld32(q, qkv + rq * ldqkv + head * DH);
-  ld32(go, dO + rq * ldo + head * DH);
-  ld32(tmp, O + rq * ldo + head * DH);
-  const float Dv = dot32r(go, tmp);
+  const int hid = g.heads * dh;
+  float q[DM], go[DM], dq[DM], tmp[DM];
+  HV::ld(q, qkv + rq * ldqkv + head * dh, dh);
+  HV::ld(go, dO + rq * ldo + head * dh, dh);
+  HV::ld(tmp, O + rq * ldo + head * dh, dh);
+  const float Dv = HV::dotr(go, tmp);
   const float L = lse[rq * g.heads + head];
   Dbuf[rq * g.heads + head] = Dv;
-#pragma unroll
-  for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+  HV::zero(dq);
   const float* brow = bias ? bias + ((long long)head * n + i) * n : nullptr;
   if (ek) {
     const int t = g.mode == 1 ? inner : 0;
     const int j0 = g.tok_per_frame ? t : 0, j1 = g.tok_per_frame ? t + 1 : g.ntok;
     for (int j = j0; j < j1; ++j) {
-      ld32(tmp, ek + ((long long)b * g.ntok + j) * hid + head * DH);
-      float s = dot32r(q, tmp);
+      HV::ld(tmp, ek + ((long long)b * g.ntok + j) * hid + head * dh, dh);
+      float s = HV::dotr(q, tmp);
       if (brow && g.bias_on_cond) s += brow[j];
       const float p = __expf(s - L);
-      float vv[DH];
-      ld32(vv, ev + ((long long)b * g.ntok + j) * hid + head * DH);
-      const float ds = p * (dot32r(go, vv) - Dv);
+      float vv[DM];
+      HV::ld(vv, ev + ((long long)b * g.ntok + j) * hid + head * dh, dh);
+      const float ds = p * (HV::dotr(go, vv) - Dv);
 #pragma unroll
-      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
+      for (int d = 0; d < DM; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
     }
   }
   for (int j = 0; j < n; ++j) {
-    const float* r = qkv + (row0 + j * stride) * ldqkv + head * DH;
-    ld32(tmp, r + hid);
-    float s = dot32r(q, tmp);
+    const float* r = qkv + (row0 + j * stride) * ldqkv + head * dh;
+    HV::ld(tmp, r + hid, dh);
+    float s = HV::dotr(q, tmp);
     if (brow) s += brow[j];
     const float p = __expf(s - L);
-    float vv[DH];
-    ld32(vv, r + 2 * hid);
-    const float ds = p * (dot32r(go, vv) - Dv);
+    float vv[DM];
+    HV::ld(vv, r + 2 * hid, dh);
+    const float ds = p * (HV::dotr(go, vv) - Dv);
 #pragma unroll
-    for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
+    for (int d = 0; d < DM; ++d) dq[d] = fmaf(ds, tmp[d], dq[d]);
   }
-  if (rot) unrotate(dq, rot, i);
+  if (rot) HV::unrotate(dq, rot, i, dh);
 #pragma unroll
-  for (int d = 0; d < DH; ++d) dq[d] *= q_scale;
-  st32(dqkv + rq * ldqkv + head * DH, dq);
+  for (int d = 0; d < DM; ++d) dq[d] *= q_scale;
+  HV::st(dqkv + rq * ldqkv + head * dh, dq, dh);
 }
 
 // ---------------------------------------------------------------- pass B: wave per (b, head, key j, group of 64-lane chunks of the inner index)
 constexpr int CHUNKS_PER_WAVE = 8;
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
+template <int DM, bool EX>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, int dh_, const float* __restrict__ qkv, int ldqkv, const float* __restrict__ ek,
                                                           const float* __restrict__ ev, const float* __restrict__ bias,
                                                           const float* __restrict__ dO, int ldo, const float* __restrict__ lse,
                                                           const float* __restrict__ Dbuf, const float* __restrict__ rot,
                                                           float* __restrict__ dqkv, float* __restrict__ dek, float* __restrict__ dev,
                                                           float* __restrict__ dbias) {
+  using HV = HeadVec<DM, EX>;
+  const int dh = EX ? DM : dh_;
   const int n = g.mode == 0 ? g.T : g.HW;
   const int ninner = g.mode == 0 ? g.HW : g.T;
   const int nchunks = (ninner + 63) / 64;
@@ -136,41 +133,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, const floa
   const int b = (int)(wave_id / ((long long)ngroups * nkeys * g.heads));
   const bool is_tok = j < g.ntok;
   const int jj = j - g.ntok;  // frame/pixel key index
-  const int hid = g.heads * DH;
+  const int hid = g.heads * dh;
   const long long stride = g.mode == 0 ? g.HW : 1;
-  float kacc[DH], vacc[DH];  // token-key accumulators over chunks (per lane partial)
-#pragma unroll
-  for (int d = 0; d < DH; ++d) { kacc[d] = 0.f; vacc[d] = 0.f; }
+  float kacc[DM], vacc[DM];  // token-key accumulators over chunks (per lane partial)
+  HV::zero(kacc);
+  HV::zero(vacc);
   float bias_acc = 0.f;  // lane i (< n, temporal only) accumulates dbias[h, i, j]
   for (int c = grp * CHUNKS_PER_WAVE; c < min((grp + 1) * CHUNKS_PER_WAVE, nchunks); ++c) {
     const int inner = c * 64 + lane;
     bool active = inner < ninner;
     if (is_tok && g.tok_per_frame && active) active = (g.mode == 1) ? (inner == j) : true;
     const long long row0 = geom_row0(g, b, active ? inner : 0);
-    float kk[DH], vv[DH], dk[DH], dv[DH];
+    float kk[DM], vv[DM], dk[DM], dv[DM];
     if (is_tok) {
-      ld32(kk, ek + ((long long)b * g.ntok + j) * hid + head * DH);
-      ld32(vv, ev + ((long long)b * g.ntok + j) * hid + head * DH);
+      HV::ld(kk, ek + ((long long)b * g.ntok + j) * hid + head * dh, dh);
+      HV::ld(vv, ev + ((long long)b * g.ntok + j) * hid + head * dh, dh);
     } else {
-      const float* r = qkv + (row0 + jj * stride) * ldqkv + head * DH;
-      ld32(kk, r + hid);
-      ld32(vv, r + 2 * hid);
+      const float* r = qkv + (row0 + jj * stride) * ldqkv + head * dh;
+      HV::ld(kk, r + hid, dh);
+      HV::ld(vv, r + 2 * hid, dh);
     }
-#pragma unroll
-    for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    HV::zero(dk);
+    HV::zero(dv);
     const bool use_bias = bias && (!is_tok || g.bias_on_cond);
     const int jb = is_tok ? j : jj;
     for (int i = 0; i < n; ++i) {
       const long long rq = row0 + i * stride;
-      float q[DH], go[DH];
-      ld32(q, qkv + rq * ldqkv + head * DH);
-      ld32(go, dO + rq * ldo + head * DH);
-      float s = dot32r(q, kk);
+      float q[DM], go[DM];
+      HV::ld(q, qkv + rq * ldqkv + head * dh, dh);
+      HV::ld(go, dO + rq * ldo + head * dh, dh);
+      float s = HV::dotr(q, kk);
       if (use_bias) s += bias[((long long)head * n + i) * n + jb];
       const float p = active ? __expf(s - lse[rq * g.heads + head]) : 0.f;
-      const float ds = p * (dot32r(go, vv) - Dbuf[rq * g.heads + head]);
+      const float ds = p * (HV::dotr(go, vv) - Dbuf[rq * g.heads + head]);
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { dk[d] = fmaf(ds, q[d], dk[d]); dv[d] = fmaf(p, go[d], dv[d]); }
+      for (int d = 0; d < DM; ++d) { dk[d] = fmaf(ds, q[d], dk[d]); dv[d] = fmaf(p, go[d], dv[d]); }
       if (use_bias && dbias) {
         const float tot = wave_sum(ds);
         if (lane == (i & 63)) bias_acc += tot;  // n <= 64 whenever a bias exists (temporal: n = T)
@@ -178,27 +175,31 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnGeom g, const floa
     }
     if (is_tok) {
 #pragma unroll
-      for (int d = 0; d < DH; ++d) { kacc[d] += dk[d]; vacc[d] += dv[d]; }
+      for (int d = 0; d < DM; ++d) { kacc[d] += dk[d]; vacc[d] += dv[d]; }
     } else if (active) {
-      if (rot) unrotate(dk, rot, jj);
-      float* o = dqkv + (row0 + jj * stride) * ldqkv + head * DH;
-      st32(o + hid, dk);
-      st32(o + 2 * hid, dv);
+      if (rot) HV::unrotate(dk, rot, jj, dh);
+      float* o = dqkv + (row0 + jj * stride) * ldqkv + head * dh;
+      HV::st(o + hid, dk, dh);
+      HV::st(o + 2 * hid, dv, dh);
     }
   }
   if (is_tok) {
-    float mine = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-      const float tk = wave_sum(kacc[d]);
-      const float tv = wave_sum(vacc[d]);
-      if (lane == d) mine = tk;
-      if (lane == DH + d) mine = tv;
-    }
     // rotary on the token keys is undone by the caller (vmm_rotary_rows with the transposed table) -- gradients here are
-    // with respect to the rotated ek that the forward kernels consumed
-    float* dst = (lane < DH ? dek : dev) + ((long long)b * g.ntok + j) * hid + head * DH + (lane & (DH - 1));
-    atomicAdd(dst, mine);
+    // with respect to the rotated ek that the forward kernels consumed.  Lanes 0..31 carry 32 columns of dek, lanes 32..63 of dev.
+#pragma unroll
+    for (int d0 = 0; d0 < DM; d0 += 32) {
+      if (!EX && d0 >= dh) break;
+      float mine = 0.f;
+#pragma unroll
+      for (int d = d0; d < (d0 + 32 < DM ? d0 + 32 : DM); ++d) {
+        const float tk = wave_sum(kacc[d]);
+        const float tv = wave_sum(vacc[d]);
+        if (lane == d - d0) mine = tk;
+        if (lane == 32 + d - d0) mine = tv;
+      }
+      const int col = d0 + (lane & 31);
+      if (col < dh) atomicAdd((lane < 32 ? dek : dev) + ((long long)b * g.ntok + j) * hid + head * dh + col, mine);
+    }
   }
   if (bias && dbias && (!is_tok || g.bias_on_cond) && lane < n) atomicAdd(&dbias[((long long)head * n + lane) * n + (is_tok ? j : jj)], bias_acc);
 }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_q_kernel(const float* __restr
 extern "C" int vmm_linattn_cross_bwd(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* ctx, const float* kstat,
                                      const float* dout, int32_t lddo, float* dctx, float* dq, int32_t lddq, float* dek, float* dev, int32_t B, int32_t T,
                                      int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {
-  if (dh != DH || (ldq & 3) || (lddo & 3) || (lddq & 3) || !ek || !ev || ntok < 1 || !kstat || heads < 1 || heads > 32 || 256 % heads) return -1;
+  if (dh != DH || (ldq & 3) || (lddo & 3) || (lddq & 3) || !ek || !ev || ntok < 1 || !kstat || heads < 1 || heads > 32) return -1;
   hipStream_t s = (hipStream_t)stream;
   const int nfh = B * T * heads;
   if (int rc = vmm_zero_async(dctx, sizeof(float) * nfh * DH * DH, s)) return rc;
@@ -566,7 +567,7 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
                                  int32_t ldo, const float* lse, const float* rot_tab, float q_scale, float* dqkv, float* dek, float* dev,
                                  float* dbias, float* dbuf, int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh,
                                  vmm_stream_t stream) {
-  if (dh != DH || (ldqkv & 3) || (ldo & 3)) return -1;
+  if (!vmm_head_dim_ok(dh) || heads < 1 || (ldqkv & 3) || (ldo & 3)) return -1;
   if (mode == 0 && !tok_per_frame) {  // temporal attention: LDS-staged workgroup-per-pixel kernel (temporal_attn_bwd.hip) where it applies
     const int rc = vmm_temporal_attention_bwd(qkv, ldqkv, ek, ev, ntok, bias, bias_on_cond, out, dout, ldo, lse, rot_tab, q_scale, dqkv, dek, dev,
                                               dbias, dbuf, B, T, HW, heads, dh, stream);
@@ -577,7 +578,8 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
   hipStream_t s = (hipStream_t)stream;
   AttnGeom g{mode, B, T, HW, heads, ek ? ntok : 0, tok_per_frame, bias_on_cond};
   const long long total = (long long)B * ninner * heads * n;
-  const bool mid_spatial = mode == 1 && HW < 256 && !bias && !rot_tab && (g.ntok == 0 || (tok_per_frame && g.ntok == T));
+  if (total <= 0) return 0;
+  const bool mid_spatial = dh == DH && mode == 1 && HW < 256 && !bias && !rot_tab && (g.ntok == 0 || (tok_per_frame && g.ntok == T));
   if (mid_spatial) {
     static bool attr_q = false;
     if (!attr_q) {
@@ -587,8 +589,11 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
     hipLaunchKernelGGL(spatial_attn_bwd_q_kernel, dim3((unsigned)(B * T * heads)), dim3(256), sizeof(float) * (size_t)HW * 2 * DH, s, g, qkv, ldqkv, ek, ev, out,
                        dout, ldo, lse, q_scale, dqkv, dbuf);
   } else {
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, out, dout, ldo, lse, rot_tab, q_scale,
-                       dqkv, dbuf);
+#define VMM_CALL(DM, EX)                                                                                                                             \
+  hipLaunchKernelGGL((attn_bwd_q_kernel<DM, EX>), dim3(cdiv(total, 256)), dim3(256), 0, s, g, dh, qkv, ldqkv, ek, ev, bias, out, dout, ldo, lse, rot_tab, \
+                     q_scale, dqkv, dbuf)
+    VMM_HEADVEC_DISPATCH(dh, VMM_CALL);
+#undef VMM_CALL
   }
   VMM_LAUNCH_CHECK();
   if (mid_spatial) {
@@ -605,8 +610,11 @@ extern "C" int vmm_attention_bwd(int32_t mode, const float* qkv, int32_t ldqkv, 
   }
   const int nchunks = (ninner + 63) / 64, ngroups = (nchunks + CHUNKS_PER_WAVE - 1) / CHUNKS_PER_WAVE;
   const long long nwaves = (long long)B * heads * (g.ntok + n) * ngroups;
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, s, g, qkv, ldqkv, ek, ev, bias, dout, ldo, lse, dbuf, rot_tab, dqkv,
-                     dek, dev, dbias);
+#define VMM_CALL(DM, EX)                                                                                                                                \
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<DM, EX>), dim3(cdiv(nwaves, 4)), dim3(256), 0, s, g, dh, qkv, ldqkv, ek, ev, bias, dout, ldo, lse, dbuf, rot_tab, \
+                     dqkv, dek, dev, dbias)
+  VMM_HEADVEC_DISPATCH(dh, VMM_CALL);
+#undef VMM_CALL
   VMM_LAUNCH_CHECK();
   return 0;
 }

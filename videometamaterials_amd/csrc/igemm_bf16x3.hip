@@ -172,8 +172,8 @@ int launch_x3(const vmm_conv_desc* d, int n, int Kpad, hipStream_t s) {
 }
 
 int check_x3(const vmm_conv_desc& d) {
-  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 64) return -1;
-  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)))) return -2;
+  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 1024) return -1;
+  if (d.rot_ncols > 0 && (!d.rot_tab || d.rot_dh < 2 || (d.rot_dh & 1))) return -2;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   if (d.a_img_mod) return -3;  // (shared source frames: the 2-D-tiled 3 x 3 kernel only)
   const long long M = (long long)d.nimg * d.Hv * d.Wv;

@@ -118,7 +118,9 @@ __device__ __forceinline__ void epilogue(const vmm_conv_desc& p, const f32x16 (&
         if (rotary) {  // wave-uniform branch
           const float partner = __shfl_xor(v, 1, 64);
           if (col < p.rot_ncols) {
-            const int fi = (col & (p.rot_dh - 1)) >> 1;  // rot_dh is a power of two (checked by the launchers)
+            // pair index inside the head: rot_dh (the head width, attn_dim_head of the temporal attentions) is even; the table carries identity
+            // pairs beyond the rotary span min(32, rot_dh) (hostmath.rotary_table)
+            const int fi = ((p.rot_dh & (p.rot_dh - 1)) ? col % p.rot_dh : (col & (p.rot_dh - 1))) >> 1;
             const float2 cs = *reinterpret_cast<const float2*>(p.rot_tab + (t * (p.rot_dh >> 1) + fi) * 2);
             v = v * cs.x + ((col & 1) ? partner : -partner) * cs.y;
           }

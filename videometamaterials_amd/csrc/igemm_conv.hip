@@ -126,8 +126,8 @@ int launch(const vmm_conv_desc& d, hipStream_t s) {
 extern "C" int vmm_conv_igemm_f32(const vmm_conv_desc* dp, vmm_stream_t stream) {
   const vmm_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
-  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 64) return -1;
-  if (d.rot_ncols > 0 && (!d.rot_tab || (d.rot_dh & (d.rot_dh - 1)))) return -2;
+  if ((d.C1 & 3) || (d.C2 & 3) || (d.lda1 & 3) || (d.C2 && (d.lda2 & 3)) || (d.Cout & 3) || d.KH * d.KW > 1024) return -1;
+  if (d.rot_ncols > 0 && (!d.rot_tab || d.rot_dh < 2 || (d.rot_dh & 1))) return -2;
   if (d.a_mode == 1 && (!d.a_coef || d.a_imgs_per_sample <= 0)) return -3;
   if (d.a_img_mod) return -3;  // (shared source frames: the 2-D-tiled 3 x 3 kernel only)
   const long long M = (long long)d.nimg * d.Hv * d.Wv;

@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
     for (int g = 0; g < 4; ++g) {
       rot[i][g] = f32x4{1.f, 0.f, 1.f, 0.f};
       if (rotary && mrow[i] < a.M) {
-        const int t = (mrow[i] / p.rot_HW) % p.rot_T;
-        rot[i][g] = *reinterpret_cast<const f32x4*>(p.rot_tab + (t * 16 + 4 * g + 2 * lk) * 2);
+        // head width rot_dh (attn_dim_head of the temporal attentions): a multiple of 32 -- the first 32-column tile of every head rotates (the rotary
+        // span is min(32, rot_dh), vddp.py:612), the others pass -- or a divisor of 32, where the head's pairs repeat inside the tile
+        const int t = (mrow[i] / p.rot_HW) % p.rot_T, half = p.rot_dh >> 1;
+        rot[i][g] = *reinterpret_cast<const f32x4*>(p.rot_tab + (t * half + ((4 * g + 2 * lk) & (min(half, 16) - 1))) * 2);
       }
     }
   }
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void proj_x3_kernel(const PJArgs a) {
           const int tile0 = nc * BN + wn * 64 + j * 32;  // wave-uniform, as is everything tested on it (Cout, q_ncols, rot_ncols are multiples of 32)
           if (tile0 >= p.Cout) continue;
           const float scale = tile0 < p.q_ncols ? p.q_scale : 1.0f;
-          const bool do_rot = tile0 < p.rot_ncols;
+          const bool do_rot = tile0 < p.rot_ncols && (p.rot_dh <= 32 || tile0 % p.rot_dh == 0);
           const int c0 = tile0 + 4 * lk;
           f32x4 bv[4], rv[4];
 #pragma unroll
@@ -540,7 +542,8 @@ static int run_proj(const vmm_conv_desc& d, const float* ln_gamma, float ln_eps,
   const bool chan_ok = (d.C1 & 3) == 0 && (d.C2 & 3) == 0 && d.C1 > 0 && K <= 256 && (d.Cout & 31) == 0 && (d.lda1 & 3) == 0 &&
                        (!d.C2 || (d.lda2 & 3) == 0) && (d.ldo & 3) == 0 && (!d.res || (d.ldres & 3) == 0);
   if (!shape_ok || !chan_ok) return 1;
-  if (d.rot_ncols > 0 && (!d.rot_tab || d.rot_dh != 32 || (d.rot_ncols & 31) || d.rot_HW <= 0 || d.rot_T <= 0)) return -2;
+  if (d.rot_ncols > 0 && (!d.rot_tab || !(d.rot_dh >= 4 && (d.rot_dh % 32 == 0 || 32 % d.rot_dh == 0)) || (d.rot_ncols & 31) || d.rot_HW <= 0 || d.rot_T <= 0))
+    return -2;
   if (d.q_ncols & 31) return -2;
   const long long M = (long long)d.nimg * d.Hv * d.Wv;
   if (M >= (1LL << 31)) return -4;

@@ -261,7 +261,7 @@ class GaussianDiffusion(nn.Module):
             st = _GraphedStep(self, shape, cond.shape[-1], w, inject=inject, ddim=ddim)
             # a small LRU: every entry owns its img / x0 / noise buffers and an instantiated graph, and a guidance sweep over many scales or shapes
             # would otherwise grow device memory for the life of the model (round-4 advisor).  Evicted entries are freed with their last reference.
-            while len(self._graph_cache) >= self.graph_cache_size:
+            while self._graph_cache and len(self._graph_cache) >= max(1, int(self.graph_cache_size)):  # (a size of 0 or less keeps one entry: the step in use)
                 self._graph_cache.pop(next(iter(self._graph_cache)))
         self._graph_cache[key] = st  # (re-inserted: most recently used last)
         st.refresh_weights()

@@ -446,8 +446,12 @@ class DataParallelTrainer:
             n_ckpt = sum(len(g["params"]) for g in opt["param_groups"])
             if n_ckpt == len(names) - 1 and None in names:
                 # a reference checkpoint written under a rotary_embedding_torch release that registers `freqs` as a buffer (the pinned 0.2.3 makes it
-                # a frozen nn.Parameter): the same order without the frozen slot
+                # a frozen nn.Parameter): the same order without the frozen slot.  The count alone cannot tell that layout from a checkpoint written in
+                # ANOTHER parameter order (this package before round 4), and the per-index shape check below cannot tell equal-shaped parameters apart
+                # (to_q / to_k / to_v, same-shape convolutions, gammas): the checkpoint's own `model` keys -- a state_dict lists parameters in
+                # parameters() order -- must name the parameters in this tree's order.
                 names = [n for n in names if n is not None]
+                self._check_model_key_order(obj["model"], names)
             elif n_ckpt != len(names):
                 raise ValueError(f"optimizer state covers {n_ckpt} parameters, this model has {len(names)} (reference order, frozen rotary table included) "
                                  f"or {len(names) - 1} (without it)")
@@ -474,6 +478,26 @@ class DataParallelTrainer:
             g = opt["param_groups"][0]
             self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
         self._ptr_sig = None  # parameters may have been re-homed: rebuild the job tables at the next step
+
+    def _check_model_key_order(self, model_sd: dict, names: list) -> None:
+        """The parameter entries of a checkpoint's `model` state_dict, in the order it lists them, against `names` (this tree's parameters() order):
+        an optimizer state indexed by position is only meaningful when the two agree."""
+        own = set(names)
+        seen = []
+        for k in model_sd:
+            k = k[len("module."):] if k.startswith("module.") else k
+            if not k.startswith("denoise_fn."):
+                continue
+            k = k[len("denoise_fn."):]
+            k = k[len("module."):] if k.startswith("module.") else k
+            k = self.unet._own_key(k)
+            if k in own:
+                seen.append(k)
+        if seen != names:
+            first = next((i for i, (a, b) in enumerate(zip(seen, names)) if a != b), min(len(seen), len(names)))
+            raise ValueError("the checkpoint's optimizer state is one slot short of this model's parameter list and its `model` entries do not follow this "
+                             f"model's parameter order (first difference at position {first}: {seen[first] if first < len(seen) else None!r} against "
+                             f"{names[first] if first < len(names) else None!r}): refusing to bind Adam moments by position")
 
     def save(self, path: str) -> None:
         torch.save(self.state_dict(), path)

@@ -38,13 +38,21 @@ def relpos_buckets(n: int, num_buckets: int = 32, max_distance: int = 32) -> tor
 
 
 def rotary_table(n_pos: int, dim_head: int, theta: float = 10000.0) -> torch.Tensor:
-    """(n_pos, dim_head/2, 2) float32 (cos, sin) of pos * theta^(-2i/d); positions 0..n_pos-1."""
+    """(n_pos, dim_head/2, 2) float32 (cos, sin) per interleaved feature pair of a head; positions 0..n_pos-1.
+
+    The reference builds RotaryEmbedding(min(32, attn_dim_head)) (vddp.py:612): the leading rot = min(32, dim_head) features rotate by
+    pos * theta^(-2i/rot), the pairs beyond them (attn_dim_head > 32) carry the identity (cos, sin) = (1, 0), so every consumer applies one
+    uniform pair rotation over the whole head and the pass-through features come out bit-exact."""
+    if dim_head < 2 or dim_head % 2:
+        raise ValueError(f"attn_dim_head {dim_head}: the rotary embedding pairs features, dim_head must be even")
     rot = min(32, dim_head)
-    if rot != dim_head:
-        raise NotImplementedError("partial rotary (attn_dim_head > 32) is not supported")
     freqs = 1.0 / (theta ** (torch.arange(0, rot, 2).float() / rot))
     ang = torch.arange(n_pos).float()[:, None] * freqs[None, :]
-    return torch.stack((ang.cos(), ang.sin()), dim=-1).contiguous()
+    tab = torch.zeros(n_pos, dim_head // 2, 2)
+    tab[..., 0] = 1.0
+    tab[:, : rot // 2, 0] = ang.cos()
+    tab[:, : rot // 2, 1] = ang.sin()
+    return tab.contiguous()
 
 
 SCHEDULE_NAMES = (

@@ -303,6 +303,11 @@ class _Builder:
         pm = getattr(model, "padding_mode", "zeros")  # 'circular': both image axes periodic; 'circular_1d': the horizontal one (vddp.py:163-243)
         self.wrap_h, self.wrap_w = int(pm == "circular"), int(pm in ("circular", "circular_1d"))
         self.heads = model.attn_heads
+        # head width of the TEMPORAL attentions (attn_dim_head, vddp.py:582, 615); the linear and the mid spatial attention keep their constructor
+        # default of 32 (Unet3D does not forward it to them, vddp.py:679, 687).  The rotary table spans min(32, dh_t) features (vddp.py:612).
+        self.dh_t = int(getattr(model, "attn_dim_head", 32))
+        if self.dh_t < 4 or self.dh_t > 128 or self.dh_t % 4:
+            raise NotImplementedError(f"attn_dim_head = {self.dh_t}: the temporal attention kernels take head widths that are multiples of 4 in 4 .. 128")
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
         prec = getattr(model, "train_precision" if training else "precision", "fp32")
@@ -560,7 +565,7 @@ class _Builder:
         d.Hout, d.Wout, d.oscale, d.ooh, d.oow = Hout or Hv, Wout or Wv, oscale, oo[0], oo[1]
         d.Cout = Cout
         d.rot_tab = rot_tab or None
-        d.rot_T, d.rot_HW, d.rot_ncols, d.rot_dh = self.T, a1.H * a1.W, rot_ncols, 32
+        d.rot_T, d.rot_HW, d.rot_ncols, d.rot_dh = self.T, a1.H * a1.W, rot_ncols, self.dh_t
         d.q_scale, d.q_ncols = q_scale, q_ncols
         d.a_mode, d.a_coef, d.a_imgs_per_sample = (1 if a_coef else 0), a_coef or None, self.T
         if self.tickets_ptr is None:  # zero-initialised (wbuf is) and left zero by the kernel; shared by all convs of the (single-stream) plan
@@ -973,10 +978,10 @@ class _Builder:
 
     def token_kv_bwd(self, site: str) -> None:
         """d(ek), d(ev) of one attention site -> dense backward jobs (collected, launched with the embedding backward)."""
-        pfx, eo, vo, geo, gvo, rotated = self.ekv_info[site]
+        pfx, eo, vo, geo, gvo, rotated, hid = self.ekv_info[site]
         if rotated:
-            self.step(self.lib.vmm_rotary_rows, (geo, self.rot_t_ptr, self.B, self.ntok, self.heads, 32), site + " un-rotate d(ek)")
-        D, hid, rows = self.m.cond_dim, 32 * self.heads, self.B * self.ntok
+            self.step(self.lib.vmm_rotary_rows, (geo, self.rot_t_ptr, self.B, self.ntok, self.heads, hid // self.heads), site + " un-rotate d(ek)")
+        D, rows = self.m.cond_dim, self.B * self.ntok
         for wname, gy in ((pfx + ".to_k.weight", geo), (pfx + ".to_v.weight", gvo)):
             self.bwd_lvl3.append(dict(x=self.tokens_ptr, w=self.wraw(wname), dy=gy, dx=self.dtokens_ptr, dw=self.pg(wname), rows=rows, K=D, N=hid))
 
@@ -1120,7 +1125,8 @@ class _Builder:
         """Residual(PreNorm(EinopsToAndFrom(Attention))) (vddp.py:396-535; 615/630/680 temporal, 687-689 mid spatial)."""
         pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         B, T, heads = self.B, self.T, self.heads
-        hid = 32 * heads
+        dh = self.dh_t if temporal else 32  # (attn_dim_head reaches the temporal attentions only, vddp.py:615 against 687)
+        hid = dh * heads
         HW = x.H * x.W
         rows = B * T * HW
         p = name + ".fn.fn.fn"
@@ -1132,7 +1138,7 @@ class _Builder:
         if site and self.m.cond_attention == "cross-attention":
             return self.cross_attn_block(name, x, site, p, linear=False, temporal=temporal)
         ntok_s = self.ntok if site else 0
-        fused_fwd = bool(temporal and not focus and self.x3 and getattr(self.m, "use_fused_temporal", True) and (x.C != 128 or _enabled("tb_c128"))
+        fused_fwd = bool(temporal and dh == 32 and not focus and self.x3 and getattr(self.m, "use_fused_temporal", True) and (x.C != 128 or _enabled("tb_c128"))
                          and self.lib.vmm_temporal_block_supported(T, ntok_s, HW, x.C, heads) > 0)
         # training: the fused block stores nothing but its output; the backward re-forms q, k, v and the probabilities on chip (temporal_block_bwd.hip)
         bwd_ws_n = int(self.lib.vmm_temporal_block_bwd_workspace(B, T, HW, x.C, heads, ntok_s)) if (
@@ -1188,20 +1194,22 @@ class _Builder:
                         self.token_kv_bwd(site)
                 self.on_backward(bwd_fused, pg_start, uj_start)
             return out
-        pj = self.proj_ok(x.C, 3 * hid)  # A-stationary projection kernel ...
+        # A-stationary projection kernel ... (its q-scale / rotary epilogue works on whole 32-column tiles: the first tile of a head rotates when the head
+        # is a multiple of 32 wide, the head's pairs repeat inside a tile when it divides 32; other widths take the generic implicit GEMM's per-column epilogue)
+        pj = self.proj_ok(x.C, 3 * hid) and hid % 32 == 0 and (not temporal or dh % 32 == 0 or 32 % dh == 0)
         ln_tr = self.ln_fused_training_ok(x.C, 3 * hid)
         fuse_ln = pj and (not self.training or ln_tr)  # ... with the PreNorm LayerNorm run while the rows are staged (training: statistics kept for the wgrad)
         ntok = self.ntok if site else 0
         # bf16-stored maps through the unfused chain (the C = 128 level of the 22-frame configuration): to_qkv and to_out on the A-stationary projection
         # kernel, the core on vmm_temporal_attention, all three with bf16 instances; anything else gets an fp32 copy of x and makes an fp32 output
-        n16 = bool(self.nat16("proj", x.H) and self.nat16("tattn", x.H) and temporal and not focus and pj and fuse_ln and self.proj_ok(hid, x.C)
+        n16 = bool(dh == 32 and self.nat16("proj", x.H) and self.nat16("tattn", x.H) and temporal and not focus and pj and fuse_ln and self.proj_ok(hid, x.C)
                    and not self.narrow_ok(hid, x.C) and not (heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16))
         tmps_x: list = []
         x = self.cast(x, n16, tmps_x)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         qkv = self.act(3 * hid, x.H, x.W, bf=n16)
-        q_scale = 32 ** -0.5
-        if not pj and self.split_k_ok(x.C, 3 * hid):
+        q_scale = dh ** -0.5
+        if not pj and self.split_k_ok(x.C, 3 * hid) and hid % 32 == 0 and (not temporal or dh % 32 == 0 or 32 % dh == 0):
             self.proj_split_k(y, p + ".to_qkv.weight", 3 * hid, qkv.ptr, name + " to_qkv", rot_tab=self.rot_ptr if temporal else 0,
                               rot_ncols=2 * hid if temporal else 0, q_scale=q_scale, q_ncols=hid)
             dq = gwq = None
@@ -1215,14 +1223,14 @@ class _Builder:
             self.free_act(y)
         ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
         pfc = 1 if self.m.per_frame_cond else 0
-        if (temporal and not focus and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
+        if (temporal and dh == 32 and not focus and self.x3 and not self.training and heads == 8 and x.C % 128 == 0 and T <= 16 and HW % 2 == 0 and ntok <= 16
                 and getattr(self.m, "use_fused_temporal", True)):
             # scores, value mix and to_out on the matrix cores in one kernel: qkv read once, the attention output never stored
             wo, _ = self.pack_linear(p + ".to_out.weight", frag=3)
             out = self.act(x.C, x.H, x.W)
             self.step(self.lib.vmm_temporal_core_bf16x3,
                       (qkv.ptr, 3 * hid, x.ptr, x.ld, wo, ek or None, ev or None, ntok, self.bias_ptr, pfc, out.ptr, out.ld, B, T, HW, x.C, heads),
-                      name + " core+to_out", flops=2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok), nbytes=4.0 * rows * (3 * hid + 2 * x.C))
+                      name + " core+to_out", flops=2.0 * rows * hid * x.C + 4.0 * rows * hid * (T + ntok), nbytes=4.0 * rows * (3 * hid + 2 * x.C))
             self.free_act(qkv)
             self.free_temps(tmps_x)
             self.plan.named[name] = out
@@ -1231,7 +1239,7 @@ class _Builder:
         lse_ptr = self.ptr(self.alloc(rows * heads)) if self.training else 0
         if temporal:
             self.step(self.lib.vmm_temporal_attention_a16 if n16 else self.lib.vmm_temporal_attention,
-                      (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, 32,
+                      (qkv.ptr, 3 * hid, ek or None, ev or None, ntok, self.bias_ptr, pfc, o.ptr, hid, B, T, HW, heads, dh,
                        lse_ptr or None), name + " core", nbytes=(2.0 if n16 else 4.0) * rows * 4 * hid)
             if focus:  # masked samples: softmax over their own frame alone = 1, the output is the value row
                 self.step(self.lib.vmm_focus_rows, (0, qkv.ptr + 8 * hid, 3 * hid, o.ptr, hid, self.focus_ptr, B, T * HW, hid), name + " focus (o = v)",
@@ -1270,7 +1278,7 @@ class _Builder:
             self.step(self.lib.vmm_attention_bwd,
                       (0 if temporal else 1, qkv.ptr, 3 * hid, ek or None, ev or None, ntok, 0 if temporal else pfc, self.bias_ptr if temporal else None,
                        pfc if temporal else 0, o.ptr, go_core.ptr, hid, lse_ptr, self.rot_ptr if temporal else None, C.c_float(q_scale), gqkv.ptr, geo or None,
-                       gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, 32), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
+                       gvo or None, self.dbias_ptr if temporal else None, self.ptr(dbuf), B, T, HW, heads, dh), name + " core bwd", nbytes=4.0 * rows * 9 * hid)
             if focus:
                 self.step(self.lib.vmm_focus_rows, (2, go.ptr, hid, gqkv.ptr + 8 * hid, 3 * hid, self.focus_ptr, B, T * HW, hid), name + " focus (dv += dO)",
                           nbytes=12.0 * rows * hid)
@@ -1292,7 +1300,8 @@ class _Builder:
         backward of the two cores (vmm_cross_attention_bwd, vmm_linattn_cross_bwd) between the usual projection / LayerNorm / token backwards."""
         pg_start, uj_start = self.pgtop, len(self.unpack_jobs)
         B, T, heads = self.B, self.T, self.heads
-        hid = 32 * heads
+        dh = self.dh_t if (temporal and not linear) else 32
+        hid = dh * heads
         HW = x.H * x.W
         rows = B * T * HW
         ek, ev = self.ekv_info[site][1], self.ekv_info[site][2]
@@ -1304,15 +1313,13 @@ class _Builder:
                              "cond_attention_tokens must equal the number of frames (vddp.py:513)")
         if ntok > 32:
             raise NotImplementedError("cross-attention with more than 32 conditioning tokens")
-        if self.training and not linear and (ntok > 16 or heads != 8):
-            raise NotImplementedError("training with cond_attention='cross-attention': the softmax core's backward takes 8 heads and at most 16 tokens")
-        pj = self.proj_ok(x.C, hid)
+        pj = self.proj_ok(x.C, hid) and hid % 32 == 0 and (not temporal or dh % 32 == 0 or 32 % dh == 0)
         ln_tr = self.ln_fused_training_ok(x.C, hid)
         fuse_ln = pj and (not self.training or ln_tr)  # (training: the LayerNorm statistics stay for the weight gradient, as at the to_qkv sites)
         y = x if fuse_ln else self.layernorm(x, name + ".fn.norm.gamma")
         wq, gwq = self.pack_linear(p + ".to_q.weight", frag=2 if pj else False)
         q = self.act(hid, x.H, x.W)
-        q_scale = 32 ** -0.5
+        q_scale = dh ** -0.5
         epi = {} if linear else dict(q_scale=q_scale, q_ncols=hid, rot_tab=self.rot_ptr if temporal else 0, rot_ncols=hid if temporal else 0)
         dq = self.conv(a1=y, w=wq, Cout=hid, out_ptr=q.ptr, ldo=hid, Hv=x.H, Wv=x.W, what=name + " to_q", proj=pj,
                        ln_gamma=self.wraw(name + ".fn.norm.gamma") if fuse_ln else 0, ln_stats=self.ptr(self.alloc(2 * rows)) if (fuse_ln and ln_tr) else 0,
@@ -1329,7 +1336,7 @@ class _Builder:
             self.step(self.lib.vmm_linattn_apply, (q.ptr, hid, self.ptr(ctx), o.ptr, hid, B, T, HW, heads, 32), name + " apply", nbytes=4.0 * rows * 2 * hid)
             self.free(ctx, ctx_n)
         else:
-            self.step(self.lib.vmm_cross_attention, (q.ptr, hid, ek, ev, ntok, self.bias_ptr if temporal else None, o.ptr, hid, B, T, HW, heads, 32),
+            self.step(self.lib.vmm_cross_attention, (q.ptr, hid, ek, ev, ntok, self.bias_ptr if temporal else None, o.ptr, hid, B, T, HW, heads, dh),
                       name + " core (tokens)", nbytes=4.0 * rows * 2 * hid)
         self.free_act(q)
         pjo = self.proj_ok(hid, x.C)
@@ -1355,10 +1362,14 @@ class _Builder:
                                                            B, T, HW, heads, 32), name + " core bwd (tokens)", nbytes=4.0 * rows * 4 * hid)
                 self.tmp_free((dctx, ctx_n))
             else:
+                nsc = int(self.lib.vmm_cross_attention_bwd_scratch(B, T, HW, heads, dh, ntok))  # (0 inside the one-pass kernel's envelope: 8 heads of 32, <= 16 tokens)
+                sc = self.alloc(nsc) if nsc else 0
                 self.step(self.lib.vmm_cross_attention_bwd,
                           (q.ptr, hid, ek, ev, ntok, self.bias_ptr if temporal else None, go.ptr, hid, self.rot_ptr if temporal else None, C.c_float(q_scale),
-                           gq.ptr, hid, geo, gvo, self.dbias_ptr if temporal else None, B, T, HW, heads, 32), name + " core bwd (tokens)",
-                          nbytes=4.0 * rows * 5 * hid)
+                           gq.ptr, hid, geo, gvo, self.dbias_ptr if temporal else None, self.ptr(sc) if nsc else None, B, T, HW, heads, dh),
+                          name + " core bwd (tokens)", nbytes=4.0 * rows * 5 * hid)
+                if nsc:
+                    self.tmp_free((sc, nsc))
             self.tmp_free(go)
             gy = self.qkv_backward(dq, p + ".to_q.weight", x, gq, gwq, name + " to_q")
             self.tmp_free(gq)
@@ -1439,7 +1450,7 @@ class _Builder:
         self.dx_off = self.alloc(B * Cx * T * H * W) if tr else 0
         self.io = (x_in_off, time_off, cond_off, mask_off, out_off, dout_off)
         # constant tables
-        rot = hostmath.rotary_table(T, 32)
+        rot = hostmath.rotary_table(T, self.dh_t)
         rot_t = rot.clone()
         rot_t[..., 1] = -rot_t[..., 1]  # transpose of the rotation (backward of rotated token keys)
         rot_off, rot_t_off = self.alloc(rot.numel()), self.alloc(rot.numel())
@@ -1594,9 +1605,10 @@ class _Builder:
 
         # rotated token keys of all temporal sites live in ONE block: a single rotary launch covers them (they were nine 3-microsecond launches)
         n_rot = (2 * len(m.in_out) + 1) if (tokens is not None and m.use_temporal_attention_cond and m.per_frame_cond) else 0
-        rot_block = self.alloc(n_rot * B * ntok * hid) if n_rot else 0
+        hid_t = self.dh_t * heads  # (the rotated keys all belong to temporal sites)
+        rot_block = self.alloc(n_rot * B * ntok * hid_t) if n_rot else 0
 
-        def add_ekv(site: str, pfx: str, rotate: bool):
+        def add_ekv(site: str, pfx: str, rotate: bool, hid: int = hid):
             if rotate:
                 eo, vo = rot_block + len(rot_sites) * B * ntok * hid, self.alloc(B * ntok * hid)
             else:
@@ -1606,7 +1618,7 @@ class _Builder:
             geo, gvo = (self.scratch(B * ntok * hid), self.scratch(B * ntok * hid)) if tr else (0, 0)
             self._touch(pfx + ".to_k.weight")
             self._touch(pfx + ".to_v.weight")
-            self.ekv_info[site] = (pfx, self.ptr(eo), self.ptr(vo), geo, gvo, rotate)
+            self.ekv_info[site] = (pfx, self.ptr(eo), self.ptr(vo), geo, gvo, rotate, hid)
             if rotate:
                 rot_sites.append(self.ptr(eo))
 
@@ -1616,16 +1628,16 @@ class _Builder:
                     if m.use_sparse_linear_attn:
                         add_ekv(f"{side}.{i}.2", f"{side}.{i}.2.fn.fn", False)
                     if m.use_temporal_attention_cond:
-                        add_ekv(f"{side}.{i}.3", f"{side}.{i}.3.fn.fn.fn", m.per_frame_cond)
+                        add_ekv(f"{side}.{i}.3", f"{side}.{i}.3.fn.fn.fn", m.per_frame_cond, hid_t)
             add_ekv("mid_spatial_attn", "mid_spatial_attn.fn.fn.fn", False)
             if m.use_temporal_attention_cond:
-                add_ekv("mid_temporal_attn", "mid_temporal_attn.fn.fn.fn", m.per_frame_cond)
+                add_ekv("mid_temporal_attn", "mid_temporal_attn.fn.fn.fn", m.per_frame_cond, hid_t)
         self.dense_level(lvl3, "embed level 3 (film + token k/v)")
         if rot_sites:
             if ntok > T:
                 raise ValueError("rotating token keys needs tokens <= frames")
             assert len(rot_sites) == n_rot
-            self.step(lib.vmm_rotary_rows, (self.ptr(rot_block), self.rot_ptr, B * n_rot, ntok, heads, 32), "rotate token keys (all sites)")
+            self.step(lib.vmm_rotary_rows, (self.ptr(rot_block), self.rot_ptr, B * n_rot, ntok, heads, self.dh_t), "rotate token keys (all sites)")
 
         def embed_bwd():
             self.dense_bwd_level(self.bwd_lvl3, "embed level 3 bwd")
