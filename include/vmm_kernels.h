@@ -202,7 +202,8 @@ typedef struct vmm_pack_job {
                 * 8: the 3 x 3 kernel (N, C, 1, 3, 3) as Winograd F(2x2, 3x3) weights U = G g G^T for vmm_conv3x3_wino_bf16x3, split, in "A" fragment order:
  *    [N/64][Cp/16][position xi*4+nu][column fragment 0..1][hi|lo][64 lanes][8], lane l = column nb*64 + mf*32 + (l & 31),
  *    channels ks*16 + (l >> 5)*8 .. +7 (TH = TW = 3, Cp a multiple of 16, N of 64; 64 (N/64) Cp bytes);
- *    1-8: direction 0 only. */
+ *    1-8: direction 0 only.
+ *    2 | 16, 3 | 16, 5 | 16, 6 | 16: the same fragment orders with IEEE-half values in the hi plane and a zero lo plane: operands of the `_fp16` entry points. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 
@@ -650,6 +651,21 @@ int vmm_loss_grad(const float* noise, const float* pred, int64_t n, int32_t squa
 typedef struct vmm_optim_job { float* p; const float* g; float* m; float* v; int64_t n; } vmm_optim_job;
 int vmm_adam_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float lr, float beta1, float beta2, float eps, int32_t step,
                   float grad_scale, vmm_stream_t stream);
+/* ---- loss scaling for the fp16-operand training leg, entirely on the device: what Accelerate(mixed_precision='fp16') wraps around the reference's step
+ * (main.py:34; vddp.py:1629-1633 accelerator.backward / opt.step) -- torch.cuda.amp.GradScaler's state machine (scale 2^16, x backoff on an inf / nan
+ * gradient with the optimiser step skipped, x growth after `interval` clean steps), no host round trip.
+ * state: 5 floats -- [0] scale, [1] growth tracker, [2] found_inf of the step in flight, [3] steps skipped, [4] optimiser steps taken.
+ *   vmm_scaler_init          state = {init_scale, 0, 0, 0, 0}
+ *   vmm_loss_grad(..., gscale = state, ...)   the loss gradient times the scale (its upstream scalar)
+ *   vmm_grad_nonfinite       state[2] = 1 when any of g[0 .. n) is inf / nan (g 16-byte aligned: the flat gradient buffer, after the all-reduce)
+ *   vmm_adam_step_scaled     vmm_adam_step with grad_scale = extra_scale / state[0] and bias corrections for step state[4] + 1; a no-op when state[2] != 0
+ *   vmm_scaler_update        GradScaler.update(): found_inf ? (scale *= backoff, tracker = 0, skipped += 1) : (steps += 1, tracker += 1,
+ *                            tracker == interval ? scale *= growth, tracker = 0); found_inf = 0 */
+int vmm_scaler_init(float* state, float init_scale, vmm_stream_t stream);
+int vmm_grad_nonfinite(const float* g, int64_t n, float* state, vmm_stream_t stream);
+int vmm_adam_step_scaled(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float lr, float beta1, float beta2, float eps, float extra_scale,
+                         const float* state, vmm_stream_t stream);
+int vmm_scaler_update(float* state, float growth, float backoff, int32_t interval, vmm_stream_t stream);
 /* m (EMA weights) = copy_only ? p : beta*m + (1-beta)*p */
 int vmm_ema_step(const vmm_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float beta, int32_t copy_only, vmm_stream_t stream);
 
@@ -670,6 +686,36 @@ int vmm_extract_geometry(const float* videos, int32_t N, int32_t C, int32_t T, i
  * out [B][nch][T_out][HW] fp32; frames t >= f are zero (cast_num_frames pads, vddp.py:1115), t >= T_out dropped. */
 int vmm_fields_to_samples(const uint8_t* frames, int32_t n_fields, int32_t f, int64_t HW, const int32_t* index, int32_t B,
                           const int32_t* chan_src, const float* coef, int32_t nch, int32_t T_out, float* out, vmm_stream_t stream);
+
+/* ---- the fp16-operand training leg (`Unet3D.train_precision = "fp16"`): the reference's own training arithmetic -- Accelerate(mixed_precision='fp16'),
+ * main.py:34; torch autocast runs every convolution / Linear / einsum of vddp.py:1044-1060 on fp16 operands with fp32 accumulation.  The single-pass
+ * instances of the kernels above on IEEE-half operands (v_mfma_f32_32x32x16_f16; activations rounded to fp16 where the `_bf16` entry points round to bf16,
+ * weight operands = vmm_pack_weights fmt | 16: fp16 planes), fp32 feature maps / master weights / accumulation / norms / softmax as everywhere else.
+ * Same arguments, envelopes and return codes as their `_bf16` twins (fp32-stored maps only).  Loss scaling: vmm_scaler_* / vmm_adam_step_scaled. */
+int vmm_conv3x3_fp16(const vmm_conv_desc* d, vmm_stream_t stream);
+int vmm_conv_s2_acc_fp16(const float* x, int32_t ldx, const float* w_packed, const float* bias, const float* res, int32_t ldres, float* out,
+                           int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                           int32_t n_tickets, vmm_stream_t stream);
+int vmm_linattn_block_fp16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                             const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                             int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream);
+int vmm_temporal_block_fp16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_packed, const float* wout_packed,
+                              const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                              const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads,
+                              float q_scale, float eps, vmm_stream_t stream);
+int vmm_conv3x3_wgrad_fp16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                           vmm_stream_t stream);
+int vmm_conv1x1_wgrad_fp16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                           vmm_stream_t stream);
+int vmm_conv1x1_wgrad_fp16_ln(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
+                              const float* ln_gamma, vmm_stream_t stream);
+int vmm_qkv_bwd_fp16(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                     float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream);
+int vmm_qkv_bwd_ln_fp16(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
+                        float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace, int64_t rows, int32_t C,
+                        int32_t Nq, vmm_stream_t stream);
+int vmm_temporal_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+int vmm_linattn_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,17 +35,22 @@ def main():
     noise = torch.randn((B, 3, T, H, W), generator=g)
     model.train()
 
-    def grads(ctx):
+    def grads(ctx, scale=1.0):
         model.zero_grad()
         with ctx:
             loss = diff.p_losses(x0, t, cond=cond, noise=noise, null_cond_prob=0.0)
-        loss.float().backward()
-        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        (loss.float() * scale).backward()  # scale: what accelerator.backward does under mixed_precision='fp16' (GradScaler.scale(loss).backward(), vddp.py:1629)
+        return float(loss.detach()), {k: p.grad.clone() / scale for k, p in model.named_parameters() if p.grad is not None}
 
     l32, g32 = grads(contextlib.nullcontext())
     out = {"config": CFG, "loss_fp32": l32, "note": "rel = ||g_autocast - g_fp32|| / ||g_fp32|| per parameter, l1 loss, reference on CPU"}
-    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
-        l16, g16 = grads(torch.autocast("cpu", dtype=dt))
+    # "fp16_scaled": fp16 autocast WITH GradScaler's initial loss scale 2^16 -- the recipe main.py:34 actually trains with (the l1 gradient 1 / N per output
+    # element is a subnormal half without it); "fp16" / "bf16": the bare autocast figures of rounds 3-5
+    for name, dt, scale in (("fp16", torch.float16, 1.0), ("bf16", torch.bfloat16, 1.0), ("fp16_scaled", torch.float16, 65536.0)):
+        l16, g16 = grads(torch.autocast("cpu", dtype=dt), scale)
+        if not all(bool(torch.isfinite(v).all()) for v in g16.values()):
+            print(name, "non-finite gradients (GradScaler would skip the step and halve the scale)")
+            continue
         rel = {k: float((g16[k].double() - v.double()).norm() / v.double().norm().clamp_min(1e-30)) for k, v in g32.items() if float(v.double().norm()) > 0}
         vals = np.array(list(rel.values()))
         out[name] = {"loss": l16, "median": float(np.median(vals)), "p10": float(np.percentile(vals, 10)), "p90": float(np.percentile(vals, 90)),

@@ -315,6 +315,98 @@ def test_reduced_precision_training_leg_inside_the_reference_autocast_deviation(
           f"{ref['fp16']['p90']:.2e}, bf16 {ref['bf16']['median']:.2e} / {ref['bf16']['p90']:.2e}")
 
 
+@pytest.mark.parametrize("cfg_name", ["lagr16", "lagr64"])
+def test_reference_precision_training_leg_fp16_inside_the_reference_fp16_autocast_deviation(gpu, cfg_name):
+    """`train_precision = "fp16"`: the reference's OWN training arithmetic (main.py:34 Accelerator(mixed_precision='fp16'): autocast runs every convolution,
+    Linear and einsum on IEEE-half operands with fp32 accumulation; accelerator.backward scales the loss by GradScaler's 2^16, vddp.py:1629).  ONE matrix
+    pass on fp16-rounded operands (v_mfma_f32_32x32x16_f16) in the forward, the data gradients, the 3 x 3 / 1 x 1 / to_qkv weight gradients and the
+    recomputing attention backward; fp32 master weights, feature maps, accumulation, norms, softmax.  Stated tolerance = what the reference's own fp16
+    autocast does to the same l1 gradients (real reference on the CPU, tests/golden/make_golden_autocast.py): per-parameter relative deviation from fp32
+    autograd, median and 90th percentile inside the reference's bare-autocast figures (`fp16`) at BOTH widths; the figures of the reference's autocast
+    run with the loss scale (`fp16_scaled`: what main.py really executes) are printed beside them and bound the median within a factor 1.5."""
+    with open(os.path.join(helpers.GOLDEN_DIR, f"autocast_{cfg_name}.json")) as f:
+        ref = json.load(f)
+    kw, sd, model, diff = _setup(cfg_name, gpu)
+    model.train_precision = "fp16"
+    _, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]
+    _, t, cond = helpers.synth_inputs(cfg_name)
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand((B, 3, T, H, W), generator=g) * 2 - 1
+    noise = torch.randn((B, 3, T, H, W), generator=g)
+    _, want = _oracle_grads(cfg_name, kw, sd, x0, t, cond, noise)
+    scale = 65536.0  # GradScaler's initial scale: the upstream gradient of the backward, as accelerator.backward hands it over
+    loss = diff.p_losses(x0.to(gpu), t.to(gpu), cond=cond.to(gpu), noise=noise.to(gpu), null_cond_prob=0.0)
+    (loss * scale).backward()
+    pl = [p_ for k_, p_ in model._plans.items() if p_.training][0]
+    used = {fn.__name__ for fn, _, _ in pl.steps} | {fn.__name__ for fn, _, _ in pl.bwd_steps}
+    assert "vmm_conv3x3_fp16" in used and not {"vmm_conv3x3_bf16x3", "vmm_conv3x3_bf16"} & used
+    if cfg_name == "lagr64":  # the fp16 instances take the layers their three-pass namesakes take
+        assert {"vmm_conv3x3_wgrad_fp16", "vmm_conv1x1_wgrad_fp16", "vmm_qkv_bwd_ln_fp16", "vmm_temporal_block_fp16", "vmm_linattn_block_fp16",
+                "vmm_temporal_block_bwd_fp16", "vmm_linattn_block_bwd_fp16", "vmm_conv_s2_acc_fp16"} <= used, sorted(used)
+        assert not {n for n in used if n.endswith("_bf16")}, sorted(used)
+        assert {j["fmt"] for j in pl.pack_jobs if j.get("fmt", 0) & 16} == {18, 19, 21, 22}  # fp16 operand planes for exactly the `_fp16` consumers
+    got = {model._ref_key(k): p.grad / scale for k, p in model.named_parameters() if p.grad is not None}
+    vals = np.array([float((got[k].double().cpu() - w.double()).norm() / w.double().norm()) for k, w in want.items()
+                     if w is not None and float(w.double().norm()) > 0 and got.get(k) is not None])
+    assert len(vals) > 300 and np.isfinite(vals).all()
+    med, p90, mx = float(np.median(vals)), float(np.percentile(vals, 90)), float(vals.max())
+    print(f"{cfg_name}: fp16 leg l1 gradient deviation median {med:.2e} p90 {p90:.2e} max {mx:.2e}; reference fp16 autocast {ref['fp16']['median']:.2e} / "
+          f"{ref['fp16']['p90']:.2e}, with its loss scale {ref['fp16_scaled']['median']:.2e} / {ref['fp16_scaled']['p90']:.2e} (max {ref['fp16_scaled']['max']:.2e})")
+    assert med < ref["fp16"]["median"] and p90 < ref["fp16"]["p90"], (med, p90, ref["fp16"]["median"], ref["fp16"]["p90"])
+    assert med < 1.5 * ref["fp16_scaled"]["median"] and mx < 0.2, (med, mx)
+    assert abs(float(loss) - ref["loss_fp32"]) < 1e-2 * abs(ref["loss_fp32"])
+
+
+def test_fp16_trainer_loss_scaling_skips_overflowed_steps_and_recovers(gpu):
+    """The device-side GradScaler of the fp16 leg (dp.py, vmm_scaler_* / vmm_adam_step_scaled; torch.cuda.amp.GradScaler's state machine, which
+    Accelerate(mixed_precision='fp16') wraps around the reference's step, main.py:34, vddp.py:1629-1633): a scale that overflows the fp16 operands makes
+    the gradients non-finite -> the optimiser launch is a no-op (parameters and moments untouched), the scale halves, the step counts as skipped; once the
+    scale fits the steps go through, follow the split-bf16 trainer's loss closely, and `interval` clean steps double the scale."""
+    from videometamaterials_amd.dp import DataParallelTrainer
+    x, t, cond = helpers.synth_inputs("lagr16")
+    g = torch.Generator().manual_seed(4)
+    x01, noise = torch.rand(x.shape, generator=g), torch.randn(x.shape, generator=g)
+    mask = torch.zeros(x.shape[0], dtype=torch.uint8, device=gpu)
+    args = (x01.to(gpu), cond.to(gpu))
+    kws = dict(t=t.to(gpu), noise=noise.to(gpu), mask=mask)
+    # the split-bf16 trainer on the same data: the trajectory to stay close to
+    _, _, m3, d3 = _setup("lagr16", gpu)
+    m3.train_precision = "bf16x3"
+    tr3 = DataParallelTrainer(d3, train_lr=1e-3)
+    ref_losses = [float(tr3.train_step(*args, **kws)) for _ in range(6)]
+    _, _, model, diff = _setup("lagr16", gpu)
+    model.train_precision = "fp16"
+    tr = DataParallelTrainer(diff, train_lr=1e-3)
+    tr.loss_scale_init, tr.loss_scale_interval = 2.0 ** 60, 3  # far beyond half's 65504: the first steps must overflow
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    l0 = float(tr.train_step(*args, **kws))
+    st = tr.loss_scale_state()
+    assert st["skipped_steps"] == 1 and st["optimizer_steps"] == 0 and st["scale"] == 2.0 ** 59, st
+    assert all(torch.equal(p.detach(), before[k]) for k, p in model.named_parameters()), "a skipped step must not move the parameters"
+    assert all(float(m.abs().max()) == 0 and float(v.abs().max()) == 0 for m, v in tr._moments.values()), "... nor Adam's moments"
+    assert abs(l0 - ref_losses[0]) < 2e-2 * ref_losses[0]  # (the forward does not depend on the scale)
+    n = 1
+    while tr.loss_scale_state()["optimizer_steps"] == 0:  # halve until the scaled gradients fit
+        tr.train_step(*args, **kws)
+        n += 1
+        assert n < 80
+    st = tr.loss_scale_state()
+    assert st["skipped_steps"] == n - 1 and st["scale"] == 2.0 ** (60 - st["skipped_steps"]) and st["scale"] >= 2.0 ** 10, st
+    moved = sum(float((p.detach() - before[k]).abs().max()) > 0 for k, p in model.named_parameters())
+    assert moved > 300
+    # clean steps from here: the tracker doubles the scale after `interval` of them, the loss follows the split-bf16 trainer's
+    losses = [float(tr.train_step(*args, **kws)) for _ in range(5)]
+    st2 = tr.loss_scale_state()
+    # (3 clean steps double the scale; when that overflows again the step is skipped and the scale halved back -- the sawtooth GradScaler runs in steady state)
+    assert st2["optimizer_steps"] + st2["skipped_steps"] == n + 5 and st2["optimizer_steps"] >= 4, st2
+    assert st2["scale"] in (st["scale"] / 2, st["scale"], st["scale"] * 2, st["scale"] * 4), (st, st2)
+    assert all(l == l for l in losses) and losses[-1] < l0
+    assert abs(losses[0] - ref_losses[1]) < 5e-2 * ref_losses[1], (losses, ref_losses)
+    # the default configuration: GradScaler's own constants
+    tr_d = DataParallelTrainer(diff, train_lr=1e-3)
+    assert (tr_d.loss_scale_init, tr_d.loss_scale_growth, tr_d.loss_scale_backoff, tr_d.loss_scale_interval) == (65536.0, 2.0, 0.5, 2000)
+
+
 @pytest.mark.parametrize("cfg_name,precision", [("lagr16", "fp32"), ("plumb16", "fp32"), ("lagr64", "bf16x3")])
 def test_input_gradient_matches_oracle(gpu, cfg_name, precision):
     """the gradient of a scalar of the denoiser output with respect to the network INPUT (the stem's data gradient on top of the

@@ -85,11 +85,11 @@ def test_bf16_throughput_mode_against_reference_golden(gpu, cfg_name):
     used = {fn.__name__ for pl in model._plans.values() for fn, _, _ in pl.steps}
     assert "vmm_conv3x3_bf16" in used and "vmm_conv3x3_bf16x3" not in used, used
     with pytest.raises(ValueError), torch.no_grad():  # (an unknown mode is an error, not a silent fp32)
-        model.precision = "fp16"
+        model.precision = "fp8"
         model._plans.clear()
         model(x.to(gpu), t.to(gpu), cond=cond.to(gpu), null_cond_prob=0.0)
     with pytest.raises(ValueError):  # (the same for the training arithmetic)
-        model.train_precision = "fp16"
+        model.train_precision = "fp8"
         model.get_plan(x.shape[0], x.shape[2], x.shape[3], x.shape[4], cond.shape[1], gpu, training=True)
 
 

@@ -220,6 +220,24 @@ SIGNATURES = {
                                 c_i32, c_i32, c_i32, c_ptr],
     "vmm_linattn_cross_bwd": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32,
                               c_i32, c_ptr],
+    # the fp16-operand twins of the single-pass entry points (train_precision = "fp16") and the device-side GradScaler
+    "vmm_conv3x3_fp16": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_s2_acc_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr],
+    "vmm_linattn_block_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_f32, c_ptr],
+    "vmm_temporal_block_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  c_i32, c_f32, c_f32, c_ptr],
+    "vmm_conv3x3_wgrad_fp16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv1x1_wgrad_fp16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv1x1_wgrad_fp16_ln": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_qkv_bwd_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_qkv_bwd_ln_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    "vmm_temporal_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_linattn_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_scaler_init": [c_ptr, c_f32, c_ptr],
+    "vmm_grad_nonfinite": [c_ptr, c_i64, c_ptr, c_ptr],
+    "vmm_adam_step_scaled": [c_ptr, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr, c_ptr],
+    "vmm_scaler_update": [c_ptr, c_f32, c_f32, c_i32, c_ptr],
     "vmm_dense_batched": [c_ptr, c_i32, c_i32, c_ptr],
     "vmm_sinusoidal_embed": [c_ptr, c_i32, c_i32, c_f32, c_ptr, c_ptr],
     "vmm_cond_tokens": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],

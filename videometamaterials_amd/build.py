@@ -23,7 +23,10 @@ OBJDIR = os.path.join(HERE, "_obj_exp" if EXPERIMENTS else "_obj")
 EXPERIMENT_SOURCES = {"conv3x3_wino.hip"}
 # compiled a second time with -DVMM_SINGLE_PASS=1 (object *_sp.o): the `_bf16` entry points of the backward kernels (vmm_common.h, VMM_X3)
 # (object suffix, VMM_SINGLE_PASS value): 1 = bf16-rounded operands (`_bf16` entry points), 2 = fp16-rounded operands (`_fp16`: the reference's autocast dtype)
-SINGLE_PASS_MODES = (("_sp", 1),)
+SINGLE_PASS_MODES = (("_sp", 1), ("_h", 2))
+# forward kernels with a single-pass template instance: compiled once more with -DVMM_SINGLE_PASS=2 (object *_h.o), exporting that instance on fp16 operands
+# alone (`vmm_conv3x3_fp16`, `vmm_conv_s2_acc_fp16`, `vmm_temporal_block_fp16`, `vmm_linattn_block_fp16`)
+FP16_FORWARD_SOURCES = {"conv3x3_bf16x3.hip", "temporal_block.hip", "linattn_block.hip"}
 SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
@@ -64,8 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
         if force or _stale(o, [s] + hdrs) or _flags_changed(cmd):
             jobs.append(cmd)
-        if os.path.basename(s) in SINGLE_PASS_SOURCES:
-            for tag, mode in SINGLE_PASS_MODES:
+        if os.path.basename(s) in SINGLE_PASS_SOURCES or os.path.basename(s) in FP16_FORWARD_SOURCES:
+            for tag, mode in (SINGLE_PASS_MODES if os.path.basename(s) in SINGLE_PASS_SOURCES else SINGLE_PASS_MODES[1:]):
                 o2 = o[:-2] + tag + ".o"
                 objs.append(o2)
                 cmd = [hipcc, *FLAGS, f"-DVMM_SINGLE_PASS={mode}", "-c", s, "-o", o2]

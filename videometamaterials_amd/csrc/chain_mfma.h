@@ -49,7 +49,7 @@ __device__ __forceinline__ F2 tofrag(const f32x16& c) {
 }
 
 __device__ __forceinline__ f32x16 mfma1(const uint4& a, const uint4& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return vmm_mfma16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
 }
 // three passes of the split product: lo.hi + hi.lo + hi.hi
 __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void identity_frags(int lane, uint4 (&I)[2]) {
     unsigned w[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const unsigned e0 = slot(s, lk, 2 * p) == lrow ? 0x3F80u : 0u, e1 = slot(s, lk, 2 * p + 1) == lrow ? 0x3F80u : 0u;
+      const unsigned e0 = slot(s, lk, 2 * p) == lrow ? VMM_ONE16 : 0u, e1 = slot(s, lk, 2 * p + 1) == lrow ? VMM_ONE16 : 0u;
       w[p] = e0 | (e1 << 16);
     }
     I[s] = uint4{w[0], w[1], w[2], w[3]};

@@ -465,8 +465,8 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
     // was issue-bound).  Split layers keep pixels as rows: their epilogue is atomics, which want 32 lanes on one 128-byte line.
     // pass-major: consecutive MFMAs never share an accumulator
     auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) {
-      if constexpr (SPLIT) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(pix, wgt, c, 0, 0, 0);
-      else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0);
+      if constexpr (SPLIT) return vmm_mfma16(pix, wgt, c);
+      else return vmm_mfma16(wgt, pix, c);
     };
     if constexpr (ONE && NJ == 2) {
       acc[0][0] = mm(ah0, bh0, acc[0][0]);
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pw_kernel(const PWArgs a_in) {
     const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
     // weights are the MFMA "A" (rows = output channels), pixels the "B" (columns): a lane holds 4 x 4 consecutive output channels of
     // one pixel.  Pass-major order: consecutive MFMAs never share an accumulator.
-    auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt, pix, c, 0, 0, 0); };
+    auto mm = [&](const bf16x8& pix, const bf16x8& wgt, f32x16 c) { return vmm_mfma16(wgt, pix, c); };
     acc[0][0] = mm(al0, bh0, acc[0][0]);
     acc[0][1] = mm(al0, bh1, acc[0][1]);
     acc[1][0] = mm(al1, bh0, acc[1][0]);
@@ -1900,6 +1900,7 @@ int dispatch_c3(const C3Args& a, int mtiles, int ksplit, bool wide, hipStream_t 
   return a.mode ? launch_c3<4, 1, 11, 1, PF, false, F32, ONE>(a, mtiles, 1, s) : launch_c3<4, 1, 11, 0, PF, false, F32, ONE>(a, mtiles, 1, s);
 }
 
+#if !VMM_FP16_OPERANDS  // (the fp16-operand build of this file exports its single-pass instances alone: the end of the file)
 // Number of GroupNorm partial-sum pairs per (sample, group) vmm_conv3x3_bf16x3(d) will leave in d->gn_part (the caller then skips
 // vmm_groupnorm_stats and hands them to vmm_groupnorm_coef), 0 when it will not.  Pure host logic.
 extern "C" int vmm_conv3x3_fuses_gn(const vmm_conv_desc* dp) {
@@ -1966,6 +1967,8 @@ extern "C" int vmm_conv3x3_bf16(const vmm_conv_desc* dp, vmm_stream_t stream) {
   return dispatch_c3<false, true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
 }
 
+#endif  // !VMM_FP16_OPERANDS
+
 // The resampling layers on the tap-subset variants of the kernel (TS, see there):
 //   up == 0: Conv3d (1,4,4) stride (1,2,2) pad (0,1,1) (Downsample, vddp.py:158): x [nimg][Hin][Win][Cin] -> out [nimg][Hin/2][Win/2][Cout],
 //            weights = vmm_pack_weights fmt 5 of the (Cout, Cin, 1, 4, 4) tensor;
@@ -2014,6 +2017,7 @@ static int s2_plan(const float* x, int32_t ldx, const float* w_frag, const float
   return 0;
 }
 
+#if !VMM_FP16_OPERANDS
 // 1 when vmm_conv_s2_bf16x3 takes the shape, 0 when it would return 1 (pure host logic)
 extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up) {
   C3Args a;
@@ -2021,6 +2025,8 @@ extern "C" int vmm_conv_s2_supported(int32_t nimg, int32_t Hin, int32_t Win, int
   bool wide;
   return s2_plan(nullptr, 0, nullptr, nullptr, nullptr, 0, nimg, Hin, Win, Cin, Cout, up, a, mtiles, wide) == 0 ? 1 : 0;
 }
+
+#endif
 
 // res != NULL: out = convolution (+ bias) + res, res rows indexed like out (may alias it): the layers' DATA gradients accumulating into a gradient
 // buffer that already holds the skip connection's share (autograd of vddp.py:155,158).  split_tickets / n_tickets as in vmm_conv_desc: the
@@ -2058,6 +2064,7 @@ static int s2_run(const float* x, int32_t ldx, const float* w_frag, const float*
   if (wide) return a.mode ? launch_s2<2, 2, 6, 1, 2, false, ONE>(a, mtiles, s) : launch_s2<2, 2, 6, 0, 2, false, ONE>(a, mtiles, s);
   return a.mode ? launch_s2<4, 1, 11, 1, 2, false, ONE>(a, mtiles, s) : launch_s2<4, 1, 11, 0, 2, false, ONE>(a, mtiles, s);
 }
+#if !VMM_FP16_OPERANDS
 extern "C" int vmm_conv_s2_acc_bf16x3(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
                                       int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
                                       int32_t n_tickets, vmm_stream_t stream) {
@@ -2115,3 +2122,24 @@ extern "C" int vmm_conv3x3_f32(const vmm_conv_desc* dp, vmm_stream_t stream) {
   if (a.total_rows <= 0) return 0;
   return dispatch_c3<true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
 }
+#else  // VMM_FP16_OPERANDS: this translation unit compiled with -DVMM_SINGLE_PASS=2 -- every 16-bit operand is IEEE half (vmm_common.h)
+
+// The single-pass instances on fp16 operands (`train_precision = "fp16"`: the reference's own autocast dtype, main.py:34): same descriptors and launch
+// geometry as vmm_conv3x3_bf16 / vmm_conv_s2_acc_bf16; weights = vmm_pack_weights fmt 2 | 16 (5 | 16, 6 | 16): fp16 planes.  fp32-stored maps only.
+extern "C" int vmm_conv3x3_fp16(const vmm_conv_desc* dp, vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  C3Args a;
+  int mtiles, ksplit;
+  bool gn = false;
+  if (d.act_bf16) return -1;
+  const int rc = plan_c3(d, a, mtiles, ksplit, gn);
+  if (rc != 0) return rc;
+  if (a.total_rows <= 0) return 0;
+  return dispatch_c3<false, true>(a, mtiles, ksplit, d.Cout >= 128, (hipStream_t)stream);
+}
+extern "C" int vmm_conv_s2_acc_fp16(const float* x, int32_t ldx, const float* w_frag, const float* bias, const float* res, int32_t ldres, float* out,
+                                    int32_t ldo, int32_t nimg, int32_t Hin, int32_t Win, int32_t Cin, int32_t Cout, int32_t up, int32_t* split_tickets,
+                                    int32_t n_tickets, vmm_stream_t stream) {
+  return s2_run<true>(x, ldx, w_frag, bias, res, ldres, out, ldo, nimg, Hin, Win, Cin, Cout, up, split_tickets, n_tickets, stream);
+}
+#endif

@@ -63,10 +63,10 @@ __device__ __forceinline__ void split8(const f32x16& c, int r0, uint4& hi, uint4
 // ONE ("bf16" throughput mode, BASELINE.json configs[3]): the hi planes only, one pass (the lo halves of the splits then have no reader)
 template <bool ONE>
 __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
-  if constexpr (ONE) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  if constexpr (ONE) return vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c);
   return c;
 }
 
@@ -253,11 +253,11 @@ __global__ __launch_bounds__(256) void linattn_combine_kernel(const LAArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float v = c[i] * sc;
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
+    unsigned short lo;
+    const unsigned short hi = vmm_split16(v, lo);
     const int lane = lk * 32 + eg * 4 + i;
-    fb[((s * 2 + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, hi);
-    fb[((s * 2 + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+    fb[((s * 2 + 0) * 64 + lane) * 8 + j] = hi;
+    fb[((s * 2 + 1) * 64 + lane) * 8 + j] = lo;
   }
 }
 
@@ -487,12 +487,14 @@ int choose_split(int frames, int HW, int* sps) { return vmm_linattn_block_split(
 
 }  // namespace
 
+#if !VMM_FP16_OPERANDS
 // floats of workspace vmm_linattn_block_bf16x3 needs (partials + context fragments)
 extern "C" int64_t vmm_linattn_block_workspace(int32_t B, int32_t T, int32_t HW) {
   int sps;
   const int ns = choose_split(B * T, HW, &sps);
   return (int64_t)B * T * ns * LH * PART + (int64_t)B * T * LH * 1024;
 }
+#endif
 
 template <bool ONE, int CC, typename ST = float>
 static int la_run(const LAArgs& a, unsigned blocks, int frames, hipStream_t s) {
@@ -535,6 +537,7 @@ static int la_launch(const void* x, int32_t ldx, const float* gamma, const float
   return C == 64 ? la_run<ONE, 64, ST>(a, blocks, B * T, s) : la_run<ONE, 128, ST>(a, blocks, B * T, s);
 }
 
+#if !VMM_FP16_OPERANDS
 extern "C" int vmm_linattn_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
                                         const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
                                         int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
@@ -552,3 +555,13 @@ extern "C" int vmm_linattn_block_bf16_a16(const void* x, int32_t ldx, const floa
                                           int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
   return la_launch<true, bf16s>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
 }
+#else
+// fp16 operands (`train_precision = "fp16"`: the reference's autocast dtype, main.py:34): the single-pass instance of this translation unit compiled with
+// -DVMM_SINGLE_PASS=2; identical arguments and workspace layout (the context fragments it leaves for the backward are fp16 too: vmm_linattn_block_bwd_fp16
+// reads them), weights = vmm_pack_weights fmt 2 | 16 / 3 | 16
+extern "C" int vmm_linattn_block_fp16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                      const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                                      int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
+  return la_launch<true>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
+}
+#endif

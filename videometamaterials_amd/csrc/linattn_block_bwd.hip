@@ -285,10 +285,10 @@ __global__ __launch_bounds__(256) void la_bwd_combine_kernel(const LBArgs a) {
   unsigned short* DB = reinterpret_cast<unsigned short*>(tb + 96 + 2048);   // A[i = e][k = d]: dctx / HW
   auto put = [](unsigned short* f, int i, int k, float v) {  // element (row i, contraction index k) of an A image in slot order
     const int s = k >> 4, lk = (k >> 2) & 1, j = (k & 3) + 4 * ((k >> 3) & 1);
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
-    f[((s * 2 + 0) * 64 + lk * 32 + i) * 8 + j] = __builtin_bit_cast(unsigned short, hi);
-    f[((s * 2 + 1) * 64 + lk * 32 + i) * 8 + j] = __builtin_bit_cast(unsigned short, lo);
+    unsigned short lo;
+    const unsigned short hi = vmm_split16(v, lo);
+    f[((s * 2 + 0) * 64 + lk * 32 + i) * 8 + j] = hi;
+    f[((s * 2 + 1) * 64 + lk * 32 + i) * 8 + j] = lo;
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -273,10 +273,10 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
           const bf16x8 Ah = __builtin_bit_cast(bf16x8, F[sx & 1][0]), Al = __builtin_bit_cast(bf16x8, F[sx & 1][1]);
           const bf16x8 Bh = __builtin_bit_cast(bf16x8, F[sx & 1][2]), Bl = __builtin_bit_cast(bf16x8, F[sx & 1][3]);
           if constexpr (!VMM_SINGLE_PASS) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
+            acc = vmm_mfma16(Ah, Bl, acc);
+            acc = vmm_mfma16(Al, Bh, acc);
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
+          acc = vmm_mfma16(Ah, Bh, acc);
         }
       };
       if (!(VMM_QB_SKIP & 1)) {
@@ -307,10 +307,10 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
             G[0][1] = *reinterpret_cast<const uint4*>(gp_ + 64 + GR_PLANE);
           }
           if constexpr (!VMM_SINGLE_PASS) {
-            gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gl, gyacc, 0, 0, 0);
-            gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl, Gh, gyacc, 0, 0, 0);
+            gyacc = vmm_mfma16(Wh, Gl, gyacc);
+            gyacc = vmm_mfma16(Wl, Gh, gyacc);
           }
-          gyacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Gh, gyacc, 0, 0, 0);
+          gyacc = vmm_mfma16(Wh, Gh, gyacc);
         }
       }
       if (LNB && p == NPIECE - 1) {

@@ -73,10 +73,10 @@ __device__ __forceinline__ void split8v(const float (&v)[8], uint4& hi, uint4& l
 // reader and the compiler drops them (and the lo weight fragments' registers) with it
 template <bool ONE>
 __device__ __forceinline__ f32x16 mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 c) {
-  if constexpr (ONE) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+  if constexpr (ONE) return vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), c);
+  c = vmm_mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c);
   return c;
 }
 
@@ -1071,7 +1071,12 @@ int tb_version() {  // read at every call (a host-side getenv per plan build / l
 // even HW (two pixels per tile) or T <= 32 (one pixel per tile, second kernel only, LDS permitting -- vmm_temporal_block_supported); or C == 128
 // with T <= 16 and an even HW (wqkv_frag then = fmt 2 of (768, 128), wout_frag = fmt 3 of (128, 256)).
 // 0: outside the envelope of all kernels; 1: first kernel only (T <= 16); 2: two-tiles-in-flight kernel (LDS permitting, T <= 32); 3: C = 128
+#if VMM_FP16_OPERANDS  // (the fp16-operand build of this file: the host query exists once, in the split-bf16 build; a private copy here)
+#define vmm_temporal_block_supported vmm_temporal_block_supported_fp16_tu
+static int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads) {
+#else
 extern "C" int vmm_temporal_block_supported(int32_t T, int32_t ntok, int32_t HW, int32_t C, int32_t heads) {
+#endif
   if (C == TC2 && heads == HEADS && T >= 1 && T <= 16 && ntok >= 0 && ntok <= 16 && !(HW & 1)) return 3;  // the C = 128 kernel (streamed weights)
   if (C != TC || heads != HEADS || T < 1 || T > 32 || ntok < 0 || ntok > 16) return 0;
   const int slots = T <= 16 ? 16 : 32;
@@ -1169,6 +1174,7 @@ static int tb_launch(const float* x, int32_t ldx, const float* gamma, const floa
   return 0;
 }
 
+#if !VMM_FP16_OPERANDS
 extern "C" int vmm_temporal_block_bf16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
                                          const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
                                          const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
@@ -1191,3 +1197,13 @@ extern "C" int vmm_temporal_block_bf16_a16(const void* x, int32_t ldx, const flo
   return tb_launch<true, bf16s>(static_cast<const float*>(x), ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, static_cast<float*>(out), ldo,
                                 B, T, HW, C, heads, q_scale, eps, stream);
 }
+#else
+// fp16 operands (`train_precision = "fp16"`: the reference's autocast dtype, main.py:34): the single-pass instance of this translation unit compiled with
+// -DVMM_SINGLE_PASS=2; identical arguments, weights = vmm_pack_weights fmt 2 | 16 / 3 | 16 (fp16 planes)
+extern "C" int vmm_temporal_block_fp16(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                       const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                       const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
+                                       int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+  return tb_launch<true>(x, ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, out, ldo, B, T, HW, C, heads, q_scale, eps, stream);
+}
+#endif

@@ -6,18 +6,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Single-pass instances of the split-bf16 BACKWARD kernels (the reduced-precision training leg, `train_precision = "bf16"`): the translation units listed in
-// build.SINGLE_PASS_SOURCES are compiled a second time with -DVMM_SINGLE_PASS=1.  In that build every split product is its hi * hi pass alone (bf16-rounded
-// operands, fp32 accumulation), the lo planes are neither formed nor multiplied where the source guards them, and the entry points carry `_bf16` where
-// the three-pass build says `_bf16x3` (VMM_X3(vmm_qkv_bwd_, ) -> vmm_qkv_bwd_bf16x3 / vmm_qkv_bwd_bf16); host-only queries (workspace sizes) exist once.
+// Single-pass instances of the split-bf16 kernels (the reduced-precision training legs): the translation units listed in build.SINGLE_PASS_SOURCES are
+// compiled again with -DVMM_SINGLE_PASS=1 (`train_precision = "bf16"`) and -DVMM_SINGLE_PASS=2 (`train_precision = "fp16"`: the reference's own autocast
+// dtype, main.py:34).  In those builds every split product is its hi * hi pass alone (16-bit rounded operands, fp32 accumulation), the lo planes are
+// neither formed nor multiplied where the source guards them, and the entry points carry `_bf16` / `_fp16` where the three-pass build says `_bf16x3`
+// (VMM_X3(vmm_qkv_bwd_, ) -> vmm_qkv_bwd_bf16x3 / vmm_qkv_bwd_bf16 / vmm_qkv_bwd_fp16); host-only queries (workspace sizes) exist once.
+//   mode 2: the 16-bit operand is IEEE half -- split_bf16_pair / vmm_split16 round to fp16 (v_cvt_pk_f16_f32, round-to-nearest-even) and leave a zero
+//   lo part, vmm_mfma16 issues v_mfma_f32_32x32x16_f16, weight operands come from vmm_pack_weights' fp16 planes (fmt | 16).  The forward kernels with a
+//   single-pass template instance (build.FP16_FORWARD_SOURCES) are compiled in mode 2 as well and export that instance alone, as `_fp16`.
 #ifndef VMM_SINGLE_PASS
 #define VMM_SINGLE_PASS 0
 #endif
-#if VMM_SINGLE_PASS
+#if VMM_SINGLE_PASS == 2
+#define VMM_X3(pre, post) pre##fp16##post
+#elif VMM_SINGLE_PASS
 #define VMM_X3(pre, post) pre##bf16##post
 #else
 #define VMM_X3(pre, post) pre##bf16x3##post
 #endif
+#define VMM_FP16_OPERANDS (VMM_SINGLE_PASS == 2)
 
 #define VMM_WAVE 64
 
@@ -80,14 +87,50 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // Split two fp32 values into packed bf16 hi | lo parts (x = hi + lo up to 2^-17 relative; both round-to-nearest-even): the operand form of
 // every split-bf16 kernel.  Five instructions per pair (v_cvt_pk_bf16_f32, shift, mask, v_pk_add_f32, v_cvt_pk_bf16_f32); gfx950 has no
 // v_fma_mix_f32_bf16 that could subtract hi straight from its packed half (the assembler rejects it: "not supported on this GPU").
+// (fp16-operand builds, VMM_SINGLE_PASS == 2: hi = the pair rounded to IEEE half, one v_cvt_pk_f16_f32; lo = 0, never multiplied)
 __device__ __forceinline__ unsigned split_bf16_pair(float x0, float x1, unsigned& lo) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   const f32x2_t v = {x0, x1};
+#if VMM_FP16_OPERANDS
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  lo = 0u;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+#else
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
   const f32x2_t r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u)};
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
   return hi;
+#endif
+}
+// one value: the 16 bits of its hi part, `lo` = the bits of what is left (0 in fp16-operand builds)
+__device__ __forceinline__ unsigned short vmm_split16(float v, unsigned short& lo) {
+#if VMM_FP16_OPERANDS
+  lo = 0;
+  return __builtin_bit_cast(unsigned short, (_Float16)v);
+#else
+  const __bf16 h = (__bf16)v;
+  lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+  return __builtin_bit_cast(unsigned short, h);
+#endif
+}
+// 1.0 as a 16-bit operand (identity fragments of the chained kernels)
+#if VMM_FP16_OPERANDS
+#define VMM_ONE16 0x3C00u
+#else
+#define VMM_ONE16 0x3F80u
+#endif
+// one k16 step on the matrix cores: eight 16-bit operand values per lane and side, given as any 16-byte type (uint4, bf16x8, ...)
+typedef __bf16 vmm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vmm_f16x8 __attribute__((ext_vector_type(8)));
+template <typename A, typename B>
+__device__ __forceinline__ f32x16 vmm_mfma16(const A& a, const B& b, f32x16 c) {
+  static_assert(sizeof(A) == 16 && sizeof(B) == 16, "eight 16-bit operand values per lane");
+#if VMM_FP16_OPERANDS
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vmm_f16x8, a), __builtin_bit_cast(vmm_f16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vmm_bf16x8, a), __builtin_bit_cast(vmm_bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 // sum over the 16 lanes of a DPP row, every lane gets it: four rotate-and-add steps (v_add_f32_dpp row_ror), no LDS permutes

@@ -299,8 +299,22 @@ __global__ __launch_bounds__(256) void unpack_tiled_kernel(const vmm_pack_job* _
 }
 
 // batched (un)pack: packed[(th*TW + tw)*Cp + c][n]  <->  torch[ n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw ]
+// the two 16-bit planes of an operand value: split bf16 hi | lo, or -- operand planes of the fp16-operand kernels, fmt | 16 -- IEEE half | 0
+__device__ __forceinline__ void pack16(float v, bool half, unsigned short& hi, unsigned short& lo) {
+  if (half) {
+    hi = __builtin_bit_cast(unsigned short, (_Float16)v);
+    lo = 0;
+  } else {
+    const __bf16 h = (__bf16)v;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
-  const vmm_pack_job jb = jobs[blockIdx.y];
+  vmm_pack_job jb = jobs[blockIdx.y];
+  const bool half = (jb.fmt & 16) != 0;  // fragment-order formats 2, 3, 5, 6 with fp16 planes (vmm_conv3x3_fp16 and the other `_fp16` entry points)
+  jb.fmt &= 15;
   if (direction == 1 && unpack_tile_cb(jb)) return;  // (scattered by unpack_tiled_kernel)
   if (jb.fmt == 1) {
     // split-bf16 operand for igemm_bf16x3.hip: [N][Kpad] hi plane then lo plane, K = (th, tw, c) padded to a multiple of 32
@@ -378,11 +392,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
       }
       float v = 0.f;
       if (kh >= 0 && kh < 4 && kw >= 0 && kw < 4) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)kh * jb.sh + (long long)kw * jb.sw];
-      const __bf16 h = (__bf16)v;
-      const __bf16 lo = (__bf16)(v - (float)h);
       const long long o = pl * 1024 + l * 8 + e;
-      dst[o] = __builtin_bit_cast(unsigned short, h);
-      dst[o + 512] = __builtin_bit_cast(unsigned short, lo);
+      pack16(v, half, dst[o], dst[o + 512]);
     }
     return;
   }
@@ -469,11 +480,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
         jb.packed[pl * 512 + (e >> 2) * 256 + l * 4 + (e & 3)] = v;
         continue;
       }
-      const __bf16 h = (__bf16)v;
-      const __bf16 lo = (__bf16)(v - (float)h);
       const long long o = pl * 1024 + l * 8 + e;
-      dst[o] = __builtin_bit_cast(unsigned short, h);
-      dst[o + 512] = __builtin_bit_cast(unsigned short, lo);
+      pack16(v, half, dst[o], dst[o + 512]);
     }
     return;
   }

@@ -140,15 +140,15 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = vmm_mfma16(Ah[i], Bl[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) if constexpr (!VMM_SINGLE_PASS) acc[i][j] = vmm_mfma16(Al[i], Bh[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = vmm_mfma16(Ah[i], Bh[j], acc[i][j]);
     }
     if (grp == 1) loader_phase(it);
     __syncthreads();

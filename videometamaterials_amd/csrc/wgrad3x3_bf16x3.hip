@@ -267,11 +267,11 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
         }
         // pass-major: consecutive MFMAs write different accumulators; lo products first
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[kw], acc[kh * 3 + kw], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = vmm_mfma16(Ah, Bl[kw], acc[kh * 3 + kw]);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) if constexpr (!VMM_SINGLE_PASS) acc[kh * 3 + kw] = vmm_mfma16(Al, Bh[kw], acc[kh * 3 + kw]);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[kw], acc[kh * 3 + kw], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = vmm_mfma16(Ah, Bh[kw], acc[kh * 3 + kw]);
       }
     }
     if (grp == 1) loader_phase(it);

@@ -358,6 +358,10 @@ class DataParallelTrainer:
                 raise N.NativeError("the native data-parallel engine runs over RCCL: the model must live on a GPU")
             self.engine = RcclEngine.create(dev, group)
         self.step = 0
+        # loss scaling of the fp16-operand leg (Unet3D.train_precision = "fp16"): torch.cuda.amp.GradScaler's defaults, which Accelerate(mixed_precision='fp16')
+        # -- the reference's configuration, main.py:34 -- uses as they are; the state lives on the device (vmm_scaler_*, include/vmm_kernels.h)
+        self.loss_scale_init, self.loss_scale_growth, self.loss_scale_backoff, self.loss_scale_interval = 65536.0, 2.0, 0.5, 2000
+        self._scaler = None
         self.bucket_floats = bucket_floats
         self._plan = None
         self._reducer = None
@@ -595,14 +599,24 @@ class DataParallelTrainer:
         pl.launch()
         sq = 1 if d.loss_type == "l2" else 0
         N.check(lib.vmm_loss_reduce(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, self._acc.data_ptr(), self._loss.data_ptr(), _stream()), "loss")
-        N.check(lib.vmm_loss_grad(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, None, pl.dout.data_ptr(), _stream()), "loss grad")
+        scaled = self.unet.train_precision == "fp16"  # fp16 operands: gradients of the l1 loss (~1e-6 per element) need the loss scale to stay representable
+        st = self._scaler_state(dev) if scaled else None
+        N.check(lib.vmm_loss_grad(noise.data_ptr(), pl.out.data_ptr(), pl.out.numel(), sq, st.data_ptr() if scaled else None, pl.dout.data_ptr(), _stream()),
+                "loss grad")
         self._reducer.start()
         pl.backward(None, on_mark=self._reducer.mark if self._reducer.active else None)
         self._reducer.backward_done()
         self._reducer.finish()
         b1, b2 = self.betas
         tab, n = self._adam_table
-        N.check(lib.vmm_adam_step(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, self.step, 1.0 / self.world, _stream()), "vmm_adam_step")
+        if scaled:
+            # GradScaler.step / update without a host round trip (vddp.py:1629-1633 under Accelerate's fp16): an inf / nan anywhere in the (all-reduced, hence
+            # rank-consistent) gradient buffer turns the optimiser launch into a no-op and halves the scale; 2000 clean steps double it
+            N.check(lib.vmm_grad_nonfinite(pl.pgrad.data_ptr(), pl.pgrad.numel(), st.data_ptr(), _stream()), "vmm_grad_nonfinite")
+            N.check(lib.vmm_adam_step_scaled(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, 1.0 / self.world, st.data_ptr(), _stream()), "vmm_adam_step_scaled")
+            N.check(lib.vmm_scaler_update(st.data_ptr(), self.loss_scale_growth, self.loss_scale_backoff, int(self.loss_scale_interval), _stream()), "vmm_scaler_update")
+        else:
+            N.check(lib.vmm_adam_step(tab.data_ptr(), n, self._max_n, self.lr, b1, b2, self.eps, self.step, 1.0 / self.world, _stream()), "vmm_adam_step")
         self.unet.bump_generation()  # written through raw pointers: autograd's version counters did not move
         ref_step = self.step - 1  # Trainer.step while this optimiser step runs: the reference counts from 0 (vddp.py:1612-1640)
         if ref_step % self.update_ema_every == 0:  # vddp.py:1637-1639, 1500-1504
@@ -610,6 +624,20 @@ class DataParallelTrainer:
             N.check(lib.vmm_ema_step(tab.data_ptr(), n, self._max_n, self.ema_decay, 1 if ref_step < self.step_start_ema else 0, _stream()), "vmm_ema_step")
             self.ema_model.denoise_fn.bump_generation()
         return self._loss
+
+    def _scaler_state(self, dev) -> torch.Tensor:
+        if self._scaler is None or self._scaler.device != torch.device(dev):
+            self._scaler = torch.empty(8, dtype=torch.float32, device=dev)
+            N.check(N.lib().vmm_scaler_init(self._scaler.data_ptr(), float(self.loss_scale_init), _stream()), "vmm_scaler_init")
+        return self._scaler
+
+    def loss_scale_state(self) -> Optional[dict]:
+        """The device-side GradScaler state of the fp16 leg (one device-to-host copy; None before its first step): scale, growth tracker, steps skipped for a
+        non-finite gradient, optimiser steps taken."""
+        if self._scaler is None:
+            return None
+        v = self._scaler[:5].cpu().tolist()
+        return {"scale": v[0], "growth_tracker": int(v[1]), "skipped_steps": int(v[3]), "optimizer_steps": int(v[4])}
 
     # ------------------------------------------------------------------ sharded sampling (vddp.py:1506-1532, 1816-1845)
     @torch.no_grad()

@@ -311,15 +311,21 @@ class _Builder:
         # split-bf16 matrix-core path for the forward contractions of inference plans (training keeps exact fp32 everywhere)
         # bf16x3: split-bf16 matrix-core GEMMs (forward, and in training also the data gradients; weight gradients stay exact fp32)
         prec = getattr(model, "train_precision" if training else "precision", "fp32")
-        if prec not in ("fp32", "bf16x3", "bf16"):
-            raise ValueError(f"unknown arithmetic mode {prec!r}: 'fp32' (exact), 'bf16x3' (split-bf16, fp32-class), 'bf16' (single pass: the sampling throughput mode and the reduced-precision training leg)")
+        if prec not in ("fp32", "bf16x3", "bf16", "fp16"):
+            raise ValueError(f"unknown arithmetic mode {prec!r}: 'fp32' (exact), 'bf16x3' (split-bf16, fp32-class), 'bf16' (single pass: the sampling throughput mode and the "
+                             "reduced-precision training leg), 'fp16' (single pass on IEEE-half operands: the reference's own autocast dtype, main.py:34)")
         # (training in "bf16": the reduced-precision leg -- one matrix pass on bf16-rounded operands wherever a kernel has such an instance, fp32 master
         # weights, fp32 activations in HBM, fp32 accumulation / norms / softmax / optimizer; the counterpart of the reference's fp16 autocast, main.py:34)
-        self.x3 = prec in ("bf16x3", "bf16")
+        self.x3 = prec in ("bf16x3", "bf16", "fp16")
         # "bf16": the 3 x 3 convolutions and the fused attention blocks run ONE matrix pass on the operands' bf16 roundings (same packed weights, same
         # launch list); the bandwidth-bound kernels keep their three passes, which cost them no time.  fp32 activations in HBM either way.
-        self.one = prec == "bf16"
-        self.a16 = bool(self.one and not training and getattr(model, "bf16_storage", True) and _enabled("a16"))
+        self.one = prec in ("bf16", "fp16")
+        # "fp16": the single-pass kernels on IEEE-half operands (v_mfma_f32_32x32x16_f16; the `_fp16` entry points, weight operands packed as fp16 planes:
+        # vmm_pack_weights fmt | 16) -- what torch autocast makes of the reference's convolutions / Linears / einsums under Accelerate(mixed_precision='fp16')
+        # (main.py:34).  The bandwidth-bound contractions (1 x 1 projections, the generic implicit GEMM, the stem) keep their three split-bf16 passes: more
+        # accurate than either 16-bit format and no slower.  fp32 feature maps in HBM.
+        self.half = prec == "fp16"
+        self.a16 = bool(self.one and not self.half and not training and getattr(model, "bf16_storage", True) and _enabled("a16"))
         self.a16_ops = set(os.environ.get("VMM_A16_OPS", "all").split(","))
         # exact-fp32 mode: the 3x3 and projection kernels run their v_mfma_f32_32x32x2_f32 variants on fp32 fragment-order weights (fmt 4)
         self.f32frag = not self.x3 and getattr(model, "use_f32_frag_kernels", True)
@@ -416,6 +422,7 @@ class _Builder:
         split-bf16 formats in bf16x3 mode; default = want_grad (raw parameter copies stay fp32)."""
         self._touch(name)
         frag = desc.pop("frag", False)
+        half = bool(desc.pop("half", False)) and self.half  # the consumer is an `_fp16` entry point: IEEE-half planes (fmt | 16)
         n_fp32, fp32_desc = n_elems, desc
         if "fmt" in desc:  # an explicit operand format (5 / 6: the resampling layers' fragment planes); n_elems is the packed size
             assert not want_grad
@@ -432,6 +439,9 @@ class _Builder:
             else:     # [N][Kpad] planes, staged through LDS (igemm_bf16x3.hip)
                 n_elems = desc["N"] * kpad
                 desc = dict(desc, fmt=1)
+        if half:
+            assert desc.get("fmt") in (2, 3, 5, 6), "fp16 planes exist for the fragment-order operand formats"
+            desc = dict(desc, fmt=desc["fmt"] | 16)
         ptr = self.wslot(n_elems)
         job = dict(name=name, packed=ptr, **desc)
         self.plan.pack_jobs.append(job)
@@ -442,6 +452,10 @@ class _Builder:
             self.unpack_jobs.append(dict(name=name, packed=gptr, accumulate=1, **fp32_desc))
         return ptr, gptr
 
+    def sp(self, stem: str, tail: str = ""):
+        """Entry point of a kernel family for the plan's arithmetic: stem + 'bf16x3' | 'bf16' | 'fp16' + tail (single-pass instances where the mode has them)."""
+        return getattr(self.lib, stem + ("fp16" if self.half else "bf16" if self.one else "bf16x3") + tail)
+
     def wraw(self, name: str) -> int:
         """Static copy of a parameter in its torch layout (one per parameter)."""
         if name not in self.raw_slots:
@@ -450,10 +464,10 @@ class _Builder:
         return self.raw_slots[name]
 
     def pack_conv(self, name: str, pad_cin_to: int = 0, frag: bool = False) -> Tuple[int, int]:
-        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, ci)][Cout]"""
+        """(Cout, Cin, 1, KH, KW) -> [(kh, kw, ci)][Cout]  (fragment order = the 3 x 3 halo kernel's operand: fp16 planes in an fp16 plan)"""
         co, ci, _, kh, kw = self.shapes[name]
         cip = max(ci, pad_cin_to)
-        return self.pack(name, kh * kw * cip * co, TH=kh, TW=kw, C=ci, Cp=cip, N=co, sn=ci * kh * kw, sc=kh * kw, sh=kw, sw=1, hs=1, ws=1, frag=frag)
+        return self.pack(name, kh * kw * cip * co, TH=kh, TW=kw, C=ci, Cp=cip, N=co, sn=ci * kh * kw, sc=kh * kw, sh=kw, sw=1, hs=1, ws=1, frag=frag, half=bool(frag))
 
     def halo_ok(self, c1: int, c2: int, cout: int, H: int, W: int) -> bool:
         """Envelope of vmm_conv3x3_bf16x3 (LDS halo patch + register-fed fragment-order weights)."""
@@ -475,18 +489,18 @@ class _Builder:
         co, ci, _, kh, kw = self.shapes[name]
         geo = dict(h0=kh - 1, hs=-1, w0=kw - 1, ws=-1) if flip else dict(hs=1, ws=1)
         return self.pack(name, kh * kw * co * nci, want_grad=False, gemm=gemm, TH=kh, TW=kw, C=co, Cp=co, N=nci, sn=kh * kw, sc=ci * kh * kw, sh=kw, sw=1,
-                         src_off=ci0 * kh * kw, frag=frag, **geo)[0]
+                         src_off=ci0 * kh * kw, frag=frag, half=bool(frag), **geo)[0]
 
-    def pack_linear(self, name: str, frag=False) -> Tuple[int, int]:
-        """(out, in[,1,1[,1]]) -> [in][out]"""
+    def pack_linear(self, name: str, frag=False, half: bool = False) -> Tuple[int, int]:
+        """(out, in[,1,1[,1]]) -> [in][out]   (half: the operand of an `_fp16` entry point -- the fused attention blocks -- in an fp16 plan)"""
         shp = self.shapes[name]
         co, ci = shp[0], shp[1]
-        return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1, frag=frag)
+        return self.pack(name, co * ci, TH=1, TW=1, C=ci, Cp=ci, N=co, sn=ci, sc=1, frag=frag, half=half)
 
-    def pack_linear_slice(self, name: str, ci0: int, nci: int, frag=False, gemm: bool = False) -> int:
+    def pack_linear_slice(self, name: str, ci0: int, nci: int, frag=False, gemm: bool = False, half: bool = False) -> int:
         """torch (out, in) restricted to input columns [ci0, ci0+nci) as [out][nci]: the k-major operand of the data gradient."""
         co, ci = self.shapes[name][0], self.shapes[name][1]
-        return self.pack(name, co * nci, want_grad=False, gemm=gemm, TH=1, TW=1, C=co, Cp=co, N=nci, sn=1, sc=ci, src_off=ci0, frag=frag)[0]
+        return self.pack(name, co * nci, want_grad=False, gemm=gemm, TH=1, TW=1, C=co, Cp=co, N=nci, sn=1, sc=ci, src_off=ci0, frag=frag, half=half)[0]
 
     def dgrad_3x3(self, name: str, ci0: int, nci: int, what: str, **kw) -> None:
         """dX[:, ci0:ci0+nci] (+)= data gradient of the 3x3 'same' conv with weight `name`: with the taps reversed it is itself a
@@ -613,20 +627,20 @@ class _Builder:
                                                                           and _enabled("qkv_bwd")) else 0
         ln = getattr(dq, "_ln", None) if dq is not None else None
         if ws_n and ln and ln_gamma_name and not (x.ld & 3) and _enabled("qkv_bwd_ln"):
-            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
+            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True, half=True)
             ws = self.alloc(ws_n)
             gx, acc = self.grad_of(x)
             gg = self.pg(ln_gamma_name) or self.scratch(x.C)
-            self.step(self.lib.vmm_qkv_bwd_ln_bf16 if self.one else self.lib.vmm_qkv_bwd_ln_bf16x3,
+            self.step(self.sp("vmm_qkv_bwd_ln_"),
                       (dq.a1, dq.lda1, ln[0], ln[1], gqkv.ptr, n_out, wd, gx.ptr, x.C, acc, gg, gwq, self.ptr(ws), rows, x.C, n_out),
                       what + " backward (data + weight gradient, LayerNorm backward)", flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 3 * x.C))
             self.tmp_free((ws, ws_n))
             return None
         gy = self.act(x.C, x.H, x.W)
         if ws_n:
-            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True)
+            wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True, half=True)
             ws = self.alloc(ws_n)
-            self.step(self.lib.vmm_qkv_bwd_bf16 if self.one else self.lib.vmm_qkv_bwd_bf16x3, (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
+            self.step(self.sp("vmm_qkv_bwd_"), (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
                                                     self.ptr(ws), rows, x.C, n_out), what + " backward (data + weight gradient)",
                       flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 2 * x.C))
             self.tmp_free((ws, ws_n))
@@ -659,7 +673,9 @@ class _Builder:
                 d._ln = (ln_stats, ln_gamma)
                 self.step(self.lib.vmm_proj_bf16x3_ln_stats, (C.byref(d), ln_gamma, C.c_float(1e-5), ln_stats), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
                 return d
-            fn = (self.lib.vmm_proj_bf16 if self.one else self.lib.vmm_proj_bf16x3) if self.x3 else self.lib.vmm_proj_f32
+            # (fp16 plans: the projections keep their three split-bf16 passes -- bandwidth-bound kernels, and their packed weights serve the x3-only
+            # instances of the same family (LayerNorm statistics, narrow streaming) as well)
+            fn = (self.lib.vmm_proj_bf16 if (self.one and not self.half) else self.lib.vmm_proj_bf16x3) if self.x3 else self.lib.vmm_proj_f32
             self.step(fn, (C.byref(d), ln_gamma or None, C.c_float(1e-5)), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
             return d
         assert not ln_gamma
@@ -667,7 +683,7 @@ class _Builder:
         if self.x3 and (x3w or not self.in_bwd):  # x3w: a backward GEMM whose weight operand was packed split-bf16 (pack(..., gemm=True))
             fn = self.lib.vmm_conv_igemm_bf16x3
             if halo:  # weights were packed in fragment order for it (halo_ok)
-                fn = self.lib.vmm_conv3x3_bf16 if self.one else self.lib.vmm_conv3x3_bf16x3
+                fn = self.sp("vmm_conv3x3_")
         self.step(fn, (C.byref(d),), what, flops=2.0 * M * K * d.Cout, nbytes=nbytes)
         return d
 
@@ -698,7 +714,7 @@ class _Builder:
             ws_n = int(self.lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), lddy))
             if ws_n:
                 ws = self.alloc(ws_n)
-                self.step(self.lib.vmm_conv3x3_wgrad_bf16 if self.one else self.lib.vmm_conv3x3_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                self.step(self.sp("vmm_conv3x3_wgrad_"), (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                           flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
@@ -711,10 +727,10 @@ class _Builder:
                 ws = self.alloc(ws_n)
                 if ln:
                     assert not gb_ptr
-                    self.step(self.lib.vmm_conv1x1_wgrad_bf16_ln if self.one else self.lib.vmm_conv1x1_wgrad_bf16x3_ln, (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
+                    self.step(self.sp("vmm_conv1x1_wgrad_", "_ln"), (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 else:
-                    self.step(self.lib.vmm_conv1x1_wgrad_bf16 if self.one else self.lib.vmm_conv1x1_wgrad_bf16x3, (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                    self.step(self.sp("vmm_conv1x1_wgrad_"), (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.tmp_free((ws, ws_n))
                 return
@@ -866,7 +882,7 @@ class _Builder:
             dr = self.conv_desc(a1=xt1, a2=xt2, w=wr, bias=self.wraw(name + ".res_conv.bias"), Cout=Cout, out_ptr=h2t.ptr, ldo=Cout, Hv=H, Wv=W,
                                 res_ptr=h2t.ptr, ldres=Cout, out_bf=nt)
             tail_fn = (self.lib.vmm_proj_narrow_bf16x3_res_silu if narrow
-                       else self.lib.vmm_proj_bf16_res_silu if self.one else self.lib.vmm_proj_bf16x3_res_silu)
+                       else self.lib.vmm_proj_bf16_res_silu if (self.one and not self.half) else self.lib.vmm_proj_bf16x3_res_silu)
             self.step(tail_fn, (C.byref(dr), c2_ptr, self.T * H * W), name + ".res_conv + out",
                       flops=2.0 * rows * kin * Cout, nbytes=4.0 * rows * (kin + 2 * Cout))
             if h2t is not h2:  # (the converted copy IS the block's output)
@@ -1003,8 +1019,8 @@ class _Builder:
         if fused_fwd and (not self.training or bwd_ws_n):
             # the two upper levels (C = 64, 128): q, k, v stay on chip (x read twice, out written once; linattn_block.hip)
             p = name + ".fn.fn"
-            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2)
-            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3)
+            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2, half=True)
+            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3, half=True)
             ws_n = int(self.lib.vmm_linattn_block_workspace(B, T, HW))
             ws = self.alloc(ws_n)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
@@ -1013,7 +1029,7 @@ class _Builder:
             xc = self.cast(x, nla, tmps)
             out = self.act(x.C, x.H, x.W, bf=nla)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * hid * 32
-            self.step(self.lib.vmm_linattn_block_bf16_a16 if nla else self.lib.vmm_linattn_block_bf16 if self.one else self.lib.vmm_linattn_block_bf16x3,
+            self.step(self.lib.vmm_linattn_block_bf16_a16 if nla else self.sp("vmm_linattn_block_"),
                       (xc.ptr, xc.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, self.wraw(p + ".to_out.bias"), ek or None, ev or None,
                        ntok_s, self.ptr(ws), out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=(6.0 if nla else 12.0) * x.n)
@@ -1021,7 +1037,7 @@ class _Builder:
             self.free(ws, ws_n)  # (a no-op in training plans: the backward reads the key-softmax partials and context fragments it holds)
             self.plan.named[name] = out
             if self.training:
-                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True)
+                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True, half=True)
                 gamma_ptr = self.wraw(name + ".fn.norm.gamma")
                 dq = self.conv_desc(a1=x, w=wq, Cout=3 * hid, out_ptr=out.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W)  # (descriptor of to_qkv for its backward; never launched)
 
@@ -1041,7 +1057,7 @@ class _Builder:
                     d.workspace = self.ptr(bws)
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
-                    self.step(self.lib.vmm_linattn_block_bwd_bf16 if self.one else self.lib.vmm_linattn_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
+                    self.step(self.sp("vmm_linattn_block_bwd_"), (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
                               nbytes=4.0 * rows * (4 * x.C + 3 * hid))
                     self.tmp_free((bws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
@@ -1145,8 +1161,8 @@ class _Builder:
             fused_fwd and self.training and getattr(self.m, "use_x3_wgrad", True) and _enabled("fused_attn_train")) else 0
         if fused_fwd and (not self.training or bwd_ws_n):
             # the two upper levels (C = 64, 128): the whole block in ONE kernel (x read once, out written once; temporal_block.hip)
-            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2)
-            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3)
+            wq, gwq = self.pack_linear(p + ".to_qkv.weight", frag=2, half=True)
+            wo, gwo = self.pack_linear(p + ".to_out.weight", frag=3, half=True)
             ek, ev = (self.ekv_info[site][1], self.ekv_info[site][2]) if site else (0, 0)
             tmps: list = []
             ntb = self.nat16("tb", x.H) and x.C == 64  # (the C = 128 kernel has no bf16-storage instance: fp32 copies there)
@@ -1154,14 +1170,14 @@ class _Builder:
             out = self.act(x.C, x.H, x.W, bf=ntb)
             flops = 2.0 * rows * x.C * 3 * hid + 2.0 * rows * hid * x.C + 4.0 * rows * heads * 32 * (T + ntok_s)
             pfc_ = 1 if self.m.per_frame_cond else 0
-            self.step(self.lib.vmm_temporal_block_bf16_a16 if ntb else self.lib.vmm_temporal_block_bf16 if self.one else self.lib.vmm_temporal_block_bf16x3,
+            self.step(self.lib.vmm_temporal_block_bf16_a16 if ntb else self.sp("vmm_temporal_block_"),
                       (xc.ptr, xc.ld, self.wraw(name + ".fn.norm.gamma"), wq, wo, ek or None, ev or None, ntok_s, self.bias_ptr,
                        pfc_, self.rot_ptr, out.ptr, out.ld, B, T, HW, x.C, heads, C.c_float(32 ** -0.5), C.c_float(1e-5)),
                       name + " fused block", flops=flops, nbytes=(4.0 if ntb else 8.0) * x.n)
             self.free_temps(tmps)
             self.plan.named[name] = out
             if self.training:
-                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True)
+                wo_t = self.pack_linear_slice(p + ".to_out.weight", 0, hid, frag=2, gemm=True, half=True)
                 gamma_ptr = self.wraw(name + ".fn.norm.gamma")
                 dq = self.conv_desc(a1=x, w=wq, Cout=3 * hid, out_ptr=out.ptr, ldo=3 * hid, Hv=x.H, Wv=x.W)  # (descriptor of to_qkv for its backward; never launched)
 
@@ -1180,7 +1196,7 @@ class _Builder:
                     d.workspace = self.ptr(ws)
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
-                    self.step(self.lib.vmm_temporal_block_bwd_bf16 if self.one else self.lib.vmm_temporal_block_bwd_bf16x3, (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
+                    self.step(self.sp("vmm_temporal_block_bwd_"), (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
                               nbytes=4.0 * rows * (2 * x.C + 3 * hid))
                     self.tmp_free((ws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
@@ -1739,13 +1755,13 @@ class _Builder:
                 d = self.act(x.C, x.H // 2, x.W // 2, bf=out16)
                 if s2_ok:
                     # Downsample as a 3 x 3 convolution over 2 x 2 input cells (halo patch in LDS, four of the nine taps per sub-pixel)
-                    wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5)[0]
+                    wd = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=ci_ * 16, sc=16, sh=4, sw=1, fmt=5, half=True)[0]
                     if in16:  # bf16-stored input (and output, unless this layer leaves the bf16 levels)
                         self.step(lib.vmm_conv_s2_acc_bf16_a16, (xsc.ptr, xsc.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
                                                                 1 if out16 else 2), nm, flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_,
                                   nbytes=2.0 * xs.n + (2.0 if out16 else 4.0) * d.n + 4.0 * 16 * ci_ * co_)
                     else:
-                        self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                        self.step(self.sp("vmm_conv_s2_acc_"),
                                   (xsc.ptr, xsc.ld, wd, self.wraw(nm + ".bias"), 0, 0, d.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 0,
                                                                self.tickets() if _enabled("s2_split") else 0, N_TICKETS), nm,
                                   flops=2.0 * B * T * d.H * d.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + d.n + 16 * ci_ * co_))
@@ -1807,13 +1823,13 @@ class _Builder:
                 u = self.act(co_, xs.H * 2, xs.W * 2, bf=out16)
                 if s2:
                     # Upsample as ONE 3 x 3 convolution over the input tile with the four output phases as 4 x Cout columns
-                    wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6)[0]
+                    wu = self.pack(nm + ".weight", 36 * ci_ * co_, want_grad=False, TH=4, TW=4, C=ci_, Cp=ci_, N=co_, sn=16, sc=co_ * 16, sh=4, sw=1, fmt=6, half=True)[0]
                     if out16:  # bf16-stored output (the input too, unless this layer enters the bf16 levels)
                         self.step(lib.vmm_conv_s2_acc_bf16_a16, (xsc.ptr, xsc.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1,
                                                                 1 if in16 else 3), nm, flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_,
                                   nbytes=(2.0 if in16 else 4.0) * xs.n + 2.0 * u.n + 4.0 * 16 * ci_ * co_)
                     else:
-                        self.step(lib.vmm_conv_s2_acc_bf16 if self.one else lib.vmm_conv_s2_acc_bf16x3,
+                        self.step(self.sp("vmm_conv_s2_acc_"),
                                   (xsc.ptr, xsc.ld, wu, self.wraw(nm + ".bias"), 0, 0, u.ptr, co_, B * T, xs.H, xs.W, ci_, co_, 1, 0, 0), nm,
                                   flops=2.0 * B * T * xs.H * xs.W * 16 * ci_ * co_, nbytes=4.0 * (xs.n + u.n + 16 * ci_ * co_))
                 for ph in range(2 if (not s2 or tr) else 0):  # (training: the phase descriptors feed the weight gradients even when the forward is one s2 launch)
