@@ -1,7 +1,7 @@
 """Soak of the training step: n optimiser steps of the Lagrangian configuration on a fixed synthetic batch (the loss must stay finite and
 fall), in either arithmetic mode.
 
-    python tools/soak_trainer.py [fp32|bf16x3] [n]
+    python tools/soak_trainer.py [fp32|bf16x3|bf16|fp16] [n]
 """
 import os
 import sys
@@ -34,4 +34,6 @@ for i in range(n):
 first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
 ok = all(map(lambda v: v == v and abs(v) < 1e6, losses)) and last < first
 print(f"mean loss first 5 steps {first:.4f} -> last 5 steps {last:.4f}: {'ok' if ok else 'FAILED'}")
+if mode == "fp16":
+    print("loss scale state:", tr.loss_scale_state())
 sys.exit(0 if ok else 1)
