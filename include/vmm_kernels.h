@@ -572,7 +572,7 @@ typedef struct vmm_attn_block_bwd {
   const float* rot_tab;                   /* temporal: [T][16][2] */
   const float* fwd_workspace;             /* linear: the workspace the forward vmm_linattn_block_bf16x3 call left (partials of the key softmax / context) */
   const float* dout; int32_t lddo;        /* gradient of the block output, rows x C */
-  float* dqkv; int32_t lddqkv;
+  float* dqkv; int32_t lddqkv;            /* rows x 768 (`_bf16` / `_fp16` instances: 16-bit elements, see "the reduced-precision training leg" below) */
   float* ln_stats;
   float* dwout_packed;
   float* dbout;                           /* linear: += [C] gradient of the to_out bias, or NULL */
@@ -595,7 +595,12 @@ int vmm_linattn_block_bwd_bf16x3(const vmm_attn_block_bwd* d, vmm_stream_t strea
 /* ---- the reduced-precision training leg (`train_precision = "bf16"`; the counterpart of the reference's fp16 autocast, main.py:34): the same backward
  * kernels, same arguments, workspaces and envelopes as their _bf16x3 namesakes, with ONE matrix pass per product on the operands' bf16 roundings (fp32
  * accumulation; the second compilation of their sources with -DVMM_SINGLE_PASS=1).  The forward and data-gradient contractions of that leg are the
- * single-pass entry points of the sampling path (vmm_conv3x3_bf16, vmm_proj_bf16, vmm_temporal_block_bf16, vmm_linattn_block_bf16, ...). */
+ * single-pass entry points of the sampling path (vmm_conv3x3_bf16, vmm_proj_bf16, vmm_temporal_block_bf16, vmm_linattn_block_bf16, ...).
+ * ONE difference in the data they exchange (round 6): the gradient of the raw qkv rows -- `vmm_attn_block_bwd.dqkv` of the block backward, `g` of
+ * vmm_qkv_bwd_* -- is rows of the operand's own 16-bit type in the single-pass instances (bf16 bits for `_bf16`, IEEE half for `_fp16`; `lddqkv` / `ldg`
+ * count ELEMENTS, the pointers keep their `float*` spelling): it is a matrix operand of the to_qkv backward and nothing else, the producer's store
+ * applies the rounding the consumer's operand conversion applied before, so the gradients are the same bit for bit and the 1.25 GB round trip per
+ * 96 x 96 site is half the bytes.  The `_bf16x3` instances keep fp32 rows. */
 int vmm_conv3x3_wgrad_bf16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
                            vmm_stream_t stream);
 int vmm_conv1x1_wgrad_bf16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
@@ -608,6 +613,9 @@ int vmm_qkv_bwd_ln_bf16(const float* x, int32_t ldx, const float* ln_stats, cons
                         float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace, int64_t rows, int32_t C,
                         int32_t Nq, vmm_stream_t stream);
 int vmm_temporal_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+/* n (a multiple of 8) elements of such 16-bit rows widened to fp32, exactly: for the shapes the one-pass vmm_qkv_bwd_* does not take (its workspace query
+ * returns 0), where the caller runs a separate weight- and data-gradient launch over fp32 rows (which round to the same 16 bits again) */
+int vmm_dqkv_widen_bf16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
 int vmm_linattn_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
@@ -716,6 +724,7 @@ int vmm_qkv_bwd_ln_fp16(const float* x, int32_t ldx, const float* ln_stats, cons
                         int32_t Nq, vmm_stream_t stream);
 int vmm_temporal_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 int vmm_linattn_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
+int vmm_dqkv_widen_fp16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from test_gpu_kernels import _attn_ref, _lib, _pack_frag, _s, relerr
 pytestmark = pytest.mark.gpu
 
 
-def _pack_frag_t(N, lib, gpu, w2d):
+def _pack_frag_t(N, lib, gpu, w2d, fmt=2):
     """(out, in) weight -> fmt-2 fragments of its TRANSPOSED use: K = out features, N = in features (the data-gradient operand, pack_linear_slice)."""
     co, ci = w2d.shape
     wg = w2d.contiguous().to(gpu)
@@ -20,16 +20,28 @@ def _pack_frag_t(N, lib, gpu, w2d):
     j = job[0]
     j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
     j.TH, j.TW, j.C, j.Cp, j.N = 1, 1, co, co, ci
-    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = 1, ci, 0, 0, 0, 0, 0, 0, 0, 2
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = 1, ci, 0, 0, 0, 0, 0, 0, 0, fmt
     tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
     N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, packed.numel(), 0, _s()), "pack")
     torch.cuda.synchronize()
     return packed
 
 
+# (entry-point suffix, element type of the dqkv rows the kernel stores, tolerance against fp32 autograd): the single-pass instances (train_precision "fp16" /
+# "bf16") hand the gradient of the qkv rows to the to_qkv backward in their operand's own 16-bit type (csrc/vmm_common.h VMM_DQKV16)
+VARIANTS = [("bf16x3", torch.float32, 1e-4), ("fp16", torch.float16, 6e-3), ("bf16", torch.bfloat16, 4e-2)]
+
+
+def _dqkv_buffer(rows, hid, dtype, gpu):
+    """rows x 768 of the variant's element type with a guard row behind it (a kernel that stored the wrong element width would write into it)."""
+    buf = torch.full((rows + 1, 3 * hid), 7.0, device=gpu, dtype=dtype)
+    return buf, buf[:rows]
+
+
+@pytest.mark.parametrize("variant,qdtype,tol", VARIANTS)
 @pytest.mark.parametrize("B,T,HW,ntok,bias_on_cond", [(2, 11, 36, 11, 1), (1, 16, 10, 0, 0), (3, 5, 130, 7, 0), (1, 11, 1152, 16, 0), (2, 1, 4, 3, 0),
                                                       (1, 11, 2, 11, 1)])
-def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond):
+def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond, variant, qdtype, tol):
     """vmm_temporal_block_bwd_bf16x3: gradient of the raw to_qkv rows, LayerNorm statistics, dW_out, dbias, d(ek), d(ev) from x and dOut alone;
     several tiles per workgroup, padded frame slots, with / without tokens and the bias on them."""
     from videometamaterials_amd import hostmath
@@ -70,13 +82,14 @@ def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond):
     dout = torch.randn(B * T * HW, Cc, generator=g)
     branch.backward(dout)
 
-    wq, woT = _pack_frag(N, lib, gpu, wqkv, 2), _pack_frag_t(N, lib, gpu, wout.detach())
+    half = 16 if variant == "fp16" else 0  # IEEE-half weight planes (vmm_pack_weights fmt | 16)
+    wq, woT = _pack_frag(N, lib, gpu, wqkv, 2 | half), _pack_frag_t(N, lib, gpu, wout.detach(), 2 | half)
     xg, gg, bg, rg = x.reshape(B * T * HW, Cc).to(gpu), gamma.to(gpu), bias.detach().to(gpu), rot.to(gpu)
     ekg = ek.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
     dg = dout.to(gpu)
     rows = B * T * HW
-    dqkv = torch.full((rows, 3 * hid), 7.0, device=gpu)
+    dqkv_all, dqkv = _dqkv_buffer(rows, hid, qdtype, gpu)
     stats = torch.full((rows, 2), 7.0, device=gpu)
     dwo = torch.full((hid, Cc), 0.5, device=gpu)  # accumulated into (+=)
     dbias = torch.full((heads, T, T), 0.25, device=gpu)
@@ -95,22 +108,24 @@ def test_fused_temporal_block_backward(gpu, B, T, HW, ntok, bias_on_cond):
     d.workspace = ws.data_ptr()
     d.B, d.T, d.HW, d.C, d.heads = B, T, HW, Cc, heads
     d.q_scale, d.eps = 32 ** -0.5, 1e-5
-    N.check(lib.vmm_temporal_block_bwd_bf16x3(C.byref(d), _s()), "temporal block backward")
+    N.check(getattr(lib, "vmm_temporal_block_bwd_" + variant)(C.byref(d), _s()), "temporal block backward")
     torch.cuda.synchronize()
     want = qkv_raw.grad.reshape(rows, 3 * hid)
-    got = dqkv.cpu()
+    got = dqkv.float().cpu()
+    assert bool((dqkv_all[rows] == 7.0).all()), "the kernel wrote past the rows of its element type"
     for i, nm in enumerate("qkv"):
-        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < 1e-4, nm
+        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < tol, nm
     assert relerr(stats.cpu()[:, 0], mean.reshape(-1)) < 1e-5 and relerr(stats.cpu()[:, 1], rstd.reshape(-1)) < 1e-5
-    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < 1e-4
-    assert relerr(dbias.cpu() - 0.25, bias.grad) < 1e-4
+    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < tol
+    assert relerr(dbias.cpu() - 0.25, bias.grad) < tol
     if ntok:
-        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
-        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4
+        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < tol
+        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < tol
 
 
+@pytest.mark.parametrize("variant,qdtype,tol", VARIANTS)
 @pytest.mark.parametrize("B,T,H,W,ntok", [(2, 3, 8, 8, 5), (1, 2, 16, 24, 0), (2, 11, 32, 32, 11), (1, 1, 4, 8, 16), (1, 3, 48, 48, 11)])
-def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok):
+def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok, variant, qdtype, tol):
     """vmm_linattn_block_bwd_bf16x3 after the fused forward (whose workspace it reads): gradient of the raw to_qkv rows, LayerNorm statistics,
     dW_out, the to_out bias gradient, d(ek), d(ev) -- against torch autograd of SpatialLinearAttention's arithmetic (vddp.py:313-378)."""
     N, lib = _lib()
@@ -142,23 +157,26 @@ def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok):
     out = torch.einsum("bhde,bhdn->bhen", ctx, qs)                  # bt h e n
     o = out.permute(0, 3, 1, 2).reshape(B * T * HW, hid)
     branch = o @ wout.t() + bout
-    dout = torch.randn(B * T * HW, Cc, generator=g)
+    # (fp16 rows of the qkv gradient: the key softmax runs over HW + ntok entries, so dq / dk are ~1 / HW of dOut -- 1e-7 at 32 x 32 for a unit dOut, below the
+    # normal range of IEEE half.  Training multiplies the loss by the GradScaler's 2^16 for exactly this reason (dp.py, vddp.py:1629-1633); the test scales dOut)
+    dout = torch.randn(B * T * HW, Cc, generator=g) * (4096.0 if variant == "fp16" else 1.0)
     branch.backward(dout)
 
     rows = B * T * HW
-    wq, wo3, woT = _pack_frag(N, lib, gpu, wqkv, 2), _pack_frag(N, lib, gpu, wout.detach(), 3), _pack_frag_t(N, lib, gpu, wout.detach())
+    half = 16 if variant == "fp16" else 0
+    wq, wo3, woT = _pack_frag(N, lib, gpu, wqkv, 2 | half), _pack_frag(N, lib, gpu, wout.detach(), 3 | half), _pack_frag_t(N, lib, gpu, wout.detach(), 2 | half)
     xg, gg, bg = x.reshape(rows, Cc).to(gpu), gamma.to(gpu), bout.detach().to(gpu)
     ekg = ek.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
     evg = ev.detach().reshape(B, ntok, hid).to(gpu) if ntok else None
     fws = torch.empty(lib.vmm_linattn_block_workspace(B, T, HW), device=gpu)
     fout = torch.empty_like(xg)
-    N.check(lib.vmm_linattn_block_bf16x3(xg.data_ptr(), Cc, gg.data_ptr(), wq.data_ptr(), wo3.data_ptr(), bg.data_ptr(), ekg.data_ptr() if ntok else None,
-                                         evg.data_ptr() if ntok else None, ntok, fws.data_ptr(), fout.data_ptr(), Cc, B, T, HW, Cc, heads,
-                                         C.c_float(1e-5), _s()), "linear attention block")
+    N.check(getattr(lib, "vmm_linattn_block_" + variant)(xg.data_ptr(), Cc, gg.data_ptr(), wq.data_ptr(), wo3.data_ptr(), bg.data_ptr(), ekg.data_ptr() if ntok else None,
+                                                         evg.data_ptr() if ntok else None, ntok, fws.data_ptr(), fout.data_ptr(), Cc, B, T, HW, Cc, heads,
+                                                         C.c_float(1e-5), _s()), "linear attention block")
     torch.cuda.synchronize()
-    assert relerr(fout.cpu() - x.reshape(rows, Cc), branch.detach()) < 5e-5
+    assert relerr(fout.cpu() - x.reshape(rows, Cc), branch.detach()) < tol / 2
     dg = dout.to(gpu)
-    dqkv = torch.full((rows, 3 * hid), 7.0, device=gpu)
+    dqkv_all, dqkv = _dqkv_buffer(rows, hid, qdtype, gpu)
     stats = torch.full((rows, 2), 7.0, device=gpu)
     dwo = torch.full((hid, Cc), 0.5, device=gpu)
     dbo = torch.full((Cc,), 0.25, device=gpu)
@@ -177,18 +195,19 @@ def test_fused_linear_attention_block_backward(gpu, B, T, H, W, ntok):
     d.workspace = ws.data_ptr()
     d.B, d.T, d.HW, d.C, d.heads = B, T, HW, Cc, heads
     d.q_scale, d.eps = 32 ** -0.5, 1e-5
-    N.check(lib.vmm_linattn_block_bwd_bf16x3(C.byref(d), _s()), "linear attention block backward")
+    N.check(getattr(lib, "vmm_linattn_block_bwd_" + variant)(C.byref(d), _s()), "linear attention block backward")
     torch.cuda.synchronize()
     want = qkv_raw.grad.reshape(rows, 3 * hid)
-    got = dqkv.cpu()
+    got = dqkv.float().cpu()
+    assert bool((dqkv_all[rows] == 7.0).all()), "the kernel wrote past the rows of its element type"
     for i, nm in enumerate("qkv"):
-        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < 1e-4, nm
+        assert relerr(got[:, i * hid:(i + 1) * hid], want[:, i * hid:(i + 1) * hid]) < tol, nm
     assert relerr(stats.cpu()[:, 0], mean.reshape(-1)) < 1e-5 and relerr(stats.cpu()[:, 1], rstd.reshape(-1)) < 1e-5
-    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < 1e-4
+    assert relerr(dwo.cpu() - 0.5, wout.grad.t()) < tol
     assert relerr(dbo.cpu() - 0.25, bout.grad) < 1e-5
     if ntok:
-        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < 1e-4
-        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < 1e-4
+        assert relerr(dek.cpu(), ek.grad.reshape(B, ntok, hid)) < tol
+        assert relerr(dev.cpu(), ev.grad.reshape(B, ntok, hid)) < tol
 
 
 def test_training_plan_uses_the_fused_blocks_and_agrees_with_the_unfused_path(gpu, monkeypatch):

@@ -1177,11 +1177,17 @@ def test_layernorm_fused_projection_statistics_and_weight_gradient(gpu, rows, Cc
     assert relerr(dw.cpu(), w.grad.t()) < 5e-5
 
 
+# (variant, element type of the rows of g, tolerance): the single-pass instances take g in their operand's own 16-bit type (csrc/vmm_common.h VMM_DQKV16)
+QKV_BWD_VARIANTS = [("bf16x3", torch.float32, 5e-5), ("fp16", torch.float16, 2e-3), ("bf16", torch.bfloat16, 1.5e-2)]
+
+
+@pytest.mark.parametrize("variant,gdtype,tol", QKV_BWD_VARIANTS)
 @pytest.mark.parametrize("rows,with_ln", [(64, False), (1920, True), (70400, True), (20032, False)])
-def test_fused_to_qkv_backward(gpu, rows, with_ln):
-    """vmm_qkv_bwd_bf16x3: data gradient gy = g W and weight gradient dW += g^T y of to_qkv (768 x 64) from ONE pass over g, y = x or LayerNorm(x)
+def test_fused_to_qkv_backward(gpu, rows, with_ln, variant, gdtype, tol):
+    """vmm_qkv_bwd_bf16x3 / _fp16 / _bf16: data gradient gy = g W and weight gradient dW += g^T y of to_qkv (768 x 64) from ONE pass over g, y = x or LayerNorm(x)
     re-formed from the forward's row statistics; against the two matrix products in fp64.  One chunk, fewer chunks than workgroups, many chunks per
-    workgroup; += semantics of dW, plain store of gy, bit-reproducible."""
+    workgroup; += semantics of dW, plain store of gy, bit-reproducible.  The single-pass instances read g as rows of 16-bit operands (what the recomputing
+    attention backward of the same build stores): the reference multiplies exactly those values, the tolerance is the 16-bit rounding of W and y."""
     N, lib = _lib()
     g_ = torch.Generator().manual_seed(rows)
     Cc, Nq = 64, 768
@@ -1194,8 +1200,12 @@ def test_fused_to_qkv_backward(gpu, rows, with_ln):
     y = (x - mean) * rstd * gamma if with_ln else x
     want_gy = g.double() @ w.double()
     want_dw = y.double().t() @ g.double()             # packed k-major [c][n]
-    wp = _pack_frag(N, lib, gpu, w.t().contiguous(), 2)  # the (K = 768, N = 64) operand: "weight (out = 64, in = 768)" = W^T
-    xg, gg = x.to(gpu), g.to(gpu)
+    g = g.to(gdtype).float()                           # (the values the kernel is handed, exactly)
+    want_gy = g.double() @ w.double()
+    want_dw = y.double().t() @ g.double()
+    wp = _pack_frag(N, lib, gpu, w.t().contiguous(), 2 | (16 if variant == "fp16" else 0))  # the (K = 768, N = 64) operand: "weight (out = 64, in = 768)" = W^T
+    xg, gg = x.to(gpu), g.to(gdtype).to(gpu)
+    fn = getattr(lib, "vmm_qkv_bwd_" + variant)
     stats = torch.cat([mean, rstd], 1).contiguous().to(gpu)
     gam = gamma.to(gpu)
     n_ws = int(lib.vmm_qkv_bwd_workspace(rows, Cc, Nq))
@@ -1205,12 +1215,12 @@ def test_fused_to_qkv_backward(gpu, rows, with_ln):
         ws = torch.full((n_ws,), float("nan"), device=gpu)
         gy = torch.full((rows, Cc), 7.0, device=gpu)
         dw = torch.ones(Cc, Nq, device=gpu)
-        rc = lib.vmm_qkv_bwd_bf16x3(xg.data_ptr(), Cc, stats.data_ptr() if with_ln else None, gam.data_ptr() if with_ln else None, gg.data_ptr(), Nq,
-                                    wp.data_ptr(), gy.data_ptr(), Cc, dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, _s())
+        rc = fn(xg.data_ptr(), Cc, stats.data_ptr() if with_ln else None, gam.data_ptr() if with_ln else None, gg.data_ptr(), Nq,
+                wp.data_ptr(), gy.data_ptr(), Cc, dw.data_ptr(), ws.data_ptr(), rows, Cc, Nq, _s())
         assert rc == 0, rc
         torch.cuda.synchronize()
-        assert relerr(gy.cpu().double(), want_gy) < 5e-5
-        assert relerr(dw.cpu().double() - 1, want_dw) < 5e-5
+        assert relerr(gy.cpu().double(), want_gy) < tol
+        assert relerr(dw.cpu().double() - 1, want_dw) < tol
         outs.append((gy, dw))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 

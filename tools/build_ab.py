@@ -23,12 +23,14 @@ if __name__ == "__main__":
             o = os.path.join("/tmp", stem + "_ab.o")
             subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-c", s, "-o", o], check=True)
         objs.append(o)
-        if os.path.basename(s) in b.SINGLE_PASS_SOURCES:
-            o2 = os.path.join(b.OBJDIR, stem + "_sp.o")
-            if stem in names or "all" in names:
-                o2 = os.path.join("/tmp", stem + "_sp_ab.o")
-                subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-DVMM_SINGLE_PASS=1", "-c", s, "-o", o2], check=True)
-            objs.append(o2)
+        base = os.path.basename(s)
+        if base in b.SINGLE_PASS_SOURCES or base in b.FP16_FORWARD_SOURCES:  # the single-pass objects of build.py (*_sp.o: bf16 operands, *_h.o: fp16 operands)
+            for tag, mode in (b.SINGLE_PASS_MODES if base in b.SINGLE_PASS_SOURCES else b.SINGLE_PASS_MODES[1:]):
+                o2 = os.path.join(b.OBJDIR, stem + tag + ".o")
+                if stem in names or "all" in names:
+                    o2 = os.path.join("/tmp", stem + tag + "_ab.o")
+                    subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, f"-DVMM_SINGLE_PASS={mode}", "-c", s, "-o", o2], check=True)
+                objs.append(o2)
     out = os.path.join(os.path.dirname(b.OUT), "libvmm_hip_ab.so")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], check=True)
     print(out)

@@ -233,6 +233,8 @@ SIGNATURES = {
     "vmm_qkv_bwd_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_qkv_bwd_ln_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_temporal_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
+    "vmm_dqkv_widen_fp16": [c_ptr, c_ptr, c_i64, c_ptr],
+    "vmm_dqkv_widen_bf16": [c_ptr, c_ptr, c_i64, c_ptr],
     "vmm_linattn_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_scaler_init": [c_ptr, c_f32, c_ptr],
     "vmm_grad_nonfinite": [c_ptr, c_i64, c_ptr, c_ptr],

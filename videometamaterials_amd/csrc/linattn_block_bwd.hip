@@ -44,7 +44,7 @@ struct LBArgs {
   const uint4* fctx;         // forward context fragments [frame][head][256]: scale ctxn as B[k = d][n = e]
   int fnsplit;
   const float* gout; int ldg;
-  float* gqkv; int ldq;
+  vmm_dqkv_t* gqkv; int ldq;        // (16-bit rows in the single-pass builds, vmm_common.h: VMM_DQKV16)
   float* ln_stats;
   float* p1;           // [frame][nsplit][head][1024]: partial dctx[d][e] (without the scale)
   float* part_wo;      // [frame * nsplit][256 * 64]
@@ -390,9 +390,9 @@ __global__ __launch_bounds__(512, 2) void la_bwd_rows_kernel(const LBArgs a) {
   // T-form matrix X{feature, pixel}: the lane's pixel row gets four 16-byte pieces (features 8 q + 4 lk .. + 3)
   unsigned q_loff = (unsigned)(lrow * a.ldq + 4 * lk);
   auto store_cols = [&](const f32x16& X, int t, int col0) {
-    float* gq = a.gqkv + ((long long)frame * a.HW + t * 32) * a.ldq + col0 + h * LD;  // wave-uniform
+    vmm_dqkv_t* gq = a.gqkv + ((long long)frame * a.HW + t * 32) * a.ldq + col0 + h * LD;  // wave-uniform
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(gq + 8 * q4 + q_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
+    for (int q4 = 0; q4 < 4; ++q4) st_dqkv4(gq + 8 * q4 + q_loff, X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]);
   };
 
   f32x4 xv, gv;
@@ -505,7 +505,7 @@ extern "C" int VMM_X3(vmm_linattn_block_bwd_, )(const vmm_attn_block_bwd* d, vmm
   a.fpart = d->fwd_workspace;
   a.fctx = reinterpret_cast<const uint4*>(d->fwd_workspace + (long long)frames * a.fnsplit * LH * LA_PART);
   a.gout = d->dout; a.ldg = d->lddo;
-  a.gqkv = d->dqkv; a.ldq = d->lddqkv; a.ln_stats = d->ln_stats;
+  a.gqkv = reinterpret_cast<vmm_dqkv_t*>(d->dqkv); a.ldq = d->lddqkv; a.ln_stats = d->ln_stats;
   a.B = d->B; a.T = d->T; a.HW = d->HW;
   a.nsplit = choose_bwd_split(frames, d->HW, &a.sps);
   a.q_scale = d->q_scale;

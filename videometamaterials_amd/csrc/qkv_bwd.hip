@@ -45,7 +45,7 @@ struct QBArgs {
   const float* x; int ldx;           // rows x 64: y itself, or (ln_stats != NULL) the un-normalised x
   const float* ln_stats;             // [rows][2] (mean, rstd) or NULL
   const float* ln_gamma;             // [64]
-  const float* g; int ldg;           // rows x 768
+  const vmm_dqkv_t* g; int ldg;      // rows x 768 (single-pass builds: the operand's 16-bit type, vmm_common.h VMM_DQKV16; ldg in elements)
   const unsigned char* wfrag;        // vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand W
   float* gy; int ldgy;               // rows x 64 (=)
   float* part;                       // [gridDim.x][PART_FLOATS]
@@ -82,11 +82,44 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   const int go = GROLE ? 4 * GRP + gt / 48 : 0, gp = GROLE ? gt % 48 : 0;  // 8 row groups x 48 column pairs
   const int yt = 64 * GRP + lane, yo0 = (yt >> 5) & 3, ycp = yt & 31;    // y item k (0 / 1): row group yo0 + 4 k, channel pair ycp
   f32x2 gvA[8];  // the role's rows in flight: the next g piece, or a y item
+#if VMM_DQKV16
+  unsigned gvG[8];  // (16-bit rows of g: a column pair per row is one dword; the y role keeps gvA)
+#else
+  f32x2 (&gvG)[8] = gvA;
+#endif
   const f32x2 lg = (!GROLE && a.ln_stats) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + 2 * ycp) : f32x2{1.f, 1.f};
   // (rows is a multiple of 64: no tail.  Addresses = a wave-uniform row base (scalar registers) + ONE 32-bit per-thread offset: eight 64-bit
   // vector-register addresses per role cost 16 registers each and pushed the first version into scratch, whose reloads sit on the same in-order
   // counter as the prefetched rows)
   unsigned g_toff = (unsigned)((8 * go) * a.ldg + 2 * gp), y_toff0 = (unsigned)(8 * yo0 * a.ldx + 2 * ycp);
+#if VMM_DQKV16
+  // 16-bit rows of g: a row's column pair is ONE dword -- already the GR image's dword (column 2 gp in the low half); the GT fragments are the same
+  // halves regrouped by column (one v_perm per dword).  No conversion, no lo planes.
+  typedef unsigned GV;
+  auto g_request = [&](long long r0, int piece, GV (&gv)[8]) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
+    const vmm_dqkv_t* gb = (VMM_QB_SKIP & 32) ? a.g + piece * NP : a.g + r0 * a.ldg + piece * NP;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const vmm_dqkv_t* rowp = gb + (long long)i * a.ldg;
+      gv[i] = (VMM_QB_SKIP & 8) ? 0x3c003c00u : *reinterpret_cast<const unsigned*>(rowp + g_toff);
+    }
+  };
+  auto g_stage = [&](int buf, const GV (&gv)[8]) {
+    unsigned char* base = sm + buf * PIECE_BUF;
+    if ((VMM_QB_SKIP & 4) && gv[0] != 12345u) return;
+    uint4 h, h1;
+    h.x = __builtin_amdgcn_perm(gv[1], gv[0], 0x05040100u); h1.x = __builtin_amdgcn_perm(gv[1], gv[0], 0x07060302u);
+    h.y = __builtin_amdgcn_perm(gv[3], gv[2], 0x05040100u); h1.y = __builtin_amdgcn_perm(gv[3], gv[2], 0x07060302u);
+    h.z = __builtin_amdgcn_perm(gv[5], gv[4], 0x05040100u); h1.z = __builtin_amdgcn_perm(gv[5], gv[4], 0x07060302u);
+    h.w = __builtin_amdgcn_perm(gv[7], gv[6], 0x05040100u); h1.w = __builtin_amdgcn_perm(gv[7], gv[6], 0x07060302u);
+    *reinterpret_cast<uint4*>(base + (2 * gp) * TP + go * 16) = h;
+    *reinterpret_cast<uint4*>(base + (2 * gp + 1) * TP + go * 16) = h1;
+    unsigned char* gr = base + 2 * GT_PLANE + (8 * go) * RP + gp * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<unsigned*>(gr + i * RP) = gv[i];
+  };
+#else
+  typedef f32x2 GV;
   auto g_request = [&](long long r0, int piece, f32x2 (&gv)[8]) {  // rows r0 + 8 go .. + 7, columns piece * 96 + 2 gp
     const float* gb = (VMM_QB_SKIP & 32) ? a.g + piece * NP : a.g + r0 * a.ldg + piece * NP;  // wave-uniform (bit 5: every chunk re-reads the first one -- L2 hits)
 #pragma unroll
@@ -125,6 +158,7 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
       *reinterpret_cast<unsigned*>(gr + GR_PLANE + i * RP) = __builtin_amdgcn_perm(l1q[i >> 1], lq[i >> 1], sel);
     }
   };
+#endif
   auto y_request = [&](long long r0, int k) {
     f32x2 (&gv)[8] = gvA;
     const float* yb = a.x + (r0 + 32 * k) * a.ldx;
@@ -183,8 +217,8 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
 
   // ---------------------------------------------------------------- prologue: piece 0 of chunk 0 staged, piece 1 requested; y of chunk 0
   if (GROLE) {
-    g_request(r_begin, 0, gvA);
-    g_stage(0, gvA);
+    g_request(r_begin, 0, gvG);
+    g_stage(0, gvG);
   } else {
     y_request(r_begin, 0);
     y_stage(r_begin, 0, 0);
@@ -198,7 +232,7 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
   asm volatile("" ::: "memory");
   if (GRP == 1) w_request(0);
   asm volatile("" ::: "memory");
-  if (GROLE) g_request(r_begin, 1, gvA);
+  if (GROLE) g_request(r_begin, 1, gvG);
   asm volatile("" ::: "memory");
   if (GRP == 0) w_request(0);
   asm volatile("" ::: "memory");
@@ -234,11 +268,11 @@ __device__ __forceinline__ void qkv_bwd_body(const QBArgs& a, unsigned char* sm)
         // (the registers are pinned HERE: the splits are plain vector arithmetic, which the scheduler otherwise lifts across the barrier into the
         // previous step -- and with them the wait for these rows, a whole matrix phase early)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(gvA[i]));
-        if (!last_piece || more_ch) g_stage((p & 1) ^ 1, gvA);
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(gvG[i]));
+        if (!last_piece || more_ch) g_stage((p & 1) ^ 1, gvG);
         __builtin_amdgcn_sched_barrier(0);  // (the request stays behind the staging)
         const bool next_chunk = p + 2 >= NPIECE;
-        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 2) % NPIECE, gvA);
+        g_request(next_chunk && more_ch ? r0 + CH : r0, (p + 2) % NPIECE, gvG);
       } else if (more_ch) {
         if (p == 2) y_stage(r0 + CH, 0, (ch + 1) & 1);
         if (p == 5) y_stage(r0 + CH, 1, (ch + 1) & 1);
@@ -490,12 +524,47 @@ int qkv_bwd_launch(QBArgs& a, float* dw_packed, float* workspace, float* dgamma,
 }
 }  // namespace
 
+#if VMM_DQKV16
+// Rows of the 16-bit qkv-row gradient widened to fp32 (exact): for the shapes this file's one-pass kernel does not take (rows no multiple of 64 -- small
+// test geometries), where the plan runs the separate weight- and data-gradient launches, which read fp32 rows and round them to the same 16 bits again.
+namespace {
+__global__ __launch_bounds__(256) void dqkv_widen_kernel(const uint4* __restrict__ src, f32x4* __restrict__ dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const uint4 u = src[i];
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#if VMM_FP16_OPERANDS
+      f[2 * k] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[k] & 0xffffu));
+      f[2 * k + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[k] >> 16));
+#else
+      f[2 * k] = __uint_as_float(w[k] << 16);
+      f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+#endif
+    }
+    dst[2 * i] = f32x4{f[0], f[1], f[2], f[3]};
+    dst[2 * i + 1] = f32x4{f[4], f[5], f[6], f[7]};
+  }
+}
+}  // namespace
+extern "C" int VMM_X3(vmm_dqkv_widen_, )(const void* src, float* dst, int64_t n, vmm_stream_t stream) {
+  if (n & 7) return 1;
+  if (n <= 0) return 0;
+  const long long n8 = n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(dqkv_widen_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src), reinterpret_cast<f32x4*>(dst), n8);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+#endif
+
 extern "C" int VMM_X3(vmm_qkv_bwd_, )(const float* x, int32_t ldx, const float* ln_stats, const float* ln_gamma, const float* g, int32_t ldg, const float* w_frag,
                                   float* gy, int32_t ldgy, float* dw_packed, float* workspace, int64_t rows, int32_t C, int32_t Nq, vmm_stream_t stream) {
   if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 1) || (ldg & 1) || (ldgy & 3) || (ln_stats && !ln_gamma)) return 1;
   if (rows <= 0) return 0;
   QBArgs a;
-  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = g; a.ldg = ldg;
+  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = reinterpret_cast<const vmm_dqkv_t*>(g); a.ldg = ldg;
   a.wfrag = reinterpret_cast<const unsigned char*>(w_frag);
   a.gy = gy; a.ldgy = ldgy; a.rows = rows;
   a.dx = nullptr; a.lddx = 0; a.accumulate = 0;
@@ -508,7 +577,7 @@ extern "C" int VMM_X3(vmm_qkv_bwd_ln_, )(const float* x, int32_t ldx, const floa
   if (C != CC || Nq != NQ || !workspace || (rows % CH) || (ldx & 3) || (ldg & 1) || (lddx & 3) || !ln_stats || !ln_gamma || !dx) return 1;
   if (rows <= 0) return 0;
   QBArgs a;
-  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = g; a.ldg = ldg;
+  a.x = x; a.ldx = ldx; a.ln_stats = ln_stats; a.ln_gamma = ln_gamma; a.g = reinterpret_cast<const vmm_dqkv_t*>(g); a.ldg = ldg;
   a.wfrag = reinterpret_cast<const unsigned char*>(w_frag);
   a.gy = nullptr; a.ldgy = 0; a.rows = rows;
   a.dx = dx; a.lddx = lddx; a.accumulate = accumulate;

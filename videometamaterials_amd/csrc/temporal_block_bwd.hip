@@ -55,7 +55,7 @@ struct TBBArgs {
   const float* bias; int bias_on_cond;
   const float* rot;   // [T][16][2] cos, sin
   const float* gout; int ldg;
-  float* gqkv; int ldq;
+  vmm_dqkv_t* gqkv; int ldq;        // (16-bit rows in the single-pass builds, vmm_common.h: VMM_DQKV16)
   float* ln_stats;
   float* part_wo;     // [grid][256 * 64]: the workgroup's dW_out in the packed-gradient layout [hd][c]
   float* part_db;     // [grid][8 * T * T]
@@ -224,20 +224,20 @@ __global__ __launch_bounds__(512, 2) void temporal_block_bwd_kernel(const TBBArg
   unsigned qr_loff = (unsigned)(4 * lk * HW * a.ldq + lrow);  // lane part of a row-form store: frame 4 lk of the register's frame group, feature lrow
   const unsigned hwq = (unsigned)(HW * a.ldq);
   auto store_rows = [&](const f32x16& X, int pp, int col0) {
-    float* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
+    vmm_dqkv_t* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t0 = (r & 3) + 8 * ((r >> 2) & 1), pm = r >> 3;  // frame slot (+ 4 lk), pixel of row row_of(r, lk)
-      if (t0 + 4 * lk < T && !((VMM_TBB_SKIP & 4) && X[r] != 12345.f)) gq[qr_loff + (unsigned)t0 * hwq + (unsigned)(pm * a.ldq)] = X[r];
+      if (t0 + 4 * lk < T && !((VMM_TBB_SKIP & 4) && X[r] != 12345.f)) st_dqkv1(gq + (qr_loff + (unsigned)t0 * hwq + (unsigned)(pm * a.ldq)), X[r]);
     }
   };
   // columns of the gradient of the raw qkv from a T-form matrix X{d, m}: the lane's row m gets four 16-byte pieces (features 8 q + 4 lk .. + 3)
   unsigned qc_loff = (unsigned)((ft * HW + pa) * a.ldq + 4 * lk);
   auto store_cols = [&](const f32x16& X, int pp, int col0) {
     if (ft < T && !((VMM_TBB_SKIP & 4) && X[0] != 12345.f)) {
-      float* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
+      vmm_dqkv_t* gq = a.gqkv + ((long long)b * T * HW + pp * 2) * a.ldq + col0 + h * DHd;  // wave-uniform
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(gq + 8 * q4 + qc_loff) = f32x4{X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]};
+      for (int q4 = 0; q4 < 4; ++q4) st_dqkv4(gq + 8 * q4 + qc_loff, X[4 * q4], X[4 * q4 + 1], X[4 * q4 + 2], X[4 * q4 + 3]);
     }
   };
 
@@ -498,7 +498,7 @@ extern "C" int VMM_X3(vmm_temporal_block_bwd_, )(const vmm_attn_block_bwd* d, vm
   a.ek = d->ek; a.ev = d->ev; a.ntok = ntok;
   a.bias = d->bias; a.bias_on_cond = d->bias_on_cond; a.rot = d->rot_tab;
   a.gout = d->dout; a.ldg = d->lddo;
-  a.gqkv = d->dqkv; a.ldq = d->lddqkv; a.ln_stats = d->ln_stats;
+  a.gqkv = reinterpret_cast<vmm_dqkv_t*>(d->dqkv); a.ldq = d->lddqkv; a.ln_stats = d->ln_stats;
   a.part_wo = d->workspace;
   a.part_db = a.part_wo + G * (HID * TC);
   a.part_ek = a.part_db + G * (HEADS * d->T * d->T);

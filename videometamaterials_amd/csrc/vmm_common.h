@@ -114,6 +114,39 @@ __device__ __forceinline__ unsigned short vmm_split16(float v, unsigned short& l
   return __builtin_bit_cast(unsigned short, h);
 #endif
 }
+// The gradient of the RAW to_qkv rows that the recomputing attention backward (temporal_block_bwd.hip, linattn_block_bwd.hip) hands to the fused to_qkv
+// backward (qkv_bwd.hip) is a matrix operand there and nothing else: 1.25 GB per 96 x 96 site as fp32, written once and read once.  The single-pass
+// builds store it in the operand's own 16-bit type (fp16 / bf16: the rounding the consumer's split applies anyway, moved to the producer's store --
+// the products see the same bits, the gradient is unchanged bit for bit, the round trip is half the bytes).  The split-bf16 build keeps fp32 rows
+// (hi | lo would be the same four bytes).  -DVMM_DQKV16=0 on a single-pass object: the fp32 rows again (A/B builds, tools/build_ab.py).
+#ifndef VMM_DQKV16
+#define VMM_DQKV16 (VMM_SINGLE_PASS != 0)
+#endif
+#if VMM_DQKV16 && !VMM_SINGLE_PASS
+#error "16-bit dqkv rows are the single-pass builds' operand type"
+#endif
+#if VMM_DQKV16
+typedef unsigned short vmm_dqkv_t;
+#else
+typedef float vmm_dqkv_t;
+#endif
+__device__ __forceinline__ void st_dqkv4(vmm_dqkv_t* p, float x0, float x1, float x2, float x3) {
+#if VMM_DQKV16
+  unsigned lo;
+  const unsigned h0 = split_bf16_pair(x0, x1, lo), h1 = split_bf16_pair(x2, x3, lo);
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+#else
+  *reinterpret_cast<f32x4*>(p) = f32x4{x0, x1, x2, x3};
+#endif
+}
+__device__ __forceinline__ void st_dqkv1(vmm_dqkv_t* p, float x) {
+#if VMM_DQKV16
+  unsigned short lo;
+  *p = vmm_split16(x, lo);
+#else
+  *p = x;
+#endif
+}
 // 1.0 as a 16-bit operand (identity fragments of the chained kernels)
 #if VMM_FP16_OPERANDS
 #define VMM_ONE16 0x3C00u

@@ -38,6 +38,8 @@ LA_PART = 32 * 32 + 64  # linear-attention partial record (attention.hip)
 GN_DIRECT_MAX = 1 << 14
 # workgroups a launch of the exact-fp32 weight-gradient kernel is split into (row slices x 64 x 64 tiles): every workgroup ends with 4 096 fp32 atomics
 WGRAD_F32_WGS = int(os.environ.get("VMM_WGRAD_F32_WGS", "2048"))
+# (A/B aid: VMM_DQKV16=0 goes with a library whose single-pass objects were built with -DVMM_DQKV16=0, i.e. fp32 rows of the qkv-row gradient; tools/check_dqkv16.py)
+DQKV16 = os.environ.get("VMM_DQKV16", "1") != "0"
 SK_SLOTS = 512    # partial-tile slots of the balanced 3 x 3 launch (two workgroups per CU; entries 2048.. of the tickets are their flags)
 N_TICKETS = 4096  # ints for the ordered split reduction of vmm_conv3x3_bf16x3 (one per output tile)
 Q_STRIDE = 4096 + 16  # quantile scratch words per sample (diffusion.hip)
@@ -633,20 +635,28 @@ class _Builder:
             gg = self.pg(ln_gamma_name) or self.scratch(x.C)
             self.step(self.sp("vmm_qkv_bwd_ln_"),
                       (dq.a1, dq.lda1, ln[0], ln[1], gqkv.ptr, n_out, wd, gx.ptr, x.C, acc, gg, gwq, self.ptr(ws), rows, x.C, n_out),
-                      what + " backward (data + weight gradient, LayerNorm backward)", flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 3 * x.C))
+                      what + " backward (data + weight gradient, LayerNorm backward)", flops=4.0 * rows * x.C * n_out, nbytes=rows * ((2.0 if gqkv.bf else 4.0) * n_out + 12.0 * x.C))
             self.tmp_free((ws, ws_n))
             return None
+        g16 = None
+        if gqkv.bf and not ws_n:
+            # the one-pass kernel does not take the shape (rows no multiple of 64: small geometries) or is switched off: the separate launches below read fp32
+            # rows -- the 16-bit rows widened exactly (they round to the same 16 bits again)
+            g16, gqkv = gqkv, self.act(n_out, x.H, x.W)
+            self.step(self.sp("vmm_dqkv_widen_"), (g16.ptr, gqkv.ptr, rows * n_out), what + " (16-bit rows of the qkv gradient widened)", nbytes=6.0 * rows * n_out)
         gy = self.act(x.C, x.H, x.W)
         if ws_n:
             wd = self.pack_linear_slice(wname, 0, x.C, frag=2, gemm=True, half=True)
             ws = self.alloc(ws_n)
             self.step(self.sp("vmm_qkv_bwd_"), (dq.a1, dq.lda1, ln[0] if ln else None, ln[1] if ln else None, gqkv.ptr, n_out, wd, gy.ptr, x.C, gwq,
                                                     self.ptr(ws), rows, x.C, n_out), what + " backward (data + weight gradient)",
-                      flops=4.0 * rows * x.C * n_out, nbytes=4.0 * rows * (n_out + 2 * x.C))
+                      flops=4.0 * rows * x.C * n_out, nbytes=rows * ((2.0 if gqkv.bf else 4.0) * n_out + 8.0 * x.C))
             self.tmp_free((ws, ws_n))
             return gy
         self.wgrad(dq, gqkv.ptr, n_out, gwq, what)
         self.dgrad_1x1(wname, 0, x.C, what + " dgrad", a1=gqkv, out_ptr=gy.ptr, ldo=x.C, Hv=x.H, Wv=x.W)
+        if g16 is not None:
+            self.tmp_free(gqkv)  # (the widened copy; the caller frees the 16-bit rows it allocated)
         return gy
 
     def ln_fused_training_ok(self, k: int, cout: int) -> bool:
@@ -1044,7 +1054,7 @@ class _Builder:
                 def bwd_fused():
                     gout, _ = self.grad_of(out)
                     self.add_into(x, gout.ptr, gout)  # residual
-                    gqkv = self.act(3 * hid, x.H, x.W)
+                    gqkv = self.act(3 * hid, x.H, x.W, bf=self.one and DQKV16)  # (single-pass builds: the to_qkv backward's 16-bit operand type, csrc/vmm_common.h VMM_DQKV16)
                     stats, bws = self.alloc(2 * rows), self.alloc(bwd_ws_n)
                     geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
                     d = N.AttnBlockBwd()
@@ -1058,7 +1068,7 @@ class _Builder:
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
                     self.step(self.sp("vmm_linattn_block_bwd_"), (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.0 * flops,
-                              nbytes=4.0 * rows * (4 * x.C + 3 * hid))
+                              nbytes=rows * (16.0 * x.C + (2.0 if gqkv.bf else 4.0) * 3 * hid))
                     self.tmp_free((bws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
                     gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv", ln_gamma_name=name + ".fn.norm.gamma")
@@ -1184,7 +1194,7 @@ class _Builder:
                 def bwd_fused():
                     gout, _ = self.grad_of(out)
                     self.add_into(x, gout.ptr, gout)  # residual
-                    gqkv = self.act(3 * hid, x.H, x.W)
+                    gqkv = self.act(3 * hid, x.H, x.W, bf=self.one and DQKV16)  # (single-pass builds: the to_qkv backward's 16-bit operand type, csrc/vmm_common.h VMM_DQKV16)
                     stats, ws = self.alloc(2 * rows), self.alloc(bwd_ws_n)
                     geo, gvo = (self.ekv_info[site][3], self.ekv_info[site][4]) if site else (0, 0)
                     d = N.AttnBlockBwd()
@@ -1197,7 +1207,7 @@ class _Builder:
                     d.B, d.T, d.HW, d.C, d.heads, d.q_scale, d.eps = B, T, HW, x.C, heads, 32 ** -0.5, 1e-5
                     self.plan.keepalive.append(d)
                     self.step(self.sp("vmm_temporal_block_bwd_"), (C.byref(d),), name + " fused block bwd (recomputation)", flops=2.2 * flops,
-                              nbytes=4.0 * rows * (2 * x.C + 3 * hid))
+                              nbytes=rows * (8.0 * x.C + (2.0 if gqkv.bf else 4.0) * 3 * hid))
                     self.tmp_free((ws, bwd_ws_n))
                     dq._ln = (self.ptr(stats), gamma_ptr)
                     gy = self.qkv_backward(dq, p + ".to_qkv.weight", x, gqkv, gwq, name + " to_qkv", ln_gamma_name=name + ".fn.norm.gamma")
