@@ -72,6 +72,10 @@ typedef struct vmm_conv_desc {
    * evenly; the pieces of a tile are added in a fixed order, so results stay bit-reproducible).  Needs split_tickets with n_tickets >= 2048 + sk_slots
    * (entries 2048.. are the pieces' flags, zero before and after every launch).  NULL: one workgroup per tile. */
   float* sk_work; int32_t sk_slots;
+  /* weight-gradient entry points with a workspace (vmm_conv3x3_wgrad_*, vmm_conv1x1_wgrad_*): != 0 = run the first stage only -- the partial blocks stay in the
+   * workspace, which the caller keeps until it has totalled them with vmm_reduce_batch (jobs from vmm_conv3x3_wgrad_reduce_job / vmm_conv1x1_wgrad_reduce_job).
+   * Every other entry point ignores the field. */
+  int32_t defer_reduce;
 } vmm_conv_desc;
 int vmm_conv_igemm_f32(const vmm_conv_desc* d, vmm_stream_t stream);
 /* Same contraction on the bf16 matrix cores with split-precision operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate;
@@ -179,6 +183,24 @@ int vmm_qkv_bwd_ln_bf16x3(const float* x, int32_t ldx, const float* ln_stats, co
                           float* dx, int32_t lddx, int32_t accumulate, float* dgamma, float* dw_packed, float* workspace, int64_t rows, int32_t C,
                           int32_t Nq, vmm_stream_t stream);
 int vmm_sum_partials(const float* part, int32_t n, int32_t ld, int32_t C, float* out, vmm_stream_t stream);
+/* ---- deferred second stages (round 6).  The weight-gradient kernels leave one partial block per row slice and total them in a fixed order with a second launch of
+ * 5-13 us; the training step's backward ran ~70 of those behind its 3 x 3 / 1 x 1 weight gradients.  A caller that sets vmm_conv_desc.defer_reduce keeps each
+ * layer's workspace alive, asks for the layer's job (host-side, nothing launched; the arguments are those of the weight-gradient call) and totals many layers
+ * at once: jobs_dev = the jobs in device memory with wg0 = the running sum of the preceding jobs' `wgs`, total_wgs = the sum of all.  Same summation order as
+ * the per-layer launches (bit-identical results).  kind 0 = plain partial rows, out[c] += sum_{k < nz} part[k ld + c], c < Cout (what vmm_sum_partials does;
+ * wgs = ceil(Cout / 16)). */
+typedef struct vmm_reduce_job {
+  const float* part; float* out;
+  const float* bias_part; float* dbias;
+  int32_t kind;                 /* 0 rows, 1 vmm_conv3x3_wgrad_* blocks, 2 vmm_conv1x1_wgrad_* blocks */
+  int32_t nz, tiles_x, tiles_y, Cin, Cout, ld, n_main, gx;
+  int32_t wgs;                  /* workgroups the job needs (filled by the *_reduce_job queries) */
+  int32_t wg0;                  /* first workgroup of the job inside the batched launch (filled by the caller) */
+  int32_t pad_;
+} vmm_reduce_job;
+int vmm_conv3x3_wgrad_reduce_job(const vmm_conv_desc* d, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job);
+int vmm_conv1x1_wgrad_reduce_job(const vmm_conv_desc* d, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job);
+int vmm_reduce_batch(const vmm_reduce_job* jobs_dev, int32_t njobs, int32_t total_wgs, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
 /* batched weight packing: packed[(th*TW + tw)*Cp + c][n] <-> torch[n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw];

@@ -1141,6 +1141,79 @@ def test_conv1x1_weight_gradient_bf16x3(gpu, rows, C1, C2, Cout, bias):
     assert lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0
 
 
+@pytest.mark.parametrize("variant", ["bf16x3", "fp16"])
+def test_deferred_weight_gradient_totals_are_the_per_layer_totals(gpu, variant):
+    """vmm_conv_desc.defer_reduce + vmm_reduce_batch: three 3 x 3 layers and three 1 x 1 layers (with / without bias, two sources, several channel blocks)
+    leave their partial blocks in their workspaces, ONE launch totals all of them (plus a plain partial-rows job) -- bit for bit what the per-layer second
+    stages give, += semantics included."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(41)
+    layers = []
+    for kind, shape in [(1, (2, 24, 24, 64, 0, 64, True)), (1, (1, 12, 12, 128, 64, 128, False)), (1, (3, 8, 16, 64, 0, 128, True)),
+                        (2, (5000, 64, 0, 768, False)), (2, (777, 256, 0, 64, True)), (2, (640, 128, 128, 128, True))]:
+        d = N.ConvDesc()
+        if kind == 1:
+            nimg, H, W, C1, C2, Cout, bias = shape
+            rows = nimg * H * W
+            d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+            d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+            d.Hout, d.Wout, d.oscale, d.Cout = H, W, 1, Cout
+        else:
+            rows, C1, C2, Cout, bias = shape
+            d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = 1, 1, rows, 1, rows, 1
+            d.KH, d.KW, d.sgn_h, d.sgn_w, d.Hout, d.Wout, d.oscale, d.Cout = 1, 1, 1, 1, 1, rows, 1, Cout
+        x1 = torch.randn(rows, C1, generator=g).to(gpu)
+        x2 = torch.randn(rows, C2, generator=g).to(gpu) if C2 else None
+        dy = torch.randn(rows, Cout, generator=g).to(gpu)
+        d.a1, d.C1, d.lda1 = x1.data_ptr(), C1, C1
+        if C2:
+            d.a2, d.C2, d.lda2 = x2.data_ptr(), C2, C2
+        stem = "vmm_conv3x3_wgrad_" if kind == 1 else "vmm_conv1x1_wgrad_"
+        n_ws = int(getattr(lib, stem + "bf16x3_workspace")(C.byref(d), Cout))
+        assert n_ws > 0
+        layers.append((kind, d, getattr(lib, stem + variant), getattr(lib, stem + "reduce_job"), (x1, x2, dy), (9 if kind == 1 else 1) * (C1 + C2), Cout, bias, n_ws))
+
+    part = torch.randn(37, 200, generator=g).to(gpu)
+
+    def run(defer):
+        outs, keep, jobs = [], [], (N.ReduceJob * (len(layers) + 1))()
+        wg = 0
+        for i, (kind, d, fn, jobfn, (x1, x2, dy), K, Cout, bias, n_ws) in enumerate(layers):
+            dw = torch.full((K, Cout), 0.25, device=gpu)  # += : starts from a quarter
+            db = torch.full((Cout,), 0.5, device=gpu)
+            ws = torch.full((n_ws,), float("nan"), device=gpu)
+            d.defer_reduce = 1 if defer else 0
+            assert fn(C.byref(d), dy.data_ptr(), Cout, dw.data_ptr(), db.data_ptr() if bias else None, ws.data_ptr(), _s()) == 0
+            if defer:
+                assert jobfn(C.byref(d), Cout, dw.data_ptr(), db.data_ptr() if bias else None, ws.data_ptr(), C.byref(jobs[i])) == 0
+                assert jobs[i].kind == kind and jobs[i].wgs > 0
+                jobs[i].wg0 = wg
+                wg += jobs[i].wgs
+            d.defer_reduce = 0
+            outs += [dw, db]
+            keep.append(ws)
+        # a plain partial-rows job (kind 0: what vmm_sum_partials does)
+        tot = torch.full((150,), 2.0, device=gpu)
+        if defer:
+            j = jobs[len(layers)]
+            j.part, j.out, j.kind, j.nz, j.ld, j.Cout, j.wgs, j.wg0 = part.data_ptr(), tot.data_ptr(), 0, 37, 200, 150, (150 + 15) // 16, wg
+            wg += j.wgs
+            torch.cuda.synchronize()
+            for k in range(0, len(outs), 2):  # nothing was totalled yet
+                assert bool((outs[k] == 0.25).all())
+            tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(gpu)
+            assert lib.vmm_reduce_batch(tab.data_ptr(), len(layers) + 1, wg, _s()) == 0
+        else:
+            assert lib.vmm_sum_partials(part.data_ptr(), 37, 200, 150, tot.data_ptr(), _s()) == 0
+        torch.cuda.synchronize()
+        return outs + [tot]
+
+    ref, got = run(False), run(True)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), i
+    assert float((ref[0] - 0.25).abs().max()) > 1.0  # (the layers did produce gradients)
+
+
 @pytest.mark.parametrize("rows,Cc,Cout", [(3000, 64, 768), (515, 128, 256), (64, 256, 64)])
 def test_layernorm_fused_projection_statistics_and_weight_gradient(gpu, rows, Cc, Cout):
     """Training forward of PreNorm(to_qkv): vmm_proj_bf16x3_ln_stats = the LayerNorm-fused projection that also leaves (mean, rstd) per row, and

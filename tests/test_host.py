@@ -258,7 +258,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     pairs = {"vmm_conv_desc": N.ConvDesc, "vmm_dense_job": N.DenseJob, "vmm_pack_job": N.PackJob, "vmm_dense_bwd_job": N.DenseBwdJob,
-             "vmm_optim_job": N.OptimJob, "vmm_attn_block_bwd": N.AttnBlockBwd}
+             "vmm_optim_job": N.OptimJob, "vmm_attn_block_bwd": N.AttnBlockBwd, "vmm_reduce_job": N.ReduceJob}
     hdr = open(os.path.join(ROOT, "include", "vmm_kernels.h")).read()
     assert set(re.findall(r"typedef struct (\w+)", hdr)) == set(pairs)
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vmm_kernels.h"', "int main(void) {"]

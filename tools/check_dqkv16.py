@@ -28,21 +28,26 @@ t = torch.tensor([17, 201][:B], device=dev)
 cond = torch.rand(B, 11, generator=g).to(dev)
 pl = model.get_plan(B, bench.T, bench.HW, bench.HW, 11, dev, training=True)
 pl.x_in.copy_(x); pl.time_in.copy_(t); pl.cond_in.copy_(cond); pl.mask_in.zero_()
-pl.launch()
 dout = (torch.randn(pl.out.shape, generator=g) * 1e-2).to(dev)
 digests = []
 for rep in range(2):
-    pl.pgrad.zero_(); pl.gscratch.zero_()
+    pl.launch()  # (a fresh forward per repetition: the backward re-uses activation slots for gradients)
     pl.backward(dout)
     torch.cuda.synchronize()
     flat = pl.pgrad.cpu().numpy()
     digests.append({k: hashlib.sha256(flat[o:o + n].tobytes()).hexdigest()[:12] for k, (o, n) in pl.param_slices.items()})
     print(prec, "finite", bool(torch.isfinite(pl.pgrad).all()), "norm %.6e" % float(pl.pgrad.double().norm()), "arena GB %.3f" % (pl.arena.numel() * 4 / 2 ** 30),
           "lib", os.environ.get("VMM_LIB_PATH", "default"))
-# Parameters whose gradient is the same bits in both repetitions (the few kernels that combine partial sums with fp32 atomics -- the 4 x 4 / 7 x 7 weight
-# gradients, bias column sums, the tiny dense layers -- are not run-to-run reproducible; everything behind the attention blocks' to_qkv is)
+# Parameters whose gradient is the same bits in both repetitions (kernels that combine partial sums with fp32 atomics -- the 4 x 4 / 7 x 7 weight
+# gradients, bias column sums, the tiny dense layers -- are not run-to-run reproducible)
 stable = sorted(k for k in digests[0] if digests[0][k] == digests[1][k])
 print(prec, "reproducible parameters", len(stable), "of", len(digests[0]))
+if os.environ.get("VMM_DIGEST_NAMES"):
+    import collections
+    bad = [k for k in digests[0] if k not in stable]
+    kinds = collections.Counter(".".join(k.split(".")[-2:]) if not k.split(".")[-2].isdigit() else k.split(".")[-1] for k in bad)
+    print(prec, "not reproducible, by parameter kind:", dict(kinds))
+    print(prec, "reproducible, by parameter kind:", dict(collections.Counter(".".join(k.split(".")[-2:]) for k in stable)))
 out = os.environ.get("VMM_DIGEST_OUT")
 if out:
     import json

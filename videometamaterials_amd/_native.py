@@ -42,6 +42,17 @@ class ConvDesc(C.Structure):
         ("wrap_h", c_i32), ("wrap_w", c_i32), ("a_img_mod", c_i32),
         ("act_bf16", c_i32),
         ("sk_work", c_ptr), ("sk_slots", c_i32),
+        ("defer_reduce", c_i32),
+    ]
+
+
+class ReduceJob(C.Structure):
+    """vmm_reduce_job (include/vmm_kernels.h)."""
+
+    _fields_ = [
+        ("part", c_ptr), ("out", c_ptr), ("bias_part", c_ptr), ("dbias", c_ptr),
+        ("kind", c_i32), ("nz", c_i32), ("tiles_x", c_i32), ("tiles_y", c_i32), ("Cin", c_i32), ("Cout", c_i32), ("ld", c_i32), ("n_main", c_i32),
+        ("gx", c_i32), ("wgs", c_i32), ("wg0", c_i32), ("pad_", c_i32),
     ]
 
 
@@ -113,6 +124,9 @@ SIGNATURES = {
     "vmm_conv_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_f32": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
+    "vmm_conv3x3_wgrad_reduce_job": [C.POINTER(ConvDesc), c_i32, c_ptr, c_ptr, c_ptr, C.POINTER(ReduceJob)],
+    "vmm_conv1x1_wgrad_reduce_job": [C.POINTER(ConvDesc), c_i32, c_ptr, c_ptr, c_ptr, C.POINTER(ReduceJob)],
+    "vmm_reduce_batch": [c_ptr, c_i32, c_i32, c_ptr],
     "vmm_conv3x3_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_bf16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_bf16x3_workspace": [C.POINTER(ConvDesc), c_i32],

@@ -524,7 +524,7 @@ int qkv_bwd_launch(QBArgs& a, float* dw_packed, float* workspace, float* dgamma,
 }
 }  // namespace
 
-#if VMM_DQKV16
+#if VMM_SINGLE_PASS  // (also in -DVMM_DQKV16=0 measurement builds: the library exports the same symbols)
 // Rows of the 16-bit qkv-row gradient widened to fp32 (exact): for the shapes this file's one-pass kernel does not take (rows no multiple of 64 -- small
 // test geometries), where the plan runs the separate weight- and data-gradient launches, which read fp32 rows and round them to the same 16 bits again.
 namespace {

@@ -14,6 +14,7 @@
 // the half of a 128-wide block that lies beyond C1 + C2 / Cout is neither loaded nor stored.
 // The bias gradient (exact fp32 column sums of dY) leaves as one partial row per slice from the ci-block-0 workgroups.
 #include "vmm_common.h"
+#include "wgrad_reduce.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
@@ -197,51 +198,12 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   }
 }
 
-// dw[ci][co] += sum over row slices z of the partial blocks (fixed order).  A workgroup takes 32 consecutive 16-byte pieces of one block
-// position and all slices: thread = (piece, slice lane), eight slice lanes, LDS tree at the end.
+// dw[ci][co] += sum over row slices z of the partial blocks (fixed order); body in wgrad_reduce.h (shared with vmm_reduce_batch)
+static_assert(BLOCK_FLOATS == vmm_reduce::W1_BLOCK_FLOATS, "partial block size");
 __global__ __launch_bounds__(256) void wgrad1_reduce_kernel(const float* __restrict__ part, int nz, int tiles_x, int tiles_y, float* __restrict__ dw, int Cin,
                                                             int Cout, const float* __restrict__ bias_part, float* __restrict__ dbias, int n_main) {
   __shared__ f32x4 red[8][32];
-  if ((int)blockIdx.x >= n_main) {  // trailing workgroups of tile 0: dbias[co] += the slices' partial rows, fixed order (was a launch of its own)
-    if (blockIdx.y != 0 || !bias_part) return;  // (workgroup-uniform)
-    const int co = ((int)blockIdx.x - n_main) * 32 + (threadIdx.x & 31), zq = threadIdx.x >> 5;  // 32 channels x 8 slice lanes
-    float s = 0.f;
-    if (co < Cout)
-      for (int z = zq; z < nz; z += 8) s += bias_part[(long long)z * Cout + co];
-    float* redf = reinterpret_cast<float*>(&red[0][0]);
-    redf[zq * 32 + (threadIdx.x & 31)] = s;
-    __syncthreads();
-    if (zq == 0 && co < Cout) {
-#pragma unroll
-      for (int k = 1; k < 8; ++k) s += redf[k * 32 + threadIdx.x];
-      dbias[co] += s;
-    }
-    return;
-  }
-  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int tile = blockIdx.y;                       // = by * tiles_x + bx
-  const int piece = blockIdx.x * 32 + e;             // ((((wq * 2 + i) * 2 + j) * 4 + q) * 64 + lane
-  const long long zstride = (long long)tiles_x * tiles_y * (BLOCK_FLOATS / 4);
-  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (long long)tile * (BLOCK_FLOATS / 4) + piece;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int z = zl; z < nz; z += 8) s += src[z * zstride];
-  red[zl][e] = s;
-  __syncthreads();
-  if (zl == 0) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) s += red[k][e];
-    const int lane = piece & 63, q = (piece >> 6) & 3, j = (piece >> 8) & 1, i = (piece >> 9) & 1, wq = piece >> 10;
-    const int bx = tile % tiles_x, by = tile / tiles_x;
-    // accumulator register 4 q + k of lane: row (ci) = k + 8 q + 4 (lane >> 5) of fragment i, column (co) = lane & 31 of fragment j
-    const int ci = bx * 128 + (wq >> 1) * 64 + i * 32 + 8 * q + 4 * (lane >> 5), co = by * 128 + (wq & 1) * 64 + j * 32 + (lane & 31);
-    if (ci < Cin && co < Cout) {  // (ci is a multiple of 4 and Cin of 64: the four rows are inside or outside together)
-      float* o = dw + (long long)ci * Cout + co;
-      o[0] += s.x;
-      o[Cout] += s.y;
-      o[2 * Cout] += s.z;
-      o[3 * Cout] += s.w;
-    }
-  }
+  vmm_reduce::w1_body(part, nz, tiles_x, tiles_y, dw, Cin, Cout, bias_part, dbias, n_main, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 static bool w1_setup(const vmm_conv_desc& d, int32_t lddy, W1Args& a, int& gz, int& tx, int& ty) {
@@ -272,6 +234,18 @@ extern "C" int64_t vmm_conv1x1_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, i
   if (!w1_setup(*dp, lddy, a, gz, tx, ty)) return 0;
   return (int64_t)gz * tx * ty * BLOCK_FLOATS + (int64_t)gz * dp->Cout;
 }
+// the second stage of vmm_conv1x1_wgrad_*(d, dy, lddy, dw_packed, dbias, workspace) (and of the _ln form) as a job of vmm_reduce_batch (d->defer_reduce)
+extern "C" int vmm_conv1x1_wgrad_reduce_job(const vmm_conv_desc* dp, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job) {
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!workspace || !job || !w1_setup(*dp, lddy, a, gz, tx, ty)) return 1;
+  const int n_main = BLOCK_FLOATS / 4 / 32;
+  job->part = workspace; job->out = dw_packed;
+  job->bias_part = dbias ? workspace + (long long)gz * tx * ty * BLOCK_FLOATS : nullptr; job->dbias = dbias;
+  job->kind = 2; job->nz = gz; job->tiles_x = tx; job->tiles_y = ty; job->Cin = dp->C1 + dp->C2; job->Cout = dp->Cout; job->ld = 0;
+  job->n_main = n_main; job->gx = n_main + (dbias ? cdiv(dp->Cout, 32) : 0); job->wgs = job->gx * tx * ty; job->wg0 = 0;
+  return 0;
+}
 #endif
 
 // dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] (and dbias[co] += sum_r dY[r][co] when dbias != NULL); d = the FORWARD descriptor of the layer;
@@ -295,6 +269,7 @@ static int w1_launch(const vmm_conv_desc* dp, const float* dy, int32_t lddy, flo
   }
   hipLaunchKernelGGL(wgrad1_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
+  if (d.defer_reduce) return 0;  // (the caller totals the blocks later: vmm_conv1x1_wgrad_reduce_job + vmm_reduce_batch)
   const int n_main = BLOCK_FLOATS / 4 / 32;
   hipLaunchKernelGGL(wgrad1_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 32) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed,
                      d.C1 + d.C2, d.Cout, a.bias_part, dbias, n_main);

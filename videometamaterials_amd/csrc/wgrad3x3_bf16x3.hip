@@ -27,6 +27,7 @@
 // is added by the ci-block-0 workgroups.
 #include <stdlib.h>
 #include "vmm_common.h"
+#include "wgrad_reduce.h"
 #include "../../include/vmm_kernels.h"
 
 namespace {
@@ -351,48 +352,12 @@ __global__ __launch_bounds__(512) void wgrad9_x3_kernel(const W9Args a) {
   }
 }
 
-// dw[(tap, ci)][co] += sum over row slices z of the partial blocks (fixed order: bit-reproducible).  A workgroup takes 32 consecutive 16-byte
-// pieces of one block position and all slices: thread = (piece, slice lane), eight slice lanes, LDS tree at the end.
+// dw[(tap, ci)][co] += sum over row slices z of the partial blocks (fixed order: bit-reproducible); body in wgrad_reduce.h (shared with vmm_reduce_batch)
+static_assert(PART_FLOATS == vmm_reduce::W9_PART_FLOATS, "partial block size");
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float* __restrict__ part, int nz, int tiles_x, int tiles_y, float* __restrict__ dw, int Cin,
                                                             int Cout, const float* __restrict__ bias_part, float* __restrict__ dbias, int n_main) {
   __shared__ f32x4 red[8][32];
-  if ((int)blockIdx.x >= n_main) {  // trailing workgroups of tile 0: dbias[co] += the slices' partial rows, fixed order (was a launch of its own)
-    if (blockIdx.y != 0 || !bias_part) return;  // (workgroup-uniform)
-    const int co = ((int)blockIdx.x - n_main) * 32 + (threadIdx.x & 31), zq = threadIdx.x >> 5;  // 32 channels x 8 slice lanes
-    float s = 0.f;
-    if (co < Cout)
-      for (int z = zq; z < nz; z += 8) s += bias_part[(long long)z * Cout + co];
-    float* redf = reinterpret_cast<float*>(&red[0][0]);
-    redf[zq * 32 + (threadIdx.x & 31)] = s;
-    __syncthreads();
-    if (zq == 0 && co < Cout) {
-#pragma unroll
-      for (int k = 1; k < 8; ++k) s += redf[k * 32 + threadIdx.x];
-      dbias[co] += s;
-    }
-    return;
-  }
-  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  const int tile = blockIdx.y;                       // = by * tiles_x + bx
-  const int piece = blockIdx.x * 32 + e;             // 16-byte piece inside the block: ((t * 4 + wq) * 4 + j) * 64 + lane
-  const long long zstride = (long long)tiles_x * tiles_y * (PART_FLOATS / 4);
-  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (long long)tile * (PART_FLOATS / 4) + piece;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int z = zl; z < nz; z += 8) s += src[z * zstride];
-  red[zl][e] = s;
-  __syncthreads();
-  if (zl == 0) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) s += red[k][e];
-    const int lane = piece & 63, j = (piece >> 6) & 3, wq = (piece >> 8) & 3, t = piece >> 10;
-    const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int ci = bx * 64 + (wq >> 1) * 32 + 8 * j + 4 * (lane >> 5), co = by * 64 + (wq & 1) * 32 + (lane & 31);
-    float* o = dw + ((long long)t * Cin + ci) * Cout + co;
-    o[0] += s.x;
-    o[Cout] += s.y;
-    o[2 * Cout] += s.z;
-    o[3 * Cout] += s.w;
-  }
+  vmm_reduce::w9_body(part, nz, tiles_x, tiles_y, dw, Cin, Cout, bias_part, dbias, n_main, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 }  // namespace
@@ -436,6 +401,21 @@ extern "C" int64_t vmm_conv3x3_wgrad_bf16x3_workspace(const vmm_conv_desc* dp, i
   return (int64_t)gz * tiles * PART_FLOATS + (int64_t)gz * dp->Cout;
 }
 
+// The second stage of the call vmm_conv3x3_wgrad_*(d, dy, lddy, dw_packed, dbias, workspace) as a job of vmm_reduce_batch: a caller that sets
+// d->defer_reduce runs the first stage alone, keeps the workspace and totals the pending blocks of many layers in one launch.  1 outside the envelope.
+extern "C" int vmm_conv3x3_wgrad_reduce_job(const vmm_conv_desc* dp, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job) {
+  W9Args a;
+  int gz = 0;
+  if (!workspace || !job || !w9_setup(*dp, lddy, a, gz)) return 1;
+  const int tx = (dp->C1 + dp->C2) / 64, ty = dp->Cout / 64;
+  const int n_main = PART_FLOATS / 4 / 32;
+  job->part = workspace; job->out = dw_packed;
+  job->bias_part = dbias ? workspace + (long long)gz * tx * ty * PART_FLOATS : nullptr; job->dbias = dbias;
+  job->kind = 1; job->nz = gz; job->tiles_x = tx; job->tiles_y = ty; job->Cin = dp->C1 + dp->C2; job->Cout = dp->Cout; job->ld = 0;
+  job->n_main = n_main; job->gx = n_main + (dbias ? cdiv(dp->Cout, 32) : 0); job->wgs = job->gx * tx * ty; job->wg0 = 0;
+  return 0;
+}
+
 // Same contract as vmm_conv_wgrad_bf16x3 (which forwards the shapes inside this kernel's envelope here, without a workspace).  Returns 1
 // (nothing launched) outside the envelope.  workspace = vmm_conv3x3_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant): the row
 // slices leave partial blocks there and a second launch totals them in a fixed order (bit-reproducible); NULL: fp32 atomics into dw_packed.
@@ -458,7 +438,7 @@ extern "C" int VMM_X3(vmm_conv3x3_wgrad_, )(const vmm_conv_desc* dp, const float
   }
   hipLaunchKernelGGL(wgrad9_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
-  if (workspace) {
+  if (workspace && !d.defer_reduce) {  // (defer_reduce: the caller totals the blocks later, vmm_conv3x3_wgrad_reduce_job + vmm_reduce_batch)
     const int n_main = PART_FLOATS / 4 / 32;
     hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 32) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty,
                        dw_packed, d.C1 + d.C2, d.Cout, dbias ? a.bias_part : nullptr, dbias, n_main);

@@ -337,6 +337,7 @@ class _Builder:
         self.gwritten: set = set()
         self.in_bwd = False
         self.job_uploads: List[Tuple[int, torch.Tensor]] = []
+        self.pending_reduce: list = []  # weight-gradient launches whose partial blocks are not totalled yet (flush_reductions)
         self.raw_slots: Dict[str, int] = {}
         self.tickets_ptr: Optional[int] = None
         self.sk_ptr: Optional[int] = None
@@ -724,9 +725,10 @@ class _Builder:
             ws_n = int(self.lib.vmm_conv3x3_wgrad_bf16x3_workspace(C.byref(d), lddy))
             if ws_n:
                 ws = self.alloc(ws_n)
-                self.step(self.sp("vmm_conv3x3_wgrad_"), (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                dd = self.deferred(d)
+                self.step(self.sp("vmm_conv3x3_wgrad_"), (C.byref(dd), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                           flops=2.0 * M * K * d.Cout, nbytes=wbytes)
-                self.tmp_free((ws, ws_n))
+                self.reduce_later(1, dd, lddy, gw_ptr, gb_ptr, ws, ws_n)
                 return
             # the 1 x 1 layers (to_qkv, to_out, res_conv): 128 x 128 channel blocks on the split-bf16 matrix cores, same reduction scheme
             ws_n = int(self.lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), lddy)) if _enabled("wgrad1x1") else 0
@@ -735,14 +737,15 @@ class _Builder:
                 raise RuntimeError("LayerNorm-fused training forward without the 1 x 1 split-bf16 weight-gradient kernel")
             if ws_n:
                 ws = self.alloc(ws_n)
+                dd = self.deferred(d)
                 if ln:
                     assert not gb_ptr
-                    self.step(self.sp("vmm_conv1x1_wgrad_", "_ln"), (C.byref(d), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
+                    self.step(self.sp("vmm_conv1x1_wgrad_", "_ln"), (C.byref(dd), dy_ptr, lddy, gw_ptr, self.ptr(ws), ln[0], ln[1]), what + " wgrad (LayerNorm operand)",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 else:
-                    self.step(self.sp("vmm_conv1x1_wgrad_"), (C.byref(d), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
+                    self.step(self.sp("vmm_conv1x1_wgrad_"), (C.byref(dd), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad",
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
-                self.tmp_free((ws, ws_n))
+                self.reduce_later(2, dd, lddy, gw_ptr, gb_ptr, ws, ws_n)
                 return
         if self.x3 and getattr(self.m, "use_x3_wgrad_generic", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
             fn = self.lib.vmm_conv_wgrad_bf16x3
@@ -757,6 +760,42 @@ class _Builder:
                   nbytes=4.0 * (d.nimg * d.Hin * d.Win * (d.C1 + d.C2) + M * d.Cout + K * d.Cout))
         if gb_ptr:
             self.tmp_free((sc, nsplit * d.Cout))
+
+    # ---- second stages of the weight-gradient launches, batched: every 3 x 3 / 1 x 1 weight gradient leaves one partial block per row slice; instead of a
+    # 5-13 us totalling launch behind each of them (70 per step) the blocks stay in their workspaces and ONE launch totals everything that is pending when the
+    # packed gradients are next scattered (flush_reductions; same summation order: the gradients are the same bits).  VMM_DISABLE=defer_reduce: per layer again.
+    def deferred(self, d: "N.ConvDesc") -> "N.ConvDesc":
+        if not (self.in_bwd and _enabled("defer_reduce")):
+            return d
+        dd = N.ConvDesc.from_buffer_copy(d)  # (the forward launches keep the original)
+        dd.defer_reduce = 1
+        self.plan.keepalive.append(dd)
+        return dd
+
+    def reduce_later(self, kind: int, dd: "N.ConvDesc", lddy: int, gw_ptr: int, gb_ptr: int, ws: int, ws_n: int) -> None:
+        if dd.defer_reduce:
+            self.pending_reduce.append((kind, dd, lddy, gw_ptr, gb_ptr, ws, ws_n))
+        else:
+            self.tmp_free((ws, ws_n))
+
+    def flush_reductions(self) -> None:
+        if not self.pending_reduce:
+            return
+        jobs = (N.ReduceJob * len(self.pending_reduce))()
+        wg = 0
+        for i, (kind, dd, lddy, gw_ptr, gb_ptr, ws, ws_n) in enumerate(self.pending_reduce):
+            fn = self.lib.vmm_conv3x3_wgrad_reduce_job if kind == 1 else self.lib.vmm_conv1x1_wgrad_reduce_job
+            rc = fn(C.byref(dd), lddy, gw_ptr, gb_ptr or None, self.ptr(ws), C.byref(jobs[i]))
+            if rc != 0:
+                raise RuntimeError(f"no reduction job for a deferred weight-gradient launch (kind {kind}, rc {rc})")
+            jobs[i].wg0 = wg
+            wg += jobs[i].wgs
+        n = len(self.pending_reduce)
+        self.step(self.lib.vmm_reduce_batch, (self._upload_table(jobs), n, wg), f"totals of the partial blocks of {n} weight-gradient launches",
+                  nbytes=4.0 * sum(p[6] for p in self.pending_reduce))
+        for _, _, _, _, _, ws, ws_n in self.pending_reduce:
+            self.tmp_free((ws, ws_n))
+        self.pending_reduce = []
 
     def colsum(self, x_ptr: int, ldx: int, rows: int, C_: int, out_ptr: int, what: str) -> None:
         if out_ptr:
@@ -1929,6 +1968,7 @@ class _Builder:
                 emit()
                 pend_lo = min(pend_lo, uj_start)
                 if marked_pg - pg_start >= span or idx == len(rev) - 1:
+                    self.flush_reductions()  # (the scatter reads the packed gradients: every pending partial block is totalled first)
                     self.emit_unpack(self.unpack_jobs[pend_lo:uj_hi], "scatter weight gradients")
                     uj_hi = min(uj_hi, pend_lo)
                     marked_pg = pg_start
