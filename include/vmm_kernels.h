@@ -225,7 +225,7 @@ typedef struct vmm_pack_job {
  *    [N/64][Cp/16][position xi*4+nu][column fragment 0..1][hi|lo][64 lanes][8], lane l = column nb*64 + mf*32 + (l & 31),
  *    channels ks*16 + (l >> 5)*8 .. +7 (TH = TW = 3, Cp a multiple of 16, N of 64; 64 (N/64) Cp bytes);
  *    1-8: direction 0 only.
- *    2 | 16, 3 | 16, 5 | 16, 6 | 16: the same fragment orders with IEEE-half values in the hi plane and a zero lo plane: operands of the `_fp16` entry points. */
+ *    1 | 16, 2 | 16, 3 | 16, 5 | 16, 6 | 16: the same orders with IEEE-half values in the hi plane and a zero lo plane: operands of the `_fp16` entry points. */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 
@@ -638,6 +638,10 @@ int vmm_temporal_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream
 /* n (a multiple of 8) elements of such 16-bit rows widened to fp32, exactly: for the shapes the one-pass vmm_qkv_bwd_* does not take (its workspace query
  * returns 0), where the caller runs a separate weight- and data-gradient launch over fp32 rows (which round to the same 16 bits again) */
 int vmm_dqkv_widen_bf16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
+/* the generic implicit GEMM of those legs (the layers no specialised kernel takes: to_qkv and its data gradient at C >= 128, res_conv, the transposed
+ * convolutions' phases): vmm_conv_igemm_bf16x3 / _batched with ONE matrix pass; the same fmt-1 weight planes (the lo plane is not read) */
+int vmm_conv_igemm_bf16(const vmm_conv_desc* d, vmm_stream_t stream);
+int vmm_conv_igemm_bf16_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream);
 int vmm_linattn_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 
 /* tiny dense layers: stage 1 writes g = dy*act_out'(z) over dy and dW/db (= or +=), stage 2 adds dx with atomics */
@@ -747,6 +751,9 @@ int vmm_qkv_bwd_ln_fp16(const float* x, int32_t ldx, const float* ln_stats, cons
 int vmm_temporal_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 int vmm_linattn_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 int vmm_dqkv_widen_fp16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
+/* (weights: vmm_pack_weights fmt 1 | 16 -- IEEE-half hi plane) */
+int vmm_conv_igemm_fp16(const vmm_conv_desc* d, vmm_stream_t stream);
+int vmm_conv_igemm_fp16_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream);
 
 #ifdef __cplusplus
 }

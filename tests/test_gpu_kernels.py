@@ -84,8 +84,11 @@ def test_conv_igemm(gpu, B, T, H, W, Cin, Cout, k, stride):
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout,k,stride", [
     (2, 3, 12, 12, 16, 32, 3, 1), (1, 2, 24, 20, 64, 64, 3, 1), (1, 1, 12, 12, 256, 128, 3, 1), (1, 2, 16, 16, 4, 16, 7, 1), (2, 2, 16, 16, 32, 32, 4, 2),
     (1, 11, 12, 12, 128, 512, 3, 1), (1, 2, 96, 96, 64, 64, 3, 1), (1, 2, 20, 20, 36, 768, 1, 1), (1, 2, 16, 16, 4, 64, 9, 1), (2, 1, 20, 12, 4, 16, 11, 1)])
-def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
-    """Split-bf16 matrix-core path: weights through vmm_pack_weights fmt 1, result within 5e-5 of the fp32 convolution."""
+@pytest.mark.parametrize("variant", ["bf16x3", "bf16", "fp16"])
+def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride, variant):
+    """Split-bf16 matrix-core path: weights through vmm_pack_weights fmt 1, result within 5e-5 of the fp32 convolution.  `_bf16` / `_fp16` (the
+    single-pass instances of the reduced-precision training legs; fmt 1 | 16 planes for fp16): what they must compute is known exactly -- the
+    fp32-accumulated convolution of the operands rounded to the 16-bit type -- and is checked at 1e-5."""
     N, lib = _lib()
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, Cin, T, H, W, generator=g)
@@ -103,9 +106,14 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
     j = job[0]
     j.torch_w, j.packed = wg.data_ptr(), packed.data_ptr()
     j.TH, j.TW, j.C, j.Cp, j.N = k, k, Cin, Cin, Cout
-    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * k * k, k * k, k, 1, 0, 1, 0, 1, 0, 1
+    j.sn, j.sc, j.sh, j.sw, j.h0, j.hs, j.w0, j.ws, j.accumulate, j.fmt = Cin * k * k, k * k, k, 1, 0, 1, 0, 1, 0, 1 | (16 if variant == "fp16" else 0)
     tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(gpu)
     N.check(lib.vmm_pack_weights(tab.data_ptr(), 1, Cout * Kpad, 0, _s()), "pack")
+    tol = 5e-5
+    if variant != "bf16x3":
+        rd = torch.float16 if variant == "fp16" else torch.bfloat16
+        ref = F.conv2d(x.to(rd).double().permute(0, 2, 1, 3, 4).reshape(B * T, Cin, H, W), w.to(rd).double(), b.double(), stride=stride, padding=pad)
+        ref_rows, tol = ref.permute(0, 2, 3, 1).reshape(-1, Cout).float(), 1e-5
     d = N.ConvDesc()
     xr, bg = rows_of(x).to(gpu), b.to(gpu)
     out = torch.zeros(B * T * Ho * Wo, Cout, device=gpu)
@@ -113,9 +121,9 @@ def test_conv_igemm_bf16x3(gpu, B, T, H, W, Cin, Cout, k, stride):
     d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = B * T, H, W, Ho, Wo, stride
     d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = k, k, -pad, -pad, 1, 1
     d.Hout, d.Wout, d.oscale, d.Cout, d.rot_dh, d.q_scale = Ho, Wo, 1, Cout, 32, 1.0
-    N.check(lib.vmm_conv_igemm_bf16x3(C.byref(d), _s()), "conv x3")
+    N.check(getattr(lib, "vmm_conv_igemm_" + variant)(C.byref(d), _s()), "conv " + variant)
     torch.cuda.synchronize()
-    assert relerr(out.cpu(), ref_rows) < 5e-5
+    assert relerr(out.cpu(), ref_rows) < tol
 
 
 @pytest.mark.parametrize("B,T,H,W,C1,C2,Cout,fused", [(1, 2, 96, 96, 64, 0, 64, True), (2, 3, 48, 48, 64, 64, 128, False), (2, 2, 24, 24, 256, 0, 256, True),

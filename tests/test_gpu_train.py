@@ -344,7 +344,8 @@ def test_reference_precision_training_leg_fp16_inside_the_reference_fp16_autocas
         assert {"vmm_conv3x3_wgrad_fp16", "vmm_conv1x1_wgrad_fp16", "vmm_qkv_bwd_ln_fp16", "vmm_temporal_block_fp16", "vmm_linattn_block_fp16",
                 "vmm_temporal_block_bwd_fp16", "vmm_linattn_block_bwd_fp16", "vmm_conv_s2_acc_fp16"} <= used, sorted(used)
         assert not {n for n in used if n.endswith("_bf16")}, sorted(used)
-        assert {j["fmt"] for j in pl.pack_jobs if j.get("fmt", 0) & 16} == {18, 19, 21, 22}  # fp16 operand planes for exactly the `_fp16` consumers
+        assert {j["fmt"] for j in pl.pack_jobs if j.get("fmt", 0) & 16} == {17, 18, 19, 21, 22}  # fp16 operand planes for exactly the `_fp16` consumers
+        assert "vmm_conv_igemm_fp16" in used and "vmm_conv_igemm_bf16x3" not in used and not [j for j in pl.pack_jobs if j.get("fmt", 0) == 1]
     got = {model._ref_key(k): p.grad / scale for k, p in model.named_parameters() if p.grad is not None}
     vals = np.array([float((got[k].double().cpu() - w.double()).norm() / w.double().norm()) for k, w in want.items()
                      if w is not None and float(w.double().norm()) > 0 and got.get(k) is not None])

@@ -248,6 +248,10 @@ SIGNATURES = {
     "vmm_qkv_bwd_ln_fp16": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     "vmm_temporal_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_dqkv_widen_fp16": [c_ptr, c_ptr, c_i64, c_ptr],
+    "vmm_conv_igemm_bf16": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_igemm_fp16": [C.POINTER(ConvDesc), c_ptr],
+    "vmm_conv_igemm_bf16_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
+    "vmm_conv_igemm_fp16_batched": [C.POINTER(ConvDesc), c_i32, c_ptr],
     "vmm_dqkv_widen_bf16": [c_ptr, c_ptr, c_i64, c_ptr],
     "vmm_linattn_block_bwd_fp16": [C.POINTER(AttnBlockBwd), c_ptr],
     "vmm_scaler_init": [c_ptr, c_f32, c_ptr],

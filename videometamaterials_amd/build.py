@@ -27,7 +27,7 @@ SINGLE_PASS_MODES = (("_sp", 1), ("_h", 2))
 # forward kernels with a single-pass template instance: compiled once more with -DVMM_SINGLE_PASS=2 (object *_h.o), exporting that instance on fp16 operands
 # alone (`vmm_conv3x3_fp16`, `vmm_conv_s2_acc_fp16`, `vmm_temporal_block_fp16`, `vmm_linattn_block_fp16`)
 FP16_FORWARD_SOURCES = {"conv3x3_bf16x3.hip", "temporal_block.hip", "linattn_block.hip"}
-SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip"}
+SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip", "igemm_bf16x3.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
 #   matrix pipe (55 % for the scalar forms; MI355X_MICROARCH.md "price of one filler beside MFMAs", LABNOTES 7.6).  Measured on one box, libraries

@@ -33,12 +33,13 @@ __device__ __forceinline__ void igemm_bf16x3_body(const vmm_conv_desc& p, int Kp
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NT = TN / 32;
   constexpr int A_PASSES = BM / 32;            // 32 rows x 8 float4 per pass of 256 threads
-  constexpr int B_ITEMS = BN * 8;              // 16-byte items per chunk (2 planes x BN rows x 4 segments)
+  constexpr int B_ITEMS = BN * 4 * (VMM_SINGLE_PASS ? 1 : 2);  // 16-byte items per chunk (planes x BN rows x 4 segments)
   constexpr int B_PASSES = (B_ITEMS + 255) / 256;
+  // (single-pass builds -- `_bf16` / `_fp16` entry points, the reduced-precision training legs: the lo planes are neither staged nor multiplied)
   __shared__ __attribute__((aligned(16))) unsigned short Ah[2][BM][XROW];
-  __shared__ __attribute__((aligned(16))) unsigned short Al[2][BM][XROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Al[VMM_SINGLE_PASS ? 1 : 2][VMM_SINGLE_PASS ? 1 : BM][XROW];
   __shared__ __attribute__((aligned(16))) unsigned short Bh[2][BN][XROW];
-  __shared__ __attribute__((aligned(16))) unsigned short Bl[2][BN][XROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Bl[VMM_SINGLE_PASS ? 1 : 2][VMM_SINGLE_PASS ? 1 : BN][XROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -84,14 +85,14 @@ __device__ __forceinline__ void igemm_bf16x3_body(const vmm_conv_desc& p, int Kp
       split2(areg[ps].x, areg[ps].y, h0, l0);
       split2(areg[ps].z, areg[ps].w, h1, l1);
       *reinterpret_cast<uint2*>(&Ah[buf][r][a_k4 * 4]) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(&Al[buf][r][a_k4 * 4]) = make_uint2(l0, l1);
+      if constexpr (!VMM_SINGLE_PASS) *reinterpret_cast<uint2*>(&Al[buf][r][a_k4 * 4]) = make_uint2(l0, l1);
     }
 #pragma unroll
     for (int ps = 0; ps < B_PASSES; ++ps) {
       const int e = tid + ps * 256;
       if (e < B_ITEMS) {
         const int seg = e & 3, n = (e >> 2) % BN, pl = e / (4 * BN);
-        unsigned short* dst = pl ? &Bl[buf][n][seg * 8] : &Bh[buf][n][seg * 8];
+        unsigned short* dst = (!VMM_SINGLE_PASS && pl) ? &Bl[VMM_SINGLE_PASS ? 0 : buf][VMM_SINGLE_PASS ? 0 : n][seg * 8] : &Bh[buf][n][seg * 8];
         *reinterpret_cast<uint4*>(dst) = breg[ps];
       }
     }
@@ -114,30 +115,32 @@ __device__ __forceinline__ void igemm_bf16x3_body(const vmm_conv_desc& p, int Kp
     if (kc + 1 < nk) load_chunk(kc + 1);
 #pragma unroll
     for (int s = 0; s < XK / 16; ++s) {
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+      uint4 ah[MT], al[MT], bh[NT], bl[NT];
       const int ko = s * 16 + lk * 8;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Ah[buf][wm * TM + i * 32 + lrow][ko]));
-        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Al[buf][wm * TM + i * 32 + lrow][ko]));
+        ah[i] = *reinterpret_cast<const uint4*>(&Ah[buf][wm * TM + i * 32 + lrow][ko]);
+        if constexpr (!VMM_SINGLE_PASS) al[i] = *reinterpret_cast<const uint4*>(&Al[buf][wm * TM + i * 32 + lrow][ko]);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bh[buf][wn * TN + j * 32 + lrow][ko]));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bl[buf][wn * TN + j * 32 + lrow][ko]));
+        bh[j] = *reinterpret_cast<const uint4*>(&Bh[buf][wn * TN + j * 32 + lrow][ko]);
+        if constexpr (!VMM_SINGLE_PASS) bl[j] = *reinterpret_cast<const uint4*>(&Bl[buf][wn * TN + j * 32 + lrow][ko]);
+      }
+      if constexpr (!VMM_SINGLE_PASS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = vmm_mfma16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = vmm_mfma16(ah[i], bl[j], acc[i][j]);
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = vmm_mfma16(ah[i], bh[j], acc[i][j]);
     }
     if (kc + 1 < nk) store_chunk(buf ^ 1);
     __syncthreads();
@@ -202,7 +205,7 @@ int run_x3(const vmm_conv_desc* dp, int n, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vmm_conv_igemm_bf16x3(const vmm_conv_desc* dp, vmm_stream_t stream) {
+extern "C" int VMM_X3(vmm_conv_igemm_, )(const vmm_conv_desc* dp, vmm_stream_t stream) {
   const int rc = check_x3(*dp);
   if (rc) return rc;
   return run_x3(dp, 1, (hipStream_t)stream);
@@ -210,7 +213,7 @@ extern "C" int vmm_conv_igemm_bf16x3(const vmm_conv_desc* dp, vmm_stream_t strea
 
 // descs[0 .. n) (n <= 4): problems of identical shape (rows, taps, channels, output columns) that differ in pointers / offsets, e.g. the
 // four output phases of ConvTranspose3d (1,4,4) stride 2 (vddp.py:155); one launch instead of n fills the chip for the small levels.
-extern "C" int vmm_conv_igemm_bf16x3_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream) {
+extern "C" int VMM_X3(vmm_conv_igemm_, _batched)(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream) {
   if (n < 1 || n > 4) return -1;
   for (int i = 0; i < n; ++i) {
     const int rc = check_x3(descs[i]);

@@ -313,7 +313,7 @@ __device__ __forceinline__ void pack16(float v, bool half, unsigned short& hi, u
 
 __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
   vmm_pack_job jb = jobs[blockIdx.y];
-  const bool half = (jb.fmt & 16) != 0;  // fragment-order formats 2, 3, 5, 6 with fp16 planes (vmm_conv3x3_fp16 and the other `_fp16` entry points)
+  const bool half = (jb.fmt & 16) != 0;  // formats 1, 2, 3, 5, 6 with fp16 planes (vmm_conv3x3_fp16 and the other `_fp16` entry points)
   jb.fmt &= 15;
   if (direction == 1 && unpack_tile_cb(jb)) return;  // (scattered by unpack_tiled_kernel)
   if (jb.fmt == 1) {
@@ -332,10 +332,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restric
         const int tw = t % jb.TW, th = t / jb.TW;
         if (c < jb.C) v = jb.torch_w[(long long)n * jb.sn + (long long)c * jb.sc + (long long)(jb.h0 + th * jb.hs) * jb.sh + (long long)(jb.w0 + tw * jb.ws) * jb.sw];
       }
-      const __bf16 h = (__bf16)v;
-      const __bf16 l = (__bf16)(v - (float)h);
-      hi[i] = __builtin_bit_cast(unsigned short, h);
-      lo[i] = __builtin_bit_cast(unsigned short, l);
+      pack16(v, half, hi[i], lo[i]);  // (fmt 1 | 16: IEEE-half hi plane, zero lo plane -- vmm_conv_igemm_fp16)
     }
     return;
   }
