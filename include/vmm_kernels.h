@@ -673,11 +673,12 @@ int vmm_conv1d_k4s2_silu_bwd(const float* x, const float* w, const float* bias, 
                              int32_t Cin, int32_t Cout, int32_t Lin, vmm_stream_t stream);
 int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t Cin, const float* w, const float* dout, int32_t B, int32_t Cout,
                                int32_t T, int32_t HW, float* drows, int32_t lddr, float* dw, float* db, vmm_stream_t stream);
-/* data gradient of the stem (init_conv, vddp.py:600; zero padding) into the NCTHW layout of the network input: dx[b, c, t, y, x] = sum_{kh, kw, co}
- * g[(b, t, y + k/2 - kh, x + k/2 - kw)][co] w[co][c][kh][kw]; g rows [B*T*H*W][Cout] (ldg), w in torch layout (Cout, Cx, 1, k, k).  Only
+/* data gradient of the stem (init_conv, vddp.py:600) into the NCTHW layout of the network input: dx[b, c, t, y, x] = sum_{kh, kw, co}
+ * g[(b, t, y + k/2 - kh, x + k/2 - kw)][co] w[co][c][kh][kw]; g rows [B*T*H*W][Cout] (ldg), w in torch layout (Cout, Cx, 1, k, k); wrap_h / wrap_w: the
+ * axis is periodic (padding_mode 'circular' / 'circular_1d', vddp.py:163-243: rows across the seam contribute), else zero padding.  Only
  * autograd users that ask for the gradient of the loss with respect to the input run it. */
 int vmm_stem_conv_dgrad(const float* g, int32_t ldg, const float* w, float* dx, int32_t B, int32_t Cx, int32_t T, int32_t H, int32_t W, int32_t Cout,
-                        int32_t k, vmm_stream_t stream);
+                        int32_t k, int32_t wrap_h, int32_t wrap_w, vmm_stream_t stream);
 /* d/dpred of mean|noise-pred| (or squared error) times the upstream scalar *gscale (NULL = 1) (vddp.py:1053-1056) */
 int vmm_loss_grad(const float* noise, const float* pred, int64_t n, int32_t squared, const float* gscale, float* dpred, vmm_stream_t stream);
 

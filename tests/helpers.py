@@ -93,6 +93,12 @@ CONFIGS = {
     "k3": (dict(dim=16, channels=1, init_kernel_size=3, padding_mode="circular"), (2, 4, 16, 16), 51),
     "k9w64": (dict(dim=64, channels=3, init_kernel_size=9, init_dim=64, cond_attention="self-stacked", cond_attention_tokens=16,
                    use_temporal_attention_cond=True, per_frame_cond=True, cond_bias=True), (1, 11, 16, 16), 11),
+    # channels (vddp.py:576, 624; main.py:63 passes len(selected_channels)): more than the four of an RGBA GIF -- the stem kernel's K order holds four
+    # channels per tap, wider inputs take the generic implicit GEMM over rows padded to a multiple of four; Lagrangian wiring at dim 16, defaults at the
+    # real widths (where four or fewer channels would take the stem kernel)
+    "chan6": (dict(dim=16, channels=6, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,
+                   per_frame_cond=True, cond_bias=True), (2, 11, 16, 16), 11),
+    "chan5w64": (dict(dim=64, channels=5), (1, 4, 16, 16), 51),
     # all of them at once (init_dim given explicitly: the reference's final_conv reads cat(x, r) as 2 * dim channels, so init_dim == dim is the only
     # value its forward accepts, vddp.py:706, 820): the configuration of the golden GRADIENT set (tests/golden/grads_ctor16.npz)
     "ctor16": (dict(dim=16, channels=3, cond_attention="self-stacked", cond_attention_tokens=16, use_temporal_attention_cond=True,

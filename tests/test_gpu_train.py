@@ -408,10 +408,12 @@ def test_fp16_trainer_loss_scaling_skips_overflowed_steps_and_recovers(gpu):
     assert (tr_d.loss_scale_init, tr_d.loss_scale_growth, tr_d.loss_scale_backoff, tr_d.loss_scale_interval) == (65536.0, 2.0, 0.5, 2000)
 
 
-@pytest.mark.parametrize("cfg_name,precision", [("lagr16", "fp32"), ("plumb16", "fp32"), ("lagr64", "bf16x3")])
+@pytest.mark.parametrize("cfg_name,precision", [("lagr16", "fp32"), ("plumb16", "fp32"), ("lagr64", "bf16x3"), ("circ64", "bf16x3"), ("circ1d16", "fp32"), ("k3", "fp32"),
+                                                ("chan6", "fp32"), ("chan5w64", "bf16x3")])
 def test_input_gradient_matches_oracle(gpu, cfg_name, precision):
     """the gradient of a scalar of the denoiser output with respect to the network INPUT (the stem's data gradient on top of the
-    backward list), against autograd through the oracle; 1 and 3 input channels."""
+    backward list), against autograd through the oracle; 1, 3, 5 and 6 input channels; both periodic padding modes (the stem's taps reach across the seam:
+    vddp.py:163-243) with the 7 x 7 and a 3 x 3 stem."""
     import videometamaterials_amd as vm
     from oracle import unet3d_oracle as uo
     kw, (B, T, H, W), _ = helpers.CONFIGS[cfg_name]

@@ -171,7 +171,7 @@ SIGNATURES = {
     "vmm_tokens_from_hidden_bwd": [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_conv1d_k4s2_silu_bwd": [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_pointwise_to_ncthw_bwd": [c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr],
-    "vmm_stem_conv_dgrad": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    "vmm_stem_conv_dgrad": [c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
     "vmm_loss_grad": [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr],
     "vmm_adam_step": [c_ptr, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_ptr],
     "vmm_ema_step": [c_ptr, c_i32, c_i64, c_f32, c_i32, c_ptr],

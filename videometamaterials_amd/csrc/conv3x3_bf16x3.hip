@@ -47,6 +47,9 @@ constexpr bool C3_INTERLEAVE = VMM_C3_INTERLEAVE;  // memory requests of step q 
 #endif
 constexpr bool C3_XCD_ORDER = VMM_C3_XCD_ORDER;  // XCD-contiguous tile numbering (-DVMM_C3_XCD_ORDER=0: A/B builds)
 constexpr int CK = 32;    // channels per chunk
+#ifndef VMM_C3_ONE_LO
+#define VMM_C3_ONE_LO 0
+#endif
 constexpr int CROW = 72;  // LDS patch row pitch in bf16: 32 hi | 32 lo | 8 pad = 144 bytes (9 x 16 B: ds_read_b128 over consecutive rows is conflict-free)
 
 struct C3Args {
@@ -351,7 +354,8 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
           split2c(v.x, v.y, h0, l0);
           split2c(v.z, v.w, h1, l1);
           *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
+          // (single-pass instances never read the lo half of a patch row: neither stored nor -- its value being dead -- formed.  -DVMM_C3_ONE_LO=1: stored, for A/B)
+          if constexpr (!ONE || VMM_C3_ONE_LO) *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
         }
       }
     }

@@ -545,7 +545,7 @@ extern "C" int vmm_pointwise_to_ncthw_bwd(const float* rows, int32_t ld, int32_t
 // for the input gradient run it (the training step never does): a plain vector-unit kernel -- a thread per (pixel, c) with the k x k x Cx x Cout weights
 // in LDS as [tap][c][co] -- for 3.8 GFLOP at the Lagrangian sizes.
 __global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ w, float* __restrict__ dx, int Cx, int T,
-                                                         int H, int W, int Cout, int k, long long nrows) {
+                                                         int H, int W, int Cout, int k, long long nrows, int wrap_h, int wrap_w) {
   extern __shared__ float ws[];  // [k*k][Cx][Cout]
   const int kk = k * k;
   for (int i = threadIdx.x; i < kk * Cx * Cout; i += blockDim.x) {
@@ -562,10 +562,12 @@ __global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict
   const long long img = r / HW;
   float acc = 0.f;
   for (int kh = 0; kh < k; ++kh) {
-    const int yy = py + pad - kh;
+    int yy = py + pad - kh;
+    if (wrap_h) yy = ((yy % H) + H) % H;  // periodic padding (vddp.py:163-243): the output row the tap reads from lies across the seam
     if (yy < 0 || yy >= H) continue;
     for (int kw = 0; kw < k; ++kw) {
-      const int xx = px + pad - kw;
+      int xx = px + pad - kw;
+      if (wrap_w) xx = ((xx % W) + W) % W;
       if (xx < 0 || xx >= W) continue;
       const float* gp = g + ((img * H + yy) * W + xx) * ldg;
       const float* wp = ws + ((kh * k + kw) * Cx + c) * Cout;
@@ -584,17 +586,17 @@ __global__ __launch_bounds__(256) void stem_dgrad_kernel(const float* __restrict
 }
 
 extern "C" int vmm_stem_conv_dgrad(const float* g, int32_t ldg, const float* w, float* dx, int32_t B, int32_t Cx, int32_t T, int32_t H, int32_t W, int32_t Cout,
-                                   int32_t k, vmm_stream_t stream) {
-  if (Cx < 1 || Cout % 4 || (ldg & 3) || k < 1 || !(k & 1) || (size_t)k * k * Cx * Cout * sizeof(float) > 64 * 1024) return -1;
+                                   int32_t k, int32_t wrap_h, int32_t wrap_w, vmm_stream_t stream) {
+  if (Cx < 1 || Cout % 4 || (ldg & 3) || k < 1 || !(k & 1) || (size_t)k * k * Cx * Cout * sizeof(float) > 160 * 1024) return -1;
   const long long nrows = (long long)B * T * H * W;
   if (nrows <= 0) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(stem_dgrad_kernel, dim3((unsigned)cdiv(nrows * Cx, 256)), dim3(256), sizeof(float) * k * k * Cx * Cout, (hipStream_t)stream, g, ldg, w, dx, Cx, T, H, W,
-                     Cout, k, nrows);
+                     Cout, k, nrows, wrap_h, wrap_w);
   VMM_LAUNCH_CHECK();
   return 0;
 }

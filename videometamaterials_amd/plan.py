@@ -248,8 +248,6 @@ class Plan:
             if on_mark is not None and i in marks:
                 on_mark(marks[i])
         if want_dx:  # d loss / d x into self.dx (B, C, T, H, W)
-            if not self.dx_steps:
-                raise NotImplementedError("the input gradient is not built for periodic padding")
             for fn, args, what in self.dx_steps:
                 N.check(fn(*args, s), what)
         return self.pgrad
@@ -1727,16 +1725,16 @@ class _Builder:
         if self.mirrored:  # (the builder's batch is what every emitter sizes its launches and buffers by)
             self.B = B = B // 2
             rows0 = B * T * H * W
-        xin = Act(self.alloc(rows0 * 4), 4, H, W, rows0 * 4)
+        Cxp = (Cx + 3) // 4 * 4  # input rows padded to a multiple of four channels (zeros; the reference takes any channel count, vddp.py:576, 624)
+        xin = Act(self.alloc(rows0 * Cxp), Cxp, H, W, rows0 * Cxp)
         xin.ptr = self.ptr(xin.off)
-        self.step(lib.vmm_ncthw_to_rows, (self.ptr(x_in_off), B, Cx, T, H * W, xin.ptr, 4), "ncthw -> rows")
+        self.step(lib.vmm_ncthw_to_rows, (self.ptr(x_in_off), B, Cx, T, H * W, xin.ptr, Cxp), "ncthw -> rows")
         k = m.init_kernel_size
-        if Cx > 4:
-            raise NotImplementedError("more than 4 input channels")
-        stem_ok = bool(self.x3 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")))
+        # (the stem kernel's K order holds four channels per tap: wider inputs take the generic implicit GEMM)
+        stem_ok = bool(self.x3 and Cx <= 4 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")))
         nstem = stem_ok and self.nat16("stem", H)
         x = self.act(m.init_dim, H, W, bf=nstem)
-        if self.x3 and m.init_dim == 64 and k % 2 == 1 and k <= 8 and rows0 * 64 < 2 ** 31 and not wrap and _enabled("stem") and (not tr or _enabled("stem_train")):
+        if stem_ok:
             # the stem on its own kernel: the tile's neighbourhood staged once in LDS, four neighbouring taps per k16 step (stem_conv.hip)
             wi = self.pack("init_conv.weight", 2048 * k, want_grad=False, TH=k, TW=k, C=Cx, Cp=Cx, N=64, sn=Cx * k * k, sc=k * k, sh=k, sw=1, fmt=7)[0]
             self.step(lib.vmm_stem_conv_bf16x3_a16 if nstem else lib.vmm_stem_conv_bf16x3,
@@ -1744,11 +1742,11 @@ class _Builder:
                       flops=2.0 * rows0 * k * k * Cx * 64, nbytes=4.0 * rows0 * (4 + 64))
             dinit = gwi = None
             if tr:  # the weight gradient works from the layer's descriptor and the plain packed layout (the operand copy itself is not used)
-                _, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
+                _, gwi = self.pack_conv("init_conv.weight", pad_cin_to=Cxp)
                 dinit = self.conv_desc(a1=xin, w=0, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr,
                                        ldo=m.init_dim, Hv=H, Wv=W)
         else:
-            wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=4)
+            wi, gwi = self.pack_conv("init_conv.weight", pad_cin_to=Cxp)
             dinit = self.conv(a1=xin, w=wi, bias=self.wraw("init_conv.bias"), Cout=m.init_dim, KH=k, KW=k, off=(-(k // 2), -(k // 2)), out_ptr=x.ptr,
                               ldo=m.init_dim, Hv=H, Wv=W, what="init_conv")
         self.free_act(xin)
@@ -1758,9 +1756,8 @@ class _Builder:
             g0, _ = self.grad_of(x0)
             self.wgrad(dinit, g0.ptr, m.init_dim, gwi, "init_conv", gb_ptr=self.pg("init_conv.bias"))
             # d loss / d x: a launch of its own list -- Plan.backward runs it only when the input gradient is asked for
-            if not wrap:
-                self.plan.dx_steps.append((lib.vmm_stem_conv_dgrad, (g0.ptr, m.init_dim, self.wraw("init_conv.weight"), self.ptr(self.dx_off), B, Cx, T, H, W,
-                                                                     m.init_dim, k), "init_conv dgrad (input gradient)"))
+            self.plan.dx_steps.append((lib.vmm_stem_conv_dgrad, (g0.ptr, m.init_dim, self.wraw("init_conv.weight"), self.ptr(self.dx_off), B, Cx, T, H, W,
+                                                                 m.init_dim, k, int(self.wrap_h), int(self.wrap_w)), "init_conv dgrad (input gradient)"))
         self.on_backward(init_bwd, pg_start, uj_start)
         x_new = self.softmax_attn_block("init_temporal_attn", x, None, temporal=True)
         self.free_act(x)
