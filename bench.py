@@ -262,8 +262,9 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
            "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
            "arithmetic": ("fp32 (exact fp32 MFMA)" if precision == "fp32"
                           else "fp16: ONE MFMA pass on fp16-rounded operands (the reference's autocast dtype, main.py:34) in forward, data gradients, 3x3 / 1x1 / to_qkv weight "
-                               "gradients and the recomputing attention backward; static loss scale 2^16 with the skip-on-overflow check of GradScaler (vddp.py:1629-1633); "
-                               "fp32 master weights, activations, accumulation, norms, softmax, Adam" if precision == "fp16"
+                               "gradients, the generic implicit GEMM and the recomputing attention backward (whose qkv-row gradient travels as fp16 operands: same operand "
+                               "bits, half the bytes); device-side GradScaler (2^16, backoff 0.5 on a non-finite gradient, growth 2 per 2000 clean steps: vddp.py:1629-1633); "
+                               "fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "fp16"
                           else "bf16: ONE MFMA pass on bf16-rounded operands in forward, data gradients, 3x3 / 1x1 / to_qkv weight gradients and the recomputing attention "
                                "backward; fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "bf16"
                           else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32"),
