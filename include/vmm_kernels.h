@@ -225,7 +225,8 @@ typedef struct vmm_pack_job {
  *    [N/64][Cp/16][position xi*4+nu][column fragment 0..1][hi|lo][64 lanes][8], lane l = column nb*64 + mf*32 + (l & 31),
  *    channels ks*16 + (l >> 5)*8 .. +7 (TH = TW = 3, Cp a multiple of 16, N of 64; 64 (N/64) Cp bytes);
  *    1-8: direction 0 only.
- *    1 | 16, 2 | 16, 3 | 16, 5 | 16, 6 | 16: the same orders with IEEE-half values in the hi plane and a zero lo plane: operands of the `_fp16` entry points. */
+ *    1 | 16, 2 | 16, 3 | 16, 5 | 16, 6 | 16: the same orders with IEEE-half values in the hi plane and a zero lo plane: operands of the `_fp16` entry points;
+ *    ... | 32: IEEE-half hi plane AND IEEE-half lo plane (w - hi): operands of the `_f16x3` entry points of the experiments library (vmm_experiments.h). */
 } vmm_pack_job;
 int vmm_pack_weights(const vmm_pack_job* jobs_dev, int32_t njobs, int32_t max_elems, int32_t direction, vmm_stream_t stream);
 

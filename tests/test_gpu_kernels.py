@@ -2132,6 +2132,40 @@ def test_linear_attention_matrix_core_row_passes(gpu, HW, ntok):
         assert relerr(dev_.cpu(), ev.grad.reshape(B, ntok, hid)) < 2e-5
 
 
+def test_attention_blocks_on_fp16_split_operands_experiment(gpu):
+    """libvmm_hip_exp.so only (skipped on the product library): vmm_temporal_block_f16x3 / vmm_linattn_block_f16x3 -- the fused attention blocks on IEEE-half
+    hi | lo operands (three passes; weights fmt | 32) -- against the split-bf16 blocks on the same inputs: two fp32-class evaluations of one block, 2e-5 apart at
+    most (the fp16 form is the closer one to fp64: tools/bench_attn_split.py)."""
+    N, lib = _lib()
+    if not hasattr(lib, "vmm_temporal_block_f16x3"):
+        pytest.skip("experiments library not loaded")
+    from videometamaterials_amd import hostmath
+    for name, argtypes in N.EXPERIMENT_SIGNATURES.items():
+        getattr(lib, name).argtypes = argtypes
+    g = torch.Generator().manual_seed(5)
+    B, T, HW, ntok, Cc, heads, hid = 2, 11, 64, 11, 64, 8, 256
+    x = (torch.randn(B * T * HW, Cc, generator=g) * 1.5 + 0.3).to(gpu)
+    wqkv, wout = torch.randn(3 * hid, Cc, generator=g) / 8, torch.randn(Cc, hid, generator=g) / 16
+    gam, bias, rot = (1 + 0.2 * torch.randn(Cc, generator=g)).to(gpu), torch.randn(heads, T, T, generator=g).to(gpu), hostmath.rotary_table(T, 32).to(gpu)
+    ek, ev = torch.randn(B, ntok, hid, generator=g).to(gpu), torch.randn(B, ntok, hid, generator=g).to(gpu)
+    bo = torch.randn(Cc, generator=g).to(gpu)
+    outs = {}
+    for v, f in (("bf16x3", 0), ("f16x3", 32)):
+        wq, wo = _pack_frag(N, lib, gpu, wqkv, 2 | f), _pack_frag(N, lib, gpu, wout, 3 | f)
+        out = torch.empty_like(x)
+        N.check(getattr(lib, "vmm_temporal_block_" + v)(x.data_ptr(), Cc, gam.data_ptr(), wq.data_ptr(), wo.data_ptr(), ek.data_ptr(), ev.data_ptr(), ntok, bias.data_ptr(), 1,
+                                                         rot.data_ptr(), out.data_ptr(), Cc, B, T, HW, Cc, heads, C.c_float(32 ** -0.5), C.c_float(1e-5), _s()), v)
+        ws = torch.empty(lib.vmm_linattn_block_workspace(B, T, HW), device=gpu)
+        out2 = torch.empty_like(x)
+        N.check(getattr(lib, "vmm_linattn_block_" + v)(x.data_ptr(), Cc, gam.data_ptr(), wq.data_ptr(), wo.data_ptr(), bo.data_ptr(), ek.data_ptr(), ev.data_ptr(), ntok,
+                                                        ws.data_ptr(), out2.data_ptr(), Cc, B, T, HW, Cc, heads, C.c_float(1e-5), _s()), v)
+        torch.cuda.synchronize()
+        outs[v] = (out.cpu(), out2.cpu())
+    assert relerr(outs["f16x3"][0] - x.cpu(), outs["bf16x3"][0] - x.cpu()) < 2e-5
+    assert relerr(outs["f16x3"][1] - x.cpu(), outs["bf16x3"][1] - x.cpu()) < 2e-5
+    assert not torch.equal(outs["f16x3"][0], outs["bf16x3"][0])  # (two operand forms, not one kernel under two names)
+
+
 @pytest.mark.parametrize("env", [{"VMM_C3_PERSISTENT": "1"}, {"VMM_C3_PERSISTENT": "2"}, {"VMM_C3_NJ1": "1"}, {}])
 def test_experiments_library(gpu, env):
     """libvmm_hip_exp.so (VMM_EXPERIMENTS=1 build, made by __graft_entry__.build()): the kernels that lost their A/B stay parity-green.  The
@@ -2146,7 +2180,7 @@ def test_experiments_library(gpu, env):
         pytest.skip("libvmm_hip_exp.so not built (VMM_EXPERIMENTS=1 python -m videometamaterials_amd.build)")
     e = dict(os.environ, VMM_LIB_PATH=exp, **env)
     e.pop("VMM_C3_LEGACY", None)
-    sel = "conv3x3_halo or fused_gn or forward_matches_reference_golden or shared_source" if env else "winograd or balanced or forward_matches_reference_golden"
+    sel = "conv3x3_halo or fused_gn or forward_matches_reference_golden or shared_source" if env else "winograd or balanced or fp16_split_operands or forward_matches_reference_golden"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_kernels.py", "tests/test_gpu_unet.py", "-k", sel],
                        cwd=root, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

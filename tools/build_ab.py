@@ -24,6 +24,12 @@ if __name__ == "__main__":
             subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-c", s, "-o", o], check=True)
         objs.append(o)
         base = os.path.basename(s)
+        if b.EXPERIMENTS and base in b.SPLIT_F16_SOURCES:  # (*_f3.o: the fp16 hi | lo three-pass objects of the experiments build)
+            o3 = os.path.join(b.OBJDIR, stem + "_f3.o")
+            if stem in names or "all" in names:
+                o3 = os.path.join("/tmp", stem + "_f3_ab.o")
+                subprocess.run(["/opt/rocm/bin/hipcc", *b.FLAGS, "-w", *flags, "-DVMM_SPLIT_F16=1", "-c", s, "-o", o3], check=True)
+            objs.append(o3)
         if base in b.SINGLE_PASS_SOURCES or base in b.FP16_FORWARD_SOURCES:  # the single-pass objects of build.py (*_sp.o: bf16 operands, *_h.o: fp16 operands)
             for tag, mode in (b.SINGLE_PASS_MODES if base in b.SINGLE_PASS_SOURCES else b.SINGLE_PASS_MODES[1:]):
                 o2 = os.path.join(b.OBJDIR, stem + tag + ".o")

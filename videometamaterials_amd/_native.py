@@ -293,6 +293,10 @@ EXPERIMENT_SIGNATURES = {
     "vmm_conv3x3_wino_bf16x3": [C.POINTER(ConvDesc), c_ptr],
     "vmm_conv3x3_wino_fuses_gn": [C.POINTER(ConvDesc)],
     "vmm_conv3x3_wino_accepts": [C.POINTER(ConvDesc)],
+    "vmm_temporal_block_f16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  c_i32, c_f32, c_f32, c_ptr],
+    "vmm_linattn_block_f16x3": [c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                 c_f32, c_ptr],
 }
 
 # include/vmm_dp.h: the data-parallel engine (RCCL bound at run time; nothing here runs unless a DP engine is created)

@@ -27,6 +27,9 @@ SINGLE_PASS_MODES = (("_sp", 1), ("_h", 2))
 # forward kernels with a single-pass template instance: compiled once more with -DVMM_SINGLE_PASS=2 (object *_h.o), exporting that instance on fp16 operands
 # alone (`vmm_conv3x3_fp16`, `vmm_conv_s2_acc_fp16`, `vmm_temporal_block_fp16`, `vmm_linattn_block_fp16`)
 FP16_FORWARD_SOURCES = {"conv3x3_bf16x3.hip", "temporal_block.hip", "linattn_block.hip"}
+# EXPERIMENTS build: the sampler's fused attention blocks compiled once more with -DVMM_SPLIT_F16=1 (object *_f3.o): three passes on IEEE-half hi | lo operands,
+# `_f16x3` entry points (include/vmm_experiments.h)
+SPLIT_F16_SOURCES = {"temporal_block.hip", "linattn_block.hip"}
 SINGLE_PASS_SOURCES = {"temporal_block_bwd.hip", "linattn_block_bwd.hip", "qkv_bwd.hip", "wgrad3x3_bf16x3.hip", "wgrad1x1_bf16x3.hip", "igemm_bf16x3.hip"}
 # -munsafe-fp-atomics: hardware fp32 atomic add (valid for the coarse-grained device memory all buffers live in) instead of a CAS loop
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32, which issue at 40 % of their rate beside a busy
@@ -67,6 +70,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
         if force or _stale(o, [s] + hdrs) or _flags_changed(cmd):
             jobs.append(cmd)
+        if EXPERIMENTS and os.path.basename(s) in SPLIT_F16_SOURCES:  # (experiments library only: measured, worth 0-4 % of a block, not used by any plan -- LABNOTES 11.2)
+            o3 = o[:-2] + "_f3.o"
+            objs.append(o3)
+            cmd = [hipcc, *FLAGS, "-DVMM_SPLIT_F16=1", "-c", s, "-o", o3]
+            if force or _stale(o3, [s] + hdrs) or _flags_changed(cmd):
+                jobs.append(cmd)
         if os.path.basename(s) in SINGLE_PASS_SOURCES or os.path.basename(s) in FP16_FORWARD_SOURCES:
             for tag, mode in (SINGLE_PASS_MODES if os.path.basename(s) in SINGLE_PASS_SOURCES else SINGLE_PASS_MODES[1:]):
                 o2 = o[:-2] + tag + ".o"

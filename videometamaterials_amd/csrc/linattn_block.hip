@@ -555,6 +555,13 @@ extern "C" int vmm_linattn_block_bf16_a16(const void* x, int32_t ldx, const floa
                                           int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
   return la_launch<true, bf16s>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
 }
+#elif VMM_SPLIT_F16
+// three passes on IEEE-half hi | lo operands (vmm_common.h, VMM_SPLIT_F16); identical arguments and workspace, weights = vmm_pack_weights fmt 2 | 32 / 3 | 32
+extern "C" int vmm_linattn_block_f16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                       const float* bias_out, const float* ek, const float* ev, int32_t ntok, float* workspace, float* out,
+                                       int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C, int32_t heads, float eps, vmm_stream_t stream) {
+  return la_launch<false>(x, ldx, gamma, wqkv_frag, wout_frag, bias_out, ek, ev, ntok, workspace, out, ldo, B, T, HW, C, heads, eps, stream);
+}
 #else
 // fp16 operands (`train_precision = "fp16"`: the reference's autocast dtype, main.py:34): the single-pass instance of this translation unit compiled with
 // -DVMM_SINGLE_PASS=2; identical arguments and workspace layout (the context fragments it leaves for the backward are fp16 too: vmm_linattn_block_bwd_fp16

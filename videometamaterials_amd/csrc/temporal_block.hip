@@ -1197,6 +1197,15 @@ extern "C" int vmm_temporal_block_bf16_a16(const void* x, int32_t ldx, const flo
   return tb_launch<true, bf16s>(static_cast<const float*>(x), ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, static_cast<float*>(out), ldo,
                                 B, T, HW, C, heads, q_scale, eps, stream);
 }
+#elif VMM_SPLIT_F16
+// Three passes on IEEE-half hi | lo operands (vmm_common.h, VMM_SPLIT_F16: the split is four vector instructions per pair instead of six): the sampler's
+// fp32-class block; identical arguments, weights = vmm_pack_weights fmt 2 | 32 / 3 | 32 (fp16 hi | fp16 lo planes)
+extern "C" int vmm_temporal_block_f16x3(const float* x, int32_t ldx, const float* gamma, const float* wqkv_frag, const float* wout_frag,
+                                        const float* ek, const float* ev, int32_t ntok, const float* bias, int32_t bias_on_cond,
+                                        const float* rot_tab, float* out, int32_t ldo, int32_t B, int32_t T, int32_t HW, int32_t C,
+                                        int32_t heads, float q_scale, float eps, vmm_stream_t stream) {
+  return tb_launch<false>(x, ldx, gamma, wqkv_frag, wout_frag, ek, ev, ntok, bias, bias_on_cond, rot_tab, out, ldo, B, T, HW, C, heads, q_scale, eps, stream);
+}
 #else
 // fp16 operands (`train_precision = "fp16"`: the reference's autocast dtype, main.py:34): the single-pass instance of this translation unit compiled with
 // -DVMM_SINGLE_PASS=2; identical arguments, weights = vmm_pack_weights fmt 2 | 16 / 3 | 16 (fp16 planes)

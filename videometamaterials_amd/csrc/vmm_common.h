@@ -24,7 +24,22 @@
 #else
 #define VMM_X3(pre, post) pre##bf16x3##post
 #endif
-#define VMM_FP16_OPERANDS (VMM_SINGLE_PASS == 2)
+// A third operand form (round 6, the fused attention blocks of the sampler): -DVMM_SPLIT_F16=1 keeps the THREE passes of the split product but splits into IEEE-half
+// hi | lo (x = hi + lo to 2^-22 for O(1) values, with an absolute floor of 3e-8 from the half denormals -- fine behind a LayerNorm).  gfx950 has no mixed-precision
+// subtract for bf16 but it has v_fma_mix_f32 for half: lo = x - hi straight from the packed half, four vector instructions per pair instead of six -- and these
+// kernels are bound by vector work in the matrix shadow (tools/ubench/split_f16mix.hip: 31.8 against 39.9 ticks per pair beside an MFMA wave).  Entry points `_f16x3`,
+// weight planes = vmm_pack_weights fmt | 32 (fp16 hi | fp16 lo).
+#ifndef VMM_SPLIT_F16
+#define VMM_SPLIT_F16 0
+#endif
+#if VMM_SPLIT_F16
+#if VMM_SINGLE_PASS
+#error "VMM_SPLIT_F16 is a three-pass form"
+#endif
+#undef VMM_X3
+#define VMM_X3(pre, post) pre##f16x3##post
+#endif
+#define VMM_FP16_OPERANDS (VMM_SINGLE_PASS == 2 || VMM_SPLIT_F16)   // the 16-bit operand TYPE is IEEE half (vmm_mfma16 issues the f16 MFMA)
 
 #define VMM_WAVE 64
 
@@ -91,7 +106,16 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ unsigned split_bf16_pair(float x0, float x1, unsigned& lo) {
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   const f32x2_t v = {x0, x1};
-#if VMM_FP16_OPERANDS
+#if VMM_SPLIT_F16
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  float r0, r1;  // x - float(hi half): one v_fma_mix_f32 each (src2 read as f16 from the low / high half of hi, negated)
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(hi));
+  const f32x2_t r = {r0, r1};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+  return hi;
+#elif VMM_FP16_OPERANDS
   typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
   lo = 0u;
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
@@ -105,7 +129,11 @@ __device__ __forceinline__ unsigned split_bf16_pair(float x0, float x1, unsigned
 }
 // one value: the 16 bits of its hi part, `lo` = the bits of what is left (0 in fp16-operand builds)
 __device__ __forceinline__ unsigned short vmm_split16(float v, unsigned short& lo) {
-#if VMM_FP16_OPERANDS
+#if VMM_SPLIT_F16
+  const _Float16 h = (_Float16)v;
+  lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+  return __builtin_bit_cast(unsigned short, h);
+#elif VMM_FP16_OPERANDS
   lo = 0;
   return __builtin_bit_cast(unsigned short, (_Float16)v);
 #else

@@ -300,10 +300,11 @@ __global__ __launch_bounds__(256) void unpack_tiled_kernel(const vmm_pack_job* _
 
 // batched (un)pack: packed[(th*TW + tw)*Cp + c][n]  <->  torch[ n*sn + c*sc + (h0 + th*hs)*sh + (w0 + tw*ws)*sw ]
 // the two 16-bit planes of an operand value: split bf16 hi | lo, or -- operand planes of the fp16-operand kernels, fmt | 16 -- IEEE half | 0
-__device__ __forceinline__ void pack16(float v, bool half, unsigned short& hi, unsigned short& lo) {
+__device__ __forceinline__ void pack16(float v, int half, unsigned short& hi, unsigned short& lo) {
   if (half) {
-    hi = __builtin_bit_cast(unsigned short, (_Float16)v);
-    lo = 0;
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = half == 2 ? __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h)) : (unsigned short)0;  // (fmt | 32: fp16 hi | fp16 lo, the `_f16x3` entry points)
   } else {
     const __bf16 h = (__bf16)v;
     hi = __builtin_bit_cast(unsigned short, h);
@@ -313,7 +314,7 @@ __device__ __forceinline__ void pack16(float v, bool half, unsigned short& hi, u
 
 __global__ __launch_bounds__(256) void pack_kernel(const vmm_pack_job* __restrict__ jobs, int direction) {
   vmm_pack_job jb = jobs[blockIdx.y];
-  const bool half = (jb.fmt & 16) != 0;  // formats 1, 2, 3, 5, 6 with fp16 planes (vmm_conv3x3_fp16 and the other `_fp16` entry points)
+  const int half = (jb.fmt & 32) ? 2 : ((jb.fmt & 16) ? 1 : 0);  // formats 1, 2, 3, 5, 6 with fp16 planes: | 16 = fp16 | 0 (`_fp16` entry points), | 32 = fp16 hi | fp16 lo (`_f16x3`)
   jb.fmt &= 15;
   if (direction == 1 && unpack_tile_cb(jb)) return;  // (scattered by unpack_tiled_kernel)
   if (jb.fmt == 1) {
