@@ -105,6 +105,62 @@ def test_two_rank_training_step_equals_one_process_on_the_concatenated_batch(gpu
         assert abs(a - b) < 1e-4 * abs(b)
 
 
+def _fp16_worker(rank, world, port, outdir):
+    """Three fp16 optimisation steps (device-side GradScaler); in step 1 rank 1 ALONE is handed a noise tensor of 1e38 -- its own gradient is not finite."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        B = helpers.CONFIGS[CFG][1][0]
+        tr = _trainer(dev, bucket_floats=200_000)
+        tr.unet.train_precision = "fp16"
+        sl = slice(rank * B, (rank + 1) * B)
+        states, w_after = [], []
+        for step in range(STEPS):
+            x, cond, t, noise, mask = (a[sl].to(dev) for a in _inputs(step))
+            if step == 1 and rank == 1:
+                noise = torch.full_like(noise, 1e38)
+            tr.train_step(x, cond, t=t, noise=noise, mask=mask)
+            torch.cuda.synchronize()
+            states.append(tr.loss_scale_state())
+            w_after.append({k: v.detach().cpu().clone() for k, v in tr.unet.state_dict().items()})
+        torch.save(dict(states=states, weights=w_after), os.path.join(outdir, f"fp16_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fp16_step_takes_the_overflow_decision_on_the_reduced_gradient(gpu, tmp_path):
+    """`train_precision = "fp16"` under data parallelism (main.py:34 + vddp.py:1629-1633 on every rank of Accelerate's DDP): the inf / nan check runs on the
+    ALL-REDUCED gradient buffer, so a rank whose own gradient overflowed and a rank whose gradient was clean take the same decision -- both skip the step, both
+    halve the scale, the replicas stay bit-identical -- and training continues on both."""
+    ctx = mp.get_context("spawn")
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_fp16_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"fp16_rank{r}.pt")) for r in range(2))
+    assert r0["states"] == r1["states"], (r0["states"], r1["states"])
+    s0, s1, s2 = r0["states"]
+    assert (s0["scale"], s0["skipped_steps"], s0["optimizer_steps"]) == (65536.0, 0, 1)
+    assert (s1["scale"], s1["skipped_steps"], s1["optimizer_steps"]) == (32768.0, 1, 1)  # the poisoned step: skipped on BOTH ranks, scale halved
+    assert (s2["scale"], s2["skipped_steps"], s2["optimizer_steps"]) == (32768.0, 1, 2)
+    for step in range(STEPS):
+        for k, w in r0["weights"][step].items():
+            assert torch.equal(w, r1["weights"][step][k]), (step, k)
+            assert torch.isfinite(w).all(), (step, k)
+    some = [k for k in r0["weights"][0] if k.endswith("proj.weight")][:4]
+    for k in some:
+        assert torch.equal(r0["weights"][0][k], r0["weights"][1][k]), k        # nothing moved in the skipped step
+        assert not torch.equal(r0["weights"][1][k], r0["weights"][2][k]), k    # and the next step trained again
+
+
 # ---------------------------------------------------------------------------------------------------------------- sharded sampling
 N_ROWS = 7
 
