@@ -72,6 +72,9 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = vm.Unet3D(**bench.LAGRANGIAN).to(dev).eval()
+    if os.environ.get("VMM_TRACE_PRECISION"):  # e.g. bf16 (the single-pass instances; VMM_TRACE_FP32_STORE=1: over fp32-stored maps, the training legs' form)
+        model.precision = os.environ["VMM_TRACE_PRECISION"]
+        model.bf16_storage = not os.environ.get("VMM_TRACE_FP32_STORE")
     B = 2 * bench.B_PER_GPU
     x = torch.randn(B, 3, bench.T, bench.HW, bench.HW, device=dev)
     t = torch.randint(0, 256, (B,), device=dev)

@@ -935,7 +935,12 @@ template <int WM, int WN, int MAXP, int MODE, int PFB, bool SPLIT, bool F32, boo
 #ifndef VMM_C3_WGS
 #define VMM_C3_WGS 2
 #endif
-__global__ __launch_bounds__(256, VMM_C3_WGS) void conv3x3_x3_kernel(const C3Args a) {
+// (single-pass instances: with a third of the matrix work per chunk the kernel is bound by the latency of its patch loads, not by the matrix pipe -- VMM_C3_ONE_WGS
+// workgroups per CU, i.e. waves per SIMD, for them)
+#ifndef VMM_C3_ONE_WGS
+#define VMM_C3_ONE_WGS 2
+#endif
+__global__ __launch_bounds__(256, (ONE ? VMM_C3_ONE_WGS : VMM_C3_WGS)) void conv3x3_x3_kernel(const C3Args a) {
   conv3x3_x3_body<WM, WN, MAXP, MODE, PFB, SPLIT, F32, 0, ONE, A16>(a);
 }
 
