@@ -50,6 +50,12 @@ constexpr int CK = 32;    // channels per chunk
 #ifndef VMM_C3_ONE_LO
 #define VMM_C3_ONE_LO 0
 #endif
+// Measurement build (-DVMM_C3_PAIR=1; built, parity-green, 2-4 % SLOWER: LABNOTES 11.7): the single-pass unsplit 3 x 3 instances stage channel chunks in PAIRS -- chunk c in
+// the hi half of a patch row, chunk c + 1 in the (otherwise dead) lo half -- so that both patches of a pair are requested together (one exposed HBM round trip per 64 channels
+// instead of two, half the chunk boundaries and barriers) and the prefetch of the next pair has 36 instead of 18 k16 steps to land.
+#ifndef VMM_C3_PAIR
+#define VMM_C3_PAIR 0
+#endif
 constexpr int CROW = 72;  // LDS patch row pitch in bf16: 32 hi | 32 lo | 8 pad = 144 bytes (9 x 16 B: ds_read_b128 over consecutive rows is conflict-free)
 
 struct C3Args {
@@ -251,20 +257,32 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
   // channel chunk -> (sub-pixel, first channel): TS == 2 walks the four sub-pixels of the cell, Cin channels each
   auto sub_of = [&](int cc) { return TS == 2 ? cc >> a.cps_shift : 0; };
   auto chan_of = [&](int cc) { return (TS == 2 ? cc & ((1 << a.cps_shift) - 1) : cc) * CK; };
-  f32x4 preg[MAXP];
+  constexpr bool PAIR = VMM_C3_PAIR && ONE && !SPLIT && !TS && !SK && NJ == 2 && !(MODE == 0 && MAXP > 8);  // (the flat 256-row tile would spill with two register sets)
+  f32x4 pregs[PAIR ? 2 : 1][MAXP];  // patch items in flight (PAIR: set 1 = the second chunk of a pair); every index below is a compile-time constant
+  f32x4 (&preg)[MAXP] = pregs[0];
+  f32x4 cfa2 = {1.f, 0.f, 1.f, 0.f}, cfb2 = cfa2;
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, PAIR ? 1 : 0>;  // (never instantiated with 1 in the chunk-by-chunk instances)
   // GroupNorm * FiLM coefficients of this thread's four channels for the chunk in flight (2-D tiles: one sample per tile).  Requested with
   // the chunk's patch loads, not when the patch is stored: a dependent L2 round trip would otherwise sit on the critical path.
   f32x4 cfa = {1.f, 0.f, 1.f, 0.f}, cfb = cfa;
-  auto load_coef = [&](int cc) {
+  auto load_coef = [&](int cc, int set = 0) {  // (set: compile-time constant at every call site -- PAIR's second chunk keeps its own coefficients)
     const int c0 = cc * CK;
     if (!TS && MODE && p.a_mode == 1 && c0 < p.C1) {
       const float* cf = p.a_coef + ((long long)(img / p.a_imgs_per_sample) * p.C1 + c0 + k4 * 4) * 2;
-      cfa = *reinterpret_cast<const f32x4*>(cf);
-      cfb = *reinterpret_cast<const f32x4*>(cf + 4);
+      if (set) {
+        cfa2 = *reinterpret_cast<const f32x4*>(cf);
+        cfb2 = *reinterpret_cast<const f32x4*>(cf + 4);
+      } else {
+        cfa = *reinterpret_cast<const f32x4*>(cf);
+        cfb = *reinterpret_cast<const f32x4*>(cf + 4);
+      }
     }
   };
-  auto load_patch = [&](int cc) {  // raw loads only, so that they stay in flight under the MFMAs; the operand transform runs at store time
-    load_coef(cc);
+  auto load_patch = [&](int cc, auto SETT) {  // raw loads only, so that they stay in flight under the MFMAs; the operand transform runs at store time
+    constexpr int SET = decltype(SETT)::value;
+    f32x4 (&preg)[MAXP] = pregs[SET];
+    load_coef(cc, SET);
     const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
@@ -288,7 +306,8 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
   // branch in the step -- it used to re-read its own patch (41 KB per workgroup for nothing).  It fetches the epilogue's bias pieces instead:
   // item ps < 8 = the 16 bytes that bias piece (j, g) = (ps >> 2, ps & 3) of this lane needs, so the epilogue finds them in registers.
   constexpr int NBIAS = (!SPLIT && !TS && !IN16) ? (MAXP < 4 * NJ ? MAXP : 4 * NJ) : 0;  // bias pieces that ride in the prefetch registers
-  auto load_patch_item = [&](int cc, int ps, bool last) {
+  auto load_patch_item = [&](int cc, int ps, bool last, auto SETT) {
+    f32x4 (&preg)[MAXP] = pregs[decltype(SETT)::value];
     const int c0 = chan_of(cc);
     const bool src1 = c0 < p.C1;
     const float* src = src1 ? p.a1 : p.a2;
@@ -313,12 +332,15 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
   };
   // (2-D tiles: the patch geometry is a compile-time constant, so only the last item keeps a row test; everything up to the LDS store is
   // selects -- the nested ifs this replaces compiled to three exec-mask branches per item, between the arrival of the patch and the barrier)
-  auto store_patch = [&](int cc) {
+  auto store_patch = [&](int cc, auto SETT) {
+    constexpr int SET = decltype(SETT)::value;
+    constexpr int HOFF = SET * CK;  // PAIR: the pair's second chunk lives in the lo half of the patch rows
+    f32x4 (&preg)[MAXP] = pregs[SET];
     const int c0 = chan_of(cc);
     const bool xform = !TS && c0 < p.C1 && p.a_mode == 1;
     const int rows_per_sample = HW * p.a_imgs_per_sample;
     // GroupNorm * FiLM coefficients of this thread's four channels: one sample per 2-D tile -> fetched once per chunk, not per item
-    f32x4 ca = cfa, cb4 = cfb;
+    f32x4 ca = SET ? cfa2 : cfa, cb4 = SET ? cfb2 : cfb;
 #pragma unroll
     for (int ps = 0; ps < MAXP; ++ps) {
       const int r = (tid >> 3) + ps * 32;
@@ -327,7 +349,7 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
       if constexpr (IN16) {
         unsigned b0 = __float_as_uint(v.x), b1 = __float_as_uint(v.y);
         if (!xform) {  // (wave-uniform) the stored bits are the operand
-          if ((ps + 1) * 32 <= PRc || r < PRc) *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(real ? b0 : 0u, real ? b1 : 0u);
+          if ((ps + 1) * 32 <= PRc || r < PRc) *reinterpret_cast<uint2*>(&Ph[r * CROW + HOFF + k4 * 4]) = make_uint2(real ? b0 : 0u, real ? b1 : 0u);
           continue;
         }
         v = f32x4{__uint_as_float(b0 << 16), __uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 << 16), __uint_as_float(b1 & 0xffff0000u)};
@@ -353,9 +375,9 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
           unsigned h0, l0, h1, l1;
           split2c(v.x, v.y, h0, l0);
           split2c(v.z, v.w, h1, l1);
-          *reinterpret_cast<uint2*>(&Ph[r * CROW + k4 * 4]) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(&Ph[r * CROW + HOFF + k4 * 4]) = make_uint2(h0, h1);
           // (single-pass instances never read the lo half of a patch row: neither stored nor -- its value being dead -- formed.  -DVMM_C3_ONE_LO=1: stored, for A/B)
-          if constexpr (!ONE || VMM_C3_ONE_LO) *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
+          if constexpr (!ONE || (VMM_C3_ONE_LO && !PAIR)) *reinterpret_cast<uint2*>(&Ph[r * CROW + CK + k4 * 4]) = make_uint2(l0, l1);
         }
       }
     }
@@ -408,7 +430,7 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
 #endif
   constexpr bool ZROWS = VMM_C3_ZERO_ROWS && !MODE;
   const int zb = PRc * CROW;  // element offset of the zero rows
-  auto load_a = [&](uint4 (&d)[4], int tap, int s) {
+  auto load_a = [&](uint4 (&d)[4], int tap, int s, int hoff = 0) {  // hoff (PAIR): CK for the pair's second chunk
     const int kh = tap / 3, kw = tap % 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -425,7 +447,7 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
       } else {
         q = TS ? Ph + abase[i][1] + (((kh - 1) * pitch + kw) * CROW + s * 16) : Ph + abase[i][kh] + (kw * CROW + s * (F32 ? 32 : 16));
       }
-      uint4 vh = *reinterpret_cast<const uint4*>(q);
+      uint4 vh = *reinterpret_cast<const uint4*>(q + hoff);
       if constexpr (ONE) {
         if (!ZROWS && !ok) vh = make_uint4(0u, 0u, 0u, 0u);
         d[2 * i] = vh;
@@ -516,97 +538,166 @@ __device__ __forceinline__ void conv3x3_x3_tile(const C3Args& a, const int tile_
     return (tr0 + (q >> 2)) * 3 + tc0 + ((q >> 1) & 1);
   };
   auto ks_of = [&](int cc, int q) { return tap_of(cc, q) * cin16 + cc * 2 + (q & 1); };
-  load_patch(c_begin);
+  if constexpr (PAIR) {
+    // ---- chunk pairs (see VMM_C3_PAIR): chunk cc in the hi half of the patch rows, chunk cc + 1 in the lo half; both requested together, one barrier pair per PAIR
+    const bool has2_first = c_begin + 1 < c_end;
+    load_patch(c_begin, Set0{});
+    if (has2_first) load_patch(c_begin + 1, Set1{});
 #pragma unroll
-  for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
-  stamp(1);
-  store_patch(c_begin);
-  if constexpr (ZROWS)
-    for (int i = tid; i < 3 * CROW / 2; i += 256) reinterpret_cast<unsigned*>(Ph + zb)[i] = 0u;  // (stays zero: no patch store reaches row PR)
-  stamp(2);
-  __syncthreads();
-  stamp(3);
-  load_a(aa[0], tap_of(c_begin, 0), 0);
-  for (int cc = c_begin; cc < c_end; ++cc) {
-    const bool more = cc + 1 < c_end;
-    const int nxt = more ? cc + 1 : cc;
-    // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
-    // instead of being hoisted out of the loop into 36 address registers
+    for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
+    stamp(1);
+    store_patch(c_begin, Set0{});
+    if (has2_first) store_patch(c_begin + 1, Set1{});
+    if constexpr (ZROWS)
+      for (int i = tid; i < 3 * CROW / 2; i += 256) reinterpret_cast<unsigned*>(Ph + zb)[i] = 0u;  // (stays zero: no patch store reaches row PR)
+    stamp(2);
+    __syncthreads();
+    stamp(3);
+    load_a(aa[0], tap_of(c_begin, 0), 0);
+    // the 18 k16 steps of chunk `cc` (half HALF of the patch rows); during them: the weight fragments run on into chunk `nxt_w`, one patch item per step of chunk
+    // `nxt_p` is requested into register set HALF (`last_p`: nothing left to prefetch -- the epilogue's bias pieces instead), and the last step requests the first
+    // patch fragments of the pair's second chunk when it follows without a barrier (`a_next_tap` >= 0)
+    auto steps = [&](auto HT, int cc, int nxt_w, int nxt_p, bool last_p, int a_next_tap) {
+      constexpr int HALF = decltype(HT)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
+        for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      // (the prefetches are issued for the last chunk too -- they re-read it: a wave-uniform branch around them is still a basic-block
-      // boundary in the middle of the step, i.e. requests in one lump between the MFMA groups)
-      if (q + PFB < NQ) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
-      else load_b(bb[(q + PFB) % NB], ks_of(nxt, q + PFB - NQ));
-      if (q == 0) load_coef(nxt);
-      if (TS) {  // eight steps for up to eleven patch items: two per step
-        if (2 * q < MAXP) load_patch_item(nxt, 2 * q, false);
-        if (2 * q + 1 < MAXP) load_patch_item(nxt, 2 * q + 1, false);
-      } else if (q < MAXP) {
-        load_patch_item(nxt, q, !more);
-      }
-      if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
-      if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-      mma_step(aa[q & 1], bb[q % NB]);
-      if constexpr (C3_INTERLEAVE && NJ == 1) {  // six MFMAs: two weight-fragment requests, four LDS fragment reads, the step's patch item
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-      if constexpr (C3_INTERLEAVE && !ONE && NJ == 2) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
-        // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
-        // longest way), not in front of them as one block during which the matrix pipe runs dry
+      for (int q = 0; q < NQ; ++q) {
+        if (q + PFB < NQ) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
+        else load_b(bb[(q + PFB) % NB], ks_of(nxt_w, q + PFB - NQ));
+        if (q == 0) load_coef(nxt_p, HALF);
+        if (q < MAXP) load_patch_item(nxt_p, q, last_p, HT);
+        if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1, HALF * CK);
+        else if (HALF == 0 && a_next_tap >= 0) load_a(aa[(q + 1) & 1], a_next_tap, 0, CK);  // (NQ is even: slot 0, as the chunk top expects)
+        if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+        mma_step(aa[q & 1], bb[q % NB]);
+        if constexpr (C3_INTERLEAVE) {  // single pass: four MFMAs, two weight-fragment requests, two LDS fragment reads per step
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one vector-memory read
+          for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the patch prefetch item(s) of this step, if any
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (C3_INTERLEAVE && ONE) {  // single pass: four MFMAs, two weight-fragment requests, two LDS fragment reads per step
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+    };
+    static_assert(NQ % 2 == 0, "the patch-fragment double buffer must close at a chunk boundary");
+    for (int cc = c_begin; cc < c_end; cc += 2) {
+      const bool has2 = cc + 1 < c_end, more = cc + 2 < c_end, more2 = cc + 3 < c_end;
+      steps(Set0{}, cc, has2 ? cc + 1 : (more ? cc + 2 : cc), more ? cc + 2 : cc, !more, has2 ? tap_of(cc + 1, 0) : -1);
+      if (has2) steps(Set1{}, cc + 1, more ? cc + 2 : cc + 1, more2 ? cc + 3 : cc + 1, !more2, -1);
+      stamp(4 + (cc - c_begin));
+      if (more) {
+        __syncthreads();  // every wave is done reading the patches of the pair
+        store_patch(cc + 2, Set0{});
+        if (more2) store_patch(cc + 3, Set1{});
+        __syncthreads();
+        stamp(5 + (cc - c_begin));
+        load_a(aa[0], tap_of(cc + 2, 0), 0);
+      }
+    }
+  } else {
+    load_patch(c_begin, Set0{});
+  #pragma unroll
+    for (int q = 0; q < PFB; ++q) load_b(bb[q], ks_of(c_begin, q));
+    stamp(1);
+    store_patch(c_begin, Set0{});
+    if constexpr (ZROWS)
+      for (int i = tid; i < 3 * CROW / 2; i += 256) reinterpret_cast<unsigned*>(Ph + zb)[i] = 0u;  // (stays zero: no patch store reaches row PR)
+    stamp(2);
+    __syncthreads();
+    stamp(3);
+    load_a(aa[0], tap_of(c_begin, 0), 0);
+    for (int cc = c_begin; cc < c_end; ++cc) {
+      const bool more = cc + 1 < c_end;
+      const int nxt = more ? cc + 1 : cc;
+      // keep the six patch bases opaque per chunk: the 18 per-step addresses then stay base + immediate (ds_read offset field)
+      // instead of being hoisted out of the loop into 36 address registers
+  #pragma unroll
+      for (int i = 0; i < 2; ++i)
+  #pragma unroll
+        for (int kh = 0; kh < 3; ++kh) asm volatile("" : "+v"(abase[i][kh]));
+  #pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        // (the prefetches are issued for the last chunk too -- they re-read it: a wave-uniform branch around them is still a basic-block
+        // boundary in the middle of the step, i.e. requests in one lump between the MFMA groups)
+        if (q + PFB < NQ) load_b(bb[(q + PFB) % NB], ks_of(cc, q + PFB));
+        else load_b(bb[(q + PFB) % NB], ks_of(nxt, q + PFB - NQ));
+        if (q == 0) load_coef(nxt);
+        if (TS) {  // eight steps for up to eleven patch items: two per step
+          if (2 * q < MAXP) load_patch_item(nxt, 2 * q, false, Set0{});
+          if (2 * q + 1 < MAXP) load_patch_item(nxt, 2 * q + 1, false, Set0{});
+        } else if (q < MAXP) {
+          load_patch_item(nxt, q, !more, Set0{});
+        }
+        if (q + 1 < NQ) load_a(aa[(q + 1) & 1], tap_of(cc, q + 1), (q + 1) & 1);
+        if constexpr (!C3_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+        mma_step(aa[q & 1], bb[q % NB]);
+        if constexpr (C3_INTERLEAVE && NJ == 1) {  // six MFMAs: two weight-fragment requests, four LDS fragment reads, the step's patch item
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        if constexpr (C3_INTERLEAVE && !ONE && NJ == 2) {  // (fp32 variant: 32 MFMAs of 64 cycles per step, the requests go between the first nine)
+          // nothing queues behind the MFMA in flight: the requests above go BETWEEN this step's MFMAs (weight fragments first: they have the
+          // longest way), not in front of them as one block during which the matrix pipe runs dry
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one vector-memory read
+          }
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the patch prefetch item(s) of this step, if any
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        if constexpr (C3_INTERLEAVE && ONE) {  // single pass: four MFMAs, two weight-fragment requests, two LDS fragment reads per step
+  #pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+  #pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      stamp(4 + 2 * (cc - c_begin));
+      if (more) {
+        __syncthreads();  // every wave is done reading the patch of chunk cc
+        store_patch(cc + 1, Set0{});
+        __syncthreads();
+        stamp(5 + 2 * (cc - c_begin));
+        load_a(aa[0], tap_of(cc + 1, 0), 0);
+      }
     }
-    stamp(4 + 2 * (cc - c_begin));
-    if (more) {
-      __syncthreads();  // every wave is done reading the patch of chunk cc
-      store_patch(cc + 1);
-      __syncthreads();
-      stamp(5 + 2 * (cc - c_begin));
-      load_a(aa[0], tap_of(cc + 1, 0), 0);
-    }
+
   }
 
   // epilogue.  Split channel reduction (gridDim.y > 1): the splits of one output tile add their partial sums in split order, so the
