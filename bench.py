@@ -270,6 +270,7 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
                           else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32"),
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
            "arena_GB": round(pl.arena_floats * 4 / 1e9, 2), "launches_per_step": len(pl.steps) + len(pl.bwd_steps),
+           "launches_note": "entry-point calls of the plan; kernel launches per step by rocprofv3: profiles/r06_c_train_kernels_*.txt (735)",
            "attention": ("fused blocks forward (no qkv rows / attention outputs / softmax statistics stored), recomputing backward kernels at the C = 64 sites"
                          if any("_block_bwd_" in fn.__name__ for fn, _, _ in pl.bwd_steps) else "unfused (qkv rows through HBM)"),
            "grad_allreduce_MB": round(pl.pgrad_floats * 4 / 1e6, 1), "allreduce_buckets": len(tr._reducer.launched) if (world > 1 or rehearse) else 0,

@@ -99,7 +99,7 @@ def worker(rank, n, cfg, q):
         for i in range(n):
             model.zero_grad(set_to_none=True)
             loss = diff.p_losses(xs * 2 - 1, ts, cond=cond, noise=nz_, null_cond_prob=0.0)
-            loss.backward()
+            (loss * float(os.environ.get("STRESS_LOSS_SCALE", "1"))).backward()  # (STRESS_PREC=fp16: 65536, the GradScaler's initial scale)
             torch.cuda.synchronize()
             gr = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None}
             if ref is None:
