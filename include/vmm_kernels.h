@@ -327,7 +327,7 @@ int vmm_temporal_attention(const float* qkv, int32_t ldqkv, const float* ek, con
 /* ---- cond_attention = 'cross-attention' (vddp.py:354-363, 476-485): queries from to_q, keys / values = the conditioning tokens alone.
  * Softmax flavour (mid spatial site: bias NULL; temporal sites: bias [heads][T][T] added to the (frames x tokens) scores, ntok == T as in the
  * reference): out[row, head*dh + e] = sum_j softmax_j(q[row, head] . ek[b][j][head] (+ bias[head][t][j])) ev[b][j][head*dh + e]; q rows
- * [(b, t, pixel)] x heads*dh (ldq), pre-scaled / pre-rotated by the projection epilogue; ek / ev [B][ntok][heads*dh], ntok <= 32. */
+ * [(b, t, pixel)] x heads*dh (ldq), pre-scaled / pre-rotated by the projection epilogue; ek / ev [B][ntok][heads*dh], ntok <= 64. */
 int vmm_cross_attention(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* bias, float* out, int32_t ldo,
                         int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream);
 /* linear flavour: the context ctx[(b, t, head)][dh][dh] = softmax_j(ek[b][j])^T ev[b][j] / HW of the tokens alone (every frame of a sample gets
@@ -338,7 +338,7 @@ int vmm_linattn_cross_context(const float* ek, const float* ev, int32_t ntok, in
  * vmm_cross_attention_bwd: q = the rows the forward consumed, dout [rows][heads*dh]; writes dq = the gradient of the RAW to_q output (the
  * projection epilogue's rotation -- rot_tab [T][dh/2][2] (cos, sin) or NULL -- and q_scale are undone here), ADDS the token gradients into
  * dek / dev [B][ntok][heads*dh] and the bias gradient into dbias [heads][T][T] (NULL allowed).  Any number of heads <= 64, dh a multiple of 4
- * in 4..128 (the temporal sites follow attn_dim_head, vddp.py:615), ntok <= 32; scratch = vmm_cross_attention_bwd_scratch floats (0 -- and NULL
+ * in 4..128 (the temporal sites follow attn_dim_head, vddp.py:615), ntok <= 64; scratch = vmm_cross_attention_bwd_scratch floats (0 -- and NULL
  * accepted -- where the one-pass kernel applies: 8 heads of 32, at most 16 tokens; otherwise the per-row ds / p records of the two-pass form).
  * vmm_linattn_cross_bwd: ctx / kstat as vmm_linattn_cross_context left them, dctx = [B*T*heads][dh*dh] scratch; writes dq, ADDS dek / dev. */
 int64_t vmm_cross_attention_bwd_scratch(int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t ntok);

@@ -93,6 +93,10 @@ CONFIGS = {
     "k3": (dict(dim=16, channels=1, init_kernel_size=3, padding_mode="circular"), (2, 4, 16, 16), 51),
     "k9w64": (dict(dim=64, channels=3, init_kernel_size=9, init_dim=64, cond_attention="self-stacked", cond_attention_tokens=16,
                    use_temporal_attention_cond=True, per_frame_cond=True, cond_bias=True), (1, 11, 16, 16), 11),
+    # cross-attention on GRU tokens (vddp.py:546-549 + 354-363): one token per sample of the conditioning signal -- 40 here, 51 for the stress-strain curves --,
+    # spatial sites only (the temporal sites' positional bias needs tokens == frames): more tokens than the softmax cross-attention kernel held until round 6
+    "crossgru16": (dict(dim=16, channels=3, cond_attention="cross-attention", cond_attention_tokens=40, use_temporal_attention_cond=False, per_frame_cond=False,
+                        cond_att_GRU=True), (2, 5, 16, 16), 40),
     # channels (vddp.py:576, 624; main.py:63 passes len(selected_channels)): more than the four of an RGBA GIF -- the stem kernel's K order holds four
     # channels per tap, wider inputs take the generic implicit GEMM over rows padded to a multiple of four; Lagrangian wiring at dim 16, defaults at the
     # real widths (where four or fewer channels would take the stem kernel)

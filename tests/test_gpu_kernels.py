@@ -887,13 +887,16 @@ def test_weight_gradient_scatter_batched(gpu):
         assert torch.equal(tw_.cpu(), ref), spec
 
 
-@pytest.mark.parametrize("B,T,HW,ntok,with_bias", [(2, 6, 20, 6, True), (3, 4, 33, 9, False), (1, 11, 64, 11, True), (2, 3, 7, 32, False), (2, 5, 16, 1, False)])
+@pytest.mark.parametrize("B,T,HW,ntok,with_bias", [(2, 6, 20, 6, True), (3, 4, 33, 9, False), (1, 11, 64, 11, True), (2, 3, 7, 32, False), (2, 5, 16, 1, False),
+                                                   (2, 2, 40, 51, False), (1, 3, 9, 64, False)])  # (51: the stress-strain signal as GRU tokens; 64: the kernel's limit)
 @pytest.mark.parametrize("heads,dh", [(8, 32), (4, 32), (3, 32), (8, 64), (2, 16), (5, 24), (1, 128)])
 def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias, heads, dh):
     """cond_attention = 'cross-attention' (vddp.py:354-363, 476-485): softmax attention of every (row, head) over the sample's conditioning tokens
     (+ the relative-position bias on the temporal sites, tokens == frames), and the linear-attention context of the tokens alone followed by
     the unchanged apply pass; both against the einsum restatement of the reference lines."""
     N, lib = _lib()
+    if 8 * ntok * heads * (dh + 1) > 160 * 1024:
+        pytest.skip("the sample's token keys / values do not fit the CU's 160 KB of LDS at this head width (the entry point returns -1)")
     hid = heads * dh  # (dh: the temporal sites follow attn_dim_head, vddp.py:615; the linear flavour below is always 32 wide)
     g = torch.Generator().manual_seed(31 + ntok)
     rows = B * T * HW
@@ -934,7 +937,7 @@ def test_cross_attention_kernels(gpu, B, T, HW, ntok, with_bias, heads, dh):
 
 
 @pytest.mark.parametrize("B,T,HW,ntok,with_bias,rotate", [(2, 6, 20, 6, True, True), (3, 4, 33, 9, False, False), (1, 11, 150, 11, True, True),
-                                                         (2, 5, 3400, 16, False, False), (2, 5, 16, 1, False, False)])
+                                                         (2, 5, 3400, 16, False, False), (2, 5, 16, 1, False, False), (2, 2, 40, 51, False, False), (1, 3, 9, 64, False, True)])
 @pytest.mark.parametrize("heads,dh", [(8, 32), (4, 32), (3, 32), (8, 64), (2, 16), (5, 24), (1, 128)])
 def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate, heads, dh):
     """Backward of the two cross-attention cores against torch autograd through the einsum restatement of vddp.py:354-363 / 476-485, including what
@@ -942,6 +945,8 @@ def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate
     gradients are ADDED to what the buffers hold."""
     N, lib = _lib()
     from videometamaterials_amd import hostmath
+    if 8 * ntok * heads * (dh + 1) > 160 * 1024:
+        pytest.skip("the sample's token keys / values do not fit the CU's 160 KB of LDS at this head width (the entry point returns -1)")
     if (heads, dh) != (8, 32) and HW > 1000:
         pytest.skip("the two-pass form: the small shapes")
     hid = heads * dh
@@ -974,7 +979,7 @@ def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate
     dek, dev_ = torch.full((B, ntok, hid), base, device=gpu), torch.full((B, ntok, hid), base, device=gpu)
     dbias = torch.full((heads, T, T), base, device=gpu) if with_bias else None
     nsc = int(lib.vmm_cross_attention_bwd_scratch(B, T, HW, heads, dh, ntok))
-    assert (nsc == 0) == ((heads, dh) == (8, 32))  # (the one-pass kernel: 8 heads of 32, at most 16 tokens)
+    assert (nsc == 0) == ((heads, dh) == (8, 32) and ntok <= 16)  # (the one-pass kernel: 8 heads of 32, at most 16 tokens)
     sc = torch.full((max(nsc, 1),), float("nan"), device=gpu)
     rc = lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), ntok, bg.data_ptr() if with_bias else None, gog.data_ptr(), hid,
                                      rotg.data_ptr() if rotate else None, scale, dq.data_ptr(), hid, dek.data_ptr(), dev_.data_ptr(),
@@ -988,8 +993,8 @@ def test_cross_attention_backward_kernels(gpu, B, T, HW, ntok, with_bias, rotate
     assert relerr(dev_.cpu() - base, ev.grad) < 2e-5
     if with_bias:
         assert relerr(dbias.cpu() - base, bias.grad) < 2e-5
-    assert lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), 33, None, gog.data_ptr(), hid, None, scale, dq.data_ptr(), hid,
-                                       dek.data_ptr(), dev_.data_ptr(), None, sc.data_ptr(), B, T, HW, heads, dh, _s()) == -1  # more than 32 tokens
+    assert lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), 65, None, gog.data_ptr(), hid, None, scale, dq.data_ptr(), hid,
+                                       dek.data_ptr(), dev_.data_ptr(), None, sc.data_ptr(), B, T, HW, heads, dh, _s()) == -1  # more than 64 tokens
     assert lib.vmm_cross_attention_bwd(q_used.data_ptr(), hid, ekg.data_ptr(), evg.data_ptr(), 17, None, gog.data_ptr(), hid, None, scale, dq.data_ptr(), hid,
                                        dek.data_ptr(), dev_.data_ptr(), None, None, B, T, HW, heads, dh, _s()) == -1  # the two-pass form without its scratch
     if dh != 32:

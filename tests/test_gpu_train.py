@@ -137,7 +137,7 @@ def test_backward_matches_reference_golden_gradients_off_default_constructor_key
 
 @pytest.mark.parametrize("cfg_name,mask_val", [("lagr16", False), ("lagr16", True), ("plumb16", False), ("hires16", False), ("lagr64", False),
                                                ("hires64t22", False), ("circ64", False), ("circ1d16", False), ("cross16", False), ("cross64", False),
-                                               ("cross64", True), ("cross16s", False), ("concat16", False), ("concat16", True), ("concat16c", False), ("gru16", False), ("gru16", True),
+                                               ("cross64", True), ("cross16s", False), ("crossgru16", False), ("crossgru16", True), ("concat16", False), ("concat16", True), ("concat16c", False), ("gru16", False), ("gru16", True),
                                                # constructor keywords off their defaults (vddp.py:575-626)
                                                ("heads4", False), ("heads3", False), ("heads3", True), ("dh16", False), ("dh64", True), ("dh64w64", False),
                                                ("dh16w64", False), ("dh64cross", False), ("dh24", False), ("groups4", False), ("groups16w64", False),

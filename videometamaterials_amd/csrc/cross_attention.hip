@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int DH = 32, TOK_MAX = 32, HSTR = DH + 1;  // (head stride 33 floats: the eight heads of a row hit eight banks)
+constexpr int DH = 32, TOK_MAX = 64, HSTR = DH + 1;  // (head stride 33 floats: the eight heads of a row hit eight banks)
 
 // thread = (row, head); grid (row blocks of a sample, B); ek / ev of the sample in LDS as [token][head][dh + 1]
 // (templated on the head slice, head_vec.h: the temporal sites follow attn_dim_head, vddp.py:615; 32 everywhere else)
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_tokens_kernel(const float*
 // to_q output (rot_tab [T][dh/2][2] (cos, sin) or NULL, q_scale: the projection epilogue undone); ADDS the token gradients into dek / dev
 // [B][ntok][heads*dh] and the bias gradient into dbias [heads][T][T] (may be NULL; only with bias).  scratch: vmm_cross_attention_bwd_scratch
 // floats (0 inside the fused kernel's envelope -- 8 heads of 32, at most 16 tokens -- where NULL is accepted).  -1: dh not a multiple of 4
-// in 4..128, ntok outside 1..32, bias with ntok != T, misaligned rows, a missing scratch.
+// in 4..128, ntok outside 1..64, bias with ntok != T, misaligned rows, a missing scratch.
 extern "C" int64_t vmm_cross_attention_bwd_scratch(int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, int32_t ntok) {
   if (dh == DH && heads == 8 && ntok <= BT_MAX) return 0;
   return 2 * (int64_t)B * T * HW * heads * ntok;
@@ -416,7 +416,7 @@ extern "C" int vmm_cross_attention_bwd(const float* q, int32_t ldq, const float*
 
 // out[row, head*dh + e] = sum_j softmax_j(q[row, head] . ek[b][j][head] (+ bias[head][t(row)][j])) ev[b][j][head*dh + e]; q rows [(b, t, pixel)] x
 // heads*dh (ldq), already scaled (and rotated for the temporal sites) by the projection's epilogue; ek / ev [B][ntok][heads*dh]; bias [heads][T][T]
-// or NULL (then T only sizes the sample: rows per sample = T * HW).  -1: dh not a multiple of 4 in 4..128, ntok outside 1..32, bias with ntok != T,
+// or NULL (then T only sizes the sample: rows per sample = T * HW).  -1: dh not a multiple of 4 in 4..128, ntok outside 1..64, bias with ntok != T,
 // misaligned rows, more than 64 heads.
 extern "C" int vmm_cross_attention(const float* q, int32_t ldq, const float* ek, const float* ev, int32_t ntok, const float* bias, float* out, int32_t ldo,
                                    int32_t B, int32_t T, int32_t HW, int32_t heads, int32_t dh, vmm_stream_t stream) {

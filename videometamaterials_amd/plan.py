@@ -1381,8 +1381,8 @@ class _Builder:
         if temporal and ntok != T:
             raise ValueError(f"cross-attention at the temporal sites adds the ({T} x {T}) positional bias to the ({T} x {ntok}) scores: "
                              "cond_attention_tokens must equal the number of frames (vddp.py:513)")
-        if ntok > 32:
-            raise NotImplementedError("cross-attention with more than 32 conditioning tokens")
+        if ntok > 64:  # (a row's scores live in registers: csrc/cross_attention.hip TOK_MAX; the 51-point stress-strain signal as GRU tokens fits)
+            raise NotImplementedError("cross-attention with more than 64 conditioning tokens")
         pj = self.proj_ok(x.C, hid) and hid % 32 == 0 and (not temporal or dh % 32 == 0 or 32 % dh == 0)
         ln_tr = self.ln_fused_training_ok(x.C, hid)
         fuse_ln = pj and (not self.training or ln_tr)  # (training: the LayerNorm statistics stay for the weight gradient, as at the to_qkv sites)
