@@ -264,10 +264,10 @@ def bench_training(vm, model, diff, dev, dist, world, rank, steps: int, precisio
                           else "fp16: ONE MFMA pass on fp16-rounded operands (the reference's autocast dtype, main.py:34) in forward, data gradients, 3x3 / 1x1 / to_qkv weight "
                                "gradients, the generic implicit GEMM and the recomputing attention backward (whose qkv-row gradient travels as fp16 operands: same operand "
                                "bits, half the bytes); device-side GradScaler (2^16, backoff 0.5 on a non-finite gradient, growth 2 per 2000 clean steps: vddp.py:1629-1633); "
-                               "fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "fp16"
+                               "fp32 master weights, activations, accumulation, norms, softmax, Adam; the 4x4 / 7x7 weight gradients on the same operands (tap-decoding 1x1 kernel)" if precision == "fp16"
                           else "bf16: ONE MFMA pass on bf16-rounded operands in forward, data gradients, 3x3 / 1x1 / to_qkv weight gradients and the recomputing attention "
-                               "backward; fp32 master weights, activations, accumulation, norms, softmax, Adam; 4x4 / 7x7 weight gradients exact fp32" if precision == "bf16"
-                          else "bf16x3: forward, data gradients and 3x3 weight gradients split-bf16 MFMA (fp32-class), other weight gradients exact fp32"),
+                               "backward; fp32 master weights, activations, accumulation, norms, softmax, Adam; the 4x4 / 7x7 weight gradients on the same operands" if precision == "bf16"
+                          else "bf16x3: forward, data gradients and all convolution / projection weight gradients split-bf16 MFMA (fp32-class)"),
            "loss": float(loss), "gemm_TFLOP_per_step": round(fl / 1e12, 3), "achieved_gemm_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
            "arena_GB": round(pl.arena_floats * 4 / 1e9, 2), "launches_per_step": len(pl.steps) + len(pl.bwd_steps),
            "launches_note": "entry-point calls of the plan; kernel launches per step by rocprofv3: profiles/r06_c_train_kernels_*.txt (735)",

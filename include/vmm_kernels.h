@@ -166,6 +166,13 @@ int vmm_conv1x1_wgrad_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t ld
  * it is staged, x[r][ci] = (a1[r][ci] - mean[r]) * rstd[r] * ln_gamma[ci] with (mean, rstd) = ln_stats[r][2]; single source (C2 == 0) */
 int vmm_conv1x1_wgrad_bf16x3_ln(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* workspace, const float* ln_stats,
                                 const float* ln_gamma, vmm_stream_t stream);
+/* The same kernel for ANY convolution geometry the descriptor states (round 6; the exact-fp32 vmm_conv_wgrad_f32 before): kernel size, stride, tap direction (sgn: the phases
+ * of the transposed convolutions), output scatter (oscale / ooh / oow), zero or periodic padding -- the 4 x 4 stride-2 layers (vddp.py:139-151), their transposed twins phase by
+ * phase, the 7 x 7 stem.  dw_packed[(kh, kw, ci)][co] += sum over output rows; dbias[co] += column sums of the dY rows the call visits.  The loader decodes its eight
+ * wave-uniform output rows on the scalar unit and offsets them by the lane's tap.  Envelope: no fused operand transform, even channel counts, KH KW (C1 + C2) a multiple
+ * of 4, Hv Wv >= 2; workspace = vmm_conv_wgrad_tap_workspace floats (0 = outside); d->defer_reduce + vmm_conv_wgrad_tap_reduce_job as for the 1 x 1 form. */
+int64_t vmm_conv_wgrad_tap_workspace(const vmm_conv_desc* d, int32_t lddy);
+int vmm_conv_wgrad_tap_bf16x3(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_stream_t stream);
 /* Backward of to_qkv at the C = 64 levels in ONE pass over the gradient g of the qkv rows (rows x 768): gy = g W (rows x 64, plain store) and
  * dw_packed[c][n] += sum_r g[r][n] y[r][c], y = x (ln_stats NULL) or the channel LayerNorm of x re-formed from ln_stats [rows][2] = (mean, rstd) and
  * ln_gamma [64] (vmm_proj_bf16x3_ln_stats).  w_frag = vmm_pack_weights fmt 2 of the (K = 768, N = 64) operand, i.e. the torch weight (768, 64) as the
@@ -200,6 +207,7 @@ typedef struct vmm_reduce_job {
 } vmm_reduce_job;
 int vmm_conv3x3_wgrad_reduce_job(const vmm_conv_desc* d, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job);
 int vmm_conv1x1_wgrad_reduce_job(const vmm_conv_desc* d, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job);
+int vmm_conv_wgrad_tap_reduce_job(const vmm_conv_desc* d, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job);
 int vmm_reduce_batch(const vmm_reduce_job* jobs_dev, int32_t njobs, int32_t total_wgs, vmm_stream_t stream);
 /* out[j] += sum_m x[m, j] (bias gradients and other per-channel reductions) */
 int vmm_colsum_accumulate(const float* x, int32_t ldx, int64_t rows, int32_t C, float* out, vmm_stream_t stream);
@@ -641,6 +649,7 @@ int vmm_temporal_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream
 int vmm_dqkv_widen_bf16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
 /* the generic implicit GEMM of those legs (the layers no specialised kernel takes: to_qkv and its data gradient at C >= 128, res_conv, the transposed
  * convolutions' phases): vmm_conv_igemm_bf16x3 / _batched with ONE matrix pass; the same fmt-1 weight planes (the lo plane is not read) */
+int vmm_conv_wgrad_tap_bf16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_stream_t stream);
 int vmm_conv_igemm_bf16(const vmm_conv_desc* d, vmm_stream_t stream);
 int vmm_conv_igemm_bf16_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream);
 int vmm_linattn_block_bwd_bf16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
@@ -754,6 +763,7 @@ int vmm_temporal_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream
 int vmm_linattn_block_bwd_fp16(const vmm_attn_block_bwd* d, vmm_stream_t stream);
 int vmm_dqkv_widen_fp16(const void* src, float* dst, int64_t n, vmm_stream_t stream);
 /* (weights: vmm_pack_weights fmt 1 | 16 -- IEEE-half hi plane) */
+int vmm_conv_wgrad_tap_fp16(const vmm_conv_desc* d, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_stream_t stream);
 int vmm_conv_igemm_fp16(const vmm_conv_desc* d, vmm_stream_t stream);
 int vmm_conv_igemm_fp16_batched(const vmm_conv_desc* descs, int32_t n, vmm_stream_t stream);
 

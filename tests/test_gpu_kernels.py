@@ -1154,6 +1154,102 @@ def test_conv1x1_weight_gradient_bf16x3(gpu, rows, C1, C2, Cout, bias):
     assert lib.vmm_conv1x1_wgrad_bf16x3_workspace(C.byref(d), Cout) == 0
 
 
+@pytest.mark.parametrize("variant,tol", [("bf16x3", 5e-5), ("fp16", 2e-3), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("geom", ["down", "down_two_sources", "up", "stem7", "circ3", "down_small"])
+def test_conv_weight_gradient_any_geometry_on_the_matrix_cores(gpu, geom, variant, tol):
+    """vmm_conv_wgrad_tap_*: the weight (and bias) gradient of whatever convolution the descriptor states, against torch autograd in fp64 -- the (1,4,4) stride-2
+    Downsample (vddp.py:139-151), the four 2 x 2 phases of the transposed Upsample (their packed slots are the taps kh = 1 - ph + 2 kh'), the 7 x 7 stem over rows
+    padded to four channels, a periodic 3 x 3 layer (the nine-tap kernel declines those); += semantics, partial last chunk, more workgroups than chunks."""
+    N, lib = _lib()
+    g = torch.Generator().manual_seed(11)
+    fn = getattr(lib, "vmm_conv_wgrad_tap_" + variant)
+
+    def rows(t):  # (n, c, h, w) -> [(n, h, w)][c]
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+    def run(d, xs, dy, K, Cout, want_w, want_b):
+        x1 = rows(xs[0]).float().to(gpu)
+        x2 = rows(xs[1]).float().to(gpu) if len(xs) > 1 else None
+        dyg = rows(dy).float().to(gpu)
+        d.a1, d.C1, d.lda1 = x1.data_ptr(), x1.shape[1], x1.shape[1]
+        if x2 is not None:
+            d.a2, d.C2, d.lda2 = x2.data_ptr(), x2.shape[1], x2.shape[1]
+        d.Cout = Cout
+        n_ws = int(lib.vmm_conv_wgrad_tap_workspace(C.byref(d), Cout))
+        assert n_ws > 0
+        outs = []
+        for _ in range(2):
+            ws = torch.full((n_ws,), float("nan"), device=gpu)
+            dw = torch.full((K, Cout), 0.5, device=gpu)
+            db = torch.full((Cout,), 0.25, device=gpu)
+            assert fn(C.byref(d), dyg.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), _s()) == 0
+            torch.cuda.synchronize()
+            assert relerr(dw.cpu().double() - 0.5, want_w) < tol, geom
+            assert relerr(db.cpu().double() - 0.25, want_b) < max(tol / 10, 3e-6), geom
+            outs.append(dw)
+        assert torch.equal(outs[0], outs[1])
+
+    if geom in ("down", "down_two_sources", "down_small"):
+        nimg, H, W, C1, C2, Cout = {"down": (3, 16, 24, 64, 0, 64), "down_two_sources": (2, 8, 8, 64, 64, 128), "down_small": (1, 4, 4, 8, 0, 12)}[geom]
+        Cin = C1 + C2
+        x = torch.randn(nimg, Cin, H, W, generator=g).double()
+        w = (torch.randn(Cout, Cin, 4, 4, generator=g) / 16).double().requires_grad_()
+        b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, w, b, stride=2, padding=1)
+        dy = torch.randn(y.shape, generator=g).double()
+        y.backward(dy)
+        d = N.ConvDesc()
+        d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H // 2, W // 2, 2
+        d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 4, 4, -1, -1, 1, 1
+        d.Hout, d.Wout, d.oscale = H // 2, W // 2, 1
+        run(d, [x[:, :C1]] + ([x[:, C1:]] if C2 else []), dy, 16 * Cin, Cout, w.grad.permute(2, 3, 1, 0).reshape(16 * Cin, Cout), b.grad)
+    elif geom == "up":
+        nimg, H, W, Cin, Cout = 2, 8, 12, 64, 64
+        x = torch.randn(nimg, Cin, H, W, generator=g).double()
+        w = (torch.randn(Cin, Cout, 4, 4, generator=g) / 16).double().requires_grad_()
+        b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+        dy = torch.randn(y.shape, generator=g).double()
+        y.backward(dy)
+        for ph in range(2):
+            for pw in range(2):
+                d = N.ConvDesc()
+                d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+                d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 2, 2, ph, pw, -1, -1
+                d.Hout, d.Wout, d.oscale, d.ooh, d.oow = 2 * H, 2 * W, 2, ph, pw
+                want = w.grad[:, :, 1 - ph::2, 1 - pw::2].permute(2, 3, 0, 1).reshape(4 * Cin, Cout)  # [(kh', kw', ci)][co], kh = 1 - ph + 2 kh'
+                want_b = dy[:, :, ph::2, pw::2].sum((0, 2, 3))  # the bias gradient of the rows this phase writes
+                run(d, [x], dy, 4 * Cin, Cout, want, want_b)
+    elif geom == "stem7":
+        nimg, H, W, Cout = 3, 16, 16, 64
+        x = torch.randn(nimg, 3, H, W, generator=g).double()
+        w = (torch.randn(Cout, 3, 7, 7, generator=g) / 12).double().requires_grad_()
+        b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, w, b, padding=3)
+        dy = torch.randn(y.shape, generator=g).double()
+        y.backward(dy)
+        xp = torch.cat([x, torch.zeros(nimg, 1, H, W, dtype=torch.float64)], 1)  # rows padded to four channels, as the plan stages the network input
+        d = N.ConvDesc()
+        d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+        d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 7, 7, -3, -3, 1, 1
+        d.Hout, d.Wout, d.oscale = H, W, 1
+        want = torch.cat([w.grad, torch.zeros(Cout, 1, 7, 7, dtype=torch.float64)], 1).permute(2, 3, 1, 0).reshape(49 * 4, Cout)
+        run(d, [xp], dy, 49 * 4, Cout, want, b.grad)
+    else:  # a 3 x 3 layer under periodic padding (vddp.py:163-243)
+        nimg, H, W, Cin, Cout = 2, 8, 8, 64, 64
+        x = torch.randn(nimg, Cin, H, W, generator=g).double()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 24).double().requires_grad_()
+        b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="circular"), w, b)
+        dy = torch.randn(y.shape, generator=g).double()
+        y.backward(dy)
+        d = N.ConvDesc()
+        d.nimg, d.Hin, d.Win, d.Hv, d.Wv, d.stride = nimg, H, W, H, W, 1
+        d.KH, d.KW, d.off_h, d.off_w, d.sgn_h, d.sgn_w = 3, 3, -1, -1, 1, 1
+        d.Hout, d.Wout, d.oscale, d.wrap_h, d.wrap_w = H, W, 1, 1, 1
+        run(d, [x], dy, 9 * Cin, Cout, w.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout), b.grad)
+
+
 @pytest.mark.parametrize("variant", ["bf16x3", "fp16"])
 def test_deferred_weight_gradient_totals_are_the_per_layer_totals(gpu, variant):
     """vmm_conv_desc.defer_reduce + vmm_reduce_batch: three 3 x 3 layers and three 1 x 1 layers (with / without bias, two sources, several channel blocks)

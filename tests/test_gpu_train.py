@@ -195,7 +195,7 @@ def test_gradients_with_focus_present_mask_match_oracle_autograd(gpu, cfg_name, 
 def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
     """train_precision = "bf16x3": forward and data gradients on the split-bf16 matrix cores (3x3 data gradients through the halo kernel
     with reversed taps, 1x1 ones through the projection kernel); weight gradients: "x3" (the default) = the 3 x 3 layers on the nine-tap
-    split-bf16 kernel, the others exact fp32; "f32" = all exact fp32; "x3+generic" = the generic split-bf16 kernel for the others (and
+    split-bf16 kernel, the 1 x 1 ones on theirs, every other geometry on the tap-decoding form of the 1 x 1 kernel; "f32" = all exact fp32; "x3+generic" = the generic split-bf16 kernel for the others (and
     for the periodic 3 x 3 layers, which the nine-tap kernel declines).  Checked with the smooth l2 loss: with l1 the loss gradient is a
     sign, and a 1e-5 forward difference flips enough of them to dominate the comparison."""
     import videometamaterials_amd as vm
@@ -231,7 +231,9 @@ def test_split_bf16_training_gradients(gpu, cfg_name, x3_wgrad):
         assert {"vmm_cross_attention_bwd", "vmm_linattn_cross_bwd"} <= used
         return
     assert "vmm_proj_bf16x3" in used and ("vmm_conv3x3_bf16x3" in used or cfg_name == "lagr16")
-    assert ("vmm_conv_wgrad_bf16x3" in used) == (x3_wgrad == "x3+generic") and ("vmm_conv_wgrad_f32" in used) == (x3_wgrad != "x3+generic")
+    # the remaining geometries (4 x 4 stride-2, transposed phases, stem; periodic 3 x 3): "x3" = the tap-decoding 1 x 1 kernel (round 6), "x3+generic" = the old generic kernel
+    assert ("vmm_conv_wgrad_bf16x3" in used) == (x3_wgrad == "x3+generic") and ("vmm_conv_wgrad_tap_bf16x3" in used) == (x3_wgrad == "x3")
+    assert ("vmm_conv_wgrad_f32" in used) == (x3_wgrad == "f32")
     assert ("vmm_conv3x3_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name == "lagr64")
     assert ("vmm_conv1x1_wgrad_bf16x3" in used) == (x3_wgrad != "f32" and cfg_name in ("lagr64", "circ64"))
 

@@ -126,6 +126,11 @@ SIGNATURES = {
     "vmm_sum_partials": [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_reduce_job": [C.POINTER(ConvDesc), c_i32, c_ptr, c_ptr, c_ptr, C.POINTER(ReduceJob)],
     "vmm_conv1x1_wgrad_reduce_job": [C.POINTER(ConvDesc), c_i32, c_ptr, c_ptr, c_ptr, C.POINTER(ReduceJob)],
+    "vmm_conv_wgrad_tap_reduce_job": [C.POINTER(ConvDesc), c_i32, c_ptr, c_ptr, c_ptr, C.POINTER(ReduceJob)],
+    "vmm_conv_wgrad_tap_workspace": [C.POINTER(ConvDesc), c_i32],
+    "vmm_conv_wgrad_tap_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv_wgrad_tap_bf16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "vmm_conv_wgrad_tap_fp16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_reduce_batch": [c_ptr, c_i32, c_i32, c_ptr],
     "vmm_conv3x3_wgrad_bf16x3": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
     "vmm_conv3x3_wgrad_bf16": [C.POINTER(ConvDesc), c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr],
@@ -321,7 +326,7 @@ DP_SIGNATURES = {
     "vmm_dp_finalize": [c_ptr],
 }
 
-RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_cross_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64, "vmm_linattn_block_bwd_workspace": c_i64, "vmm_groupnorm_bwd_scratch": c_i64}  # everything else returns int (0 = ok)
+RESTYPES = {"vmm_dp_last_error": C.c_char_p, "vmm_attention_bwd_scratch": c_i64, "vmm_cross_attention_bwd_scratch": c_i64, "vmm_linattn_block_workspace": c_i64, "vmm_conv3x3_wgrad_bf16x3_workspace": c_i64, "vmm_conv1x1_wgrad_bf16x3_workspace": c_i64, "vmm_conv_wgrad_tap_workspace": c_i64, "vmm_qkv_bwd_workspace": c_i64, "vmm_temporal_block_bwd_workspace": c_i64, "vmm_linattn_block_bwd_workspace": c_i64, "vmm_groupnorm_bwd_scratch": c_i64}  # everything else returns int (0 = ok)
 
 _lib = None
 

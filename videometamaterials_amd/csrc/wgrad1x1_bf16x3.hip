@@ -37,8 +37,13 @@ struct W1Args {
   int nchunks, chunks_per_wg;
   const float* ln_stats;  // non-NULL: x = (a1 - mean[r]) * rstd[r] * ln_gamma[ci], (mean, rstd) = ln_stats[r][2] (PreNorm LayerNorm, vddp.py:245-254)
   const float* ln_gamma;
+  // TAP instances (vmm_conv_wgrad_tap_*): the K axis is (tap, input channel), K = KH KW (C1 + C2); output row r = (img, a, b) meets the input pixel
+  // (a stride + off_h + sgn_h kh, b stride + off_w + sgn_w kw) of tap (kh, kw) (zero or periodic padding) and the dY row of the descriptor's output scatter
+  int Ktot, hw, wv;
+  unsigned hw_magic, wv_magic;  // floor(2^32 / d) + 1: n / d = mulhi(n, magic) while n d < 2^32 (checked by the launcher)
 };
 
+template <bool TAP>
 __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const vmm_conv_desc& p = a.p;
@@ -56,17 +61,48 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   // ---------------------------------------------------------------- loader: thread = (8-row piece `oct`, channel pair `cp`) of BOTH operands
   const int oct = wave, cp = tid & 63;  // (oct = tid >> 6 is the wave: wave-uniform, so the per-row LayerNorm statistics below are scalar loads)
   const int xc = ci0 + 2 * cp, yc = co0 + 2 * cp;
-  const bool x_ok = xc < Cin, y_ok = yc < p.Cout;
-  const bool x_src1 = xc < p.C1;
-  const float* xsrc = x_src1 ? p.a1 + xc : p.a2 + (xc - p.C1);
+  const bool x_ok = xc < (TAP ? a.Ktot : Cin), y_ok = yc < p.Cout;
+  // TAP: this thread's column pair of K = (tap, channel): the tap's offset into the input grid, the channel inside its source (a pair never straddles taps: Cin is even)
+  const int tap = TAP ? (x_ok ? xc / Cin : 0) : 0;
+  const int xci = TAP ? xc - tap * Cin : xc;
+  const int tkh = TAP ? tap / p.KW : 0, tkw = TAP ? tap - tkh * p.KW : 0;
+  const int dih = TAP ? p.off_h + p.sgn_h * tkh : 0, diw = TAP ? p.off_w + p.sgn_w * tkw : 0;
+  const bool x_src1 = xci < p.C1;
+  const float* xsrc = x_src1 ? p.a1 + xci : p.a2 + (xci - p.C1);
   const int xld = x_src1 ? p.lda1 : p.lda2;
   const float* ysrc = a.dy + yc;
   f32x2 xv[8], yv[8], sv[8];
+  unsigned xmask = 0xffu;  // TAP: which of the eight rows in flight read inside the image (the others are padding: staged as zeros)
   f32x2 bsum = {0.f, 0.f};
   const bool ln = a.ln_stats != nullptr;  // (workgroup-uniform)
   const f32x2 lg = (ln && x_ok) ? *reinterpret_cast<const f32x2*>(a.ln_gamma + xc) : f32x2{1.f, 1.f};
   // (every load is unconditional: rows past the end and channels past the layer re-read row 0 / channel 0 and are zeroed when staged)
-  auto request = [&](long long r0) {
+  auto request = [&](long long r0) __attribute__((always_inline)) {  // (the TAP body is long: not inlined, its captures -- the rows in flight -- would live in scratch)
+    if constexpr (TAP) {
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long long r = r0 + i;
+        const bool v = r < a.rows;
+        // (r is wave-uniform -- a wave owns eight rows, its lanes the column pairs --: the decode runs on the scalar unit)
+        const unsigned ru = v ? (unsigned)r : 0u;
+        const unsigned img = __umulhi(ru, a.hw_magic);
+        const unsigned rem = ru - img * (unsigned)a.hw;
+        const unsigned oa = __umulhi(rem, a.wv_magic);
+        const unsigned ob = rem - oa * (unsigned)a.wv;
+        int ih = (int)oa * p.stride + dih, iw = (int)ob * p.stride + diw;
+        if (p.wrap_h) ih = ih < 0 ? ih + p.Hin : (ih >= p.Hin ? ih - p.Hin : ih);  // periodic padding (vddp.py:163-243)
+        if (p.wrap_w) iw = iw < 0 ? iw + p.Win : (iw >= p.Win ? iw - p.Win : iw);
+        const bool okx = v && x_ok && (unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win;
+        const long long xrow = ((long long)img * p.Hin + ih) * p.Win + iw;
+        const long long orow = ((long long)img * p.Hout + (int)oa * p.oscale + p.ooh) * p.Wout + (int)ob * p.oscale + p.oow;
+        xv[i] = *reinterpret_cast<const f32x2*>(okx ? xsrc + xrow * xld : p.a1);
+        yv[i] = *reinterpret_cast<const f32x2*>((v && y_ok) ? ysrc + orow * a.lddy : a.dy);
+        m |= (okx ? 1u : 0u) << i;
+      }
+      xmask = m;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long r = r0 + i;
@@ -76,7 +112,7 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
       if (ln) sv[i] = *reinterpret_cast<const f32x2*>(a.ln_stats + 2 * (v ? r : 0));
     }
   };
-  auto stage = [&](long long r0, int buf) {
+  auto stage = [&](long long r0, int buf) __attribute__((always_inline)) {
     unsigned char* base = sm + buf * BUF + oct * 16;
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
@@ -85,7 +121,7 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
       for (int c = 0; c < 2; ++c) {
         float e[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows) ? (op ? yv[i][c] : xv[i][c]) : 0.f;
+        for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows && (!TAP || op || ((xmask >> i) & 1u))) ? (op ? yv[i][c] : xv[i][c]) : 0.f;
         if (ln && !op) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) e[i] = (ok && r0 + i < a.rows) ? (e[i] - sv[i][0]) * (sv[i][1] * lg[c]) : 0.f;
@@ -117,7 +153,7 @@ __global__ __launch_bounds__(512) void wgrad1_x3_kernel(const W1Args a) {
   __syncthreads();
 
   const int a_lane = (wu * 64 + l31) * PITCH + half * 16, b_lane = 2 * PLANE + (wv * 64 + l31) * PITCH + half * 16;
-  auto loader_phase = [&](int it) {
+  auto loader_phase = [&](int it) __attribute__((always_inline)) {
     if (it + 1 < n_it) {
       stage(r_begin + (long long)(it + 1) * CH + 8 * oct, (it + 1) & 1);
       if (it + 2 < n_it) request(r_begin + (long long)(it + 2) * CH + 8 * oct);
@@ -223,6 +259,36 @@ static bool w1_setup(const vmm_conv_desc& d, int32_t lddy, W1Args& a, int& gz, i
   return true;
 }
 
+// TAP form: any kernel size / stride / output scatter of the descriptor (the 4 x 4 stride-2 convolutions, the four phases of the transposed ones, the 7 x 7 stem),
+// zero or periodic padding; no fused operand transform; channel counts even, K = KH KW (C1 + C2) a multiple of four
+static bool w1_setup_tap(const vmm_conv_desc& d, int32_t lddy, W1Args& a, int& gz, int& tx, int& ty) {
+  const int Cin = d.C1 + d.C2;
+  const bool shape_ok = d.KH >= 1 && d.KW >= 1 && d.KH * d.KW <= 1024 && d.stride >= 1 && d.oscale >= 1 && d.a_mode == 0 && !d.a_img_mod && d.Hv > 0 && d.Wv > 0 && d.Hout > 0 &&
+                        d.Wout > 0;
+  const bool chan_ok = d.C1 > 0 && (d.C1 & 1) == 0 && (d.C2 & 1) == 0 && (d.Cout & 1) == 0 && (d.lda1 & 1) == 0 && (!d.C2 || (d.lda2 & 1) == 0) && (lddy & 1) == 0 &&
+                       ((long long)d.KH * d.KW * Cin) % 4 == 0;
+  if (!shape_ok || !chan_ok || d.nimg <= 0 || d.Hin <= 0 || d.Win <= 0) return false;
+  a.p = d;
+  a.rows = (long long)d.nimg * d.Hv * d.Wv;
+  a.hw = d.Hv * d.Wv;
+  a.wv = d.Wv;
+  // (the magic divisions: n / d = mulhi(n, floor(2^32 / d) + 1) holds while n d < 2^32)
+  if (a.rows * a.hw >= (1ll << 32) || (long long)a.hw * a.wv >= (1ll << 32) || (long long)d.nimg * d.Hin * d.Win >= (1ll << 31) ||
+      (long long)d.nimg * d.Hout * d.Wout >= (1ll << 31))
+    return false;
+  if (a.hw < 2 || a.wv < 2) return false;  // (a divisor of 1 has no 32-bit magic; such layers stay on the generic kernel)
+  a.hw_magic = (unsigned)(0x100000000ull / (unsigned)a.hw) + 1u;
+  a.wv_magic = (unsigned)(0x100000000ull / (unsigned)a.wv) + 1u;
+  a.Ktot = d.KH * d.KW * Cin;
+  a.nchunks = (int)((a.rows + CH - 1) / CH);
+  tx = (a.Ktot + 127) / 128;
+  ty = (d.Cout + 127) / 128;
+  const int nz = max(1, min(a.nchunks, 256 / (tx * ty)));
+  a.chunks_per_wg = (a.nchunks + nz - 1) / nz;
+  gz = (a.nchunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  return true;
+}
+
 }  // namespace
 
 // floats of workspace vmm_conv1x1_wgrad_bf16x3 wants for this layer; 0 = outside the kernel's envelope (1 x 1, stride 1, identity rows, no fused
@@ -248,6 +314,58 @@ extern "C" int vmm_conv1x1_wgrad_reduce_job(const vmm_conv_desc* dp, int32_t ldd
 }
 #endif
 
+#if !VMM_SINGLE_PASS
+// ... and of the TAP form (vmm_conv_wgrad_tap_*): workspace floats (0 = outside its envelope), the deferred second stage as a vmm_reduce_batch job
+extern "C" int64_t vmm_conv_wgrad_tap_workspace(const vmm_conv_desc* dp, int32_t lddy) {
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!w1_setup_tap(*dp, lddy, a, gz, tx, ty)) return 0;
+  return (int64_t)gz * tx * ty * BLOCK_FLOATS + (int64_t)gz * dp->Cout;
+}
+extern "C" int vmm_conv_wgrad_tap_reduce_job(const vmm_conv_desc* dp, int32_t lddy, float* dw_packed, float* dbias, float* workspace, vmm_reduce_job* job) {
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!workspace || !job || !w1_setup_tap(*dp, lddy, a, gz, tx, ty)) return 1;
+  const int n_main = BLOCK_FLOATS / 4 / 32;
+  job->part = workspace; job->out = dw_packed;
+  job->bias_part = dbias ? workspace + (long long)gz * tx * ty * BLOCK_FLOATS : nullptr; job->dbias = dbias;
+  job->kind = 2; job->nz = gz; job->tiles_x = tx; job->tiles_y = ty; job->Cin = a.Ktot; job->Cout = dp->Cout; job->ld = 0;
+  job->n_main = n_main; job->gx = n_main + (dbias ? cdiv(dp->Cout, 32) : 0); job->wgs = job->gx * tx * ty; job->wg0 = 0;
+  return 0;
+}
+#endif
+
+// dw_packed[(kh, kw, ci)][co] += sum over output rows of x[input pixel of the tap][ci] dY[output row][co] for ANY convolution geometry the descriptor states -- kernel
+// size, stride, tap direction (sgn: the transposed convolutions' phases), output scatter (oscale / ooh / oow), zero or periodic padding -- on the matrix cores
+// (the 4 x 4 stride-2 layers, the four 2 x 2 phases of the transposed ones, the 7 x 7 stem: exact-fp32 kernel before round 6).  The 1 x 1 kernel with a loader that
+// decodes its eight wave-uniform rows once (scalar unit) and offsets them by the lane's tap.  dbias[co] += column sums of the dY rows the call visits.
+extern "C" int VMM_X3(vmm_conv_wgrad_tap_, )(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace,
+                                         vmm_stream_t stream) {
+  const vmm_conv_desc& d = *dp;
+  W1Args a;
+  int gz = 0, tx = 0, ty = 0;
+  if (!workspace || !w1_setup_tap(d, lddy, a, gz, tx, ty)) return 1;
+  a.ln_stats = nullptr;
+  a.ln_gamma = nullptr;
+  a.dy = dy; a.lddy = lddy;
+  a.part = workspace;
+  a.bias_part = dbias ? workspace + (long long)gz * tx * ty * BLOCK_FLOATS : nullptr;
+  const size_t shm = 2 * (size_t)BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad1_x3_kernel<true>, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
+  VMM_LAUNCH_CHECK();
+  if (d.defer_reduce) return 0;
+  const int n_main = BLOCK_FLOATS / 4 / 32;
+  hipLaunchKernelGGL(wgrad1_reduce_kernel, dim3(n_main + (dbias ? cdiv(d.Cout, 32) : 0), tx * ty), dim3(256), 0, (hipStream_t)stream, workspace, gz, tx, ty, dw_packed,
+                     a.Ktot, d.Cout, a.bias_part, dbias, n_main);
+  VMM_LAUNCH_CHECK();
+  return 0;
+}
+
 // dw_packed[ci][co] += sum_r x[r][ci] dY[r][co] (and dbias[co] += sum_r dY[r][co] when dbias != NULL); d = the FORWARD descriptor of the layer;
 // workspace = vmm_conv1x1_wgrad_bf16x3_workspace(d, lddy) floats (contents irrelevant).  Returns 1 (nothing launched) outside the envelope.
 static int w1_launch(const vmm_conv_desc* dp, const float* dy, int32_t lddy, float* dw_packed, float* dbias, float* workspace, const float* ln_stats,
@@ -264,10 +382,10 @@ static int w1_launch(const vmm_conv_desc* dp, const float* dy, int32_t lddy, flo
   const size_t shm = 2 * (size_t)BUF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad1_x3_kernel, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wgrad1_x3_kernel<false>, dim3(tx, ty, gz), dim3(512), shm, (hipStream_t)stream, a);
   VMM_LAUNCH_CHECK();
   if (d.defer_reduce) return 0;  // (the caller totals the blocks later: vmm_conv1x1_wgrad_reduce_job + vmm_reduce_batch)
   const int n_main = BLOCK_FLOATS / 4 / 32;

@@ -752,6 +752,20 @@ class _Builder:
                               flops=2.0 * M * K * d.Cout, nbytes=wbytes)
                 self.reduce_later(2, dd, lddy, gw_ptr, gb_ptr, ws, ws_n)
                 return
+        if (self.x3 and getattr(self.m, "use_x3_wgrad", True) and not getattr(self.m, "use_x3_wgrad_generic", False) and _enabled("wgrad_tap")
+                and not getattr(d, "_ln", None)):
+            # every other geometry (the 4 x 4 stride-2 layers, the transposed ones' phases, the stem): the 1 x 1 kernel with a tap-decoding loader (round 6;
+            # the exact-fp32 kernel below before)
+            ws_n = int(self.lib.vmm_conv_wgrad_tap_workspace(C.byref(d), lddy))
+            if ws_n:
+                ws = self.alloc(ws_n)
+                # (the four phases of a transposed convolution add into ONE bias gradient: their second stages run one after the other, each behind its own launch --
+                # jobs of one batched launch must not share a destination)
+                dd = d if (gb_ptr and d.oscale > 1) else self.deferred(d)
+                self.step(self.sp("vmm_conv_wgrad_tap_"), (C.byref(dd), dy_ptr, lddy, gw_ptr, gb_ptr or None, self.ptr(ws)), what + " wgrad", flops=2.0 * M * K * d.Cout,
+                          nbytes=wbytes)
+                self.reduce_later(3, dd, lddy, gw_ptr, gb_ptr, ws, ws_n)
+                return
         if self.x3 and getattr(self.m, "use_x3_wgrad_generic", False):  # opt-in: 128 x 128 tiles, split-bf16 operands (measured slower)
             fn = self.lib.vmm_conv_wgrad_bf16x3
             tiles = -(-K // 128) * -(-d.Cout // 128)
@@ -787,9 +801,11 @@ class _Builder:
         if not self.pending_reduce:
             return
         jobs = (N.ReduceJob * len(self.pending_reduce))()
+        dests = [p[3] for p in self.pending_reduce] + [p[4] for p in self.pending_reduce if p[4]]
+        assert len(dests) == len(set(dests)), "two jobs of one batched reduction share a destination (their += would race)"
         wg = 0
         for i, (kind, dd, lddy, gw_ptr, gb_ptr, ws, ws_n) in enumerate(self.pending_reduce):
-            fn = self.lib.vmm_conv3x3_wgrad_reduce_job if kind == 1 else self.lib.vmm_conv1x1_wgrad_reduce_job
+            fn = {1: self.lib.vmm_conv3x3_wgrad_reduce_job, 2: self.lib.vmm_conv1x1_wgrad_reduce_job, 3: self.lib.vmm_conv_wgrad_tap_reduce_job}[kind]
             rc = fn(C.byref(dd), lddy, gw_ptr, gb_ptr or None, self.ptr(ws), C.byref(jobs[i]))
             if rc != 0:
                 raise RuntimeError(f"no reduction job for a deferred weight-gradient launch (kind {kind}, rc {rc})")

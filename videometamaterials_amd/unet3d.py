@@ -115,7 +115,7 @@ class Unet3D(nn.Module):
         # matrix-core arithmetic of the contractions: "bf16x3" = split-bf16 operands, fp32 accumulate (~1e-5 relative, 5x the MFMA
         # rate); "fp32" = exact fp32 MFMA (1e-6).  `precision` governs inference / sampling, `train_precision` the training plans
         # (forward, data gradients and -- with use_x3_wgrad, the default -- the 3 x 3 / 1 x 1 weight gradients on the split-bf16 kernels, ~1e-5
-        # relative per contraction; the remaining layers' weight gradients are exact fp32).  With the reference's l1 loss
+        # relative per contraction; since round 6 the remaining geometries -- 4 x 4 stride-2, transposed phases, the stem -- too, on the tap-decoding form of the 1 x 1 kernel).  With the reference's l1 loss
         # the gradient is sign(pred - noise) / N, and a 1e-5 forward error flips enough signs to move parameter gradients by ~2e-3
         # (an order of magnitude inside the reference's own fp16-autocast deviation, tests/test_gpu_train.py).
         # "bf16" = the throughput mode of BASELINE.json configs[3]: one matrix pass on bf16-rounded operands in the 3 x 3 convolutions
